@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, read-only).  The
+reference's Python never enters this repo: this script imports it in place,
+feeds it inputs, and stores inputs + outputs as .npz data.
+
+Two third-party modules the reference imports are absent from this image and
+are replaced by minimal stand-ins *for the import only* (SURVEY.md 8c):
+  * torch_geometric.utils.scatter  -> sum-scatter via index_add_ (the only
+    reduce the reference ever uses on this path; newtonnet.py:214,226, output.py:246)
+  * les.Les                        -> empty nn.Module (only constructed, never
+    called, unless a 'charge' head exists; output.py:227-231)
+
+Fixtures written:
+  aspirin_frames.npz     z, train frames 0-7 + test frame 0 positions/energies/forces (data from the xyz files)
+  ckpt_state.npz         the shipped best_model.pt parameters, renamed to the current key layout, fp32+fp64 views
+  case_*.npz             inputs + reference outputs (edge_index, dist_edge, dir_edge, per-layer nodes, energy, force)
+  kat_md_traj.npz        K1: 201 frames of md.traj (positions, energy, forces)
+  kat_test_set.npz       K2: 500 test frames (positions, energies, forces) + the log.csv MAEs
+"""
+import io
+import json
+import math
+import os
+import pickle
+import struct
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+# ----------------------------------------------------------------------------
+# import the reference with the two stand-ins
+# ----------------------------------------------------------------------------
+def _install_shims():
+    def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
+        assert reduce == 'sum' and dim == 0
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        out = src.new_zeros((dim_size,) + tuple(src.shape[1:]))
+        return out.index_add_(0, index, src)
+
+    tg = types.ModuleType('torch_geometric')
+    tgu = types.ModuleType('torch_geometric.utils')
+    tgu.scatter = scatter
+    tg.utils = tgu
+    sys.modules['torch_geometric'] = tg
+    sys.modules['torch_geometric.utils'] = tgu
+
+    class Les(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.atomwise = nn.Identity()
+            self.ewald = nn.Identity()
+            self.bec = nn.Identity()
+
+    les = types.ModuleType('les')
+    les.Les = Les
+    sys.modules['les'] = les
+
+
+def import_reference():
+    _install_shims()
+    sys.path.insert(0, REF)
+    from newtonnet.models.newtonnet import NewtonNet  # noqa
+    return NewtonNet
+
+
+# ----------------------------------------------------------------------------
+# data readers (extxyz, ASE ULM .traj) -- written here, no ase in this image
+# ----------------------------------------------------------------------------
+SYM2Z = {'H': 1, 'C': 6, 'N': 7, 'O': 8}
+
+
+def read_extxyz(path, max_frames=None):
+    frames = []
+    with open(path) as f:
+        while True:
+            line = f.readline()
+            if not line.strip():
+                break
+            n = int(line)
+            header = f.readline()
+            energy = float(header.split('energy=')[1].split()[0])
+            z, pos, frc = [], [], []
+            for _ in range(n):
+                t = f.readline().split()
+                z.append(SYM2Z[t[0]])
+                pos.append([float(v) for v in t[1:4]])
+                frc.append([float(v) for v in t[4:7]])
+            frames.append((np.array(z), np.array(pos), energy, np.array(frc)))
+            if max_frames and len(frames) >= max_frames:
+                break
+    return frames
+
+
+def read_ulm(path):
+    """Minimal reader for ASE's ULM container ('- of Ulm' magic)."""
+    raw = open(path, 'rb').read()
+    assert raw[:8] == b'- of Ulm'
+    version, nitems, pos0 = struct.unpack('<qqq', raw[24:48])
+    offsets = np.frombuffer(raw, '<i8', nitems, pos0)
+
+    def resolve(obj, base):
+        if isinstance(obj, dict):
+            if 'ndarray' in obj and len(obj) == 1:
+                shape, dtype, off = obj['ndarray']
+                cnt = int(np.prod(shape)) if shape else 1
+                return np.frombuffer(raw, np.dtype(dtype), cnt, off).reshape(shape).copy()
+            return {(k[:-1] if k.endswith('.') else k): resolve(v, base) for k, v in obj.items()}
+        return obj
+
+    items = []
+    for off in offsets:
+        (ln,) = struct.unpack('<q', raw[off:off + 8])
+        items.append(resolve(json.loads(raw[off + 8:off + 8 + ln].decode()), off))
+    return items
+
+
+# ----------------------------------------------------------------------------
+# checkpoint: old-layout whole-module pickle -> current key names
+# ----------------------------------------------------------------------------
+class _StubUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith('newtonnet'):
+            return type(name, (nn.Module,), {'__module__': module})
+        return super().find_class(module, name)
+
+
+class _StubPickle:
+    Unpickler = _StubUnpickler
+    load = staticmethod(lambda f, **kw: _StubUnpickler(f, **kw).load())
+    __name__ = 'stub_pickle'
+
+
+def load_checkpoint_state():
+    path = f'{REF}/scripts/md17_model/training_1/models/best_model.pt'
+    mod = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_StubPickle)
+    sd = {}
+    for k, v in mod.state_dict().items():
+        k = k.replace('embedding_layer.edge_embedding.frequencies',
+                      'embedding_layers.edge_embedding.embedding.frequencies')
+        k = k.replace('embedding_layer.', 'embedding_layers.')
+        sd[k] = v.detach().clone()
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# run the reference
+# ----------------------------------------------------------------------------
+def run_reference(NewtonNet, sd, z, pos, cell, batch, dtype, n_features=128, n_basis=20, n_interactions=3,
+                  cutoff=5.0):
+    model = NewtonNet(cutoff=cutoff, n_features=n_features, n_basis=n_basis, n_interactions=n_interactions,
+                      output_properties=['energy', 'gradient_force'])
+    model.to(torch.float64)      # widen first: load_state_dict copies INTO the existing (fp32) parameters
+    model.load_state_dict({k: v.to(torch.float64) for k, v in sd.items()}, strict=True)
+    model.to(dtype)
+    model.eval()
+    pos = pos.to(dtype).clone()
+    cell = cell.to(dtype).clone()
+    layers = []
+    hooks = [il.register_forward_hook(lambda m, i, o: layers.append((o[0].detach().clone(), o[1].detach().clone())))
+             for il in model.interaction_layers]
+    edge = {}
+    h2 = model.embedding_layers.edge_embedding.register_forward_hook(
+        lambda m, i, o: edge.update(dist_edge=o[0].detach().clone(), dir_edge=o[1].detach().clone()))
+    out = model(z, pos, cell, batch)
+    for h in hooks + [h2]:
+        h.remove()
+    res = dict(energy=out.energy.detach(), forces=out.gradient_force.detach(), edge_index=out.edge_index,
+               dist_edge=edge['dist_edge'], dir_edge=edge['dir_edge'])
+    for l, (a, f) in enumerate(layers):
+        res[f'atom_node_{l}'] = a
+        res[f'force_node_{l}'] = f
+    return res
+
+
+def to_np(d):
+    return {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def random_state_via_reference(NewtonNet, seed, **kw):
+    """Seeded random weights exactly as the reference constructs them (torch.manual_seed + default init)."""
+    torch.manual_seed(seed)
+    model = NewtonNet(output_properties=['energy', 'gradient_force'], **kw)
+    model.to(torch.float64)
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def periodic_box(n_side, spacing, jitter, seed, species=(1, 6, 7, 8)):
+    """SURVEY 8d config-5 recipe at a small size: simple-cubic lattice + uniform jitter."""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.arange(n_side ** 3)
+    grid = torch.stack([idx // (n_side * n_side), (idx // n_side) % n_side, idx % n_side], 1).double() * spacing
+    pos = grid + (torch.rand(grid.shape, generator=g, dtype=torch.float64) - 0.5) * 2 * jitter
+    z = torch.tensor(species)[torch.randint(0, len(species), (n_side ** 3,), generator=g)]
+    L = n_side * spacing
+    pos = pos % L
+    return z, pos, torch.eye(3, dtype=torch.float64).unsqueeze(0) * L
+
+
+FULL_CASES = ('aspirin1', 'ethanol4', 'mixed')
+
+
+def main():
+    NewtonNet = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    # -- raw data -------------------------------------------------------------
+    train = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_train/raw/aspirin_ccsd-train.xyz', 8)
+    test = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_test/raw/aspirin_ccsd-test.xyz')
+    z_asp = train[0][0]
+    np.savez_compressed(f'{OUT}/aspirin_frames.npz', z=z_asp,
+                        train_pos=np.stack([f[1] for f in train]), train_energy=np.array([f[2] for f in train]),
+                        train_forces=np.stack([f[3] for f in train]),
+                        test0_pos=test[0][1], test0_energy=test[0][2], test0_forces=test[0][3])
+
+    # -- checkpoint -----------------------------------------------------------
+    ck = load_checkpoint_state()
+    np.savez_compressed(f'{OUT}/ckpt_state.npz', **{k: v.to(torch.float64).numpy() for k, v in ck.items()})
+    print('checkpoint params:', sum(v.numel() for v in ck.values()))
+
+    rnd = random_state_via_reference(NewtonNet, 0, cutoff=5.0, n_features=128, n_basis=20, n_interactions=3)
+    # constructed in fp32 then widened, so fp32 storage is lossless
+    assert all(torch.equal(v, v.float().double()) for v in rnd.values())
+    np.savez_compressed(f'{OUT}/rand_state_seed0.npz', **{k: v.float().numpy() for k, v in rnd.items()})
+
+    zt = torch.tensor(z_asp, dtype=torch.long)
+
+    def mol_batch(frames_pos):
+        B = len(frames_pos)
+        z = zt.repeat(B)
+        pos = torch.tensor(np.concatenate(frames_pos), dtype=torch.float64)
+        batch = torch.repeat_interleave(torch.arange(B), len(z_asp))
+        return z, pos, torch.zeros(B, 3, 3, dtype=torch.float64), batch
+
+    cases = {}
+    # 1 aspirin frame / 8-frame batch, random + checkpoint weights
+    cases['aspirin1'] = mol_batch([test[0][1]])
+    cases['aspirin8'] = mol_batch([f[1] for f in train])
+    # ethanol-shaped 9-atom molecules, batch of 4
+    eth0 = torch.tensor([[0.00, 0.00, 0.00], [1.52, 0.00, 0.00], [2.05, 1.32, 0.00],
+                         [-0.39, 1.02, 0.00], [-0.39, -0.51, 0.89], [-0.39, -0.51, -0.89],
+                         [1.90, -0.53, 0.88], [1.90, -0.53, -0.88], [3.01, 1.30, 0.00]], dtype=torch.float64)
+    g = torch.Generator().manual_seed(0)
+    eth = [(eth0 + 0.1 * torch.randn(9, 3, generator=g, dtype=torch.float64)).numpy() for _ in range(4)]
+    cases['ethanol4'] = (torch.tensor([6, 6, 8, 1, 1, 1, 1, 1, 1]).repeat(4),
+                         torch.tensor(np.concatenate(eth)), torch.zeros(4, 3, 3, dtype=torch.float64),
+                         torch.repeat_interleave(torch.arange(4), 9))
+    # mixed sizes: aspirin (21) + ethanol (9) + a single atom (zero-edge molecule) + a far-apart pair (no edges)
+    far = np.array([[0.0, 0, 0], [9.0, 0, 0]])
+    cases['mixed'] = (torch.cat([zt, torch.tensor([6, 6, 8, 1, 1, 1, 1, 1, 1]), torch.tensor([8]), torch.tensor([1, 1])]),
+                      torch.tensor(np.concatenate([train[1][1], eth[0], np.zeros((1, 3)), far])),
+                      torch.zeros(4, 3, 3, dtype=torch.float64),
+                      torch.tensor([0] * 21 + [1] * 9 + [2] + [3, 3]))
+    # periodic orthorhombic box 6^3 = 216 atoms, L = 12.77 (> 2r): reference PBC == true minimum image
+    zb, pb, cb = periodic_box(6, 100.0 / 47.0, 0.5, 0)
+    cases['pbc216'] = (zb, pb, cb, torch.zeros(216, dtype=torch.long))
+    # two periodic boxes of different (orthorhombic) shape in one batch
+    zb2, pb2, _ = periodic_box(5, 2.4, 0.4, 1)
+    cb2 = torch.diag(torch.tensor([12.0, 12.0, 12.0], dtype=torch.float64)).unsqueeze(0)
+    cases['pbc_batch2'] = (torch.cat([zb, zb2]), torch.cat([pb, pb2]), torch.cat([cb, cb2]),
+                           torch.cat([torch.zeros(216, dtype=torch.long), torch.ones(125, dtype=torch.long)]))
+
+    for name, (z, pos, cell, batch) in cases.items():
+        for wname, sd in (('rand', rnd), ('ckpt', ck)):
+            if wname == 'ckpt' and not name.startswith('aspirin'):
+                continue
+            rec = dict(z=z.numpy(), pos=pos.numpy(), cell=cell.numpy(), batch=batch.numpy())
+            for dt, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+                r = run_reference(NewtonNet, sd, z, pos, cell, batch, dt)
+                for k, v in to_np(r).items():
+                    big = k.startswith(('atom_node', 'force_node', 'dist_edge', 'dir_edge'))
+                    if big and (tag == 'f32' or name not in FULL_CASES):
+                        continue  # per-layer / per-edge tensors: fp64 only, small cases only (fixture size)
+                    rec[f'{tag}_{k}'] = v
+            np.savez_compressed(f'{OUT}/case_{name}_{wname}.npz', **rec)
+            print(name, wname, 'E =', rec['f64_energy'][:2], 'edges =', rec['f64_edge_index'].shape[1],
+                  'f32 edges equal:', np.array_equal(rec['f64_edge_index'], rec['f32_edge_index']))
+
+    # -- K1: md.traj ------------------------------------------------------------
+    items = read_ulm(f'{REF}/scripts/md17_md/md.traj')
+    numbers = items[0]['numbers']
+    P = np.stack([it['positions'] for it in items])
+    E = np.array([it['calculator']['energy'] for it in items])
+    Fr = np.stack([it['calculator']['forces'] for it in items])
+    np.savez_compressed(f'{OUT}/kat_md_traj.npz', numbers=numbers, positions=P, energy=E, forces=Fr)
+    print('K1 frames', len(items), 'E0', E[0])
+
+    # -- K2: test set + log.csv final row ------------------------------------------
+    import csv
+    rows = list(csv.DictReader(open(f'{REF}/scripts/md17_model/training_1/log.csv')))
+    final = rows[-1]
+    np.savez_compressed(f'{OUT}/kat_test_set.npz', z=test[0][0], positions=np.stack([f[1] for f in test]),
+                        energy=np.array([f[2] for f in test]), forces=np.stack([f[3] for f in test]),
+                        log_test_energy_mae=float(final['test_energy_mae']),
+                        log_test_force_mae=float(final['test_gradient_force_mae']))
+    print('K2', final['test_energy_mae'], final['test_gradient_force_mae'])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,88 @@
+"""Pin the CPU oracle (oracle/newtonnet_ref.py) against the reference's own outputs.
+
+The golden files were produced by running the reference in the build container
+(tests/golden/gen_golden.py).  K1 / K2 are the only known answers the reference
+ships."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import newtonnet_ref as ref
+from tests import util
+
+CASES = ['aspirin1_rand', 'aspirin1_ckpt', 'aspirin8_rand', 'aspirin8_ckpt', 'ethanol4_rand', 'mixed_rand',
+         'pbc216_rand', 'pbc_batch2_rand']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_matches_reference_fp64(case):
+    z, pos, cell, batch, c = util.case_inputs(case)
+    sd = util.load_state(case.split('_')[-1])
+    out = ref.energy_forces(sd, z, pos, cell, batch, keep_intermediates=True)
+    assert np.array_equal(out['edge_index'].numpy(), c['f64_edge_index'])       # bit-exact neighbor indices
+    np.testing.assert_allclose(out['energy'].numpy(), c['f64_energy'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out['forces'].numpy(), c['f64_forces'], rtol=1e-10, atol=1e-12)
+    if 'f64_dist_edge' in c:
+        np.testing.assert_allclose(out['dist_edge'].numpy(), c['f64_dist_edge'], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(out['dir_edge'].numpy(), c['f64_dir_edge'], rtol=1e-12, atol=1e-14)
+        for l, (a, f) in enumerate(out['layers']):
+            np.testing.assert_allclose(a.numpy(), c[f'f64_atom_node_{l}'], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(f.numpy(), c[f'f64_force_node_{l}'], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_oracle_matches_reference_fp32(case):
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    sd = util.load_state(case.split('_')[-1], torch.float32)
+    out = ref.energy_forces(sd, z, pos, cell, batch)
+    assert np.array_equal(out['edge_index'].numpy(), c['f32_edge_index'])
+    assert np.all(np.abs(out['energy'].numpy().astype(np.float64) - c['f32_energy']) <= util.energy_tol(c['f32_energy']))
+    # fp32-vs-fp32: same op sequence, threaded reductions may reorder -> small tolerance
+    assert np.abs(out['forces'].numpy() - c['f32_forces']).max() < 2e-5
+
+
+def test_zero_edge_molecules_do_not_crash():
+    z, pos, cell, batch, c = util.case_inputs('mixed_rand')
+    out = ref.energy_forces(util.load_state('rand'), z, pos, cell, batch)
+    assert out['energy'].shape == (4,)
+    ei = out['edge_index'].numpy()
+    assert not np.isin(ei, [30, 31, 32]).any()          # lone atom and the 9 A pair have no edges
+    assert np.all(out['forces'].numpy()[30:] == 0)
+
+
+def test_K1_md_traj_fp32():
+    """K1: scripts/md17_md/md.traj -- 201 frames written by the authors' CUDA fp32 run."""
+    k = util.load_npz('kat_md_traj.npz')
+    sd = util.load_state('ckpt', torch.float32)
+    n_frames, n_atoms = k['positions'].shape[:2]
+    z = torch.from_numpy(k['numbers']).long().repeat(n_frames)
+    pos = torch.from_numpy(k['positions']).reshape(-1, 3).float()
+    batch = torch.repeat_interleave(torch.arange(n_frames), n_atoms)
+    out = ref.energy_forces(sd, z, pos, torch.zeros(n_frames, 3, 3), batch)
+    e = out['energy'].numpy().astype(np.float64)
+    assert np.all(np.abs(e - k['energy']) <= util.energy_tol(k['energy']))
+    assert abs(e[0] - (-17591.826171875)) <= 2e-3       # md.log line 2 / K3
+    df = np.abs(out['forces'].numpy().reshape(n_frames, n_atoms, 3) - k['forces'])
+    assert df.max() < 5e-5 and df.mean() < 1e-5
+
+
+def test_K2_logcsv_final_row_fp64():
+    """K2: log.csv `final` row -- fp64 test-set MAEs of best_model.pt over the 500 test frames."""
+    k = util.load_npz('kat_test_set.npz')
+    sd = util.load_state('ckpt', torch.float64)
+    n_frames, n_atoms = k['positions'].shape[:2]
+    z = torch.from_numpy(k['z']).long().repeat(n_frames)
+    pos = torch.from_numpy(k['positions']).reshape(-1, 3)
+    batch = torch.repeat_interleave(torch.arange(n_frames), n_atoms)
+    out = ref.energy_forces(sd, z, pos, torch.zeros(n_frames, 3, 3, dtype=torch.float64), batch)
+    e_mae = np.abs(out['energy'].numpy() - k['energy']).mean()
+    f_mae = np.abs(out['forces'].numpy().reshape(n_frames, n_atoms, 3) - k['forces']).mean()
+    assert abs(e_mae - float(k['log_test_energy_mae'])) < 1e-11
+    assert abs(f_mae - float(k['log_test_force_mae'])) < 1e-12
+    assert out['edge_index'].shape[1] == 151366
+
+
+def test_candidate_pair_order_unsorted_batch():
+    batch = torch.tensor([1, 0, 1, 0, 2])
+    p = ref.candidate_pairs(batch).numpy()
+    assert p.T.tolist() == [[1, 3], [3, 1], [0, 2], [2, 0]]
