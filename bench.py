@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the NewtonNet hot path on MI355X: atom-steps/s for energy+force on batched MD17-aspirin.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--conformers 1024]
+
+One "step" = one full pass of the hot path over one batch resident in HBM: neighbor list + edge embedding +
+3 interaction layers + energy head + analytic force adjoint (BASELINE.json configs[1]: 1024 aspirin
+conformers, fp32).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank evaluates its
+own 1024-conformer shard -- conformers are independent, there is no data-path collective ("weak" scaling) --
+and the time is the max over ranks between two barriers.
+
+Prints ONE JSON line (see README / DESIGN.md for the fields).  `roofline` is measured live with HIP events on
+the launch stream (the library's timer hook) in a separate instrumented pass, so the events never sit inside
+the timed region.  `cpu_baseline` times the CPU oracle (oracle/newtonnet_ref.py, a parity-checked restatement
+of the reference's PyTorch path) on the host cores of the same box, on rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak
+
+
+def synthetic_aspirin(n_conf, seed, device):
+    """aspirin test-frame-0 geometry + N(0, 0.05^2) noise, cell = 0."""
+    with np.load(os.path.join(ROOT, 'tests', 'golden', 'aspirin_frames.npz')) as f:
+        z0, p0 = f['z'], f['test0_pos']
+    g = torch.Generator().manual_seed(seed)
+    n = len(z0)
+    pos = torch.from_numpy(p0).float().repeat(n_conf, 1) + 0.05 * torch.randn(n_conf * n, 3, generator=g)
+    z = torch.from_numpy(z0).long().repeat(n_conf)
+    batch = torch.repeat_interleave(torch.arange(n_conf), n)
+    cell = torch.zeros(n_conf, 3, 3)
+    return z.to(device), pos.to(device), cell.to(device), batch.to(device)
+
+
+def algorithmic_counts(N, E, L=3, F=128):
+    """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step."""
+    edge_fwd = L * (1568 * E + 4608 * N)
+    edge_bwd = L * (3136 * E + 6144 * N)
+    # dense linears actually needed for energy + force (layer-0 phi2 branch is identically zero and skipped):
+    # forward: node MLP 2, edge MLPs 4 (2 in layer 0), update 1 (M=3N), head 2 ; adjoint: the transposes
+    fl = 0
+    for l in range(L):
+        n_edge_mlp = 1 if l == 0 else 2
+        fwd = 2 * N + 2 * n_edge_mlp * E + 3 * N
+        bwd = 3 * N + 2 * n_edge_mlp * E + (2 * N if l > 0 else 2 * N)
+        fl += (fwd + bwd) * 2 * F * F
+    fl += (2 * N + 2 * N) * 2 * F * F
+    return edge_fwd, edge_bwd, fl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--conformers', type=int, default=1024)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--weights', default='seed0', choices=['seed0', 'ckpt'])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} '
+                         f'(WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    from newtonnet_amd import hip
+    from newtonnet_amd.models import NewtonNet
+
+    torch.manual_seed(0)                       # reference init sequence (newtonnet_train.py:62)
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    if args.weights == 'ckpt':
+        with np.load(os.path.join(ROOT, 'tests', 'golden', 'ckpt_state.npz')) as f:
+            model.load_state_dict({k: torch.from_numpy(f[k]).float() for k in f.files})
+    model = model.to(device)
+    model.eval()
+
+    z, pos, cell, batch = synthetic_aspirin(args.conformers, seed=rank, device=device)
+    N = z.shape[0]
+
+    def step():
+        return model(z, pos, cell, batch)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    E = int(out.edge_index.shape[1])
+    value = world * N * args.steps / dt
+
+    # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream --------------------
+    roofline = edge_roofline = None
+    classes = {}
+    if rank == 0:
+        n_inst = max(3, min(10, args.steps))
+        hip.timers_enable(True)
+        for _ in range(n_inst):
+            step()
+        torch.cuda.synchronize()
+        tm = hip.timers_read(reset=True)
+        hip.timers_enable(False)
+        classes = {k: {'ms_per_step': v[0] / n_inst, 'launches_per_step': v[1] / n_inst} for k, v in tm.items()}
+        edge_fwd_b, edge_bwd_b, lin_flops = algorithmic_counts(N, E)
+        lin_ms = classes['linear_mfma']['ms_per_step']
+        edge_ms = classes['edge_all']['ms_per_step']
+        lin_tf = lin_flops / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
+        edge_gbs = (edge_fwd_b + edge_bwd_b) / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
+        mfma = {'bound': 'mfma', 'kernel': 'lin128_kernel (all dense 128x128 linears of one step)',
+                'achieved': round(lin_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(lin_tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                'ms_per_step': round(lin_ms, 4), 'flops_per_step': lin_flops}
+        hbm = {'bound': 'hbm', 'kernel': 'msg_fwd/force_fwd/force_bwd/msg_bwd (edge kernels of one step)',
+               'achieved': round(edge_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+               'frac': round(edge_gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'ms_per_step': round(edge_ms, 4),
+               'algorithmic_bytes_per_step': edge_fwd_b + edge_bwd_b}
+        roofline, edge_roofline = (mfma, hbm) if lin_ms >= edge_ms else (hbm, mfma)
+
+    # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import newtonnet_ref as ref          # timed CPU baseline leg (allowed use of the oracle)
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        zc, pc, cc, bc = z.cpu(), pos.cpu(), cell.cpu(), batch.cpu()
+        ref.energy_forces(sd, zc, pc, cc, bc)            # warm-up
+        best = float('inf')
+        reps = 0
+        t_start = time.perf_counter()
+        while reps < 2 or (time.perf_counter() - t_start < 15.0 and reps < 5):
+            t1 = time.perf_counter()
+            ref_out = ref.energy_forces(sd, zc, pc, cc, bc)
+            best = min(best, time.perf_counter() - t1)
+            reps += 1
+        f_err = (out.gradient_force.cpu() - ref_out['forces']).abs()
+        cpu_baseline = {'value': round(N / best, 1), 'unit': 'atom-steps/s', 'cores': cores, 'kind': 'port',
+                        'sample': f'same {args.conformers}-conformer batch, fp32, eval mode, energy+autograd force, '
+                                  f'min of {reps} reps after 1 warm-up ({best:.2f} s/rep)',
+                        'force_mae_gpu_vs_cpu_fp32': float(f_err.mean()), 'force_max_gpu_vs_cpu_fp32': float(f_err.max())}
+
+    if rank == 0:
+        line = {
+            'metric': 'atom-steps/sec (energy+force) on batched MD17 aspirin',
+            'value': round(value, 1), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
+                                   f'fp32, energy+force, neighbor list included (BASELINE.json configs[1])',
+                       'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
+                       'parallelism': f'{world} independent shard(s), no data-path collective'},
+            'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,
+            'cpu_baseline': cpu_baseline,
+        }
+        if cpu_baseline:
+            line['gpu_over_cpu'] = round(value / cpu_baseline['value'], 1)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

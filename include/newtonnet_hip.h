@@ -1,0 +1,181 @@
+/*
+ * newtonnet_hip.h -- C ABI of libnewtonnet_hip.so (gfx950 / MI355X).
+ *
+ * The reference (THGLab/NewtonNet v2.1.0) is pure Python: the hot path has no
+ * FFI of its own.  The entry points below are the operations its model forward
+ * dispatches through PyTorch, cut where a maintainer would bind a native
+ * extension (INTEGRATION.md shows the ctypes stub).  Each one cites the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - all floating-point data is fp32, row-major, contiguous; indices are
+ *     int32 inside the library and int64 where the reference API exposes them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     nothing synchronises the device except where stated;
+ *   - the library never allocates device memory: callers own every buffer
+ *     (PyTorch does, in the shipped host code);
+ *   - return value 0 = success, anything else = error; nnhip_last_error()
+ *     returns a static description for the calling thread.
+ *   - F = n_features must be 128 and nb = n_basis must be 20 (the reference's
+ *     defaults, scripts/config.yml:30-36); other sizes return NNHIP_E_UNSUPPORTED.
+ */
+#ifndef NEWTONNET_HIP_H
+#define NEWTONNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNHIP_F 128
+#define NNHIP_NB 20
+#define NNHIP_MAX_LAYERS 8
+
+enum {
+  NNHIP_OK = 0,
+  NNHIP_E_INVALID = 1,      /* bad argument */
+  NNHIP_E_UNSUPPORTED = 2,  /* n_features / n_basis / n_layers outside the built kernels */
+  NNHIP_E_WORKSPACE = 3,    /* workspace too small */
+  NNHIP_E_HIP = 4           /* a HIP runtime call or kernel launch failed */
+};
+
+int nnhip_version(void);
+const char* nnhip_last_error(void);
+
+/* --------------------------------------------------------------------------
+ * Parameters of one model, in the reference's state_dict layout
+ * (nn.Linear weights are [out][in] row-major).
+ * Replaces: the nn.Module parameter storage of
+ *   newtonnet/models/newtonnet.py:116-205 and newtonnet/models/output.py:88-96,
+ *   newtonnet/layers/scalers.py:42-45.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  const float* node0_w;  /* interaction_layers.l.message_nodepart.0.weight [F][F] */
+  const float* node0_b;  /* ...message_nodepart.0.bias   [F] */
+  const float* node2_w;  /* ...message_nodepart.2.weight [F][F] */
+  const float* node2_b;  /* ...message_nodepart.2.bias   [F] */
+  const float* edge_w;   /* ...message_edgepart.weight   [F][nb] */
+  const float* eq1_0_w;  /* ...equiv_message1.0.weight   [F][F] */
+  const float* eq1_2_w;  /* ...equiv_message1.2.weight   [F][F] */
+  const float* eq2_0_w;  /* ...equiv_message2.0.weight   [F][F] */
+  const float* eq2_2_w;  /* ...equiv_message2.2.weight   [F][F] */
+  const float* update_w; /* ...equiv_update.weight       [F][F] */
+} nnhip_layer_params;
+
+typedef struct {
+  int32_t n_features; /* 128 */
+  int32_t n_basis;    /* 20 */
+  int32_t n_layers;   /* 1..NNHIP_MAX_LAYERS */
+  float cutoff;       /* Angstrom */
+  const float* node_embedding; /* embedding_layers.node_embedding.weight [119][F] */
+  const float* frequencies;    /* embedding_layers.edge_embedding.embedding.frequencies [nb] */
+  nnhip_layer_params layer[NNHIP_MAX_LAYERS];
+  const float* head0_w; /* output_layers.k.layers.0.weight [F][F] */
+  const float* head0_b; /* [F] */
+  const float* head2_w; /* output_layers.k.layers.2.weight [F][F] */
+  const float* head2_b; /* [F] */
+  const float* head4_w; /* output_layers.k.layers.4.weight [1][F] */
+  const float* head4_b; /* [1] */
+  const float* scale;   /* scalers.k.scale.weight [119] (NULL = 1) */
+  const float* shift;   /* scalers.k.shift.weight [119] (NULL = 0) */
+} nnhip_model;
+
+/* --------------------------------------------------------------------------
+ * Neighbor list.
+ * Replaces: RadiusGraph.forward, newtonnet/layers/representations.py:57-100
+ *   (all ordered pairs inside a molecule, i != j, optional single-image
+ *   minimum-image shift d -= cell @ round(solve(cell^T, d)), strict ||d|| < r).
+ * Contract: `batch` is non-decreasing (PyG collation order).  Edges come out
+ * sorted by (molecule, i, j) -- the reference's order -- so the list is a CSR
+ * over the RECEIVER i = edge_index[0].
+ *
+ * nnhip_graph_count: writes row_ptr[N+1] (exclusive scan of the in-degree) and
+ *   mol_ptr[B+1].  status[0] is set non-zero if `batch` is not sorted.
+ *   The caller reads E = row_ptr[N] (a device->host copy; the only sync).
+ * nnhip_graph_fill: writes col[E] (sender j), rev[E] (index of the reverse
+ *   edge (j,i); the edge set is symmetric), disp[E][3] = pos_i - pos_j (after
+ *   the image shift) and, if non-NULL, edge_index[2][E] int64 (reference API).
+ * ------------------------------------------------------------------------ */
+int nnhip_graph_count(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
+                      float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, void* stream);
+
+int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                     const int32_t* row_ptr, int32_t n_atoms, int32_t n_mol, int32_t n_edges, float cutoff,
+                     int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Edge embedding.
+ * Replaces: ScaledNorm.forward (representations.py:118-133), PolynomialCutoff
+ *   p=9 (:155-171), RadialBesselLayer.forward (:223-235) and their product (:41).
+ * geo[E][4]  = (ux, uy, uz, r)    dir_edge and |disp|
+ * rbf[E][nb] = env(x) * sin(w_n x)/x,  x = r/cutoff        (= dist_edge)
+ * drbf[E][nb]= d rbf / d x   (kept for the force adjoint)
+ * ------------------------------------------------------------------------ */
+int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies, int32_t n_basis,
+                     float* geo, float* rbf, float* drbf, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Whole hot path: energy and forces (= -dE/dpos) for a batch.
+ * Replaces: NewtonNet.forward after the graph build, i.e.
+ *   EmbeddingNet.forward newtonnet/models/newtonnet.py:139-161 (node part),
+ *   InteractionNet.forward :207-231 for every layer,
+ *   EnergyOutput.forward output.py:98-100, ScaleShift.forward scalers.py:47-59,
+ *   EnergyAggregator.forward output.py:245-247,
+ *   and the reverse sweep torch.autograd.grad performs for
+ *   GradientForceOutput (output.py:66-73,109-113), written out analytically.
+ *
+ * workspace: nnhip_workspace_bytes(...) bytes, 256-byte aligned.  Per-layer
+ * intermediates stay in it after the call; nnhip_workspace_layout() reports
+ * where (used by the parity tests).
+ * Optional outputs (may be NULL): atom_energy[N], atom_node[N][F],
+ * force_node[N][3][F], virial[B][3][3] (= -dE/d strain, output.py:154-165).
+ * forces may be NULL (energy only: forward sweep only).
+ * ------------------------------------------------------------------------ */
+size_t nnhip_workspace_bytes(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers);
+
+typedef struct {
+  /* byte offsets into the workspace; per-layer arrays indexed by layer */
+  size_t m[NNHIP_MAX_LAYERS];      /* [N][F]   message_nodepart output */
+  size_t hn[NNHIP_MAX_LAYERS];     /* [N][F]   message_nodepart hidden pre-activation */
+  size_t msg[NNHIP_MAX_LAYERS];    /* [E][F]   message */
+  size_t h12[NNHIP_MAX_LAYERS];    /* [E][2F]  equiv_message{1,2} hidden pre-activations */
+  size_t phi1[NNHIP_MAX_LAYERS];   /* [E][F] */
+  size_t phi2[NNHIP_MAX_LAYERS];   /* [E][F] */
+  size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */
+  size_t a_out[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the layer */
+  size_t f_out[NNHIP_MAX_LAYERS];  /* [N][3][F] force_node after the layer */
+  size_t q[NNHIP_MAX_LAYERS];      /* [N][3][F] equiv_update(force_node) */
+  size_t a0;                       /* [N][F]   embedded atom_node */
+  size_t e1, e2;                   /* [N][F]   head hidden pre-activations */
+  size_t g_x;                      /* [L][E]   dE/dx per layer */
+  size_t g_u;                      /* [L][E][3] dE/d dir per layer (only [E][4] rows: gx,guy..) */
+  size_t g_a;                      /* [N][F]   running dE/d atom_node */
+  size_t g_f;                      /* [N][3][F] running dE/d force_node */
+  size_t total;
+} nnhip_ws_layout;
+
+int nnhip_workspace_layout(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers, nnhip_ws_layout* out);
+
+int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const int64_t* batch, const int32_t* mol_ptr,
+                        const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const float* geo,
+                        const float* rbf, const float* drbf, const float* disp, int32_t n_atoms, int32_t n_edges,
+                        int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
+                        float* virial, float* atom_energy, float* atom_node, float* force_node, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
+ * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
+ * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = dense MFMA linears,
+ *          2 = everything else.  Disabled (0) by default.
+ * ------------------------------------------------------------------------ */
+#define NNHIP_N_TIMER_CLASSES 8
+int nnhip_timers_enable(int32_t on);
+int nnhip_timers_read(double* ms_per_class, int64_t* launches_per_class, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEWTONNET_HIP_H */

@@ -1,0 +1,11 @@
+#!/usr/bin/env bash
+# Build libnewtonnet_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU present.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../lib"
+mkdir -p "$out"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC \
+  "$here/graph.hip" "$here/edge.hip" "$here/lin128.hip" "$here/pipeline.hip" \
+  -o "$out/libnewtonnet_hip.so" "$@"
+echo "built $out/libnewtonnet_hip.so"

@@ -1,0 +1,88 @@
+// Shared device helpers for the gfx950 kernels of libnewtonnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/newtonnet_hip.h"
+
+#define NF NNHIP_F    // 128 features: one wave = 64 lanes x float2
+#define NB NNHIP_NB   // 20 radial basis functions
+#define WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (host) -------------------------------------------------
+void nnhip_set_error(const char* fmt, ...);
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      nnhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return NNHIP_E_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// ---- timers (host) ---------------------------------------------------------
+enum { TC_EDGE = 0, TC_LIN = 1, TC_OTHER = 2, TC_EDGE_FWD_MSG = 3, TC_EDGE_FWD_FORCE = 4, TC_EDGE_BWD_FORCE = 5,
+       TC_EDGE_BWD_MSG = 6, TC_GRAPH = 7 };
+struct ScopedTimer {
+  int cls;
+  hipStream_t s;
+  hipEvent_t e0;
+  bool on;
+  ScopedTimer(int cls, hipStream_t s);
+  ~ScopedTimer();
+};
+
+// ---- device helpers ----------------------------------------------------------
+// v_exp_f32 + v_rcp_f32 (about 1 ulp each): well inside the fp32 tolerance of the path
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  const float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// Block b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every XCD a
+// contiguous range of tiles so that the rows a molecule's atoms gather from stay in one L2.
+// Bijective for any n_blocks.  A speed choice only: correctness never depends on placement.
+__device__ __forceinline__ int xcd_tile(int b, int n_blocks) {
+  const int q = n_blocks >> 3, r = n_blocks & 7;
+  const int x = b & 7, k = b >> 3;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ float2 operator*(float2 a, float2 b) { return make_float2(a.x * b.x, a.y * b.y); }
+__device__ __forceinline__ float2 operator*(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 fma2(float2 a, float2 b, float2 c) { return make_float2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
+__device__ __forceinline__ float2 fma2(float2 a, float s, float2 c) { return make_float2(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)); }
+
+// ---- dense 128x128 linear launcher (lin128.hip) ---------------------------------
+enum { PRO_NONE = 0, PRO_SILU = 1 };
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_DSILU = 2, EPI_ACC = 3 };
+struct LinGroup {
+  const float* A;
+  const float* W;     // [128 out][128 in] row-major
+  float* C;
+  const float* bias;  // EPI_BIAS: [128]
+  const float* H;     // EPI_DSILU: C = acc * silu'(H[m][n])
+};
+struct LinArgs {
+  LinGroup g[2];      // blockIdx.y selects (two independent linears of the same shape in one launch)
+  int M;
+  int lda, ldc, ldh;  // row strides in floats
+};
+int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s);
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

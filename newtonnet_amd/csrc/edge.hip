@@ -1,0 +1,484 @@
+// Per-edge message-passing kernels and their adjoints (gfx950, fp32).
+//
+// Replaces the edge loop of InteractionNet.forward (newtonnet/models/newtonnet.py:207-231):
+//   :210-215  msg = (W_e rbf_e) * m[i] * m[j];  atom_node += scatter_sum(msg, i)          -> msg_fwd_kernel
+//   :219-227  force_node += scatter_sum(phi1_e (x) dir_e + phi2_e * force_node[j], i)     -> force_fwd_kernel
+// and the reverse sweep torch.autograd.grad runs through them for the gradient force
+// (newtonnet/models/output.py:66-73)                                                      -> *_bwd_kernel
+//
+// Layout / mapping: the edge list is a CSR over the receiver i (graph.hip).  One 64-lane wavefront owns
+// one receiver row; lane l holds features 2l, 2l+1, so every [F]=128-float row access is one fully
+// coalesced 512-byte transaction and the per-row sums live in registers: deterministic segmented
+// reductions, no float atomics.  Sender-side scatters of the adjoint are turned into receiver-side
+// gathers through the reverse-edge index (the edge set is symmetric).  Per-edge scalars (col, dir, rbf)
+// are wave-uniform and come in through the scalar cache.  HBM-bound: no MFMA here.
+#include "common.h"
+
+#define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
+
+__device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
+  const int tile = xcd_tile(blockIdx.x, n_rows_padded_blocks);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return tile * ROWS_PER_BLOCK + wave;
+}
+
+// W_e rows for this lane's two features: we[0][n] = W_e[2l][n], we[1][n] = W_e[2l+1][n]
+__device__ __forceinline__ void load_we(const float* __restrict__ edge_w, int lane, float (&we)[2][NB]) {
+  const float4* p = reinterpret_cast<const float4*>(edge_w + (size_t)lane * 2 * NB);
+#pragma unroll
+  for (int k = 0; k < (2 * NB) / 4; ++k) {
+    const float4 v = p[k];
+    const int o = 4 * k;
+    (&we[0][0])[o] = v.x;
+    (&we[0][0])[o + 1] = v.y;
+    (&we[0][0])[o + 2] = v.z;
+    (&we[0][0])[o + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ float2 edge_filter(const float (&we)[2][NB], const float* __restrict__ rb) {
+  float2 eps = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const float r = rb[n];  // wave-uniform address -> scalar load
+    eps.x = fmaf(we[0][n], r, eps.x);
+    eps.y = fmaf(we[1][n], r, eps.y);
+  }
+  return eps;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: message + invariant aggregation
+//   msg[e] = eps_e * m[i] * m[j];  a_mid[i] = a_in[i] + sum_{e in row i} msg[e]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+msg_fwd_kernel(const float* __restrict__ m, const float* __restrict__ rbf, const float* __restrict__ edge_w,
+               const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ a_in,
+               float* __restrict__ msg, float* __restrict__ a_mid, int n_atoms) {
+  const int i = wave_row(gridDim.x);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  float we[2][NB];
+  load_we(edge_w, lane, we);
+  const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
+  float2 acc = make_float2(0.f, 0.f);
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  for (int e = beg; e < end; ++e) {
+    const int j = col[e];
+    const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
+    const float2 eps = edge_filter(we, rbf + (size_t)e * NB);
+    const float2 v = eps * mi * mj;
+    st2(msg + (size_t)e * NF + 2 * lane, v);
+    acc = acc + v;
+  }
+  st2(a_mid + (size_t)i * NF + 2 * lane, ld2(a_in + (size_t)i * NF + 2 * lane) + acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: equivariant messages + aggregation
+//   f_out[i][k] = f_in[i][k] + sum_e ( phi1[e] * u_e[k] + phi2[e] * f_in[j][k] )
+// HAS_F = false for the first layer, where force_node == 0 (newtonnet.py:143): the phi2 term vanishes.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_F>
+__global__ void __launch_bounds__(256)
+force_fwd_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2, const float* __restrict__ geo,
+                 const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ f_in,
+                 float* __restrict__ f_out, int n_atoms) {
+  const int i = wave_row(gridDim.x);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  float2 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    acc[k] = HAS_F ? ld2(f_in + ((size_t)i * 3 + k) * NF + 2 * lane) : make_float2(0.f, 0.f);
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  for (int e = beg; e < end; ++e) {
+    const float4 g = reinterpret_cast<const float4*>(geo)[e];  // (ux,uy,uz,r), wave-uniform
+    const float2 p1 = ld2(phi1 + (size_t)e * NF + 2 * lane);
+    acc[0] = fma2(p1, g.x, acc[0]);
+    acc[1] = fma2(p1, g.y, acc[1]);
+    acc[2] = fma2(p1, g.z, acc[2]);
+    if (HAS_F) {
+      const int j = col[e];
+      const float2 p2 = ld2(phi2 + (size_t)e * NF + 2 * lane);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) st2(f_out + ((size_t)i * 3 + k) * NF + 2 * lane, acc[k]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint of force_fwd for receiver row i, given gf = dE/d f_out:
+//   g_phi1[e]   = sum_k gf[i][k] u_e[k]                      -> g_h12[e][0:F]   (feeds the MLP adjoint GEMMs)
+//   g_phi2[e]   = sum_k gf[i][k] * f_in[j][k]                -> g_h12[e][F:2F]
+//   g_u[e][k]   = < gf[i][k] , phi1[e] >                     (wave reduction)
+//   g_fin[i][k] = gf[i][k] + sum_{e in row i} phi2[rev e] * gf[j][k]
+//                 (the sender-side scatter  g_fin[j] += phi2[e] * gf[i]  re-indexed by the reverse edge)
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_F>
+__global__ void __launch_bounds__(256)
+force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
+                 const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                 const int* __restrict__ rev, const float* __restrict__ f_in, float* __restrict__ g_h12,
+                 float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms) {
+  const int i = wave_row(gridDim.x);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  float2 gfi[3], acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    gfi[k] = ld2(gf + ((size_t)i * 3 + k) * NF + 2 * lane);
+    acc[k] = gfi[k];
+  }
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  for (int e = beg; e < end; ++e) {
+    const float4 g = reinterpret_cast<const float4*>(geo)[e];
+    const float2 p1 = ld2(phi1 + (size_t)e * NF + 2 * lane);
+    float2 gp1 = gfi[0] * g.x;
+    gp1 = fma2(gfi[1], g.y, gp1);
+    gp1 = fma2(gfi[2], g.z, gp1);
+    st2(g_h12 + (size_t)e * 2 * NF + 2 * lane, gp1);
+    float s0 = fmaf(gfi[0].x, p1.x, gfi[0].y * p1.y);
+    float s1 = fmaf(gfi[1].x, p1.x, gfi[1].y * p1.y);
+    float s2 = fmaf(gfi[2].x, p1.x, gfi[2].y * p1.y);
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) reinterpret_cast<float4*>(g_u)[e] = make_float4(s0, s1, s2, 0.f);
+    if (HAS_F) {
+      const int j = col[e];
+      const int r = rev[e];
+      const float2 p2r = ld2(phi2 + (size_t)r * NF + 2 * lane);
+      float2 gp2 = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
+        acc[k] = fma2(p2r, ld2(gf + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
+      }
+      st2(g_h12 + (size_t)e * 2 * NF + NF + 2 * lane, gp2);
+    }
+  }
+  if (HAS_F) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st2(g_fin + ((size_t)i * 3 + k) * NF + 2 * lane, acc[k]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint of msg_fwd for receiver row i.  g_msg[e] holds the MLP-side gradient of msg[e]; the
+// aggregation a_mid = a_in + sum msg adds g_a[i] to every message of row i:
+//   gm_e  = g_msg[e]      + g_a[i]        gm_r = g_msg[rev e] + g_a[j]
+//   g_x[e]  = < gm_e * m[i] * m[j] , W_e drbf_e >                       (wave reduction)
+//   g_m[i]  = sum_{e in row i} (gm_e + gm_r) * eps_e * m[j]
+//             (receiver term + the sender term of the reverse edge; eps_rev == eps_e since x is symmetric)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, const float* __restrict__ m,
+               const float* __restrict__ rbf, const float* __restrict__ drbf, const float* __restrict__ edge_w,
+               const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ rev,
+               float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms) {
+  const int i = wave_row(gridDim.x);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  float we[2][NB];
+  load_we(edge_w, lane, we);
+  const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
+  const float2 gai = ld2(g_a + (size_t)i * NF + 2 * lane);
+  float2 acc = make_float2(0.f, 0.f);
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  for (int e = beg; e < end; ++e) {
+    const int j = col[e];
+    const int r = rev[e];
+    const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
+    const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
+    const float2 gm_e = ld2(g_msg + (size_t)e * NF + 2 * lane) + gai;
+    const float2 gm_r = ld2(g_msg + (size_t)r * NF + 2 * lane) + gaj;
+    const float2 eps = edge_filter(we, rbf + (size_t)e * NB);
+    const float2 deps = edge_filter(we, drbf + (size_t)e * NB);
+    const float2 t = gm_e * mi * mj;
+    const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
+    if (lane == 0) g_x[e] = gx;
+    acc = fma2((gm_e + gm_r) * eps, mj, acc);
+  }
+  st2(g_m + (size_t)i * NF + 2 * lane, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry adjoint -> forces (and virial).  For edge e = (i,j) with disp d = pos_i - pos_j, r = |d|, u = d/r,
+// x = r/rc:   g_d[e] = (g_x/rc) u + (g_u - (g_u.u) u)/r,  summed over layers.  pos_i enters row i's edges
+// with +1 and the reverse edges with -1:  dE/dpos_i = sum_{e in row i} (g_d[e] - g_d[rev e]);  force = -that.
+// The strain derivative (virial, output.py:154-165) is  -sum_e d_e (x) g_d[e]  per molecule.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+edge_gd_kernel(const float* __restrict__ g_x /*[L][E]*/, const float* __restrict__ g_u /*[L][E][4]*/,
+               const float* __restrict__ geo, int n_edges, int n_layers, float inv_rc, float* __restrict__ g_d /*[E][4]*/) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  float gx = 0.f, gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
+  for (int l = 0; l < n_layers; ++l) {
+    gx += g_x[(size_t)l * n_edges + e];
+    const float4 v = reinterpret_cast<const float4*>(g_u)[(size_t)l * n_edges + e];
+    gu0 += v.x;
+    gu1 += v.y;
+    gu2 += v.z;
+  }
+  const float4 g = reinterpret_cast<const float4*>(geo)[e];
+  const float ir = 1.0f / g.w;
+  const float dot = gu0 * g.x + gu1 * g.y + gu2 * g.z;
+  const float a = gx * inv_rc - dot * ir;
+  reinterpret_cast<float4*>(g_d)[e] =
+      make_float4(fmaf(a, g.x, gu0 * ir), fmaf(a, g.y, gu1 * ir), fmaf(a, g.z, gu2 * ir), 0.f);
+}
+
+__global__ void __launch_bounds__(256)
+force_out_kernel(const float* __restrict__ g_d, const int* __restrict__ row_ptr, const int* __restrict__ rev,
+                 int n_atoms, float* __restrict__ forces) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+    const float4 a = reinterpret_cast<const float4*>(g_d)[e];
+    const float4 b = reinterpret_cast<const float4*>(g_d)[rev[e]];
+    fx -= (a.x - b.x);
+    fy -= (a.y - b.y);
+    fz -= (a.z - b.z);
+  }
+  forces[3 * (size_t)i] = fx;
+  forces[3 * (size_t)i + 1] = fy;
+  forces[3 * (size_t)i + 2] = fz;
+}
+
+// virial[b] = - sum_{e in molecule b} disp_e (x) g_d[e]   (symmetrised like the reference's strain, newtonnet.py:153)
+__global__ void __launch_bounds__(64)
+virial_kernel(const float* __restrict__ g_d, const float* __restrict__ disp, const int* __restrict__ row_ptr,
+              const int* __restrict__ mol_ptr, int n_mol, float* __restrict__ virial) {
+  const int b = blockIdx.x;
+  if (b >= n_mol) return;
+  const int lane = threadIdx.x;
+  const int e0 = row_ptr[mol_ptr[b]], e1 = row_ptr[mol_ptr[b + 1]];
+  double s[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = 0.0;
+  for (int e = e0 + lane; e < e1; e += 64) {
+    const float4 g = reinterpret_cast<const float4*>(g_d)[e];
+    const float d[3] = {disp[3 * (size_t)e], disp[3 * (size_t)e + 1], disp[3 * (size_t)e + 2]};
+    const float gg[3] = {g.x, g.y, g.z};
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s[p * 3 + q] += (double)d[p] * (double)gg[q];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    s[k] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) virial[(size_t)b * 9 + p * 3 + q] = (float)(-0.5 * (s[p * 3 + q] + s[q * 3 + p]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// node-level elementwise pieces (N x F; an order of magnitude less traffic than the edge tensors)
+// ---------------------------------------------------------------------------------------------
+// atom_node = Embedding[z]   (newtonnet.py:142)
+__global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restrict__ table, int n_atoms,
+                             float* __restrict__ a0) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
+  if (t >= (size_t)n_atoms * (NF / 4)) return;
+  const int i = (int)(t / (NF / 4)), c = (int)(t % (NF / 4));
+  reinterpret_cast<float4*>(a0)[t] = reinterpret_cast<const float4*>(table + (size_t)z[i] * NF)[c];
+}
+
+// a_out = a_mid + sum_k f[k] * q[k]     (newtonnet.py:230-231, q = equiv_update(force_node))
+__global__ void node_update_fwd_kernel(const float* __restrict__ a_mid, const float* __restrict__ f,
+                                       const float* __restrict__ q, int n_atoms, float* __restrict__ a_out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_atoms * NF) return;
+  const size_t i = t / NF, c = t % NF;
+  float v = a_mid[t];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v = fmaf(f[(i * 3 + k) * NF + c], q[(i * 3 + k) * NF + c], v);
+  a_out[t] = v;
+}
+
+// adjoint of the update, elementwise part:  tmp[i][k] = g_a[i] * f[i][k]  (GEMM input: x W_u),
+//   gf[i][k] = g_fout[i][k] + g_a[i] * q[i][k]   (the GEMM then accumulates tmp W_u into gf)
+__global__ void node_update_bwd_kernel(const float* __restrict__ g_a, const float* __restrict__ f,
+                                       const float* __restrict__ q, const float* __restrict__ g_fout /*or NULL*/,
+                                       int n_atoms, float* __restrict__ tmp, float* __restrict__ gf) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_atoms * 3 * NF) return;
+  const size_t i = t / (3 * NF), c = t % NF;
+  const float ga = g_a[i * NF + c];
+  tmp[t] = ga * f[t];
+  gf[t] = fmaf(ga, q[t], g_fout ? g_fout[t] : 0.f);
+}
+
+// energy head tail (output.py:98-100 last Linear, scalers.py:55-58) and the seed of the reverse sweep:
+//   eps_i = <silu(e2_i), w4> + b4;  E_i = eps_i * scale[z_i] + shift[z_i]
+//   g_e2[i] = scale[z_i] * w4 * silu'(e2_i)          (dE_b/dE_i = 1, output.py:69)
+__global__ void __launch_bounds__(256)
+head_out_kernel(const float* __restrict__ e2, const float* __restrict__ w4, const float* __restrict__ b4,
+                const float* __restrict__ scale, const float* __restrict__ shift, const int64_t* __restrict__ z,
+                int n_atoms, float* __restrict__ atom_energy, float* __restrict__ g_e2) {
+  const int i = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float2 h = ld2(e2 + (size_t)i * NF + 2 * lane);
+  const float2 w = ld2(w4 + 2 * lane);
+  const float s = wave_sum(fmaf(silu_f(h.x), w.x, silu_f(h.y) * w.y));
+  const long zi = z[i];
+  const float sc = scale ? scale[zi] : 1.0f;
+  const float sh = shift ? shift[zi] : 0.0f;
+  if (lane == 0) atom_energy[i] = fmaf(s + b4[0], sc, sh);
+  if (g_e2) st2(g_e2 + (size_t)i * NF + 2 * lane, make_float2(sc * w.x * dsilu_f(h.x), sc * w.y * dsilu_f(h.y)));
+}
+
+// E_b = sum of atom energies of molecule b  (output.py:246).  fp64 accumulation, one rounding.
+__global__ void mol_energy_kernel(const float* __restrict__ atom_energy, const int* __restrict__ mol_ptr, int n_mol,
+                                  float* __restrict__ energy) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_mol) return;
+  double s = 0.0;
+  for (int i = mol_ptr[b]; i < mol_ptr[b + 1]; ++i) s += (double)atom_energy[i];
+  energy[b] = (float)s;
+}
+
+// out[m][n][k] = in[m][k][n] for a list of 128x128 matrices (weights for the adjoint GEMMs)
+struct TransposeList {
+  const float* src[40];
+  float* dst[40];
+};
+__global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
+  __shared__ float tile[32][33];
+  const float* __restrict__ src = L.src[blockIdx.z];
+  float* __restrict__ dst = L.dst[blockIdx.z];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(size_t)(by + r) * NF + bx + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) dst[(size_t)(bx + r) * NF + by + tx] = tile[tx][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (used by pipeline.hip)
+// ---------------------------------------------------------------------------------------------
+static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, ROWS_PER_BLOCK); }
+
+int launch_msg_fwd(const float* m, const float* rbf, const float* edge_w, const int* row_ptr, const int* col,
+                   const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
+  ScopedTimer t0(TC_EDGE, s);
+  ScopedTimer t1(TC_EDGE_FWD_MSG, s);
+  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, rbf, edge_w, row_ptr, col, a_in, msg, a_mid, n_atoms);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
+                     const int* col, const float* f_in, float* f_out, int n_atoms, hipStream_t s) {
+  ScopedTimer t0(TC_EDGE, s);
+  ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
+  if (has_f)
+    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, f_in, f_out, n_atoms);
+  else
+    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, f_in, f_out, n_atoms);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
+                     const int* row_ptr, const int* col, const int* rev, const float* f_in, float* g_h12, float* g_u,
+                     float* g_fin, int n_atoms, hipStream_t s) {
+  ScopedTimer t0(TC_EDGE, s);
+  ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
+  if (has_f)
+    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, rev, f_in, g_h12, g_u,
+                                                               g_fin, n_atoms);
+  else
+    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, rev, f_in, g_h12, g_u,
+                                                                g_fin, n_atoms);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const float* rbf, const float* drbf,
+                   const float* edge_w, const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
+                   int n_atoms, hipStream_t s) {
+  ScopedTimer t0(TC_EDGE, s);
+  ScopedTimer t1(TC_EDGE_BWD_MSG, s);
+  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, rbf, drbf, edge_w, row_ptr, col, rev, g_m, g_x,
+                                                    n_atoms);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const int* row_ptr,
+                        const int* rev, const int* mol_ptr, int n_atoms, int n_edges, int n_mol, int n_layers,
+                        float cutoff, float* g_d, float* forces, float* virial, hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  if (n_edges > 0) {
+    edge_gd_kernel<<<cdiv(n_edges, 256), 256, 0, s>>>(g_x, g_u, geo, n_edges, n_layers, 1.0f / cutoff, g_d);
+    LAUNCH_CHECK();
+  }
+  force_out_kernel<<<cdiv(n_atoms, 256), 256, 0, s>>>(g_d, row_ptr, rev, n_atoms, forces);
+  LAUNCH_CHECK();
+  if (virial) {
+    virial_kernel<<<n_mol, 64, 0, s>>>(g_d, disp, row_ptr, mol_ptr, n_mol, virial);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  embed_kernel<<<cdiv((long)n_atoms * (NF / 4), 256), 256, 0, s>>>(z, table, n_atoms, a0);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_node_update_fwd(const float* a_mid, const float* f, const float* q, int n_atoms, float* a_out,
+                           hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  node_update_fwd_kernel<<<cdiv((long)n_atoms * NF, 256), 256, 0, s>>>(a_mid, f, q, n_atoms, a_out);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_node_update_bwd(const float* g_a, const float* f, const float* q, const float* g_fout, int n_atoms,
+                           float* tmp, float* gf, hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  node_update_bwd_kernel<<<cdiv((long)n_atoms * 3 * NF, 256), 256, 0, s>>>(g_a, f, q, g_fout, n_atoms, tmp, gf);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
+                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
+                    float* energy, hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, atom_energy, g_e2);
+  LAUNCH_CHECK();
+  mol_energy_kernel<<<cdiv(n_mol, 256), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  TransposeList L;
+  if (count > 40) return NNHIP_E_INVALID;
+  for (int k = 0; k < count; ++k) {
+    L.src[k] = src[k];
+    L.dst[k] = dst[k];
+  }
+  transpose128_kernel<<<dim3(NF / 32, NF / 32, count), 256, 0, s>>>(L);
+  LAUNCH_CHECK();
+  return 0;
+}

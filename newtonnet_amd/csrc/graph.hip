@@ -1,0 +1,273 @@
+// Neighbor list + edge embedding kernels (gfx950).
+//
+// Replaces RadiusGraph.forward (newtonnet/layers/representations.py:57-100), ScaledNorm (:118-133),
+// PolynomialCutoff p=9 (:155-171) and RadialBesselLayer (:223-235) of the reference.
+//
+// The edge list is produced directly in the reference's order -- (molecule, i, j) ascending -- which
+// makes it a CSR over the receiver i; every later aggregation is a deterministic segmented sum
+// (no float atomics).  HBM-bound integer/float32 work: one thread per receiver row, molecule-local
+// position reads served by L1/L2.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// molecule extents from the (sorted) batch vector
+// ---------------------------------------------------------------------------------------------
+__global__ void mol_ptr_kernel(const int64_t* __restrict__ batch, int n_atoms, int n_mol, int* __restrict__ mol_ptr,
+                               int* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const long b = batch[i];
+  const long bp = (i == 0) ? -1 : batch[i - 1];
+  if (b < bp || b < 0 || b >= n_mol) {
+    atomicOr(status, 1);
+    return;
+  }
+  for (long k = bp + 1; k <= b; ++k) mol_ptr[k] = i;  // also covers empty molecule ids in between
+  if (i == n_atoms - 1)
+    for (long k = b + 1; k <= n_mol; ++k) mol_ptr[k] = n_atoms;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair predicate shared by the count and fill passes (must be bit-identical in both)
+// ---------------------------------------------------------------------------------------------
+struct CellInfo {
+  bool pbc;
+  float c[9];    // cell, rows = lattice vectors (ASE convention, ase_interface.py:136)
+  float inv[9];  // inverse of cell^T (fp32 of an fp64 inverse)
+};
+
+__device__ __forceinline__ CellInfo load_cell(const float* __restrict__ cell, long b) {
+  CellInfo ci;
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    ci.c[k] = cell[b * 9 + k];
+    any |= (ci.c[k] != 0.0f);
+  }
+  ci.pbc = any;
+  if (any) {
+    // A = cell^T ; frac = A^{-1} d   (representations.py:92)
+    double a[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[r * 3 + c] = (double)ci.c[c * 3 + r];
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    const double id = 1.0 / det;
+    ci.inv[0] = (float)(c00 * id);
+    ci.inv[1] = (float)((a[2] * a[7] - a[1] * a[8]) * id);
+    ci.inv[2] = (float)((a[1] * a[5] - a[2] * a[4]) * id);
+    ci.inv[3] = (float)(c01 * id);
+    ci.inv[4] = (float)((a[0] * a[8] - a[2] * a[6]) * id);
+    ci.inv[5] = (float)((a[2] * a[3] - a[0] * a[5]) * id);
+    ci.inv[6] = (float)(c02 * id);
+    ci.inv[7] = (float)((a[1] * a[6] - a[0] * a[7]) * id);
+    ci.inv[8] = (float)((a[0] * a[4] - a[1] * a[3]) * id);
+  }
+  return ci;
+}
+
+// disp = pos_i - pos_j with the reference's single-image shift; returns ||disp||.  fp32 with FMA contraction
+// switched off, so that the count and fill passes (and a plain CPU evaluation of the same expressions)
+// agree on the strict `< r` predicate.
+__device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float xj, float yj, float zj,
+                                           const CellInfo& ci, float& dx, float& dy, float& dz) {
+#pragma clang fp contract(off)
+  dx = xi - xj;
+  dy = yi - yj;
+  dz = zi - zj;
+  if (ci.pbc) {
+    const float f0 = (ci.inv[0] * dx + ci.inv[1] * dy) + ci.inv[2] * dz;
+    const float f1 = (ci.inv[3] * dx + ci.inv[4] * dy) + ci.inv[5] * dz;
+    const float f2 = (ci.inv[6] * dx + ci.inv[7] * dy) + ci.inv[8] * dz;
+    const float n0 = rintf(f0), n1 = rintf(f1), n2 = rintf(f2);  // round-half-even == torch.round
+    // d -= cell @ n   (as the reference writes it, representations.py:93)
+    dx = dx - ((ci.c[0] * n0 + ci.c[1] * n1) + ci.c[2] * n2);
+    dy = dy - ((ci.c[3] * n0 + ci.c[4] * n1) + ci.c[5] * n2);
+    dz = dz - ((ci.c[6] * n0 + ci.c[7] * n1) + ci.c[8] * n2);
+  }
+  const float r2 = (dx * dx + dy * dy) + dz * dz;
+  return sqrtf(r2);
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
+                  const int* __restrict__ mol_ptr, int n_atoms, float cutoff, int* __restrict__ deg,
+                  const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
+                  float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const long b = batch[i];
+  const int s = mol_ptr[b], e = mol_ptr[b + 1];
+  const CellInfo ci = load_cell(cell, b);
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  int cnt = 0;
+  int w = FILL ? row_ptr[i] : 0;
+  for (int j = s; j < e; ++j) {
+    if (j == i) continue;
+    float dx, dy, dz;
+    const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
+    if (r < cutoff) {
+      if (FILL) {
+        col[w] = j;
+        erow[w] = i;
+        disp[3 * (long)w] = dx;
+        disp[3 * (long)w + 1] = dy;
+        disp[3 * (long)w + 2] = dz;
+        if (edge_index) {
+          edge_index[w] = i;
+          edge_index[(long)n_edges + w] = j;
+        }
+        ++w;
+      } else {
+        ++cnt;
+      }
+    }
+  }
+  if (!FILL) deg[i] = cnt;
+}
+
+// exclusive scan of deg[n] -> row_ptr[n+1]; one workgroup (n is at most a few 1e5..1e6 here)
+// (deg may alias row_ptr: every thread sums its chunk before anything is overwritten, and reads each
+// element before replacing it)
+__global__ void __launch_bounds__(1024) scan_rows_kernel(const int* deg, int n, int* row_ptr) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += deg[k];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;  // exclusive prefix of this thread's chunk
+  for (int k = lo; k < hi; ++k) {
+    const int d = deg[k];
+    row_ptr[k] = run;
+    run += d;
+  }
+  if (t == 1023) row_ptr[n] = part[1023];
+}
+
+// reverse-edge index: for e = (i, j) find e' = (j, i) by binary search in row j (cols ascending)
+// (erow may alias rev: a thread reads only its own erow slot, before writing it)
+__global__ void edge_rev_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, const int* erow,
+                                int n_edges, int* rev) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int i = erow[e], j = col[e];
+  int lo = row_ptr[j], hi = row_ptr[j + 1] - 1, found = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int c = col[mid];
+    if (c == i) {
+      found = mid;
+      break;
+    }
+    if (c < i) lo = mid + 1; else hi = mid - 1;
+  }
+  rev[e] = found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge embedding: geo = (dir, r), rbf = env(x) sin(w x)/x, drbf = d rbf/dx.  Evaluated in fp64 and
+// rounded once (E x nb values; the cost is negligible next to the [E,F] tensors and it removes the
+// cancellation of the p=9 polynomial envelope near x -> 1 from the fp32 error budget).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, const float* __restrict__ freq, int nb,
+                  float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const double dx = disp[3 * (long)e], dy = disp[3 * (long)e + 1], dz = disp[3 * (long)e + 2];
+  const double r = sqrt(dx * dx + dy * dy + dz * dz);
+  const double ir = 1.0 / r;
+  float4 g;
+  g.x = (float)(dx * ir);
+  g.y = (float)(dy * ir);
+  g.z = (float)(dz * ir);
+  g.w = (float)r;
+  reinterpret_cast<float4*>(geo)[e] = g;
+  const double x = r / (double)cutoff;
+  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
+  const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);   // 1 - 55x^9 + 99x^10 - 45x^11
+  const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);        // -495x^8 + 990x^9 - 495x^10
+  const double ix = 1.0 / x;
+  for (int n = 0; n < nb; ++n) {
+    const double w = (double)freq[n];
+    double s, c;
+    sincos(w * x, &s, &c);
+    const double bes = s * ix;
+    const double dbes = (w * c - bes) * ix;
+    rbf[(long)e * nb + n] = (float)(env * bes);
+    drbf[(long)e * nb + n] = (float)(denv * bes + env * dbes);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms,
+                                 int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
+                                 void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms < 0 || n_mol < 0 || !mol_ptr || !row_ptr || !status) {
+    nnhip_set_error("nnhip_graph_count: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  ScopedTimer tm(TC_GRAPH, stream);
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+  HIP_TRY(hipMemsetAsync(mol_ptr, 0, sizeof(int32_t) * (n_mol + 1), stream));
+  HIP_TRY(hipMemsetAsync(row_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
+  if (n_atoms == 0) return NNHIP_OK;
+  mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status);
+  LAUNCH_CHECK();
+  // in-degrees are counted into row_ptr[0..N) and scanned in place
+  graph_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, cutoff, row_ptr,
+                                                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  LAUNCH_CHECK();
+  scan_rows_kernel<<<1, 1024, 0, stream>>>(row_ptr, n_atoms, row_ptr);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                                const int32_t* row_ptr, int32_t n_atoms, int32_t n_mol, int32_t n_edges, float cutoff,
+                                int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)n_mol;
+  if (n_atoms < 0 || n_edges < 0) {
+    nnhip_set_error("nnhip_graph_fill: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  // `rev` doubles as the receiver-of-edge scratch during the fill; edge_rev_kernel then replaces it in place
+  graph_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, cutoff, nullptr,
+                                                                  row_ptr, col, rev, disp, edge_index, n_edges);
+  LAUNCH_CHECK();
+  edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,
+                                int32_t n_basis, float* geo, float* rbf, float* drbf, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_basis != NB) {
+    nnhip_set_error("nnhip_edge_embed: n_basis=%d unsupported (built for %d)", n_basis, NB);
+    return NNHIP_E_UNSUPPORTED;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, frequencies, n_basis, geo, rbf, drbf);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}

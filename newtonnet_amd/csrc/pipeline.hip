@@ -1,0 +1,372 @@
+// Host-side orchestration of the hot path behind the C ABI (include/newtonnet_hip.h): workspace carving,
+// the forward sweep and the analytic reverse sweep (energy -> forces), error strings, event timers.
+//
+// Mirrors NewtonNet.forward (newtonnet/models/newtonnet.py:74-104) for output_properties
+// ['energy', 'gradient_force'] and replaces torch.autograd.grad (newtonnet/models/output.py:66-73) by explicit
+// adjoint kernels.  Every launch goes to the caller's stream; nothing here synchronises.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+// ---- pieces defined in the other translation units ---------------------------------------------------
+int launch_msg_fwd(const float* m, const float* rbf, const float* edge_w, const int* row_ptr, const int* col,
+                   const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
+int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
+                     const int* col, const float* f_in, float* f_out, int n_atoms, hipStream_t s);
+int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
+                     const int* row_ptr, const int* col, const int* rev, const float* f_in, float* g_h12, float* g_u,
+                     float* g_fin, int n_atoms, hipStream_t s);
+int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const float* rbf, const float* drbf,
+                   const float* edge_w, const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
+                   int n_atoms, hipStream_t s);
+int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const int* row_ptr,
+                        const int* rev, const int* mol_ptr, int n_atoms, int n_edges, int n_mol, int n_layers,
+                        float cutoff, float* g_d, float* forces, float* virial, hipStream_t s);
+int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s);
+int launch_node_update_fwd(const float* a_mid, const float* f, const float* q, int n_atoms, float* a_out, hipStream_t s);
+int launch_node_update_bwd(const float* g_a, const float* f, const float* q, const float* g_fout, int n_atoms,
+                           float* tmp, float* gf, hipStream_t s);
+int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
+                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
+                    float* energy, hipStream_t s);
+int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
+
+// ---- errors ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void nnhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* nnhip_last_error(void) { return g_err; }
+extern "C" int nnhip_version(void) { return 100; }
+
+// ---- timers ------------------------------------------------------------------------------------------
+struct TimerRec {
+  int cls;
+  hipEvent_t e0, e1;
+};
+static bool g_timers_on = false;
+static std::vector<TimerRec> g_pending;
+static std::vector<hipEvent_t> g_event_pool;
+static double g_ms[NNHIP_N_TIMER_CLASSES];
+static int64_t g_cnt[NNHIP_N_TIMER_CLASSES];
+
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+ScopedTimer::ScopedTimer(int c, hipStream_t st) : cls(c), s(st), e0(nullptr), on(g_timers_on) {
+  if (on) {
+    e0 = get_event();
+    if (e0) (void)hipEventRecord(e0, s); else on = false;
+  }
+}
+ScopedTimer::~ScopedTimer() {
+  if (!on) return;
+  hipEvent_t e1 = get_event();
+  if (!e1) return;
+  (void)hipEventRecord(e1, s);
+  g_pending.push_back({cls, e0, e1});
+}
+extern "C" int nnhip_timers_enable(int32_t on) {
+  g_timers_on = on != 0;
+  return NNHIP_OK;
+}
+extern "C" int nnhip_timers_read(double* ms, int64_t* cnt, int32_t reset) {
+  for (auto& r : g_pending) {
+    float t = 0.f;
+    HIP_TRY(hipEventSynchronize(r.e1));
+    HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    g_ms[r.cls] += t;
+    g_cnt[r.cls] += 1;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_pending.clear();
+  for (int k = 0; k < NNHIP_N_TIMER_CLASSES; ++k) {
+    if (ms) ms[k] = g_ms[k];
+    if (cnt) cnt[k] = g_cnt[k];
+    if (reset) {
+      g_ms[k] = 0;
+      g_cnt[k] = 0;
+    }
+  }
+  return NNHIP_OK;
+}
+
+// ---- workspace ---------------------------------------------------------------------------------------
+struct WsInternal {
+  nnhip_ws_layout pub;
+  size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
+  size_t headT[2];                 // head0^T, head2^T
+  size_t g_h12;                    // [E][2F] adjoint scratch (g_phi -> g_h)
+  size_t g_msg;                    // [E][F]
+  size_t g_m;                      // [N][F]
+  size_t g_hn;                     // [N][F]
+  size_t g_e;                      // [N][F] head adjoint scratch (g_e2 then g_e1)
+  size_t tmp3;                     // [N][3][F]
+  size_t g_f2;                     // [N][3][F] second g_f buffer (ping-pong)
+  size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
+  size_t g_d;                      // [E][4]
+  size_t atom_energy;              // [N]
+};
+
+static size_t carve(size_t& off, size_t bytes) {
+  const size_t o = off;
+  off += (bytes + 255) & ~(size_t)255;
+  return o;
+}
+
+static void make_layout(int N, int E, int B, int L, WsInternal& w) {
+  (void)B;
+  memset(&w, 0, sizeof(w));
+  size_t off = 0;
+  const size_t nf = (size_t)N * NF * 4, ef = (size_t)E * NF * 4;
+  w.pub.a0 = carve(off, nf);
+  for (int l = 0; l < L; ++l) {
+    w.pub.m[l] = carve(off, nf);
+    w.pub.hn[l] = carve(off, nf);
+    w.pub.msg[l] = carve(off, ef);
+    w.pub.h12[l] = carve(off, 2 * ef);
+    w.pub.phi1[l] = carve(off, ef);
+    w.pub.phi2[l] = carve(off, ef);
+    w.pub.a_mid[l] = carve(off, nf);
+    w.pub.a_out[l] = carve(off, nf);
+    w.pub.f_out[l] = carve(off, 3 * nf);
+    w.pub.q[l] = carve(off, 3 * nf);
+    for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
+  }
+  w.headT[0] = carve(off, NF * NF * 4);
+  w.headT[1] = carve(off, NF * NF * 4);
+  w.pub.e1 = carve(off, nf);
+  w.pub.e2 = carve(off, nf);
+  w.pub.g_x = carve(off, (size_t)L * E * 4);
+  w.pub.g_u = carve(off, (size_t)L * E * 16);
+  w.pub.g_a = carve(off, nf);
+  w.pub.g_f = carve(off, 3 * nf);
+  w.g_f2 = carve(off, 3 * nf);
+  w.gf_mid = carve(off, 3 * nf);
+  w.tmp3 = carve(off, 3 * nf);
+  w.g_h12 = carve(off, 2 * ef);
+  w.g_msg = carve(off, ef);
+  w.g_m = carve(off, nf);
+  w.g_hn = carve(off, nf);
+  w.g_e = carve(off, nf);
+  w.g_d = carve(off, (size_t)E * 16);
+  w.atom_energy = carve(off, (size_t)N * 4);
+  w.pub.total = off;
+}
+
+extern "C" size_t nnhip_workspace_bytes(int32_t N, int32_t E, int32_t B, int32_t L) {
+  if (N < 0 || E < 0 || L < 1 || L > NNHIP_MAX_LAYERS) return 0;
+  WsInternal w;
+  make_layout(N, E, B, L, w);
+  return w.pub.total;
+}
+
+extern "C" int nnhip_workspace_layout(int32_t N, int32_t E, int32_t B, int32_t L, nnhip_ws_layout* out) {
+  if (!out || N < 0 || E < 0 || L < 1 || L > NNHIP_MAX_LAYERS) {
+    nnhip_set_error("nnhip_workspace_layout: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  WsInternal w;
+  make_layout(N, E, B, L, w);
+  *out = w.pub;
+  return NNHIP_OK;
+}
+
+// ---- linear helpers ----------------------------------------------------------------------------------
+static int lin1(int pro, int epi, const float* A, int lda, const float* W, float* C, int ldc, const float* bias,
+                const float* H, int ldh, int M, hipStream_t s) {
+  LinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g[0] = {A, W, C, bias, H};
+  a.M = M;
+  a.lda = lda;
+  a.ldc = ldc;
+  a.ldh = ldh;
+  return launch_lin(pro, epi, a, 1, s);
+}
+static int lin2(int pro, int epi, LinGroup g0, LinGroup g1, int lda, int ldc, int ldh, int M, hipStream_t s) {
+  LinArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g[0] = g0;
+  a.g[1] = g1;
+  a.M = M;
+  a.lda = lda;
+  a.ldc = ldc;
+  a.ldh = ldh;
+  return launch_lin(pro, epi, a, 2, s);
+}
+#define TRY(x)            \
+  do {                    \
+    int _r = (x);         \
+    if (_r) return _r;    \
+  } while (0)
+
+// ---- the hot path --------------------------------------------------------------------------------------
+extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const int64_t* batch,
+                                   const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
+                                   const int32_t* rev, const float* geo, const float* rbf, const float* drbf,
+                                   const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
+                                   size_t workspace_bytes, float* energy, float* forces, float* virial,
+                                   float* atom_energy_out, float* atom_node_out, float* force_node_out,
+                                   void* stream_) {
+  (void)batch;
+  hipStream_t s = (hipStream_t)stream_;
+  if (!model || !energy || N < 0 || E < 0 || B < 0) {
+    nnhip_set_error("nnhip_energy_forces: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (model->n_features != NF || model->n_basis != NB || model->n_layers < 1 || model->n_layers > NNHIP_MAX_LAYERS) {
+    nnhip_set_error("nnhip_energy_forces: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d/%d/1..%d)",
+                    model->n_features, model->n_basis, model->n_layers, NF, NB, NNHIP_MAX_LAYERS);
+    return NNHIP_E_UNSUPPORTED;
+  }
+  const int L = model->n_layers;
+  WsInternal w;
+  make_layout(N, E, B, L, w);
+  if (workspace_bytes < w.pub.total || (!workspace && w.pub.total)) {
+    nnhip_set_error("nnhip_energy_forces: workspace %zu < required %zu bytes", workspace_bytes, w.pub.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  if (((uintptr_t)workspace & 255) != 0) {
+    nnhip_set_error("nnhip_energy_forces: workspace must be 256-byte aligned");
+    return NNHIP_E_INVALID;
+  }
+  if (N == 0) {
+    if (B > 0) HIP_TRY(hipMemsetAsync(energy, 0, sizeof(float) * B, s));
+    return NNHIP_OK;
+  }
+  char* ws = (char*)workspace;
+  auto P = [&](size_t off) { return (float*)(ws + off); };
+  const bool want_forces = forces != nullptr;
+
+  // transposed weights for the reverse sweep (tiny; redone every call so they always match the parameters)
+  if (want_forces) {
+    const float* src[40];
+    float* dst[40];
+    int c = 0;
+    for (int l = 0; l < L; ++l) {
+      const nnhip_layer_params& lp = model->layer[l];
+      const float* ws_[7] = {lp.node0_w, lp.node2_w, lp.eq1_0_w, lp.eq1_2_w, lp.eq2_0_w, lp.eq2_2_w, lp.update_w};
+      for (int k = 0; k < 7; ++k) {
+        if (c == 40) {
+          TRY(launch_transposes(src, dst, c, s));
+          c = 0;
+        }
+        src[c] = ws_[k];
+        dst[c] = P(w.wT[l][k]);
+        ++c;
+      }
+    }
+    if (c + 2 > 40) {
+      TRY(launch_transposes(src, dst, c, s));
+      c = 0;
+    }
+    src[c] = model->head0_w;
+    dst[c++] = P(w.headT[0]);
+    src[c] = model->head2_w;
+    dst[c++] = P(w.headT[1]);
+    TRY(launch_transposes(src, dst, c, s));
+  }
+
+  // ------------------------------------------------------------------ forward sweep
+  TRY(launch_embed(z, model->node_embedding, N, P(w.pub.a0), s));
+  const float* a_in = P(w.pub.a0);
+  const float* f_in = nullptr;  // force_node == 0 entering the first layer (newtonnet.py:143)
+  for (int l = 0; l < L; ++l) {
+    const nnhip_layer_params& lp = model->layer[l];
+    const bool has_f = l > 0;
+    // message_nodepart: hn = a W0^T + b0 ; m = silu(hn) W2^T + b2
+    TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
+    TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
+    // messages + invariant update
+    TRY(launch_msg_fwd(P(w.pub.m[l]), rbf, lp.edge_w, row_ptr, col, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
+    // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
+    if (E > 0) {
+      float* h12 = P(w.pub.h12[l]);
+      if (has_f) {
+        TRY(lin2(PRO_NONE, EPI_STORE, {P(w.pub.msg[l]), lp.eq1_0_w, h12, nullptr, nullptr},
+                 {P(w.pub.msg[l]), lp.eq2_0_w, h12 + NF, nullptr, nullptr}, NF, 2 * NF, 0, E, s));
+        TRY(lin2(PRO_SILU, EPI_STORE, {h12, lp.eq1_2_w, P(w.pub.phi1[l]), nullptr, nullptr},
+                 {h12 + NF, lp.eq2_2_w, P(w.pub.phi2[l]), nullptr, nullptr}, 2 * NF, NF, 0, E, s));
+      } else {
+        TRY(lin1(PRO_NONE, EPI_STORE, P(w.pub.msg[l]), NF, lp.eq1_0_w, h12, 2 * NF, nullptr, nullptr, 0, E, s));
+        TRY(lin1(PRO_SILU, EPI_STORE, h12, 2 * NF, lp.eq1_2_w, P(w.pub.phi1[l]), NF, nullptr, nullptr, 0, E, s));
+      }
+    }
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, f_in, P(w.pub.f_out[l]), N, s));
+    // equiv_update + energy update
+    TRY(lin1(PRO_NONE, EPI_STORE, P(w.pub.f_out[l]), NF, lp.update_w, P(w.pub.q[l]), NF, nullptr, nullptr, 0, 3 * N, s));
+    TRY(launch_node_update_fwd(P(w.pub.a_mid[l]), P(w.pub.f_out[l]), P(w.pub.q[l]), N, P(w.pub.a_out[l]), s));
+    a_in = P(w.pub.a_out[l]);
+    f_in = P(w.pub.f_out[l]);
+  }
+  // energy head
+  TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, model->head0_w, P(w.pub.e1), NF, model->head0_b, nullptr, 0, N, s));
+  TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.e1), NF, model->head2_w, P(w.pub.e2), NF, model->head2_b, nullptr, 0, N, s));
+  float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
+  TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
+                      atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
+  if (atom_node_out) HIP_TRY(hipMemcpyAsync(atom_node_out, a_in, (size_t)N * NF * 4, hipMemcpyDeviceToDevice, s));
+  if (force_node_out) HIP_TRY(hipMemcpyAsync(force_node_out, f_in, (size_t)N * 3 * NF * 4, hipMemcpyDeviceToDevice, s));
+  if (!want_forces) return NNHIP_OK;
+
+  // ------------------------------------------------------------------ reverse sweep
+  // head: g_e1 = (g_e2 H2) * silu'(e1) ; g_a = g_e1 H0
+  TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_e), NF, P(w.headT[1]), P(w.g_e), NF, nullptr, P(w.pub.e1), NF, N, s));
+  TRY(lin1(PRO_NONE, EPI_STORE, P(w.g_e), NF, P(w.headT[0]), P(w.pub.g_a), NF, nullptr, nullptr, 0, N, s));
+  float* g_fout = nullptr;  // dE/d force_node after the last layer is zero
+  float* g_fbuf[2] = {P(w.pub.g_f), P(w.g_f2)};
+  int pp = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    const nnhip_layer_params& lp = model->layer[l];
+    const bool has_f = l > 0;
+    const float* f_prev = has_f ? P(w.pub.f_out[l - 1]) : nullptr;
+    // update adjoint: gf = g_fout + g_a * q + (g_a * f) W_u
+    TRY(launch_node_update_bwd(P(w.pub.g_a), P(w.pub.f_out[l]), P(w.pub.q[l]), g_fout, N, P(w.tmp3), P(w.gf_mid), s));
+    TRY(lin1(PRO_NONE, EPI_ACC, P(w.tmp3), NF, P(w.wT[l][6]), P(w.gf_mid), NF, nullptr, nullptr, 0, 3 * N, s));
+    // force-message adjoint
+    float* g_fin = g_fbuf[pp];
+    TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, rev, f_prev,
+                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, s));
+    if (E > 0) {
+      float* gh = P(w.g_h12);
+      float* h12 = P(w.pub.h12[l]);
+      // g_h_k = (g_phi_k V_k2) * silu'(h_k)   (in place) ; g_msg = g_h_1 V_10 + g_h_2 V_20
+      if (has_f) {
+        TRY(lin2(PRO_NONE, EPI_DSILU, {gh, P(w.wT[l][3]), gh, nullptr, h12},
+                 {gh + NF, P(w.wT[l][5]), gh + NF, nullptr, h12 + NF}, 2 * NF, 2 * NF, 2 * NF, E, s));
+      } else {
+        TRY(lin1(PRO_NONE, EPI_DSILU, gh, 2 * NF, P(w.wT[l][3]), gh, 2 * NF, nullptr, h12, 2 * NF, E, s));
+      }
+      TRY(lin1(PRO_NONE, EPI_STORE, gh, 2 * NF, P(w.wT[l][2]), P(w.g_msg), NF, nullptr, nullptr, 0, E, s));
+      if (has_f)
+        TRY(lin1(PRO_NONE, EPI_ACC, gh + NF, 2 * NF, P(w.wT[l][4]), P(w.g_msg), NF, nullptr, nullptr, 0, E, s));
+    }
+    // message adjoint -> g_m, g_x
+    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), rbf, drbf, lp.edge_w, row_ptr, col, rev, P(w.g_m),
+                       P(w.pub.g_x) + (size_t)l * E, N, s));
+    // message_nodepart adjoint: g_hn = (g_m W2) * silu'(hn) ; g_a += g_hn W0
+    TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_m), NF, P(w.wT[l][1]), P(w.g_hn), NF, nullptr, P(w.pub.hn[l]), NF, N, s));
+    TRY(lin1(PRO_NONE, EPI_ACC, P(w.g_hn), NF, P(w.wT[l][0]), P(w.pub.g_a), NF, nullptr, nullptr, 0, N, s));
+    g_fout = has_f ? g_fin : nullptr;
+    pp ^= 1;
+  }
+  TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, row_ptr, rev, mol_ptr, N, E, B, L, model->cutoff,
+                          P(w.g_d), forces, virial, s));
+  return NNHIP_OK;
+}

@@ -1,0 +1,203 @@
+"""ctypes binding of libnewtonnet_hip.so (C ABI: include/newtonnet_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is
+in the shared library.  There is no fallback: if the library is missing or a
+call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libnewtonnet_hip.so')
+BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
+
+NNHIP_F = 128
+NNHIP_NB = 20
+NNHIP_MAX_LAYERS = 8
+N_TIMER_CLASSES = 8
+TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',
+                 'edge_msg_bwd', 'graph')
+
+_fp = C.POINTER(C.c_float)
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('node0_w', 'node0_b', 'node2_w', 'node2_b', 'edge_w', 'eq1_0_w', 'eq1_2_w',
+                                         'eq2_0_w', 'eq2_2_w', 'update_w')]
+
+
+class Model(C.Structure):
+    _fields_ = [('n_features', C.c_int32), ('n_basis', C.c_int32), ('n_layers', C.c_int32), ('cutoff', C.c_float),
+                ('node_embedding', C.c_void_p), ('frequencies', C.c_void_p),
+                ('layer', LayerParams * NNHIP_MAX_LAYERS),
+                ('head0_w', C.c_void_p), ('head0_b', C.c_void_p), ('head2_w', C.c_void_p), ('head2_b', C.c_void_p),
+                ('head4_w', C.c_void_p), ('head4_b', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
+
+class WsLayout(C.Structure):
+    _fields_ = ([(n, C.c_size_t * NNHIP_MAX_LAYERS) for n in ('m', 'hn', 'msg', 'h12', 'phi1', 'phi2', 'a_mid', 'a_out',
+                                                               'f_out', 'q')]
+                + [(n, C.c_size_t) for n in ('a0', 'e1', 'e2', 'g_x', 'g_u', 'g_a', 'g_f', 'total')])
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into newtonnet_amd/lib/libnewtonnet_hip.so."""
+    r = subprocess.run(['bash', BUILD_SCRIPT], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise HipLibraryError(f'hipcc build failed:\n{r.stdout}\n{r.stderr}')
+    if verbose:
+        print(r.stdout.strip())
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library.  Fails loudly when it is absent (no CPU path exists in this package)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `bash {BUILD_SCRIPT}`.  newtonnet_amd has no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    L.nnhip_version.restype = C.c_int
+    L.nnhip_last_error.restype = C.c_char_p
+    L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
+    L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp]
+    L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.nnhip_workspace_bytes.restype = sz
+    L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
+    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
+                                      vp, vp, vp, vp, vp, vp, vp]
+    L.nnhip_timers_enable.argtypes = [i32]
+    L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
+               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read'):
+        getattr(L, fn).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
+                    'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
+                    'nnhip_timers_read')
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipLibraryError(f'{what} failed (code {rc}): {lib().nnhip_last_error().decode()}')
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise NotImplementedError(f'{name}: the HIP path computes in float32 (got {t.dtype})')
+    return t.contiguous()
+
+
+class Graph:
+    """Neighbor list + edge embedding of one batch (device tensors)."""
+    __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
+                 'rbf', 'drbf')
+
+
+def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
+                frequencies: torch.Tensor, want_edge_index: bool = True) -> Graph:
+    """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU."""
+    L = lib()
+    dev = pos.device
+    pos = _f32c(pos, 'pos')
+    cell = _f32c(cell, 'cell')
+    batch = batch.contiguous()
+    if batch.dtype != torch.int64:
+        batch = batch.long()
+    N, B = pos.shape[0], cell.shape[0]
+    g = Graph()
+    g.n_atoms, g.n_mol = N, B
+    meta = torch.empty(B + 1 + N + 1 + 1, dtype=torch.int32, device=dev)
+    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]
+    st = _stream(dev)
+    _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
+                               _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
+    tail = meta[B + N + 1:].tolist()          # (E, status): the one device->host sync of the path
+    E, bad = int(tail[0]), int(tail[1])
+    if bad:
+        raise ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
+    g.n_edges = E
+    ints = torch.empty(2 * E, dtype=torch.int32, device=dev)
+    g.col, g.rev = ints[:E], ints[E:]
+    g.disp = torch.empty(E, 3, dtype=torch.float32, device=dev)
+    g.edge_index = torch.empty(2, E, dtype=torch.int64, device=dev) if want_edge_index else None
+    _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
+                              float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
+           'nnhip_graph_fill')
+    nb = frequencies.numel()
+    g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
+    g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev)
+    g.drbf = torch.empty(E, nb, dtype=torch.float32, device=dev)
+    _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), nb,
+                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), st), 'nnhip_edge_embed')
+    return g
+
+
+def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
+    out = WsLayout()
+    _check(lib().nnhip_workspace_layout(N, E, B, n_layers, C.byref(out)), 'nnhip_workspace_layout')
+    return out
+
+
+def energy_forces(model: Model, z: torch.Tensor, batch: torch.Tensor, g: Graph, want_forces: bool = True,
+                  want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None):
+    """Run the whole hot path.  Returns dict(energy, forces, virial, atom_energy, atom_node, force_node, workspace)."""
+    L = lib()
+    dev = z.device
+    N, E, B = g.n_atoms, g.n_edges, g.n_mol
+    need = L.nnhip_workspace_bytes(N, E, B, model.n_layers)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    out = dict(workspace=workspace)
+    out['energy'] = torch.empty(B, dtype=torch.float32, device=dev)
+    out['forces'] = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_forces else None
+    out['virial'] = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if (want_virial and want_forces) else None
+    out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
+    out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
+                                 _ptr(g.rev), _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.disp), N, E, B,
+                                 _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
+                                 _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
+                                 _ptr(out['force_node']), _stream(dev)), 'nnhip_energy_forces')
+    return out
+
+
+def timers_enable(on: bool):
+    _check(lib().nnhip_timers_enable(1 if on else 0), 'nnhip_timers_enable')
+
+
+def timers_read(reset: bool = True):
+    ms = (C.c_double * N_TIMER_CLASSES)()
+    cnt = (C.c_int64 * N_TIMER_CLASSES)()
+    _check(lib().nnhip_timers_read(ms, cnt, 1 if reset else 0), 'nnhip_timers_read')
+    return {name: (ms[k], cnt[k]) for k, name in enumerate(TIMER_CLASSES)}

@@ -1,0 +1,185 @@
+"""NewtonNet on MI355X: same constructor / forward / state_dict as the reference model
+(newtonnet/models/newtonnet.py:12-113), with the forward executed by hand-written HIP kernels.
+
+The nn.Modules below only hold parameters under the reference's names, so state_dicts interchange:
+  embedding_layers.node_embedding.weight, embedding_layers.edge_embedding.embedding.frequencies,
+  interaction_layers.{l}.message_nodepart.{0,2}.{weight,bias}, .message_edgepart.weight,
+  .equiv_message{1,2}.{0,2}.weight, .equiv_update.weight,
+  output_layers.{k}.layers.{0,2,4}.{weight,bias}, scalers.{k}.{scale,shift}.weight
+forward(z, pos, cell, batch) needs tensors on a ROCm device: there is no CPU implementation in this
+package (the parity oracle lives in oracle/ and is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from newtonnet_amd import hip
+from newtonnet_amd.layers.activations import HIP_FUSED, get_activation_by_string
+from newtonnet_amd.layers.representations import EdgeEmbedding
+from newtonnet_amd.layers.scalers import get_scaler_by_string
+from newtonnet_amd.models.output import (CustomOutputSet, DerivativeProperty, EnergyOutput, GradientForceOutput,
+                                         StressOutput, VirialOutput, get_aggregator_by_string, get_output_by_string)
+
+
+class EmbeddingNet(nn.Module):
+    """Node embedding table + edge-embedding hyper-parameters (newtonnet.py:116-137)."""
+    def __init__(self, cutoff, n_features, n_basis):
+        super().__init__()
+        self.n_features = n_features
+        self.node_embedding = nn.Embedding(118 + 1, n_features, padding_idx=0)
+        self.edge_embedding = EdgeEmbedding(cutoff=cutoff, n_basis=n_basis)
+        self.requires_dr = False
+
+
+class InteractionNet(nn.Module):
+    """Parameters of one message-passing layer (newtonnet.py:175-205)."""
+    def __init__(self, n_features, n_basis, activation, layer_norm):
+        super().__init__()
+        self.n_features = n_features
+        self.message_nodepart = nn.Sequential(nn.Linear(n_features, n_features), activation,
+                                              nn.Linear(n_features, n_features))
+        self.message_edgepart = nn.Linear(n_basis, n_features, bias=False)
+        self.equiv_message1 = nn.Sequential(nn.Linear(n_features, n_features, bias=False), activation,
+                                            nn.Linear(n_features, n_features, bias=False))
+        self.equiv_message2 = nn.Sequential(nn.Linear(n_features, n_features, bias=False), activation,
+                                            nn.Linear(n_features, n_features, bias=False))
+        self.equiv_update = nn.Linear(n_features, n_features, bias=False)
+        self.layer_norm = nn.LayerNorm(n_features) if layer_norm else None
+
+
+class NewtonNet(nn.Module):
+    """Molecular Newtonian message passing, MI355X-native.
+
+    Parameters (identical to the reference, newtonnet.py:26-35):
+        cutoff, n_features, n_basis, n_interactions, activation, layer_norm, output_properties
+    """
+    def __init__(self, cutoff: float = 5.0, n_features: int = 128, n_basis: int = 20, n_interactions: int = 3,
+                 activation: str = 'swish', layer_norm: bool = False, output_properties: list = []) -> None:
+        super().__init__()
+        self.activation_name = activation
+        act = get_activation_by_string(activation)
+        self.embedding_layers = EmbeddingNet(cutoff=cutoff, n_features=n_features, n_basis=n_basis)
+        self.interaction_layers = nn.ModuleList([
+            InteractionNet(n_features=n_features, n_basis=n_basis, activation=act, layer_norm=layer_norm)
+            for _ in range(n_interactions)])
+        self.output_properties = output_properties
+        self.output_layers = nn.ModuleList()
+        self.scalers = nn.ModuleList()
+        self.aggregators = nn.ModuleList()
+        for key in self.output_properties:
+            output_layer = get_output_by_string(key, n_features, act)
+            self.output_layers.append(output_layer)
+            if isinstance(output_layer, DerivativeProperty):
+                self.embedding_layers.requires_dr = True
+            self.scalers.append(get_scaler_by_string(key))
+            self.aggregators.append(get_aggregator_by_string(key))
+
+    # ------------------------------------------------------------------------------------------
+    def train(self, mode=True):
+        """As the reference (newtonnet.py:106-113): flips create_graph on derivative heads; returns None."""
+        super().train(mode)
+        for output_layer in self.output_layers:
+            if isinstance(output_layer, DerivativeProperty):
+                output_layer.create_graph = mode
+
+    # ------------------------------------------------------------------------------------------
+    def _hip_model(self, energy_idx: int) -> hip.Model:
+        emb = self.embedding_layers
+        F, nb, L = emb.n_features, emb.edge_embedding.n_basis, len(self.interaction_layers)
+        if F != hip.NNHIP_F or nb != hip.NNHIP_NB or not (1 <= L <= hip.NNHIP_MAX_LAYERS):
+            raise NotImplementedError(f'HIP kernels are built for n_features={hip.NNHIP_F}, n_basis={hip.NNHIP_NB}, '
+                                      f'1..{hip.NNHIP_MAX_LAYERS} interactions (got {F}, {nb}, {L})')
+        if self.activation_name not in HIP_FUSED:
+            raise NotImplementedError(f"HIP kernels fuse SiLU only (activation='{self.activation_name}')")
+        if any(il.layer_norm is not None for il in self.interaction_layers):
+            raise NotImplementedError('layer_norm=True is not on the HIP hot path (reference default is False)')
+
+        def p(t):
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise NotImplementedError(f'HIP path needs float32 parameters on the GPU (got {t.dtype} on {t.device}); '
+                                          f'call model.to(torch.float32).to("cuda")')
+            if not t.is_contiguous():
+                raise ValueError('non-contiguous parameter')
+            return t.data_ptr()
+
+        m = hip.Model()
+        m.n_features, m.n_basis, m.n_layers = F, nb, L
+        m.cutoff = float(emb.edge_embedding.cutoff)
+        m.node_embedding = p(emb.node_embedding.weight)
+        m.frequencies = p(emb.edge_embedding.embedding.frequencies)
+        for l, il in enumerate(self.interaction_layers):
+            lp = m.layer[l]
+            lp.node0_w, lp.node0_b = p(il.message_nodepart[0].weight), p(il.message_nodepart[0].bias)
+            lp.node2_w, lp.node2_b = p(il.message_nodepart[2].weight), p(il.message_nodepart[2].bias)
+            lp.edge_w = p(il.message_edgepart.weight)
+            lp.eq1_0_w, lp.eq1_2_w = p(il.equiv_message1[0].weight), p(il.equiv_message1[2].weight)
+            lp.eq2_0_w, lp.eq2_2_w = p(il.equiv_message2[0].weight), p(il.equiv_message2[2].weight)
+            lp.update_w = p(il.equiv_update.weight)
+        head = self.output_layers[energy_idx].layers
+        m.head0_w, m.head0_b = p(head[0].weight), p(head[0].bias)
+        m.head2_w, m.head2_b = p(head[2].weight), p(head[2].bias)
+        m.head4_w, m.head4_b = p(head[4].weight), p(head[4].bias)
+        sc = self.scalers[energy_idx]
+        m.scale = p(sc.scale.weight) if sc.scale is not None else None
+        m.shift = p(sc.shift.weight) if sc.shift is not None else None
+        return m
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, z, pos, cell, batch):
+        """Network forward pass (newtonnet.py:74-104).
+
+        z int64 [N]; pos float32 [N,3]; cell float32 [B,3,3] (all-zero = non-periodic); batch int64 [N], sorted.
+        Returns a CustomOutputSet with z, pos, atom_node, force_node, edge_index, cell, displacement, batch and one
+        attribute per output property (`energy` [B], `gradient_force` [N,3], ...).
+        """
+        if not pos.is_cuda:
+            raise RuntimeError('newtonnet_amd.NewtonNet runs on an MI355X (ROCm) device only: move the model and the '
+                               'inputs to "cuda".  There is no CPU path in this package.')
+        keys = list(self.output_properties)
+        if 'energy' not in keys:
+            raise NotImplementedError("the HIP hot path needs the 'energy' head (output_properties)")
+        for key in keys:
+            if key not in ('energy', 'gradient_force', 'virial', 'stress'):
+                raise NotImplementedError(f"output property '{key}' is outside the MI355X hot path")
+        deriv_layers = [ol for ol in self.output_layers if isinstance(ol, DerivativeProperty)]
+        if any(ol.create_graph for ol in deriv_layers) and torch.is_grad_enabled():
+            raise NotImplementedError(
+                'train-mode forward (create_graph=True: force-loss backward through the kernels) is not built yet; '
+                'call model.eval() for inference.  See DESIGN.md "what comes next".')
+        energy_idx = keys.index('energy')
+        want_forces = len(deriv_layers) > 0
+        want_virial = any(isinstance(ol, (VirialOutput, StressOutput)) for ol in deriv_layers)
+
+        emb = self.embedding_layers
+        # the reference marks the caller's tensor (newtonnet.py:150-152); kept for API parity
+        displacement = torch.eye(3, dtype=pos.dtype, device=pos.device).repeat(cell.shape[0], 1, 1)
+        if emb.requires_dr and pos.is_leaf and pos.is_floating_point():
+            pos.requires_grad = True
+            displacement.requires_grad = True
+
+        with torch.no_grad():
+            model = self._hip_model(energy_idx)
+            zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
+            g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
+                                emb.edge_embedding.embedding.frequencies)
+            res = hip.energy_forces(model, zc, batch, g, want_forces=want_forces, want_virial=want_virial)
+
+        outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
+                                  edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
+        if want_forces:
+            outputs.pos_grad = -res['forces']
+            if want_virial:
+                outputs.displacement_grad = -res['virial']
+        for key in keys:
+            if key == 'energy':
+                outputs.energy = res['energy']
+            elif key == 'gradient_force':
+                outputs.gradient_force = res['forces']
+            elif key == 'virial':
+                outputs.virial = res['virial']
+            elif key == 'stress':
+                outputs.stress = -res['virial'] / cell.det().view(-1, 1, 1)
+        return outputs

@@ -1,0 +1,81 @@
+"""Output heads of the hot path (mirror of newtonnet/models/output.py, energy + gradient-force subset).
+
+The modules are parameter holders / markers with the reference's names: NewtonNet.forward reads them to
+decide what the HIP pipeline must produce.  EnergyOutput's three linears run in csrc/lin128.hip and
+csrc/edge.hip:head_out_kernel; the gradient force is the analytic reverse sweep in csrc/pipeline.hip
+(replacing torch.autograd.grad at output.py:66-73).
+"""
+from torch import nn
+
+SUPPORTED = ('energy', 'gradient_force', 'virial', 'stress')
+
+
+def get_output_by_string(key, n_features=None, activation=None):
+    if key == 'energy':
+        return EnergyOutput(n_features, activation)
+    if key == 'gradient_force':
+        return GradientForceOutput()
+    if key == 'virial':
+        return VirialOutput()
+    if key == 'stress':
+        return StressOutput()
+    if key in ('direct_force', 'hessian', 'charge', 'bec'):
+        raise NotImplementedError(
+            f'Output type {key} is outside the MI355X hot path (energy / gradient_force / virial / stress); '
+            f'see DESIGN.md "out of scope"')
+    raise NotImplementedError(f'Output type {key} is not implemented yet')
+
+
+def get_aggregator_by_string(key):
+    if key == 'energy':
+        return EnergyAggregator()
+    if key in ('gradient_force', 'direct_force', 'hessian', 'virial', 'stress', 'charge', 'bec'):
+        return NullAggregator()
+    raise NotImplementedError(f'Aggregate type {key} is not implemented yet')
+
+
+class CustomOutputSet:
+    """Attribute bag returned by NewtonNet.forward (output.py:51-54)."""
+    def __init__(self, **outputs):
+        for key, value in outputs.items():
+            setattr(self, key, value)
+
+
+class DirectProperty(nn.Module):
+    pass
+
+
+class DerivativeProperty(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.create_graph = False  # set by NewtonNet.train() / .eval()  (newtonnet.py:106-113)
+
+
+class EnergyOutput(DirectProperty):
+    """Linear -> act -> Linear -> act -> Linear(F, 1)  (output.py:88-96); keys layers.{0,2,4}.{weight,bias}."""
+    def __init__(self, n_features, activation):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Linear(n_features, n_features), activation,
+            nn.Linear(n_features, n_features), activation,
+            nn.Linear(n_features, 1))
+
+
+class GradientForceOutput(DerivativeProperty):
+    """force = -dE/dpos (output.py:102-113)."""
+
+
+class VirialOutput(DerivativeProperty):
+    """virial = -dE/d(strain) (output.py:154-165)."""
+
+
+class StressOutput(DerivativeProperty):
+    """stress = (dE/d strain) / det(cell) (output.py:167-180)."""
+
+
+class EnergyAggregator(nn.Module):
+    """Per-molecule sum of atomic energies (output.py:245-247); done by mol_energy_kernel."""
+
+
+class NullAggregator(nn.Module):
+    pass

@@ -1,0 +1,182 @@
+"""GPU parity tests: the HIP hot path (through the C ABI) against the pinned CPU oracle and the golden vectors.
+
+Tolerances (fp32 path vs fp64 oracle on the same fp32 inputs):
+  edge_index bit-exact; force MAE <= 1e-5 eV/A and max <= 5e-5 eV/A; energy within 2 fp32 ulp of |E|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['aspirin1_rand', 'aspirin1_ckpt', 'aspirin8_rand', 'aspirin8_ckpt', 'ethanol4_rand', 'mixed_rand',
+         'pbc216_rand', 'pbc_batch2_rand']
+
+
+def make_model(which, props=('energy', 'gradient_force')):
+    from newtonnet_amd.models import NewtonNet
+    model = NewtonNet(output_properties=list(props))
+    sd = util.load_state(which, torch.float32)
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    model = model.to('cuda')
+    model.eval()
+    return model, sd
+
+
+def check_forces(got, want, scale=1.0):
+    d = np.abs(got.astype(np.float64) - want)
+    assert d.mean() <= util.FORCE_MAE_TOL * scale, f'force MAE {d.mean():.3e}'
+    assert d.max() <= util.FORCE_MAX_TOL * scale, f'force max err {d.max():.3e}'
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_golden_case(case):
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    model, _ = make_model(case.split('_')[-1])
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    # neighbor indices: bit-exact against the reference's own output (fp32 run and fp64 run agree in the fixtures)
+    assert np.array_equal(out.edge_index.cpu().numpy(), c['f32_edge_index'])
+    assert out.edge_index.dtype == torch.int64
+    e = out.energy.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(e - c['f64_energy']) <= util.energy_tol(c['f64_energy'])), (e, c['f64_energy'])
+    # force scale: the pbc boxes are dense random lattices with forces ~10x the molecular ones
+    fscale = max(1.0, np.abs(c['f64_forces']).max() / 5.0)
+    check_forces(out.gradient_force.cpu().numpy(), c['f64_forces'], fscale)
+    if 'f64_atom_node_2' in c:
+        a = out.atom_node.cpu().numpy()
+        f = out.force_node.cpu().numpy()
+        np.testing.assert_allclose(a, c['f64_atom_node_2'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(f, c['f64_force_node_2'], rtol=2e-4, atol=2e-5)
+
+
+def test_intermediates_against_trace():
+    """Every workspace intermediate of the forward and reverse sweeps vs the fp64 CPU trace."""
+    from newtonnet_amd import hip
+    from tests import trace
+    case = 'mixed_rand'
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    model, sd = make_model('rand')
+    T = trace.trace({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    m = model._hip_model(0)
+    g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0,
+                        model.embedding_layers.edge_embedding.embedding.frequencies)
+    assert np.array_equal(g.edge_index.cpu().numpy(), T['edge_index'].numpy())
+    res = hip.energy_forces(m, z.cuda(), batch.cuda(), g)
+    torch.cuda.synchronize()
+    N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
+    lay = hip.workspace_layout(N, E, B, L)
+    ws = res['workspace']
+
+    def view(off, shape):
+        n = int(np.prod(shape))
+        return ws[off:off + 4 * n].view(torch.float32).reshape(shape).cpu().double()
+
+    def close(name, got, want, rtol=1e-4):
+        err = (got - want).abs().max().item()
+        ref_scale = max(want.abs().max().item(), 1e-3)
+        assert err <= rtol * ref_scale, f'{name}: max err {err:.3e} vs scale {ref_scale:.3e}'
+
+    close('rbf', g.rbf.cpu().double(), T['rbf'], 1e-6)
+    close('dir', g.geo[:, :3].cpu().double(), T['u'], 1e-6)
+    for l in range(L):
+        close(f'm{l}', view(lay.m[l], (N, 128)), T[f'm_{l}'])
+        close(f'msg{l}', view(lay.msg[l], (E, 128)), T[f'msg_{l}'])
+        close(f'phi1{l}', view(lay.phi1[l], (E, 128)), T[f'phi1_{l}'])
+        if l > 0:
+            close(f'phi2{l}', view(lay.phi2[l], (E, 128)), T[f'phi2_{l}'])
+        close(f'f_out{l}', view(lay.f_out[l], (N, 3, 128)), T[f'f_out_{l}'])
+        close(f'a_out{l}', view(lay.a_out[l], (N, 128)), T[f'a_out_{l}'])
+        close(f'g_x{l}', view(lay.g_x + 4 * l * E, (E,)), T[f'g_x_{l}'], 2e-4)
+        close(f'g_u{l}', view(lay.g_u + 16 * l * E, (E, 4))[:, :3], T[f'g_u_{l}'], 2e-4)
+
+
+def test_K1_md_traj_through_hip():
+    """K1 (scripts/md17_md/md.traj): 201 frames, authors' CUDA fp32 energies/forces, checkpoint weights."""
+    k = util.load_npz('kat_md_traj.npz')
+    model, _ = make_model('ckpt')
+    n_frames, n_atoms = k['positions'].shape[:2]
+    z = torch.from_numpy(k['numbers']).long().repeat(n_frames).cuda()
+    pos = torch.from_numpy(k['positions']).reshape(-1, 3).float().cuda()
+    batch = torch.repeat_interleave(torch.arange(n_frames), n_atoms).cuda()
+    out = model(z, pos, torch.zeros(n_frames, 3, 3, device='cuda'), batch)
+    e = out.energy.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(e - k['energy']) <= util.energy_tol(k['energy']))
+    df = np.abs(out.gradient_force.cpu().numpy().reshape(n_frames, n_atoms, 3) - k['forces'])
+    assert df.max() < 5e-5 and df.mean() < 1e-5, (df.max(), df.mean())
+
+
+def test_K2_test_set_mae_through_hip():
+    """K2 (log.csv final row): test-set MAEs over the 500 test frames as one batch (fp64 in the reference;
+    the fp32 HIP path must land within fp32 noise of the logged values)."""
+    k = util.load_npz('kat_test_set.npz')
+    model, _ = make_model('ckpt')
+    n_frames, n_atoms = k['positions'].shape[:2]
+    z = torch.from_numpy(k['z']).long().repeat(n_frames).cuda()
+    pos = torch.from_numpy(k['positions']).reshape(-1, 3).float().cuda()
+    batch = torch.repeat_interleave(torch.arange(n_frames), n_atoms).cuda()
+    out = model(z, pos, torch.zeros(n_frames, 3, 3, device='cuda'), batch)
+    assert out.edge_index.shape[1] == 151366
+    e_mae = np.abs(out.energy.cpu().numpy().astype(np.float64) - k['energy']).mean()
+    f_mae = np.abs(out.gradient_force.cpu().numpy().reshape(n_frames, n_atoms, 3).astype(np.float64) - k['forces']).mean()
+    assert abs(e_mae - float(k['log_test_energy_mae'])) < 1e-3      # fp32 ulp of |E| ~ 2e-3
+    assert abs(f_mae - float(k['log_test_force_mae'])) < 1e-5
+
+
+def test_properties_config2_size():
+    """Full BASELINE config-2 size (1024 conformers): size-independent properties --
+    net force per molecule ~ 0, determinism (bitwise) across two runs, permutation of molecules."""
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 1024, 21
+    g = torch.Generator().manual_seed(0)
+    pos = (torch.from_numpy(a['test0_pos']).float().repeat(B, 1)
+           + 0.05 * torch.randn(B * n, 3, generator=g)).cuda()
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    cell = torch.zeros(B, 3, 3, device='cuda')
+    model, _ = make_model('rand')
+    o1 = model(z, pos, cell, batch)
+    o2 = model(z, pos, cell, batch)
+    assert torch.equal(o1.energy, o2.energy) and torch.equal(o1.gradient_force, o2.gradient_force)  # deterministic
+    net = o1.gradient_force.reshape(B, n, 3).sum(1).abs().max().item()
+    assert net < 2e-4, net
+    # reverse the molecule order: per-molecule results must be identical (bitwise: same per-row arithmetic)
+    perm = torch.arange(B - 1, -1, -1, device='cuda')
+    pos_p = pos.reshape(B, n, 3)[perm].reshape(-1, 3).contiguous()
+    o3 = model(z, pos_p, cell, batch)
+    assert torch.equal(o3.energy, o1.energy[perm])
+    assert torch.equal(o3.gradient_force.reshape(B, n, 3), o1.gradient_force.reshape(B, n, 3)[perm])
+
+
+def test_rotation_translation_invariance():
+    z, pos, cell, batch, c = util.case_inputs('aspirin8_rand', torch.float32)
+    model, _ = make_model('rand')
+    g = torch.Generator().manual_seed(1)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    pos_r = (pos.double() @ q.T + torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)).float()
+    o0 = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    o1 = model(z.cuda(), pos_r.cuda(), cell.cuda(), batch.cuda())
+    assert np.array_equal(o0.edge_index.cpu().numpy(), o1.edge_index.cpu().numpy())
+    assert (o0.energy - o1.energy).abs().max().item() < 1e-4
+    f_rot = o0.gradient_force.cpu().double() @ q.T
+    assert (f_rot - o1.gradient_force.cpu().double()).abs().max().item() < 5e-5
+
+
+def test_empty_and_degenerate_inputs():
+    model, _ = make_model('rand')
+    # a single isolated atom: no edges, energy = head(embedding)
+    out = model(torch.tensor([8], device='cuda'), torch.zeros(1, 3, device='cuda'), torch.zeros(1, 3, 3, device='cuda'),
+                torch.zeros(1, dtype=torch.long, device='cuda'))
+    assert out.edge_index.shape == (2, 0) and out.energy.shape == (1,)
+    assert torch.all(out.gradient_force == 0)
+    # unsorted batch is rejected
+    with pytest.raises(ValueError):
+        model(torch.tensor([1, 1, 1], device='cuda'), torch.rand(3, 3, device='cuda'),
+              torch.zeros(2, 3, 3, device='cuda'), torch.tensor([1, 0, 1], device='cuda'))
+    # CPU tensors are rejected loudly (no CPU path)
+    with pytest.raises(RuntimeError):
+        model(torch.tensor([1]), torch.zeros(1, 3), torch.zeros(1, 3, 3), torch.zeros(1, dtype=torch.long))
