@@ -166,6 +166,18 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const int64_
                         float* virial, float* atom_energy, float* atom_node, float* force_node, void* stream);
 
 /* --------------------------------------------------------------------------
+ * One dense 128 -> 128 linear on the matrix cores (fp32 MFMA, exact fp32):
+ *   C[M][128] = epilogue( prologue(A)[M][128] . W^T ),   W = [128 out][128 in] (nn.Linear layout)
+ * Replaces: torch.nn.functional.linear for the F x F layers of the path
+ *   (message_nodepart newtonnet.py:181-185, equiv_message1/2 :188-197, equiv_update :199,
+ *   EnergyOutput.layers output.py:90-95) and the x W products of their adjoints (pass W^T).
+ * prologue: 0 none, 1 A <- silu(A).   epilogue: 0 store, 1 + bias[n], 2 * silu'(H[m][n]), 3 C += result.
+ * lda/ldc/ldh are row strides in floats (>= 128).  C may alias A only exactly (same pointer, ldc == lda).
+ * ------------------------------------------------------------------------ */
+int nnhip_linear128(const float* A, int32_t lda, const float* W, float* C, int32_t ldc, const float* bias,
+                    const float* H, int32_t ldh, int32_t M, int32_t prologue, int32_t epilogue, void* stream);
+
+/* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = dense MFMA linears,

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnewtonnet_hip.so')
+LIB_PATH = os.path.join(_HERE, 'lib', os.environ.get('NNHIP_LIB_NAME', 'libnewtonnet_hip.so'))  # env: tooling only
 BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
 
 NNHIP_F = 128
@@ -84,10 +84,11 @@ def lib():
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
+    L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
-               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read'):
+               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -95,7 +96,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
-                    'nnhip_timers_read')
+                    'nnhip_timers_read', 'nnhip_linear128')
 
 
 def _check(rc: int, what: str):
@@ -189,6 +190,27 @@ def energy_forces(model: Model, z: torch.Tensor, batch: torch.Tensor, g: Graph, 
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
                                  _ptr(out['force_node']), _stream(dev)), 'nnhip_energy_forces')
+    return out
+
+
+PRO_NONE, PRO_SILU = 0, 1
+EPI_STORE, EPI_BIAS, EPI_DSILU, EPI_ACC = 0, 1, 2, 3
+
+
+def linear128(A: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+              H: Optional[torch.Tensor] = None, prologue: int = PRO_NONE, epilogue: int = EPI_STORE) -> torch.Tensor:
+    """C = epilogue(prologue(A) @ W.T) for [M,128] x [128,128] on the fp32 matrix cores (csrc/lin128.hip).
+    A / out / H may be row-strided views (last dim contiguous)."""
+    assert A.dim() == 2 and A.shape[1] == NNHIP_F and A.stride(1) == 1 and A.dtype == torch.float32
+    assert W.shape == (NNHIP_F, NNHIP_F) and W.is_contiguous() and W.dtype == torch.float32
+    M = A.shape[0]
+    if out is None:
+        out = torch.empty(M, NNHIP_F, dtype=torch.float32, device=A.device)
+    assert out.shape == A.shape and out.stride(1) == 1
+    ldh = H.stride(0) if H is not None else 0
+    _check(lib().nnhip_linear128(_ptr(A), A.stride(0) if M > 1 else NNHIP_F, _ptr(W), _ptr(out),
+                                 out.stride(0) if M > 1 else NNHIP_F, _ptr(bias), _ptr(H), ldh, M, prologue, epilogue,
+                                 _stream(A.device)), 'nnhip_linear128')
     return out
 
 

@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Collect the rocprofv3 evidence for one round on the GPU box (run through gpurun):
+#   1. kernel trace + stats of the default bench command
+#   2. PMC pass: FETCH_SIZE (3 TCC slots)        3. PMC pass: WRITE_SIZE (2 TCC slots)
+# Counters are collected in their own runs with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots).
+# usage: tools/profile_round.sh <tag>      -> gpurun_out/<tag>_{trace,fetch,write}/ + text summaries
+set -uo pipefail
+tag="${1:-r01}"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out
+mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${tag}_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${tag}_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_write.log 2>&1
+python3 tools/rocpd_stats.py $out/${tag}_trace/t_results.db --by-grid > $out/${tag}_kernel_stats.txt
+python3 tools/rocpd_pmc.py $out/${tag}_fetch/f_results.db > $out/${tag}_pmc_fetch.txt
+python3 tools/rocpd_pmc.py $out/${tag}_write/w_results.db > $out/${tag}_pmc_write.txt
+head -25 $out/${tag}_kernel_stats.txt; head -12 $out/${tag}_pmc_fetch.txt; head -12 $out/${tag}_pmc_write.txt
