@@ -132,7 +132,9 @@ int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const flo
  * where (used by the parity tests).
  * Optional outputs (may be NULL): atom_energy[N], atom_node[N][F],
  * force_node[N][3][F], virial[B][3][3] (= -dE/d strain, output.py:154-165).
- * forces may be NULL (energy only: forward sweep only).
+ * forces may be NULL (energy only: forward sweep only).  pos / cell are read only for the virial (may be NULL
+ * otherwise); with periodic cells the virial follows the reference's own strain formula, including the
+ * `cell @ n` image shift of representations.py:93.
  * ------------------------------------------------------------------------ */
 size_t nnhip_workspace_bytes(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers);
 
@@ -159,7 +161,8 @@ typedef struct {
 
 int nnhip_workspace_layout(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers, nnhip_ws_layout* out);
 
-int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const int64_t* batch, const int32_t* mol_ptr,
+int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                        const int32_t* mol_ptr,
                         const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const float* geo,
                         const float* rbf, const float* drbf, const float* disp, int32_t n_atoms, int32_t n_edges,
                         int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,

@@ -250,25 +250,62 @@ force_out_kernel(const float* __restrict__ g_d, const int* __restrict__ row_ptr,
   forces[3 * (size_t)i + 2] = fz;
 }
 
-// virial[b] = - sum_{e in molecule b} disp_e (x) g_d[e]   (symmetrised like the reference's strain, newtonnet.py:153)
+// virial[b] = -dE/d(displacement_b)  (output.py:154-165), the derivative w.r.t. the symmetric strain S the reference
+// applies as pos @ S and cell @ S (newtonnet.py:153-155).  With d_e = (pos_i - pos_j) S - (cell S) n_e, exactly as
+// RadiusGraph writes the image shift (representations.py:93):
+//     dE/dS[a][b] = sum_e ( dp_e[a] g_d[e][b] - (cell^T g_d[e])[a] n_e[b] ),   virial = -sym(dE/dS)
+// n_e (the integer image) is recovered from dp_e - disp_e = cell n_e.  One wave per molecule, lane per atom row.
 __global__ void __launch_bounds__(64)
-virial_kernel(const float* __restrict__ g_d, const float* __restrict__ disp, const int* __restrict__ row_ptr,
+virial_kernel(const float* __restrict__ g_d, const float* __restrict__ disp, const float* __restrict__ pos,
+              const float* __restrict__ cell, const int* __restrict__ row_ptr, const int* __restrict__ col,
               const int* __restrict__ mol_ptr, int n_mol, float* __restrict__ virial) {
   const int b = blockIdx.x;
   if (b >= n_mol) return;
   const int lane = threadIdx.x;
-  const int e0 = row_ptr[mol_ptr[b]], e1 = row_ptr[mol_ptr[b + 1]];
+  double c[9], ic[9];
+  bool pbc = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    c[k] = (double)cell[(size_t)b * 9 + k];
+    pbc |= (c[k] != 0.0);
+  }
+  if (pbc) {
+    const double c00 = c[4] * c[8] - c[5] * c[7], c01 = c[5] * c[6] - c[3] * c[8], c02 = c[3] * c[7] - c[4] * c[6];
+    const double id = 1.0 / (c[0] * c00 + c[1] * c01 + c[2] * c02);
+    ic[0] = c00 * id; ic[1] = (c[2] * c[7] - c[1] * c[8]) * id; ic[2] = (c[1] * c[5] - c[2] * c[4]) * id;
+    ic[3] = c01 * id; ic[4] = (c[0] * c[8] - c[2] * c[6]) * id; ic[5] = (c[2] * c[3] - c[0] * c[5]) * id;
+    ic[6] = c02 * id; ic[7] = (c[1] * c[6] - c[0] * c[7]) * id; ic[8] = (c[0] * c[4] - c[1] * c[3]) * id;
+  }
   double s[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) s[k] = 0.0;
-  for (int e = e0 + lane; e < e1; e += 64) {
-    const float4 g = reinterpret_cast<const float4*>(g_d)[e];
-    const float d[3] = {disp[3 * (size_t)e], disp[3 * (size_t)e + 1], disp[3 * (size_t)e + 2]};
-    const float gg[3] = {g.x, g.y, g.z};
+  for (int i = mol_ptr[b] + lane; i < mol_ptr[b + 1]; i += 64) {
+    const double pi[3] = {pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+    for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+      const int j = col[e];
+      const float4 g4 = reinterpret_cast<const float4*>(g_d)[e];
+      const double g[3] = {g4.x, g4.y, g4.z};
+      double dp[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+      for (int a = 0; a < 3; ++a) dp[a] = pi[a] - (double)pos[3 * (size_t)j + a];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) s[p * 3 + q] += (double)d[p] * (double)gg[q];
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s[a * 3 + q] += dp[a] * g[q];
+      if (pbc) {
+        double sh[3], n[3], ctg[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sh[a] = dp[a] - (double)disp[3 * (size_t)e + a];   // = (cell n)[a]
+#pragma unroll
+        for (int a = 0; a < 3; ++a) n[a] = rint(ic[a * 3] * sh[0] + ic[a * 3 + 1] * sh[1] + ic[a * 3 + 2] * sh[2]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ctg[a] = c[a] * g[0] + c[3 + a] * g[1] + c[6 + a] * g[2];  // (cell^T g)[a]
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) s[a * 3 + q] -= ctg[a] * n[q];
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -419,9 +456,10 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const f
   return 0;
 }
 
-int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const int* row_ptr,
-                        const int* rev, const int* mol_ptr, int n_atoms, int n_edges, int n_mol, int n_layers,
-                        float cutoff, float* g_d, float* forces, float* virial, hipStream_t s) {
+int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
+                        const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
+                        int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
+                        float* virial, hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
   if (n_edges > 0) {
     edge_gd_kernel<<<cdiv(n_edges, 256), 256, 0, s>>>(g_x, g_u, geo, n_edges, n_layers, 1.0f / cutoff, g_d);
@@ -430,7 +468,7 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
   force_out_kernel<<<cdiv(n_atoms, 256), 256, 0, s>>>(g_d, row_ptr, rev, n_atoms, forces);
   LAUNCH_CHECK();
   if (virial) {
-    virial_kernel<<<n_mol, 64, 0, s>>>(g_d, disp, row_ptr, mol_ptr, n_mol, virial);
+    virial_kernel<<<n_mol, 64, 0, s>>>(g_d, disp, pos, cell, row_ptr, col, mol_ptr, n_mol, virial);
     LAUNCH_CHECK();
   }
   return 0;

@@ -23,9 +23,10 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const float* rbf, const float* drbf,
                    const float* edge_w, const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
                    int n_atoms, hipStream_t s);
-int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const int* row_ptr,
-                        const int* rev, const int* mol_ptr, int n_atoms, int n_edges, int n_mol, int n_layers,
-                        float cutoff, float* g_d, float* forces, float* virial, hipStream_t s);
+int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
+                        const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
+                        int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
+                        float* virial, hipStream_t s);
 int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s);
 int launch_node_update_fwd(const float* a_mid, const float* f, const float* q, int n_atoms, float* a_out, hipStream_t s);
 int launch_node_update_bwd(const float* g_a, const float* f, const float* q, const float* g_fout, int n_atoms,
@@ -217,14 +218,13 @@ static int lin2(int pro, int epi, LinGroup g0, LinGroup g1, int lda, int ldc, in
   } while (0)
 
 // ---- the hot path --------------------------------------------------------------------------------------
-extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const int64_t* batch,
+extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                                    const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
                                    const int32_t* rev, const float* geo, const float* rbf, const float* drbf,
                                    const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                                    size_t workspace_bytes, float* energy, float* forces, float* virial,
                                    float* atom_energy_out, float* atom_node_out, float* force_node_out,
                                    void* stream_) {
-  (void)batch;
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -366,7 +366,11 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     g_fout = has_f ? g_fin : nullptr;
     pp ^= 1;
   }
-  TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, row_ptr, rev, mol_ptr, N, E, B, L, model->cutoff,
-                          P(w.g_d), forces, virial, s));
+  if (virial && (!pos || !cell)) {
+    nnhip_set_error("nnhip_energy_forces: virial needs pos and cell");
+    return NNHIP_E_INVALID;
+  }
+  TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, pos, cell, row_ptr, col, rev, mol_ptr, N, E, B, L,
+                          model->cutoff, P(w.g_d), forces, virial, s));
   return NNHIP_OK;
 }

@@ -82,7 +82,7 @@ def lib():
     L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.nnhip_workspace_bytes.restype = sz
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
-    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
+    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_timers_enable.argtypes = [i32]
@@ -169,7 +169,7 @@ def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
     return out
 
 
-def energy_forces(model: Model, z: torch.Tensor, batch: torch.Tensor, g: Graph, want_forces: bool = True,
+def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
                   want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None):
     """Run the whole hot path.  Returns dict(energy, forces, virial, atom_energy, atom_node, force_node, workspace)."""
     L = lib()
@@ -185,7 +185,8 @@ def energy_forces(model: Model, z: torch.Tensor, batch: torch.Tensor, g: Graph, 
     out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
     out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
     out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
-    _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
+    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
                                  _ptr(g.rev), _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.disp), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),

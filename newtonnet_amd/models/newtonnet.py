@@ -165,7 +165,8 @@ class NewtonNet(nn.Module):
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies)
-            res = hip.energy_forces(model, zc, batch, g, want_forces=want_forces, want_virial=want_virial)
+            res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
+                                    want_virial=want_virial)
 
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
                                   edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)

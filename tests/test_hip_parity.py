@@ -64,7 +64,7 @@ def test_intermediates_against_trace():
     g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0,
                         model.embedding_layers.edge_embedding.embedding.frequencies)
     assert np.array_equal(g.edge_index.cpu().numpy(), T['edge_index'].numpy())
-    res = hip.energy_forces(m, z.cuda(), batch.cuda(), g)
+    res = hip.energy_forces(m, z.cuda(), pos.cuda(), cell.cuda(), g)
     torch.cuda.synchronize()
     N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
     lay = hip.workspace_layout(N, E, B, L)
@@ -180,3 +180,22 @@ def test_empty_and_degenerate_inputs():
     # CPU tensors are rejected loudly (no CPU path)
     with pytest.raises(RuntimeError):
         model(torch.tensor([1]), torch.zeros(1, 3), torch.zeros(1, 3, 3), torch.zeros(1, dtype=torch.long))
+
+
+@pytest.mark.parametrize('case', ['aspirin8_rand', 'pbc216_rand', 'pbc_batch2_rand'])
+def test_virial_and_stress(case):
+    """virial = -dE/d(strain), stress = (dE/d strain)/det(cell) (output.py:154-180) vs the oracle's autograd through the
+    reference's own strain construction (including the `cell @ n` image shift)."""
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    periodic = bool((cell != 0).any())
+    props = ['energy', 'gradient_force', 'virial'] + (['stress'] if periodic else [])
+    model, sd = make_model('rand', props)
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    scale = max(1.0, want['virial'].abs().max().item())
+    assert (out.virial.cpu().double() - want['virial']).abs().max().item() < 2e-5 * scale
+    if periodic:
+        stress = -want['virial'] / cell.double().det().view(-1, 1, 1)
+        assert (out.stress.cpu().double() - stress).abs().max().item() < 2e-5 * scale / cell.det().abs().min().item() + 1e-9
+    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), max(1.0, want['forces'].abs().max().item() / 5))
