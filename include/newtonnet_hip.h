@@ -181,6 +181,18 @@ int nnhip_linear128(const float* A, int32_t lda, const float* W, float* C, int32
                     const float* H, int32_t ldh, int32_t M, int32_t prologue, int32_t epilogue, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Differentiable building blocks of the train-mode forward (both are linear maps and each other's adjoints, so
+ * torch.autograd can differentiate through them twice: force-loss training, output.py:66-73 + trainer.py:307-309).
+ * Replaces: torch_geometric.utils.scatter(..., reduce='sum') (newtonnet.py:214,226; output.py:246) and the
+ *   index gathers m[edge_index[k]], force_node[edge_index[1]] (newtonnet.py:211,223).
+ *   segment_sum: out[i][:] = sum_{e in [row_ptr[i], row_ptr[i+1])} x[e][:]   (CSR rows; deterministic, no atomics)
+ *   gather_rows: out[e][:] = x[idx[e]][:]
+ * width = floats per row (even).
+ * ------------------------------------------------------------------------ */
+int nnhip_segment_sum(const float* x, const int32_t* row_ptr, int32_t n_rows, int32_t width, float* out, void* stream);
+int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_out, int32_t width, float* out, void* stream);
+
+/* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = dense MFMA linears,

@@ -520,3 +520,61 @@ int launch_transposes(const float* const* src, float* const* dst, int count, hip
   LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone differentiable building blocks for the train-mode forward (newtonnet_amd/train_ops.py).
+// They are linear maps and each other's adjoints, so autograd can differentiate through them twice
+// (force-loss training: output.py:66-73 with create_graph=True, trainer.py:307-309).
+//   segment_sum:  out[i][:] = sum_{e in [row_ptr[i], row_ptr[i+1])} x[e][:]      (deterministic scatter_sum)
+//   gather_rows:  out[e][:] = x[idx[e]][:]
+// One wave per output row; width (floats per row) must be a multiple of 2.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+segment_sum_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr, int n_rows, int width,
+                   float* __restrict__ out) {
+  const int i = blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (i >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  for (int c = 2 * lane; c < width; c += 128) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int e = beg; e < end; ++e) acc = acc + ld2(x + (size_t)e * width + c);
+    st2(out + (size_t)i * width + c, acc);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ idx, int n_out, int width,
+                   float* __restrict__ out) {
+  const int e = blockIdx.x * ROWS_PER_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (e >= n_out) return;
+  const int lane = threadIdx.x & 63;
+  const int j = idx[e];
+  for (int c = 2 * lane; c < width; c += 128) st2(out + (size_t)e * width + c, ld2(x + (size_t)j * width + c));
+}
+
+extern "C" int nnhip_segment_sum(const float* x, const int32_t* row_ptr, int32_t n_rows, int32_t width, float* out,
+                                 void* stream) {
+  if (!row_ptr || !out || n_rows < 0 || width < 2 || (width & 1)) {
+    nnhip_set_error("nnhip_segment_sum: bad arguments (width must be even)");
+    return NNHIP_E_INVALID;
+  }
+  if (n_rows == 0) return NNHIP_OK;
+  ScopedTimer t0(TC_EDGE, (hipStream_t)stream);
+  segment_sum_kernel<<<cdiv(n_rows, ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(x, row_ptr, n_rows, width, out);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_out, int32_t width, float* out,
+                                 void* stream) {
+  if (!idx || !out || n_out < 0 || width < 2 || (width & 1)) {
+    nnhip_set_error("nnhip_gather_rows: bad arguments (width must be even)");
+    return NNHIP_E_INVALID;
+  }
+  if (n_out == 0) return NNHIP_OK;
+  ScopedTimer t0(TC_EDGE, (hipStream_t)stream);
+  gather_rows_kernel<<<cdiv(n_out, ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(x, idx, n_out, width, out);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}

@@ -85,10 +85,12 @@ def lib():
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    L.nnhip_segment_sum.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.nnhip_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
-               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128'):
+               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -96,7 +98,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
-                    'nnhip_timers_read', 'nnhip_linear128')
+                    'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows')
 
 
 def _check(rc: int, what: str):
@@ -212,6 +214,26 @@ def linear128(A: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = No
     _check(lib().nnhip_linear128(_ptr(A), A.stride(0) if M > 1 else NNHIP_F, _ptr(W), _ptr(out),
                                  out.stride(0) if M > 1 else NNHIP_F, _ptr(bias), _ptr(H), ldh, M, prologue, epilogue,
                                  _stream(A.device)), 'nnhip_linear128')
+    return out
+
+
+def segment_sum(x: torch.Tensor, row_ptr: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """out[i] = sum of x[row_ptr[i]:row_ptr[i+1]] over dim 0 (deterministic CSR scatter-sum)."""
+    x = _f32c(x, 'x')
+    width = x[0].numel() if x.shape[0] else int(torch.tensor(x.shape[1:]).prod())
+    out = torch.empty((n_rows,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _check(lib().nnhip_segment_sum(_ptr(x), _ptr(row_ptr), n_rows, width, _ptr(out), _stream(x.device)),
+           'nnhip_segment_sum')
+    return out
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[e] = x[idx[e]] (idx int32)."""
+    x = _f32c(x, 'x')
+    width = int(torch.tensor(x.shape[1:]).prod())
+    out = torch.empty((idx.numel(),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    _check(lib().nnhip_gather_rows(_ptr(x), _ptr(idx), idx.numel(), width, _ptr(out), _stream(x.device)),
+           'nnhip_gather_rows')
     return out
 
 

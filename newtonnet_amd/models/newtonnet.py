@@ -145,10 +145,7 @@ class NewtonNet(nn.Module):
             if key not in ('energy', 'gradient_force', 'virial', 'stress'):
                 raise NotImplementedError(f"output property '{key}' is outside the MI355X hot path")
         deriv_layers = [ol for ol in self.output_layers if isinstance(ol, DerivativeProperty)]
-        if any(ol.create_graph for ol in deriv_layers) and torch.is_grad_enabled():
-            raise NotImplementedError(
-                'train-mode forward (create_graph=True: force-loss backward through the kernels) is not built yet; '
-                'call model.eval() for inference.  See DESIGN.md "what comes next".')
+        train_graph = any(ol.create_graph for ol in deriv_layers) and torch.is_grad_enabled()
         energy_idx = keys.index('energy')
         want_forces = len(deriv_layers) > 0
         want_virial = any(isinstance(ol, (VirialOutput, StressOutput)) for ol in deriv_layers)
@@ -159,6 +156,9 @@ class NewtonNet(nn.Module):
         if emb.requires_dr and pos.is_leaf and pos.is_floating_point():
             pos.requires_grad = True
             displacement.requires_grad = True
+
+        if train_graph:
+            return self._forward_train(z, pos, cell, batch, keys, energy_idx, displacement)
 
         with torch.no_grad():
             model = self._hip_model(energy_idx)
@@ -183,4 +183,26 @@ class NewtonNet(nn.Module):
                 outputs.virial = res['virial']
             elif key == 'stress':
                 outputs.stress = -res['virial'] / cell.det().view(-1, 1, 1)
+        return outputs
+
+    # ------------------------------------------------------------------------------------------
+    def _forward_train(self, z, pos, cell, batch, keys, energy_idx, displacement):
+        """Train mode (create_graph=True): outputs stay attached to autograd so a force loss can be back-propagated
+        (trainer.py:301-313).  Built from twice-differentiable HIP primitives, see newtonnet_amd/train_ops.py."""
+        from newtonnet_amd import train_ops
+        for key in keys:
+            if key not in ('energy', 'gradient_force'):
+                raise NotImplementedError(f"train-mode forward supports energy / gradient_force (got '{key}')")
+        self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
+        if not pos.requires_grad:
+            raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
+        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx)
+        outputs = CustomOutputSet(z=z, pos=pos, atom_node=atom_node, force_node=force_node, edge_index=g.edge_index,
+                                  cell=cell, displacement=displacement, batch=batch)
+        outputs.energy = energy
+        if 'gradient_force' in keys:
+            (pos_grad,) = torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True,
+                                              retain_graph=True)
+            outputs.pos_grad = pos_grad
+            outputs.gradient_force = -pos_grad
         return outputs

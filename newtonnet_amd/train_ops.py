@@ -1,0 +1,106 @@
+"""Train-mode forward of the hot path: differentiable twice (force-loss training).
+
+The reference trains by back-propagating through the autograd force (`create_graph=True`, output.py:66-73;
+trainer.py:307-309).  Here the graph build, the scatter-sums and the row gathers are HIP kernels wrapped as
+autograd Functions that are linear maps and each other's adjoints (nnhip_segment_sum / nnhip_gather_rows), so
+torch.autograd can differentiate the backward pass again; the dense linears go to the vendor GEMM through
+torch.nn.functional.linear (plain library GEMMs) and the remaining elementwise algebra is torch on the GPU.
+The fused inference kernels (csrc/pipeline.hip) are not used in train mode.
+
+Mirrors: EmbeddingNet.forward newtonnet.py:139-161, EdgeEmbedding.forward representations.py:20-43,
+InteractionNet.forward newtonnet.py:207-237, EnergyOutput/ScaleShift/EnergyAggregator output.py:98-100,
+scalers.py:55-58, output.py:246.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as Fn
+
+from newtonnet_amd import hip
+
+
+class _EdgeGraph:
+    """Index arrays of one batch for the Functions below (int32 on the device)."""
+    def __init__(self, g: hip.Graph):
+        self.row_ptr, self.col, self.rev = g.row_ptr, g.col, g.rev
+        self.row = g.edge_index[0].to(torch.int32)          # receiver of each edge
+        self.n_atoms, self.n_edges = g.n_atoms, g.n_edges
+
+
+class SegmentSum(torch.autograd.Function):
+    """out[i] = sum_{e in row i} x[e]  (scatter_sum over the receiver, newtonnet.py:214,226)."""
+    @staticmethod
+    def forward(ctx, x, eg):
+        ctx.eg = eg
+        return hip.segment_sum(x, eg.row_ptr, eg.n_atoms)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return Gather.apply(gy.contiguous(), ctx.eg, 'row'), None
+
+
+class Gather(torch.autograd.Function):
+    """out[e] = x[idx[e]] with idx = receiver ('row'), sender ('col') or reverse edge ('rev')."""
+    @staticmethod
+    def forward(ctx, x, eg, which):
+        ctx.eg, ctx.which = eg, which
+        return hip.gather_rows(x, getattr(eg, which))
+
+    @staticmethod
+    def backward(ctx, gy):
+        eg, which = ctx.eg, ctx.which
+        gy = gy.contiguous()
+        if which == 'row':
+            return SegmentSum.apply(gy, eg), None, None
+        if which == 'col':   # scatter over the sender == segment-sum of the reverse-edge permutation
+            return SegmentSum.apply(Gather.apply(gy, eg, 'rev'), eg), None, None
+        return Gather.apply(gy, eg, 'rev'), None, None      # rev is an involution
+
+
+def _envelope(x, p=9):
+    return 1.0 - 0.5 * (p + 1) * (p + 2) * x.pow(p) + p * (p + 2) * x.pow(p + 1) - 0.5 * p * (p + 1) * x.pow(p + 2)
+
+
+def _mlp(seq, x):
+    return Fn.linear(Fn.silu(Fn.linear(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
+
+
+def forward_train(model, z, pos, cell, batch, energy_idx: int):
+    """Returns (energy [B], atom_node, force_node, edge_index, graph); everything attached to autograd."""
+    emb = model.embedding_layers
+    ee = emb.edge_embedding
+    with torch.no_grad():
+        g = hip.build_graph(pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies)
+    eg = _EdgeGraph(g)
+    i, j = g.edge_index[0], g.edge_index[1]
+    # disp = pos_i - pos_j - (constant periodic image shift found by the neighbor kernel)
+    shift = (pos.detach()[i] - pos.detach()[j]) - g.disp
+    disp = pos[i] - pos[j] - shift
+    r = disp.norm(dim=-1, keepdim=True)
+    u = disp / r
+    x = r / ee.cutoff
+    rbf = _envelope(x) * (torch.sin(ee.embedding.frequencies * x) / x)
+
+    a = emb.node_embedding(z)
+    f = torch.zeros(z.shape[0], 3, emb.n_features, dtype=pos.dtype, device=pos.device)
+    for l, il in enumerate(model.interaction_layers):
+        m = _mlp(il.message_nodepart, a)
+        msg = Fn.linear(rbf, il.message_edgepart.weight) * Gather.apply(m, eg, 'row') * Gather.apply(m, eg, 'col')
+        a = a + SegmentSum.apply(msg, eg)
+        phi1 = _mlp(il.equiv_message1, msg)
+        eq = phi1.unsqueeze(1) * u.unsqueeze(2)
+        if l > 0:   # force_node == 0 entering the first layer (newtonnet.py:143)
+            eq = eq + _mlp(il.equiv_message2, msg).unsqueeze(1) * Gather.apply(f, eg, 'col')
+        f = f + SegmentSum.apply(eq.contiguous(), eg)
+        a = a + (f * Fn.linear(f, il.equiv_update.weight)).sum(dim=1)
+
+    head = model.output_layers[energy_idx].layers
+    e = Fn.linear(Fn.silu(Fn.linear(Fn.silu(Fn.linear(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),
+                  head[4].weight, head[4].bias)
+    sc = model.scalers[energy_idx]
+    if sc.scale is not None:
+        e = e * sc.scale(z)
+    if sc.shift is not None:
+        e = e + sc.shift(z)
+    energy = torch.zeros(cell.shape[0], dtype=e.dtype, device=e.device).index_add_(0, batch, e.reshape(-1))
+    return energy, a, f, g

@@ -1,0 +1,115 @@
+"""GPU tests of the train-mode path (BASELINE.json configs[2]: force-loss backward through the HIP kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(which='rand'):
+    from newtonnet_amd.models import NewtonNet
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    sd = util.load_state(which, torch.float32)
+    model.load_state_dict(sd)
+    return model.to('cuda'), sd
+
+
+def test_segment_sum_and_gather_double_backward():
+    """SegmentSum / Gather are each other's adjoints: first and second derivatives match torch index ops."""
+    from newtonnet_amd import hip, train_ops
+    z, pos, cell, batch, c = util.case_inputs('mixed_rand', torch.float32)
+    freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
+    g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+    eg = train_ops._EdgeGraph(g)
+    i, j = g.edge_index[0], g.edge_index[1]
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(g.n_atoms, 3, 128, device='cuda', generator=gen, requires_grad=True)
+    w = torch.randn(g.n_edges, 3, 128, device='cuda', generator=gen)
+
+    def f_hip(x):
+        y = train_ops.Gather.apply(x, eg, 'col') * w + train_ops.Gather.apply(x, eg, 'row')
+        return train_ops.SegmentSum.apply(y * y, eg)
+
+    def f_ref(x):
+        y = x[j] * w + x[i]
+        return torch.zeros_like(x).index_add_(0, i, y * y)
+
+    for f in (f_hip, f_ref):
+        pass
+    out_h, out_r = f_hip(x), f_ref(x)
+    assert torch.allclose(out_h, out_r, rtol=1e-5, atol=1e-5)
+    v = torch.randn_like(out_h)
+    (g1h,) = torch.autograd.grad((out_h * v).sum(), x, create_graph=True)
+    (g1r,) = torch.autograd.grad((out_r * v).sum(), x, create_graph=True)
+    assert torch.allclose(g1h, g1r, rtol=1e-4, atol=1e-4)
+    (g2h,) = torch.autograd.grad(g1h.pow(2).sum(), x)
+    (g2r,) = torch.autograd.grad(g1r.pow(2).sum(), x)
+    assert torch.allclose(g2h, g2r, rtol=1e-3, atol=1e-2 * g2r.abs().max().item())
+
+
+@pytest.mark.parametrize('case', ['ethanol4_rand', 'mixed_rand', 'pbc216_rand'])
+def test_train_forward_matches_eval_and_oracle(case):
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    model, sd = make_model()
+    model.eval()
+    o_eval = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    model.train()
+    p = pos.cuda().requires_grad_(True)
+    o_train = model(z.cuda(), p, cell.cuda(), batch.cuda())
+    assert o_train.energy.requires_grad and o_train.gradient_force.requires_grad
+    assert np.array_equal(o_train.edge_index.cpu().numpy(), c['f32_edge_index'])
+    fscale = max(1.0, np.abs(c['f64_forces']).max() / 5.0)
+    assert (o_train.energy - o_eval.energy).abs().max().item() < 2e-5 * max(1.0, o_eval.energy.abs().max().item())
+    assert (o_train.gradient_force - o_eval.gradient_force).abs().max().item() < 2e-5 * fscale
+    d = np.abs(o_train.gradient_force.detach().cpu().numpy().astype(np.float64) - c['f64_forces'])
+    assert d.mean() <= util.FORCE_MAE_TOL * fscale and d.max() <= util.FORCE_MAX_TOL * fscale
+
+
+def test_parameter_gradients_match_oracle_double_backward():
+    """config 3 shape: ethanol-like molecules, loss = MSE(E) + 50 MSE(F) (scripts/config.yml:45-51).
+    fp32 HIP path vs fp64 oracle: relative gradient-norm error <= 1e-4 per parameter tensor group."""
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, c = util.case_inputs('ethanol4_rand', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    e_lab = torch.randn(4, generator=g)
+    f_lab = torch.randn(36, 3, generator=g)
+    model, sd = make_model()
+    model.train()
+    p = pos.cuda().requires_grad_(True)
+    out = model(z.cuda(), p, cell.cuda(), batch.cuda())
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(
+        out.gradient_force, f_lab.cuda())
+    loss.backward()
+    want_loss, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(),
+                                              batch, e_lab.double(), f_lab.double())
+    assert abs(loss.item() - want_loss.item()) <= 1e-4 * abs(want_loss.item())
+    tot_err = tot_ref = 0.0
+    for name, prm in model.named_parameters():
+        if not prm.requires_grad:
+            continue
+        got = prm.grad.detach().cpu().double() if prm.grad is not None else torch.zeros_like(want[name])
+        w = want[name]
+        err, nrm = (got - w).norm().item(), w.norm().item()
+        tot_err += err ** 2
+        tot_ref += nrm ** 2
+        assert err <= 1e-4 * max(nrm, 1e-3 * np.sqrt(max(tot_ref, 1e-30))) + 1e-7, (name, err, nrm)
+    assert np.sqrt(tot_err) <= 1e-4 * np.sqrt(tot_ref)
+    # layer-0 equiv_message2 multiplies force_node == 0: exactly-zero gradient
+    assert model.interaction_layers[0].equiv_message2[0].weight.grad is None or \
+        model.interaction_layers[0].equiv_message2[0].weight.grad.abs().max().item() == 0.0
+
+
+def test_train_step_reduces_loss():
+    from newtonnet_amd.distributed import TrainStep
+    z, pos, cell, batch, c = util.case_inputs('ethanol4_rand', torch.float32)
+    g = torch.Generator().manual_seed(5)
+    e_lab = (torch.randn(4, generator=g) * 0.1 - 0.9).cuda()
+    f_lab = (torch.randn(36, 3, generator=g) * 0.1).cuda()
+    model, _ = make_model()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)             # scripts/config.yml:52-54
+    step = TrainStep(model, opt, w_energy=1.0, w_force=50.0, clip_grad=1.0)
+    losses = [step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab).item() for _ in range(8)]
+    assert losses[-1] < losses[0], losses
