@@ -43,6 +43,19 @@ def synthetic_aspirin(n_conf, seed, device):
     return z.to(device), pos.to(device), cell.to(device), batch.to(device)
 
 
+def synthetic_box(n_atoms, n_side, seed, device):
+    """first n_atoms sites of an n_side^3 simple-cubic lattice (spacing 100/n_side A) +
+    U(-0.5, 0.5) A jitter, species uniform over {1,6,7,8}, one periodic molecule, cell = diag(100)."""
+    g = torch.Generator().manual_seed(seed)
+    a = 100.0 / n_side
+    idx = torch.arange(n_atoms)
+    grid = torch.stack([idx // (n_side * n_side), (idx // n_side) % n_side, idx % n_side], 1).double() * a
+    pos = ((grid + (torch.rand(n_atoms, 3, generator=g, dtype=torch.float64) - 0.5)) % 100.0).float()
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (n_atoms,), generator=g)]
+    cell = (torch.eye(3) * 100.0).unsqueeze(0)
+    return z.to(device), pos.to(device), cell.to(device), torch.zeros(n_atoms, dtype=torch.long, device=device)
+
+
 def algorithmic_counts(N, E, L=3, F=128):
     """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step."""
     edge_fwd = L * (1568 * E + 4608 * N)
@@ -67,6 +80,8 @@ def main():
     ap.add_argument('--conformers', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--weights', default='seed0', choices=['seed0', 'ckpt'])
+    ap.add_argument('--workload', default='aspirin', choices=['aspirin', 'box100k'],
+                    help="aspirin = BASELINE configs[1] (the headline); box100k = configs[4], 100k-atom periodic box")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -93,7 +108,10 @@ def main():
     model = model.to(device)
     model.eval()
 
-    z, pos, cell, batch = synthetic_aspirin(args.conformers, seed=rank, device=device)
+    if args.workload == 'box100k':
+        z, pos, cell, batch = synthetic_box(100000, 47, seed=rank, device=device)
+    else:
+        z, pos, cell, batch = synthetic_aspirin(args.conformers, seed=rank, device=device)
     N = z.shape[0]
 
     def step():
@@ -149,7 +167,7 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'aspirin':
         from oracle import newtonnet_ref as ref          # timed CPU baseline leg (allowed use of the oracle)
         # Bounded sample: the first 256 conformers of the same batch (about 1.5 s per evaluation), on 16 host threads
         # -- the measured sweet spot of torch CPU on the GPU box (tools/cpu_sweep.py: 8/16/32/64 threads give
@@ -180,8 +198,10 @@ def main():
             'value': round(value, 1), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
-                                   f'fp32, energy+force, neighbor list included (BASELINE.json configs[1])',
+            'config': {'workload': (f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
+                                    f'fp32, energy+force, neighbor list included (BASELINE.json configs[1])')
+                       if args.workload == 'aspirin' else
+                       'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,

@@ -107,6 +107,21 @@ int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, 
                      int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream);
 
 /* --------------------------------------------------------------------------
+ * O(N) variant of the neighbor list for ONE large orthorhombic periodic box (BASELINE config 5; the reference's
+ * all-pairs build, representations.py:74-85, needs O(N^2) memory and cannot run it).  Bit-identical output to
+ * nnhip_graph_count/fill (same predicate, same displacement arithmetic, same edge order); candidates are pruned
+ * with a grid of cells >= cutoff wide.  box_len_host = the three diagonal cell entries (HOST pointer); every
+ * length must be >= 3 x cutoff (else NNHIP_E_UNSUPPORTED: use the all-pairs entry points).
+ * scratch: nnhip_graph_cells_scratch_bytes() bytes, kept between the count and fill calls.
+ * ------------------------------------------------------------------------ */
+size_t nnhip_graph_cells_scratch_bytes(int32_t n_atoms, const float* box_len_host, float cutoff);
+int nnhip_graph_count_cells(const float* pos, const float* cell, int32_t n_atoms, float cutoff,
+                            const float* box_len_host, void* scratch, int32_t* mol_ptr, int32_t* row_ptr, void* stream);
+int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms, int32_t n_edges, float cutoff,
+                           const float* box_len_host, void* scratch, const int32_t* row_ptr, int32_t* col, int32_t* rev,
+                           float* disp, int64_t* edge_index, void* stream);
+
+/* --------------------------------------------------------------------------
  * Edge embedding.
  * Replaces: ScaledNorm.forward (representations.py:118-133), PolynomialCutoff
  *   p=9 (:155-171), RadialBesselLayer.forward (:223-235) and their product (:41).

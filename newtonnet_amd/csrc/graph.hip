@@ -271,3 +271,199 @@ extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
+
+// =============================================================================================
+// O(N) neighbor list for ONE large orthorhombic periodic box (BASELINE config 5: 100k atoms, which the
+// reference's O(N^2) all-pairs build cannot hold in memory).
+//
+// Same predicate, same displacement arithmetic (pair_disp) and same (i, j)-ascending edge order as the
+// all-pairs kernel above, so the two paths return bit-identical lists; only the candidate set is pruned:
+// atoms are binned on a grid of cells >= cutoff wide, a row looks at the 27 surrounding cells, and each
+// row is sorted by j.  Preconditions (checked by the caller, newtonnet_amd/hip.py): one molecule, diagonal
+// cell, every box length >= 3 cells.  Integer atomics only (bin counters): the result is deterministic.
+// =============================================================================================
+struct CellGrid {
+  int nb[3];
+  float inv_len[3];  // 1 / L_k
+};
+
+__device__ __forceinline__ int bin_coord(float p, float inv_len, int nb) {
+  float s = p * inv_len;
+  s -= floorf(s);                      // wrapped fractional coordinate in [0, 1)
+  int b = (int)(s * (float)nb);
+  return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
+}
+
+__global__ void __launch_bounds__(256)
+cells_bin_count_kernel(const float* __restrict__ pos, int n_atoms, CellGrid g, int* __restrict__ bin_of,
+                       int* __restrict__ bin_cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int bx = bin_coord(pos[3 * i], g.inv_len[0], g.nb[0]);
+  const int by = bin_coord(pos[3 * i + 1], g.inv_len[1], g.nb[1]);
+  const int bz = bin_coord(pos[3 * i + 2], g.inv_len[2], g.nb[2]);
+  const int b = (bx * g.nb[1] + by) * g.nb[2] + bz;
+  bin_of[i] = b;
+  atomicAdd(&bin_cnt[b], 1);
+}
+
+__global__ void __launch_bounds__(256)
+cells_bin_fill_kernel(const int* __restrict__ bin_of, const int* __restrict__ bin_ptr, int n_atoms,
+                      int* __restrict__ cursor, int* __restrict__ bin_atoms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int b = bin_of[i];
+  bin_atoms[bin_ptr[b] + atomicAdd(&cursor[b], 1)] = i;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+cells_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int* __restrict__ bin_of,
+                  const int* __restrict__ bin_ptr, const int* __restrict__ bin_atoms, CellGrid g, int n_atoms,
+                  float cutoff, int* __restrict__ deg, const int* __restrict__ row_ptr, int* col,
+                  int* __restrict__ erow, float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const CellInfo ci = load_cell(cell, 0);
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  const int b = bin_of[i];
+  const int bz = b % g.nb[2], by = (b / g.nb[2]) % g.nb[1], bx = b / (g.nb[2] * g.nb[1]);
+  const int base = FILL ? row_ptr[i] : 0;
+  int cnt = 0;
+  for (int dx = -1; dx <= 1; ++dx) {
+    const int cx = (bx + dx + g.nb[0]) % g.nb[0];
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int cy = (by + dy + g.nb[1]) % g.nb[1];
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int cz = (bz + dz + g.nb[2]) % g.nb[2];
+        const int cb = (cx * g.nb[1] + cy) * g.nb[2] + cz;
+        for (int k = bin_ptr[cb]; k < bin_ptr[cb + 1]; ++k) {
+          const int j = bin_atoms[k];
+          if (j == i) continue;
+          float ddx, ddy, ddz;
+          const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, ddx, ddy, ddz);
+          if (r < cutoff) {
+            if (FILL) {  // insertion sort by j inside this row's slice of col[]
+              int p = base + cnt;
+              while (p > base && col[p - 1] > j) {
+                col[p] = col[p - 1];
+                --p;
+              }
+              col[p] = j;
+            }
+            ++cnt;
+          }
+        }
+      }
+    }
+  }
+  if (!FILL) {
+    deg[i] = cnt;
+    return;
+  }
+  for (int w = base; w < base + cnt; ++w) {
+    const int j = col[w];
+    float ddx, ddy, ddz;
+    pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, ddx, ddy, ddz);
+    erow[w] = i;
+    disp[3 * (long)w] = ddx;
+    disp[3 * (long)w + 1] = ddy;
+    disp[3 * (long)w + 2] = ddz;
+    if (edge_index) {
+      edge_index[w] = i;
+      edge_index[(long)n_edges + w] = j;
+    }
+  }
+}
+
+static int make_grid(const float* box_len_host, float cutoff, CellGrid& g, int& n_bins) {
+  n_bins = 1;
+  for (int k = 0; k < 3; ++k) {
+    if (!(box_len_host[k] > 0.f)) return NNHIP_E_INVALID;
+    g.nb[k] = (int)floorf(box_len_host[k] / (cutoff * 1.0001f));  // cells strictly wider than the cutoff
+    if (g.nb[k] < 3) return NNHIP_E_UNSUPPORTED;
+    if (g.nb[k] > 1024) g.nb[k] = 1024;
+    g.inv_len[k] = 1.0f / box_len_host[k];
+    n_bins *= g.nb[k];
+  }
+  return NNHIP_OK;
+}
+
+// scratch: bin_of[N] | bin_cnt/bin_ptr[n_bins+1] | cursor[n_bins] | bin_atoms[N]   (int32)
+extern "C" size_t nnhip_graph_cells_scratch_bytes(int32_t n_atoms, const float* box_len_host, float cutoff) {
+  CellGrid g;
+  int n_bins;
+  if (make_grid(box_len_host, cutoff, g, n_bins) != NNHIP_OK) return 0;
+  return sizeof(int32_t) * ((size_t)2 * n_atoms + 2 * (size_t)n_bins + 2);
+}
+
+static int cells_common(const float* pos, int n_atoms, const float* box_len_host, float cutoff, void* scratch,
+                        CellGrid& g, int*& bin_of, int*& bin_ptr, int*& cursor, int*& bin_atoms, bool build,
+                        hipStream_t stream) {
+  int n_bins;
+  const int rc = make_grid(box_len_host, cutoff, g, n_bins);
+  if (rc != NNHIP_OK) {
+    nnhip_set_error("nnhip_graph_*_cells: box must be orthorhombic with every length >= 3 x cutoff");
+    return rc;
+  }
+  int* s = (int*)scratch;
+  bin_of = s;
+  bin_ptr = s + n_atoms;
+  cursor = bin_ptr + n_bins + 1;
+  bin_atoms = cursor + n_bins;
+  if (build) {
+    HIP_TRY(hipMemsetAsync(bin_ptr, 0, sizeof(int) * (2 * (size_t)n_bins + 1), stream));
+    cells_bin_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, n_atoms, g, bin_of, bin_ptr);
+    LAUNCH_CHECK();
+    scan_rows_kernel<<<1, 1024, 0, stream>>>(bin_ptr, n_bins, bin_ptr);
+    LAUNCH_CHECK();
+    cells_bin_fill_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(bin_of, bin_ptr, n_atoms, cursor, bin_atoms);
+    LAUNCH_CHECK();
+  }
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_graph_count_cells(const float* pos, const float* cell, int32_t n_atoms, float cutoff,
+                                       const float* box_len_host, void* scratch, int32_t* mol_ptr, int32_t* row_ptr,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms <= 0 || !scratch || !row_ptr || !mol_ptr) {
+    nnhip_set_error("nnhip_graph_count_cells: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  ScopedTimer tm(TC_GRAPH, stream);
+  CellGrid g;
+  int *bin_of, *bin_ptr, *cursor, *bin_atoms;
+  const int rc = cells_common(pos, n_atoms, box_len_host, cutoff, scratch, g, bin_of, bin_ptr, cursor, bin_atoms, true, stream);
+  if (rc) return rc;
+  const int32_t mp[2] = {0, n_atoms};
+  HIP_TRY(hipMemcpyAsync(mol_ptr, mp, sizeof(mp), hipMemcpyHostToDevice, stream));
+  cells_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cutoff,
+                                                                   row_ptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  LAUNCH_CHECK();
+  scan_rows_kernel<<<1, 1024, 0, stream>>>(row_ptr, n_atoms, row_ptr);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms, int32_t n_edges, float cutoff,
+                                      const float* box_len_host, void* scratch, const int32_t* row_ptr, int32_t* col,
+                                      int32_t* rev, float* disp, int64_t* edge_index, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms <= 0 || n_edges < 0 || !scratch) {
+    nnhip_set_error("nnhip_graph_fill_cells: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  CellGrid g;
+  int *bin_of, *bin_ptr, *cursor, *bin_atoms;
+  const int rc = cells_common(pos, n_atoms, box_len_host, cutoff, scratch, g, bin_of, bin_ptr, cursor, bin_atoms, false, stream);
+  if (rc) return rc;
+  cells_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cutoff,
+                                                                  nullptr, row_ptr, col, rev, disp, edge_index, n_edges);
+  LAUNCH_CHECK();
+  edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}

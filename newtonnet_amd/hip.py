@@ -79,6 +79,10 @@ def lib():
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp]
+    L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
+    L.nnhip_graph_cells_scratch_bytes.restype = sz
+    L.nnhip_graph_count_cells.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp]
+    L.nnhip_graph_fill_cells.argtypes = [vp, vp, i32, i32, f32, _fp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.nnhip_workspace_bytes.restype = sz
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
@@ -90,7 +94,8 @@ def lib():
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
-               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows'):
+               'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
+               'nnhip_graph_fill_cells'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -98,7 +103,8 @@ def lib():
 
 EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
-                    'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows')
+                    'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
+                    'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells')
 
 
 def _check(rc: int, what: str):
@@ -118,6 +124,9 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise NotImplementedError(f'{name}: the HIP path computes in float32 (got {t.dtype})')
     return t.contiguous()
+
+
+CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fast
 
 
 class Graph:
@@ -142,8 +151,21 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     meta = torch.empty(B + 1 + N + 1 + 1, dtype=torch.int32, device=dev)
     g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]
     st = _stream(dev)
-    _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
-                               _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
+    # One big orthorhombic periodic box -> O(N) cell-list kernels (bit-identical output to the all-pairs kernels).
+    box = None
+    if B == 1 and N >= CELL_LIST_MIN_ATOMS:
+        c = cell.reshape(3, 3).cpu()
+        diag = torch.diagonal(c)
+        if bool((c - torch.diag(diag) == 0).all()) and bool((diag >= 3.0003 * cutoff).all()):
+            box = (C.c_float * 3)(*[float(v) for v in diag])
+    if box is not None:
+        scratch = torch.empty(L.nnhip_graph_cells_scratch_bytes(N, box, float(cutoff)), dtype=torch.uint8, device=dev)
+        status.zero_()
+        _check(L.nnhip_graph_count_cells(_ptr(pos), _ptr(cell), N, float(cutoff), box, _ptr(scratch), _ptr(g.mol_ptr),
+                                         _ptr(g.row_ptr), st), 'nnhip_graph_count_cells')
+    else:
+        _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
+                                   _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
     tail = meta[B + N + 1:].tolist()          # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
     if bad:
@@ -153,9 +175,14 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     g.col, g.rev = ints[:E], ints[E:]
     g.disp = torch.empty(E, 3, dtype=torch.float32, device=dev)
     g.edge_index = torch.empty(2, E, dtype=torch.int64, device=dev) if want_edge_index else None
-    _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
-                              float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
-           'nnhip_graph_fill')
+    if box is not None:
+        _check(L.nnhip_graph_fill_cells(_ptr(pos), _ptr(cell), N, E, float(cutoff), box, _ptr(scratch), _ptr(g.row_ptr),
+                                        _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
+               'nnhip_graph_fill_cells')
+    else:
+        _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
+                                  float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
+               'nnhip_graph_fill')
     nb = frequencies.numel()
     g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
     g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev)

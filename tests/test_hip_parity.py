@@ -199,3 +199,60 @@ def test_virial_and_stress(case):
         stress = -want['virial'] / cell.double().det().view(-1, 1, 1)
         assert (out.stress.cpu().double() - stress).abs().max().item() < 2e-5 * scale / cell.det().abs().min().item() + 1e-9
     check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), max(1.0, want['forces'].abs().max().item() / 5))
+
+
+def periodic_lattice(n_side, n_atoms, seed=0):
+    """SURVEY 8(d) config-5 recipe at reduced size: first n_atoms sites of an n_side^3 simple-cubic lattice,
+    spacing 100/47 A, + U(-0.5, 0.5) jitter, species uniform over {1,6,7,8}, cell = n_side * spacing."""
+    g = torch.Generator().manual_seed(seed)
+    a = 100.0 / 47.0
+    idx = torch.arange(n_atoms)
+    grid = torch.stack([idx // (n_side * n_side), (idx // n_side) % n_side, idx % n_side], 1).double() * a
+    pos = (grid + (torch.rand(n_atoms, 3, generator=g, dtype=torch.float64) - 0.5)) % (n_side * a)
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (n_atoms,), generator=g)]
+    cell = torch.eye(3, dtype=torch.float64).unsqueeze(0) * (n_side * a)
+    return z, pos.float(), cell.float(), torch.zeros(n_atoms, dtype=torch.long)
+
+
+@pytest.mark.parametrize('n_side,n_atoms', [(10, 1000), (15, 3000)])
+def test_periodic_box_config5_recipe(n_side, n_atoms):
+    """Config 5 (100k-atom box) cannot be run by the reference (O(N^2) memory); parity is established on 1000- and
+    3000-atom boxes of the same recipe against the O(N^2) oracle."""
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch = periodic_lattice(n_side, n_atoms)
+    model, sd = make_model('rand')
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert np.array_equal(out.edge_index.cpu().numpy(), want['edge_index'].numpy())
+    deg = out.edge_index.shape[1] / n_atoms
+    assert 45 < deg < 60, deg                              # density 0.1 A^-3 -> ~52 neighbours
+    e = out.energy.cpu().double().numpy()
+    assert np.all(np.abs(e - want['energy'].numpy()) <= np.maximum(util.energy_tol(want['energy'].numpy()), 1e-4 * np.abs(e)))
+    fs = max(1.0, want['forces'].abs().max().item() / 5.0)
+    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), fs)
+
+
+def test_cell_list_equals_all_pairs():
+    """The O(N) cell-list kernels return bit-identical graphs to the all-pairs kernels (same predicate, same order)."""
+    from newtonnet_amd import hip
+    z, pos, cell, batch = periodic_lattice(15, 3000, seed=2)
+    freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
+    old = hip.CELL_LIST_MIN_ATOMS
+    try:
+        hip.CELL_LIST_MIN_ATOMS = 1 << 30
+        g_all = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+        hip.CELL_LIST_MIN_ATOMS = 1
+        g_cell = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+    finally:
+        hip.CELL_LIST_MIN_ATOMS = old
+    assert g_all.n_edges == g_cell.n_edges > 0
+    for name in ('row_ptr', 'col', 'rev', 'edge_index', 'disp', 'rbf'):
+        assert torch.equal(getattr(g_all, name), getattr(g_cell, name)), name
+    # atoms far outside the box (unwrapped coordinates) bin correctly too
+    pos2 = pos + torch.tensor([31.9149, -63.8298, 95.7447]) * torch.randint(-1, 2, (3000, 1)).float()
+    hip.CELL_LIST_MIN_ATOMS = 1 << 30
+    g1 = hip.build_graph(pos2.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+    hip.CELL_LIST_MIN_ATOMS = 1
+    g2 = hip.build_graph(pos2.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+    hip.CELL_LIST_MIN_ATOMS = old
+    assert torch.equal(g1.edge_index, g2.edge_index) and torch.equal(g1.disp, g2.disp)
