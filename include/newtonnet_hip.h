@@ -196,6 +196,17 @@ int nnhip_linear128(const float* A, int32_t lda, const float* W, float* C, int32
                     const float* H, int32_t ldh, int32_t M, int32_t prologue, int32_t epilogue, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Fused two-layer edge MLP (Linear -> SiLU -> Linear, no bias) and its adjoint; the hidden tile stays in registers.
+ * Replaces: equiv_message1 / equiv_message2 (newtonnet.py:188-197, called at :218,:222) -- ~87 % of the FLOPs.
+ *   mode 0 (forward):  H = X W1^T (written: the adjoint needs it),  Y = silu(H) W2^T
+ *   mode 1 (adjoint):  G = (X W1^T) * silu'(H) (H read),            Y = G W2^T   (accumulate != 0: Y += ...)
+ *                      call with X = g_phi, W1 = V2^T, W2 = V1^T to get Y = g_msg.
+ * W1, W2: [128][128] row-major.  ldx / ldh / ldy: row strides in floats (>= 128, multiples of 4).
+ * ------------------------------------------------------------------------ */
+int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const float* W2, float* H, int32_t ldh, float* Y,
+                 int32_t ldy, int32_t M, int32_t mode, int32_t accumulate, void* stream);
+
+/* --------------------------------------------------------------------------
  * Differentiable building blocks of the train-mode forward (both are linear maps and each other's adjoints, so
  * torch.autograd can differentiate through them twice: force-loss training, output.py:66-73 + trainer.py:307-309).
  * Replaces: torch_geometric.utils.scatter(..., reduce='sum') (newtonnet.py:214,226; output.py:246) and the

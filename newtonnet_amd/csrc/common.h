@@ -85,4 +85,16 @@ struct LinArgs {
 };
 int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s);
 
+// ---- fused two-layer edge MLP launcher (mlp128.hip) -------------------------------
+enum { MODE_FWD = 0, MODE_BWD = 1 };
+struct MlpArgs {
+  const float* X;   // [M][ldx]  stage-1 input (msg, or g_phi)
+  const float* W1;  // [128][128] row-major, stage 1:  H^T = W1 . X^T
+  const float* W2;  // [128][128] row-major, stage 2:  Y^T = W2 . act^T
+  float* H;         // [M][ldh]  FWD: output (pre-activation);  BWD: input (pre-activation of the forward)
+  float* Y;         // [M][ldy]  stage-2 output
+  int M, ldx, ldh, ldy;
+};
+int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -296,17 +296,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // messages + invariant update
     TRY(launch_msg_fwd(P(w.pub.m[l]), rbf, lp.edge_w, row_ptr, col, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
-    if (E > 0) {
+    if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
       float* h12 = P(w.pub.h12[l]);
-      if (has_f) {
-        TRY(lin2(PRO_NONE, EPI_STORE, {P(w.pub.msg[l]), lp.eq1_0_w, h12, nullptr, nullptr},
-                 {P(w.pub.msg[l]), lp.eq2_0_w, h12 + NF, nullptr, nullptr}, NF, 2 * NF, 0, E, s));
-        TRY(lin2(PRO_SILU, EPI_STORE, {h12, lp.eq1_2_w, P(w.pub.phi1[l]), nullptr, nullptr},
-                 {h12 + NF, lp.eq2_2_w, P(w.pub.phi2[l]), nullptr, nullptr}, 2 * NF, NF, 0, E, s));
-      } else {
-        TRY(lin1(PRO_NONE, EPI_STORE, P(w.pub.msg[l]), NF, lp.eq1_0_w, h12, 2 * NF, nullptr, nullptr, 0, E, s));
-        TRY(lin1(PRO_SILU, EPI_STORE, h12, 2 * NF, lp.eq1_2_w, P(w.pub.phi1[l]), NF, nullptr, nullptr, 0, E, s));
-      }
+      TRY(launch_mlp(MODE_FWD, false, {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), E, NF, 2 * NF, NF}, s));
+      if (has_f)
+        TRY(launch_mlp(MODE_FWD, false,
+                       {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), E, NF, 2 * NF, NF}, s));
     }
     TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, f_in, P(w.pub.f_out[l]), N, s));
     // equiv_update + energy update
@@ -344,18 +339,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, rev, f_prev,
                          P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, s));
     if (E > 0) {
-      float* gh = P(w.g_h12);
+      // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
+      float* gp = P(w.g_h12);   // [E][2F]: g_phi1 | g_phi2 written by force_bwd
       float* h12 = P(w.pub.h12[l]);
-      // g_h_k = (g_phi_k V_k2) * silu'(h_k)   (in place) ; g_msg = g_h_1 V_10 + g_h_2 V_20
-      if (has_f) {
-        TRY(lin2(PRO_NONE, EPI_DSILU, {gh, P(w.wT[l][3]), gh, nullptr, h12},
-                 {gh + NF, P(w.wT[l][5]), gh + NF, nullptr, h12 + NF}, 2 * NF, 2 * NF, 2 * NF, E, s));
-      } else {
-        TRY(lin1(PRO_NONE, EPI_DSILU, gh, 2 * NF, P(w.wT[l][3]), gh, 2 * NF, nullptr, h12, 2 * NF, E, s));
-      }
-      TRY(lin1(PRO_NONE, EPI_STORE, gh, 2 * NF, P(w.wT[l][2]), P(w.g_msg), NF, nullptr, nullptr, 0, E, s));
+      TRY(launch_mlp(MODE_BWD, false, {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), E, 2 * NF, 2 * NF, NF}, s));
       if (has_f)
-        TRY(lin1(PRO_NONE, EPI_ACC, gh + NF, 2 * NF, P(w.wT[l][4]), P(w.g_msg), NF, nullptr, nullptr, 0, E, s));
+        TRY(launch_mlp(MODE_BWD, true, {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), E, 2 * NF, 2 * NF, NF}, s));
     }
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), rbf, drbf, lp.edge_w, row_ptr, col, rev, P(w.g_m),

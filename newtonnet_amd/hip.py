@@ -89,13 +89,14 @@ def lib():
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.nnhip_segment_sum.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
-               'nnhip_graph_fill_cells'):
+               'nnhip_graph_fill_cells', 'nnhip_mlp128'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -104,7 +105,8 @@ def lib():
 EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
-                    'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells')
+                    'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
+                    'nnhip_mlp128')
 
 
 def _check(rc: int, what: str):
@@ -242,6 +244,15 @@ def linear128(A: torch.Tensor, W: torch.Tensor, out: Optional[torch.Tensor] = No
                                  out.stride(0) if M > 1 else NNHIP_F, _ptr(bias), _ptr(H), ldh, M, prologue, epilogue,
                                  _stream(A.device)), 'nnhip_linear128')
     return out
+
+
+def mlp128(X: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, H: torch.Tensor, Y: torch.Tensor, mode: int = 0,
+           accumulate: bool = False) -> torch.Tensor:
+    """Fused Linear->SiLU->Linear (mode 0: writes H, Y) or its adjoint (mode 1: reads H); csrc/mlp128.hip."""
+    M = X.shape[0]
+    _check(lib().nnhip_mlp128(_ptr(X), X.stride(0), _ptr(W1), _ptr(W2), _ptr(H), H.stride(0), _ptr(Y), Y.stride(0), M,
+                              mode, 1 if accumulate else 0, _stream(X.device)), 'nnhip_mlp128')
+    return Y
 
 
 def segment_sum(x: torch.Tensor, row_ptr: torch.Tensor, n_rows: int) -> torch.Tensor:
