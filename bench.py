@@ -69,7 +69,9 @@ def algorithmic_counts(N, E, L=3, F=128):
         bwd = 3 * N + 2 * n_edge_mlp * E + (2 * N if l > 0 else 2 * N)
         fl += (fwd + bwd) * 2 * F * F
     fl += (2 * N + 2 * N) * 2 * F * F
-    return edge_fwd, edge_bwd, fl
+    n_mlp = sum(1 if l == 0 else 2 for l in range(L))          # fused edge-MLP launches: fwd + adjoint each
+    mlp_fl = 2 * n_mlp * 2 * E * 2 * F * F
+    return edge_fwd, edge_bwd, fl, mlp_fl
 
 
 def main():
@@ -150,15 +152,23 @@ def main():
         tm = hip.timers_read(reset=True)
         hip.timers_enable(False)
         classes = {k: {'ms_per_step': v[0] / n_inst, 'launches_per_step': v[1] / n_inst} for k, v in tm.items()}
-        edge_fwd_b, edge_bwd_b, lin_flops = algorithmic_counts(N, E)
+        edge_fwd_b, edge_bwd_b, lin_flops, mlp_flops = algorithmic_counts(N, E)
         lin_ms = classes['linear_mfma']['ms_per_step']
+        mlp_ms = classes['mlp128']['ms_per_step']
+        mlp_n = max(classes['mlp128']['launches_per_step'], 1)
         edge_ms = classes['edge_all']['ms_per_step']
+        mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         lin_tf = lin_flops / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
         edge_gbs = (edge_fwd_b + edge_bwd_b) / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
-        mfma = {'bound': 'mfma', 'kernel': 'lin128_kernel (all dense 128x128 linears of one step)',
-                'achieved': round(lin_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(lin_tf / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
-                'ms_per_step': round(lin_ms, 4), 'flops_per_step': lin_flops}
+        # dominant kernel: the fused two-layer edge MLP (mlp128_kernel, forward + adjoint launches)
+        mfma = {'bound': 'mfma', 'kernel': 'mlp128_kernel (fused Linear-SiLU-Linear over edges, fwd + adjoint)',
+                'achieved': round(mlp_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(mlp_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                'traffic': None, 'traffic_note': 'PMC passes are separate runs: profiles/r01_*_pmc_{fetch,write}_size.txt',
+                'launches_per_step': mlp_n, 'avg_launch_us': round(1e3 * mlp_ms / mlp_n, 2),
+                'flops_per_launch': mlp_flops / mlp_n, 'ms_per_step': round(mlp_ms, 4),
+                'all_dense_kernels': {'achieved': round(lin_tf, 2), 'ms_per_step': round(lin_ms, 4),
+                                      'flops_per_step': lin_flops}}
         hbm = {'bound': 'hbm', 'kernel': 'msg_fwd/force_fwd/force_bwd/msg_bwd (edge kernels of one step)',
                'achieved': round(edge_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(edge_gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'ms_per_step': round(edge_ms, 4),

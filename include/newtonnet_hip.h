@@ -221,10 +221,11 @@ int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_out, int32_t
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
- * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = dense MFMA linears,
- *          2 = everything else.  Disabled (0) by default.
+ * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,
+ *          3-6 = msg_fwd / force_fwd / force_bwd / msg_bwd, 7 = graph build, 8 = fused edge-MLP kernel (mlp128),
+ *          9 = single linears (lin128).  Disabled (0) by default.
  * ------------------------------------------------------------------------ */
-#define NNHIP_N_TIMER_CLASSES 8
+#define NNHIP_N_TIMER_CLASSES 10
 int nnhip_timers_enable(int32_t on);
 int nnhip_timers_read(double* ms_per_class, int64_t* launches_per_class, int32_t reset);
 

@@ -205,6 +205,7 @@ static int launch_lin_t(const LinArgs& a, int groups, hipStream_t s) {
 int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_LIN1, s);
 #define CASE(P, E) \
   if (pro == P && epi == E) return launch_lin_t<P, E>(a, groups, s);
   CASE(PRO_NONE, EPI_STORE)

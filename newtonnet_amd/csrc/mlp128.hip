@@ -179,6 +179,7 @@ static int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_MLP, s);
   if (mode == MODE_FWD && !accum) return launch_mlp_t<MODE_FWD, false>(a, s);
   if (mode == MODE_BWD && !accum) return launch_mlp_t<MODE_BWD, false>(a, s);
   if (mode == MODE_BWD && accum) return launch_mlp_t<MODE_BWD, true>(a, s);

@@ -20,9 +20,9 @@ BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
 NNHIP_F = 128
 NNHIP_NB = 20
 NNHIP_MAX_LAYERS = 8
-N_TIMER_CLASSES = 8
+N_TIMER_CLASSES = 10
 TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',
-                 'edge_msg_bwd', 'graph')
+                 'edge_msg_bwd', 'graph', 'mlp128', 'lin128')
 
 _fp = C.POINTER(C.c_float)
 
