@@ -62,7 +62,26 @@ def _envelope(x, p=9):
 
 
 def _mlp(seq, x):
-    return Fn.linear(Fn.silu(Fn.linear(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
+    return _lin(Fn.silu(_lin(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
+
+
+class _Fp32(torch.autograd.Function):
+    """Identity that pins a tensor (and its gradient) to float32 at the boundary of a bf16 autocast region."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float()
+
+
+def _lin(x, weight, bias=None):
+    """Dense linear.  Under `torch.autocast('cuda', torch.bfloat16)` (BASELINE configs[2]: bf16 training step) the vendor
+    GEMM runs with bf16 operands and fp32 accumulation; everything around it (gathers, segment sums, products,
+    the radial basis) stays fp32."""
+    y = Fn.linear(x, weight, bias)
+    return y.float() if y.dtype != torch.float32 else y
 
 
 def forward_train(model, z, pos, cell, batch, energy_idx: int):
@@ -85,18 +104,20 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int):
     f = torch.zeros(z.shape[0], 3, emb.n_features, dtype=pos.dtype, device=pos.device)
     for l, il in enumerate(model.interaction_layers):
         m = _mlp(il.message_nodepart, a)
-        msg = Fn.linear(rbf, il.message_edgepart.weight) * Gather.apply(m, eg, 'row') * Gather.apply(m, eg, 'col')
+        with torch.autocast('cuda', enabled=False):   # K = 20 radial filter: always fp32
+            eps = Fn.linear(rbf.float(), il.message_edgepart.weight.float())
+        msg = eps * Gather.apply(m, eg, 'row') * Gather.apply(m, eg, 'col')
         a = a + SegmentSum.apply(msg, eg)
         phi1 = _mlp(il.equiv_message1, msg)
         eq = phi1.unsqueeze(1) * u.unsqueeze(2)
         if l > 0:   # force_node == 0 entering the first layer (newtonnet.py:143)
             eq = eq + _mlp(il.equiv_message2, msg).unsqueeze(1) * Gather.apply(f, eg, 'col')
         f = f + SegmentSum.apply(eq.contiguous(), eg)
-        a = a + (f * Fn.linear(f, il.equiv_update.weight)).sum(dim=1)
+        a = a + (f * _lin(f, il.equiv_update.weight)).sum(dim=1)
 
     head = model.output_layers[energy_idx].layers
-    e = Fn.linear(Fn.silu(Fn.linear(Fn.silu(Fn.linear(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),
-                  head[4].weight, head[4].bias)
+    e = _lin(Fn.silu(_lin(Fn.silu(_lin(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),
+             head[4].weight, head[4].bias)
     sc = model.scalers[energy_idx]
     if sc.scale is not None:
         e = e * sc.scale(z)

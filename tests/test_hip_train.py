@@ -113,3 +113,30 @@ def test_train_step_reduces_loss():
     step = TrainStep(model, opt, w_energy=1.0, w_force=50.0, clip_grad=1.0)
     losses = [step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab).item() for _ in range(8)]
     assert losses[-1] < losses[0], losses
+
+
+def test_bf16_autocast_training_gradients():
+    """BASELINE configs[2] ("bf16"): the dense linears of the train-mode path under torch.autocast(bfloat16) (bf16
+    operands, fp32 accumulation; gathers / segment sums / radial basis stay fp32).  The reference has no bf16
+    (precision.py:3-13), so parity is against the fp64 oracle: relative gradient-norm error <= 2e-2."""
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, c = util.case_inputs('ethanol4_rand', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    e_lab, f_lab = torch.randn(4, generator=g), torch.randn(36, 3, generator=g)
+    model, sd = make_model()
+    model.train()
+    p = pos.cuda().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model(z.cuda(), p, cell.cuda(), batch.cuda())
+        loss = torch.nn.functional.mse_loss(out.energy.float(), e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(
+            out.gradient_force.float(), f_lab.cuda())
+    loss.backward()
+    want_loss, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(),
+                                              batch, e_lab.double(), f_lab.double())
+    err = ref_n = 0.0
+    for name, prm in model.named_parameters():
+        if prm.requires_grad and prm.grad is not None:
+            err += (prm.grad.detach().cpu().double() - want[name]).norm().item() ** 2
+            ref_n += want[name].norm().item() ** 2
+    assert abs(loss.item() - want_loss.item()) <= 2e-2 * abs(want_loss.item())
+    assert np.sqrt(err) <= 2e-2 * np.sqrt(ref_n), (np.sqrt(err), np.sqrt(ref_n))
