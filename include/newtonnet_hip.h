@@ -126,11 +126,14 @@ int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms,
  * Replaces: ScaledNorm.forward (representations.py:118-133), PolynomialCutoff
  *   p=9 (:155-171), RadialBesselLayer.forward (:223-235) and their product (:41).
  * geo[E][4]  = (ux, uy, uz, r)    dir_edge and |disp|
- * rbf[E][nb] = env(x) * sin(w_n x)/x,  x = r/cutoff        (= dist_edge)
- * drbf[E][nb]= d rbf / d x   (kept for the force adjoint)
+ * rbf[E][nb] = env(x) * sin(w_n x)/x,  x = r/cutoff        (= dist_edge; may be NULL)
+ * drbf[E][nb]= d rbf / d x                                  (may be NULL)
+ * xg[E][2]   = (g0, bits of u): x = (g0 + u) / 4096, the position of the edge on the radial-filter table that
+ *              nnhip_energy_forces interpolates instead of contracting rbf with message_edgepart.weight per edge
+ *              (may be NULL)
  * ------------------------------------------------------------------------ */
 int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies, int32_t n_basis,
-                     float* geo, float* rbf, float* drbf, void* stream);
+                     float* geo, float* rbf, float* drbf, int32_t* xg, void* stream);
 
 /* --------------------------------------------------------------------------
  * Whole hot path: energy and forces (= -dE/dpos) for a batch.
@@ -179,7 +182,7 @@ int nnhip_workspace_layout(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int3
 int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                         const int32_t* mol_ptr,
                         const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const float* geo,
-                        const float* rbf, const float* drbf, const float* disp, int32_t n_atoms, int32_t n_edges,
+                        const int32_t* xg, const float* disp, int32_t n_atoms, int32_t n_edges,
                         int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
                         float* virial, float* atom_energy, float* atom_node, float* force_node, void* stream);
 

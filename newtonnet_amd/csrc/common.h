@@ -8,6 +8,8 @@
 #define NF NNHIP_F    // 128 features: one wave = 64 lanes x float2
 #define NB NNHIP_NB   // 20 radial basis functions
 #define WAVE 64
+#define FT_G 4096            // radial-filter table: intervals on x = r/cutoff in [0, 1)
+#define FT_ROWS (FT_G + 3)   // rows for x_g = (g - 1) / FT_G  (4-point stencil at both ends)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

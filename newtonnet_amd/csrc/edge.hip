@@ -22,29 +22,27 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
   return tile * ROWS_PER_BLOCK + wave;
 }
 
-// W_e rows for this lane's two features: we[0][n] = W_e[2l][n], we[1][n] = W_e[2l+1][n]
-__device__ __forceinline__ void load_we(const float* __restrict__ edge_w, int lane, float (&we)[2][NB]) {
-  const float4* p = reinterpret_cast<const float4*>(edge_w + (size_t)lane * 2 * NB);
-#pragma unroll
-  for (int k = 0; k < (2 * NB) / 4; ++k) {
-    const float4 v = p[k];
-    const int o = 4 * k;
-    (&we[0][0])[o] = v.x;
-    (&we[0][0])[o + 1] = v.y;
-    (&we[0][0])[o + 2] = v.z;
-    (&we[0][0])[o + 3] = v.w;
-  }
+// Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx by cubic interpolation of
+// per-layer tables T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 4096 intervals,
+// built in fp64 on every call).  Evaluating the 20-term contraction per (edge, feature) on the VALU was the
+// bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the tables turn it into
+// coalesced 512-B L2 reads and a handful of FMAs.  Interpolation error ~ h^4 |d4f/dx4| / 24 ~ 1e-9 relative
+// (h = 1/4096, fourth derivative ~ (20 pi)^4): far below fp32 eps for both tables.
+struct FilterW {
+  float w[4];   // value weights at nodes -1, 0, 1, 2
+};
+__device__ __forceinline__ FilterW filter_weights(float u) {
+  FilterW f;
+  const float um1 = u - 1.f, um2 = u - 2.f, up1 = u + 1.f;
+  f.w[0] = -u * um1 * um2 * (1.f / 6.f);
+  f.w[1] = up1 * um1 * um2 * 0.5f;
+  f.w[2] = -up1 * u * um2 * 0.5f;
+  f.w[3] = up1 * u * um1 * (1.f / 6.f);
+  return f;
 }
-
-__device__ __forceinline__ float2 edge_filter(const float (&we)[2][NB], const float* __restrict__ rb) {
-  float2 eps = make_float2(0.f, 0.f);
+__device__ __forceinline__ void filter_rows(const float* __restrict__ table, int g0, int lane, float2 (&t)[4]) {
 #pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    const float r = rb[n];  // wave-uniform address -> scalar load
-    eps.x = fmaf(we[0][n], r, eps.x);
-    eps.y = fmaf(we[1][n], r, eps.y);
-  }
-  return eps;
+  for (int k = 0; k < 4; ++k) t[k] = ld2(table + (size_t)(g0 + k) * NF + 2 * lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -52,21 +50,25 @@ __device__ __forceinline__ float2 edge_filter(const float (&we)[2][NB], const fl
 //   msg[e] = eps_e * m[i] * m[j];  a_mid[i] = a_in[i] + sum_{e in row i} msg[e]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-msg_fwd_kernel(const float* __restrict__ m, const float* __restrict__ rbf, const float* __restrict__ edge_w,
+msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ a_in,
                float* __restrict__ msg, float* __restrict__ a_mid, int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  float we[2][NB];
-  load_we(edge_w, lane, we);
   const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
   float2 acc = make_float2(0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const int j = col[e];
+    const int2 gx = xg[e];   // wave-uniform
+    float2 t[4];
+    filter_rows(table, gx.x, lane, t);
     const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
-    const float2 eps = edge_filter(we, rbf + (size_t)e * NB);
+    const FilterW fw = filter_weights(__int_as_float(gx.y));
+    float2 eps = t[0] * fw.w[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) eps = fma2(t[k], fw.w[k], eps);
     const float2 v = eps * mi * mj;
     st2(msg + (size_t)e * NF + 2 * lane, v);
     acc = acc + v;
@@ -170,20 +172,18 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 // adjoint of msg_fwd for receiver row i.  g_msg[e] holds the MLP-side gradient of msg[e]; the
 // aggregation a_mid = a_in + sum msg adds g_a[i] to every message of row i:
 //   gm_e  = g_msg[e]      + g_a[i]        gm_r = g_msg[rev e] + g_a[j]
-//   g_x[e]  = < gm_e * m[i] * m[j] , W_e drbf_e >                       (wave reduction)
+//   g_x[e]  = < gm_e * m[i] * m[j] , d eps_e/dx >                       (wave reduction)
 //   g_m[i]  = sum_{e in row i} (gm_e + gm_r) * eps_e * m[j]
 //             (receiver term + the sender term of the reverse edge; eps_rev == eps_e since x is symmetric)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, const float* __restrict__ m,
-               const float* __restrict__ rbf, const float* __restrict__ drbf, const float* __restrict__ edge_w,
+               const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ rev,
                float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  float we[2][NB];
-  load_we(edge_w, lane, we);
   const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
   const float2 gai = ld2(g_a + (size_t)i * NF + 2 * lane);
   float2 acc = make_float2(0.f, 0.f);
@@ -195,8 +195,18 @@ msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, c
     const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
     const float2 gm_e = ld2(g_msg + (size_t)e * NF + 2 * lane) + gai;
     const float2 gm_r = ld2(g_msg + (size_t)r * NF + 2 * lane) + gaj;
-    const float2 eps = edge_filter(we, rbf + (size_t)e * NB);
-    const float2 deps = edge_filter(we, drbf + (size_t)e * NB);
+    const int2 gxi = xg[e];   // wave-uniform
+    float4 td[4];   // (T, D) pairs of this lane's two features, rows g0 .. g0+3 of the interleaved table
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      td[k] = *reinterpret_cast<const float4*>(table + (size_t)FT_ROWS * NF + ((size_t)(gxi.x + k) * NF + 2 * lane) * 2);
+    const FilterW fw = filter_weights(__int_as_float(gxi.y));
+    float2 eps = make_float2(td[0].x, td[0].z) * fw.w[0], deps = make_float2(td[0].y, td[0].w) * fw.w[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      eps = fma2(make_float2(td[k].x, td[k].z), fw.w[k], eps);
+      deps = fma2(make_float2(td[k].y, td[k].w), fw.w[k], deps);
+    }
     const float2 t = gm_e * mi * mj;
     const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
     if (lane == 0) g_x[e] = gx;
@@ -409,11 +419,12 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // ---------------------------------------------------------------------------------------------
 static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, ROWS_PER_BLOCK); }
 
-int launch_msg_fwd(const float* m, const float* rbf, const float* edge_w, const int* row_ptr, const int* col,
+int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, rbf, edge_w, row_ptr, col, a_in, msg, a_mid, n_atoms);
+  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, a_in, msg,
+                                                     a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -445,12 +456,12 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
   return 0;
 }
 
-int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const float* rbf, const float* drbf,
-                   const float* edge_w, const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
+int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
+                   const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
                    int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
-  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, rbf, drbf, edge_w, row_ptr, col, rev, g_m, g_x,
+  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, rev, g_m, g_x,
                                                     n_atoms);
   LAUNCH_CHECK();
   return 0;

@@ -183,7 +183,7 @@ __global__ void edge_rev_kernel(const int* __restrict__ row_ptr, const int* __re
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, const float* __restrict__ freq, int nb,
-                  float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf) {
+                  float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   const double dx = disp[3 * (long)e], dy = disp[3 * (long)e + 1], dz = disp[3 * (long)e + 2];
@@ -196,6 +196,13 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, con
   g.w = (float)r;
   reinterpret_cast<float4*>(geo)[e] = g;
   const double x = r / (double)cutoff;
+  if (xg) {  // position on the radial-filter table grid (edge.hip): interval index and fraction, fraction in fp64 accuracy
+    const double t = x * (double)FT_G;
+    int g0 = (int)floor(t);
+    g0 = g0 < 0 ? 0 : (g0 > FT_G - 1 ? FT_G - 1 : g0);
+    xg[e] = make_int2(g0, __float_as_int((float)(t - (double)g0)));
+  }
+  if (!rbf) return;
   const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
   const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);   // 1 - 55x^9 + 99x^10 - 45x^11
   const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);        // -495x^8 + 990x^9 - 495x^10
@@ -207,7 +214,7 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, con
     const double bes = s * ix;
     const double dbes = (w * c - bes) * ix;
     rbf[(long)e * nb + n] = (float)(env * bes);
-    drbf[(long)e * nb + n] = (float)(denv * bes + env * dbes);
+    if (drbf) drbf[(long)e * nb + n] = (float)(denv * bes + env * dbes);
   }
 }
 
@@ -258,8 +265,69 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   return NNHIP_OK;
 }
 
+// Radial-filter tables of one layer, x_g = (g - 1) / FT_G, g = 0 .. FT_G + 2 (fp64 evaluation, one rounding):
+//   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)          (values)
+//   D[g][f] = sum_n W_e[f][n] d rbf_n/dx (x_g)    (derivatives, tabulated separately: differentiating the fp32 value
+//             table would amplify its rounding by FT_G)
+// stored as table[0 .. FT_ROWS)[F] = T (forward kernel) followed by an interleaved copy [FT_ROWS][F][2] = (T, D) pairs, so
+// that the adjoint kernel gets both with one 16-byte load per lane and row.  The message kernels interpolate both with
+// the same 4-point cubic weights (edge.hip).
+struct FilterTableArgs {
+  const float* edge_w[NNHIP_MAX_LAYERS];
+  float* table[NNHIP_MAX_LAYERS];
+  const float* freq;
+};
+__global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
+  __shared__ double rb[NB], drb[NB];
+  const int g = blockIdx.x, l = blockIdx.y;
+  const double x = (double)(g - 1) / (double)FT_G;
+  if (threadIdx.x < NB) {
+    const double w = (double)a.freq[threadIdx.x];
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
+    const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);
+    const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);
+    double bes, dbes;
+    if (x == 0.0) {
+      bes = w;       // sin(wx)/x -> w
+      dbes = 0.0;    // even function of x
+    } else {
+      double sn, cs;
+      sincos(w * x, &sn, &cs);
+      bes = sn / x;
+      dbes = (w * cs - bes) / x;
+    }
+    rb[threadIdx.x] = env * bes;
+    drb[threadIdx.x] = denv * bes + env * dbes;
+  }
+  __syncthreads();
+  const float* __restrict__ we = a.edge_w[l] + (size_t)threadIdx.x * NB;
+  double acc = 0.0, dacc = 0.0;
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    acc += (double)we[n] * rb[n];
+    dacc += (double)we[n] * drb[n];
+  }
+  a.table[l][(size_t)g * NF + threadIdx.x] = (float)acc;
+  float2* td = reinterpret_cast<float2*>(a.table[l] + (size_t)FT_ROWS * NF);
+  td[(size_t)g * NF + threadIdx.x] = make_float2((float)acc, (float)dacc);
+}
+
+int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq,
+                         hipStream_t s) {
+  ScopedTimer tm(TC_OTHER, s);
+  FilterTableArgs a;
+  for (int l = 0; l < n_layers; ++l) {
+    a.edge_w[l] = edge_w[l];
+    a.table[l] = tables[l];
+  }
+  a.freq = freq;
+  filter_table_kernel<<<dim3(FT_ROWS, n_layers), NF, 0, s>>>(a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,
-                                int32_t n_basis, float* geo, float* rbf, float* drbf, void* stream_) {
+                                int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_basis != NB) {
     nnhip_set_error("nnhip_edge_embed: n_basis=%d unsupported (built for %d)", n_basis, NB);
@@ -267,7 +335,8 @@ extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff
   }
   if (n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
-  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, frequencies, n_basis, geo, rbf, drbf);
+  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, frequencies, n_basis, geo, rbf, drbf,
+                                                            reinterpret_cast<int2*>(xg));
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

@@ -13,15 +13,16 @@
 #include "common.h"
 
 // ---- pieces defined in the other translation units ---------------------------------------------------
-int launch_msg_fwd(const float* m, const float* rbf, const float* edge_w, const int* row_ptr, const int* col,
+int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, hipStream_t s);
+int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
                      const int* col, const float* f_in, float* f_out, int n_atoms, hipStream_t s);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* rev, const float* f_in, float* g_h12, float* g_u,
                      float* g_fin, int n_atoms, hipStream_t s);
-int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const float* rbf, const float* drbf,
-                   const float* edge_w, const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
+int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
+                   const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
                    int n_atoms, hipStream_t s);
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
@@ -122,6 +123,7 @@ struct WsInternal {
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
   size_t atom_energy;              // [N]
+  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values + [FT_ROWS][F][2] (value, d/dx)
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -148,6 +150,7 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
     w.pub.f_out[l] = carve(off, 3 * nf);
     w.pub.q[l] = carve(off, 3 * nf);
     for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
+    w.ftab[l] = carve(off, (size_t)3 * FT_ROWS * NF * 4);
   }
   w.headT[0] = carve(off, NF * NF * 4);
   w.headT[1] = carve(off, NF * NF * 4);
@@ -220,7 +223,7 @@ static int lin2(int pro, int epi, LinGroup g0, LinGroup g1, int lda, int ldc, in
 // ---- the hot path --------------------------------------------------------------------------------------
 extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                                    const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
-                                   const int32_t* rev, const float* geo, const float* rbf, const float* drbf,
+                                   const int32_t* rev, const float* geo, const int32_t* xg,
                                    const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                                    size_t workspace_bytes, float* energy, float* forces, float* virial,
                                    float* atom_energy_out, float* atom_node_out, float* force_node_out,
@@ -283,6 +286,17 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(launch_transposes(src, dst, c, s));
   }
 
+  // radial-filter tables (one per layer; rebuilt every call so they always match message_edgepart.weight)
+  {
+    const float* ew[NNHIP_MAX_LAYERS];
+    float* tb[NNHIP_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) {
+      ew[l] = model->layer[l].edge_w;
+      tb[l] = P(w.ftab[l]);
+    }
+    TRY(launch_filter_tables(ew, tb, L, model->frequencies, s));
+  }
+
   // ------------------------------------------------------------------ forward sweep
   TRY(launch_embed(z, model->node_embedding, N, P(w.pub.a0), s));
   const float* a_in = P(w.pub.a0);
@@ -294,7 +308,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
     TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
     // messages + invariant update
-    TRY(launch_msg_fwd(P(w.pub.m[l]), rbf, lp.edge_w, row_ptr, col, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
+    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
     if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
       float* h12 = P(w.pub.h12[l]);
@@ -347,7 +361,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
         TRY(launch_mlp(MODE_BWD, true, {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), E, 2 * NF, 2 * NF, NF}, s));
     }
     // message adjoint -> g_m, g_x
-    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), rbf, drbf, lp.edge_w, row_ptr, col, rev, P(w.g_m),
+    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, rev, P(w.g_m),
                        P(w.pub.g_x) + (size_t)l * E, N, s));
     // message_nodepart adjoint: g_hn = (g_m W2) * silu'(hn) ; g_a += g_hn W0
     TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_m), NF, P(w.wT[l][1]), P(w.g_hn), NF, nullptr, P(w.pub.hn[l]), NF, N, s));

@@ -78,7 +78,7 @@ def lib():
     L.nnhip_last_error.restype = C.c_char_p
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
-    L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp]
+    L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, vp]
     L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
     L.nnhip_graph_cells_scratch_bytes.restype = sz
     L.nnhip_graph_count_cells.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp]
@@ -86,7 +86,7 @@ def lib():
     L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.nnhip_workspace_bytes.restype = sz
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
-    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
+    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
@@ -134,11 +134,11 @@ CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fa
 class Graph:
     """Neighbor list + edge embedding of one batch (device tensors)."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf')
+                 'rbf', 'drbf', 'xg')
 
 
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
-                frequencies: torch.Tensor, want_edge_index: bool = True) -> Graph:
+                frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False) -> Graph:
     """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU."""
     L = lib()
     dev = pos.device
@@ -187,10 +187,11 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
                'nnhip_graph_fill')
     nb = frequencies.numel()
     g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
-    g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev)
-    g.drbf = torch.empty(E, nb, dtype=torch.float32, device=dev)
+    g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None     # dist_edge (tests / API)
+    g.drbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None
+    g.xg = torch.empty(E, 2, dtype=torch.int32, device=dev)
     _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), nb,
-                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), st), 'nnhip_edge_embed')
+                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), st), 'nnhip_edge_embed')
     return g
 
 
@@ -218,7 +219,7 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
     out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
-                                 _ptr(g.rev), _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.disp), N, E, B,
+                                 _ptr(g.rev), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
                                  _ptr(out['force_node']), _stream(dev)), 'nnhip_energy_forces')

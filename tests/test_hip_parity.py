@@ -62,7 +62,7 @@ def test_intermediates_against_trace():
     T = trace.trace({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
     m = model._hip_model(0)
     g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0,
-                        model.embedding_layers.edge_embedding.embedding.frequencies)
+                        model.embedding_layers.edge_embedding.embedding.frequencies, want_rbf=True)
     assert np.array_equal(g.edge_index.cpu().numpy(), T['edge_index'].numpy())
     res = hip.energy_forces(m, z.cuda(), pos.cuda(), cell.cuda(), g)
     torch.cuda.synchronize()
@@ -240,9 +240,9 @@ def test_cell_list_equals_all_pairs():
     old = hip.CELL_LIST_MIN_ATOMS
     try:
         hip.CELL_LIST_MIN_ATOMS = 1 << 30
-        g_all = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+        g_all = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq, want_rbf=True)
         hip.CELL_LIST_MIN_ATOMS = 1
-        g_cell = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+        g_cell = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq, want_rbf=True)
     finally:
         hip.CELL_LIST_MIN_ATOMS = old
     assert g_all.n_edges == g_cell.n_edges > 0

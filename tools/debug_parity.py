@@ -51,7 +51,7 @@ def run(case):
     dev = 'cuda'
     zc, pc, cc, bc = z.to(dev), pos.to(dev), cell.to(dev), batch.to(dev)
     m = model._hip_model(0)
-    g = hip.build_graph(pc, cc, bc, 5.0, model.embedding_layers.edge_embedding.embedding.frequencies)
+    g = hip.build_graph(pc, cc, bc, 5.0, model.embedding_layers.edge_embedding.embedding.frequencies, want_rbf=True)
     print(f'== {case}: N={g.n_atoms} E={g.n_edges} (ref {T["edge_index"].shape[1]}) B={g.n_mol}')
     ei_ok = np.array_equal(g.edge_index.cpu().numpy(), T['edge_index'].numpy())
     print('  edge_index bit-exact:', ei_ok)
