@@ -128,7 +128,7 @@ int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms,
  * geo[E][4]  = (ux, uy, uz, r)    dir_edge and |disp|
  * rbf[E][nb] = env(x) * sin(w_n x)/x,  x = r/cutoff        (= dist_edge; may be NULL)
  * drbf[E][nb]= d rbf / d x                                  (may be NULL)
- * xg[E][2]   = (g0, bits of u): x = (g0 + u) / 4096, the position of the edge on the radial-filter table that
+ * xg[E][2]   = (g0, bits of u): x = (g0 + u) / FT_G, the position of the edge on the radial-filter table that
  *              nnhip_energy_forces interpolates instead of contracting rbf with message_edgepart.weight per edge
  *              (may be NULL)
  * ------------------------------------------------------------------------ */

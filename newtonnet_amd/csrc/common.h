@@ -64,6 +64,19 @@ __device__ __forceinline__ int xcd_tile(int b, int n_blocks) {
 
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 __device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+// streaming variants (edge tensors are touched once per kernel: keep them from evicting the gathered node rows in L2)
+__device__ __forceinline__ float2 ld2_nt(const float* p) {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void st2_nt(float* p, float2 v) {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 w;
+  w.x = v.x;
+  w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<v2*>(p));
+}
 __device__ __forceinline__ float2 operator*(float2 a, float2 b) { return make_float2(a.x * b.x, a.y * b.y); }
 __device__ __forceinline__ float2 operator*(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }

@@ -96,13 +96,13 @@ force_fwd_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2,
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];  // (ux,uy,uz,r), wave-uniform
-    const float2 p1 = ld2(phi1 + (size_t)e * NF + 2 * lane);
+    const float2 p1 = ld2_nt(phi1 + (size_t)e * NF + 2 * lane);
     acc[0] = fma2(p1, g.x, acc[0]);
     acc[1] = fma2(p1, g.y, acc[1]);
     acc[2] = fma2(p1, g.z, acc[2]);
     if (HAS_F) {
       const int j = col[e];
-      const float2 p2 = ld2(phi2 + (size_t)e * NF + 2 * lane);
+      const float2 p2 = ld2_nt(phi2 + (size_t)e * NF + 2 * lane);
 #pragma unroll
       for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
     }
@@ -137,11 +137,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];
-    const float2 p1 = ld2(phi1 + (size_t)e * NF + 2 * lane);
+    const float2 p1 = ld2_nt(phi1 + (size_t)e * NF + 2 * lane);
     float2 gp1 = gfi[0] * g.x;
     gp1 = fma2(gfi[1], g.y, gp1);
     gp1 = fma2(gfi[2], g.z, gp1);
-    st2(g_h12 + (size_t)e * 2 * NF + 2 * lane, gp1);
+    st2_nt(g_h12 + (size_t)e * 2 * NF + 2 * lane, gp1);
     float s0 = fmaf(gfi[0].x, p1.x, gfi[0].y * p1.y);
     float s1 = fmaf(gfi[1].x, p1.x, gfi[1].y * p1.y);
     float s2 = fmaf(gfi[2].x, p1.x, gfi[2].y * p1.y);
@@ -152,14 +152,14 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     if (HAS_F) {
       const int j = col[e];
       const int r = rev[e];
-      const float2 p2r = ld2(phi2 + (size_t)r * NF + 2 * lane);
+      const float2 p2r = ld2_nt(phi2 + (size_t)r * NF + 2 * lane);
       float2 gp2 = make_float2(0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
         acc[k] = fma2(p2r, ld2(gf + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
       }
-      st2(g_h12 + (size_t)e * 2 * NF + NF + 2 * lane, gp2);
+      st2_nt(g_h12 + (size_t)e * 2 * NF + NF + 2 * lane, gp2);
     }
   }
   if (HAS_F) {
