@@ -256,3 +256,54 @@ def test_cell_list_equals_all_pairs():
     g2 = hip.build_graph(pos2.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
     hip.CELL_LIST_MIN_ATOMS = old
     assert torch.equal(g1.edge_index, g2.edge_index) and torch.equal(g1.disp, g2.disp)
+
+
+def test_triclinic_cell_follows_reference_formula():
+    """Triclinic box: the reference's image shift is d -= cell @ round(solve(cell^T, d)) (representations.py:92-93), which
+    differs from the true minimum image for non-symmetric cells; the HIP path must reproduce the reference, not physics."""
+    from oracle import newtonnet_ref as ref
+    g = torch.Generator().manual_seed(7)
+    n = 150
+    cell = torch.tensor([[[12.0, 0.0, 0.0], [2.5, 13.0, 0.0], [1.0, -1.5, 14.0]]])
+    pos = (torch.rand(n, 3, generator=g) @ cell[0]).float()
+    # keep atoms >= 0.9 A apart so energies stay tame
+    keep = [0]
+    for i in range(1, n):
+        if (pos[keep] - pos[i]).norm(dim=1).min() > 0.9:
+            keep.append(i)
+    pos = pos[keep]
+    n = len(keep)
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (n,), generator=g)]
+    batch = torch.zeros(n, dtype=torch.long)
+    model, sd = make_model('rand')
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert np.array_equal(out.edge_index.cpu().numpy(), want['edge_index'].numpy())
+    fs = max(1.0, want['forces'].abs().max().item() / 5.0)
+    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), fs)
+
+
+def test_large_nonperiodic_cluster_and_high_degree_rows():
+    """One 1500-atom non-periodic cluster (all-pairs kernel, rows with > 64 neighbours) plus small molecules in one batch."""
+    from oracle import newtonnet_ref as ref
+    g = torch.Generator().manual_seed(11)
+    side = 12
+    idx = torch.arange(1500)
+    grid = torch.stack([idx // (side * side), (idx // side) % side, idx % side], 1).float() * 1.7
+    pos_big = grid + (torch.rand(1500, 3, generator=g) - 0.5) * 0.6
+    a = util.load_npz('aspirin_frames.npz')
+    pos = torch.cat([torch.from_numpy(a['train_pos'][0]).float(), pos_big, torch.from_numpy(a['train_pos'][1]).float()])
+    z = torch.cat([torch.from_numpy(a['z']).long(), torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (1500,), generator=g)],
+                   torch.from_numpy(a['z']).long()])
+    batch = torch.cat([torch.zeros(21), torch.ones(1500), torch.full((21,), 2)]).long()
+    cell = torch.zeros(3, 3, 3)
+    model, sd = make_model('rand')
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    ei = out.edge_index.cpu().numpy()
+    assert np.array_equal(ei, want['edge_index'].numpy())
+    assert np.bincount(ei[0]).max() > 64
+    e = out.energy.cpu().double().numpy()
+    assert np.all(np.abs(e - want['energy'].numpy()) <= np.maximum(util.energy_tol(want['energy'].numpy()), 2e-5 * np.abs(e)))
+    fs = max(1.0, want['forces'].abs().max().item() / 5.0)
+    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), fs)

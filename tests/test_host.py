@@ -98,3 +98,31 @@ def test_unknown_keys_raise_like_reference():
         get_precision_by_string('int8')
     with pytest.raises(NotImplementedError):
         get_output_by_string('nope')
+
+
+def test_whole_module_pickle_roundtrip(tmp_path):
+    """trainer.py:219 / ase_interface.py:87: models are saved and loaded as whole-module pickles; kernel handles must not
+    live in picklable attributes."""
+    from newtonnet_amd.models import NewtonNet
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    path = tmp_path / 'best_model.pt'
+    torch.save(model, path)
+    loaded = torch.load(path, map_location='cpu', weights_only=False)
+    assert isinstance(loaded, NewtonNet) and loaded.output_properties == ['energy', 'gradient_force']
+    for (k0, v0), (k1, v1) in zip(model.state_dict().items(), loaded.state_dict().items()):
+        assert k0 == k1 and torch.equal(v0, v1)
+
+
+def test_model_surgery_like_ase_interface():
+    """ase_interface.py:97-121 appends / pops heads on the live module lists."""
+    from newtonnet_amd.layers import get_scaler_by_string
+    from newtonnet_amd.models import NewtonNet, get_aggregator_by_string, get_output_by_string
+    model = NewtonNet(output_properties=['energy'])
+    assert model.embedding_layers.requires_dr is False
+    model.output_properties.append('gradient_force')
+    model.output_layers.append(get_output_by_string('gradient_force'))
+    model.scalers.append(get_scaler_by_string('gradient_force'))
+    model.aggregators.append(get_aggregator_by_string('gradient_force'))
+    assert len(model.output_layers) == 2 and model.scalers[1].scale is None
+    with pytest.raises(NotImplementedError):
+        get_output_by_string('hessian')
