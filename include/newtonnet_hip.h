@@ -107,6 +107,15 @@ int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, 
                      int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Undirected pairs.  msg = (W_e rbf) * m[i] * m[j] (newtonnet.py:211) is symmetric under i <-> j, and so is everything
+ * equiv_message1/2 compute from it (newtonnet.py:218,222): nnhip_energy_forces evaluates msg / hidden / phi once per
+ * undirected pair.  pid[e] = pair row of directed edge e (pairs numbered in CSR order of their i < j edge);
+ * pair_ptr[N+1] = first pair owned by each row.  n_edges must be even (symmetric edge set).
+ * ------------------------------------------------------------------------ */
+int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, const int32_t* rev, int32_t n_atoms, int32_t n_edges,
+                      int32_t* pair_ptr, int32_t* pid, void* stream);
+
+/* --------------------------------------------------------------------------
  * O(N) variant of the neighbor list for ONE large orthorhombic periodic box (BASELINE config 5; the reference's
  * all-pairs build, representations.py:74-85, needs O(N^2) memory and cannot run it).  Bit-identical output to
  * nnhip_graph_count/fill (same predicate, same displacement arithmetic, same edge order); candidates are pruned
@@ -160,10 +169,10 @@ typedef struct {
   /* byte offsets into the workspace; per-layer arrays indexed by layer */
   size_t m[NNHIP_MAX_LAYERS];      /* [N][F]   message_nodepart output */
   size_t hn[NNHIP_MAX_LAYERS];     /* [N][F]   message_nodepart hidden pre-activation */
-  size_t msg[NNHIP_MAX_LAYERS];    /* [E][F]   message */
-  size_t h12[NNHIP_MAX_LAYERS];    /* [E][2F]  equiv_message{1,2} hidden pre-activations */
-  size_t phi1[NNHIP_MAX_LAYERS];   /* [E][F] */
-  size_t phi2[NNHIP_MAX_LAYERS];   /* [E][F] */
+  size_t msg[NNHIP_MAX_LAYERS];    /* [P][F]   message, one row per undirected pair (P = E/2, row pid[e]) */
+  size_t h12[NNHIP_MAX_LAYERS];    /* [P][2F]  equiv_message{1,2} hidden pre-activations */
+  size_t phi1[NNHIP_MAX_LAYERS];   /* [P][F] */
+  size_t phi2[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */
   size_t a_out[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the layer */
   size_t f_out[NNHIP_MAX_LAYERS];  /* [N][3][F] force_node after the layer */
@@ -181,7 +190,7 @@ int nnhip_workspace_layout(int32_t n_atoms, int32_t n_edges, int32_t n_mol, int3
 
 int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                         const int32_t* mol_ptr,
-                        const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const float* geo,
+                        const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
                         const int32_t* xg, const float* disp, int32_t n_atoms, int32_t n_edges,
                         int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
                         float* virial, float* atom_energy, float* atom_node, float* force_node, void* stream);

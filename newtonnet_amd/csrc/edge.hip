@@ -10,8 +10,13 @@
 // one receiver row; lane l holds features 2l, 2l+1, so every [F]=128-float row access is one fully
 // coalesced 512-byte transaction and the per-row sums live in registers: deterministic segmented
 // reductions, no float atomics.  Sender-side scatters of the adjoint are turned into receiver-side
-// gathers through the reverse-edge index (the edge set is symmetric).  Per-edge scalars (col, dir, rbf)
-// are wave-uniform and come in through the scalar cache.  HBM-bound: no MFMA here.
+// gathers (the edge set is symmetric).  Per-edge scalars (col, dir, table position) are wave-uniform and come
+// in through the scalar cache.  HBM-bound: no MFMA here.
+//
+// Pair space: msg, the MLP hidden tiles and phi1 / phi2 are symmetric under i <-> j (graph.hip, "Undirected pairs"),
+// so they are stored once per undirected pair p = pid[e] ([P = E/2][128] arrays).  The row of the LOWER endpoint owns
+// the pair (its upper edges i < j map to a contiguous run of pair rows) and is the only writer of msg[p] and
+// g_phi[p]; both endpoints read.
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
@@ -47,12 +52,13 @@ __device__ __forceinline__ void filter_rows(const float* __restrict__ table, int
 
 // ---------------------------------------------------------------------------------------------
 // forward: message + invariant aggregation
-//   msg[e] = eps_e * m[i] * m[j];  a_mid[i] = a_in[i] + sum_{e in row i} msg[e]
+//   msg[pid e] = eps_e * m[i] * m[j] (written by the row with i < j);  a_mid[i] = a_in[i] + sum_{e in row i} msg_e
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const float* __restrict__ table,
-               const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ a_in,
-               float* __restrict__ msg, float* __restrict__ a_mid, int n_atoms) {
+               const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
+               const float* __restrict__ a_in, float* __restrict__ msg /*[P][F]*/, float* __restrict__ a_mid,
+               int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -70,7 +76,7 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
 #pragma unroll
     for (int k = 1; k < 4; ++k) eps = fma2(t[k], fw.w[k], eps);
     const float2 v = eps * mi * mj;
-    st2(msg + (size_t)e * NF + 2 * lane, v);
+    if (j > i) st2(msg + (size_t)pid[e] * NF + 2 * lane, v);   // the lower endpoint writes the shared pair row
     acc = acc + v;
   }
   st2(a_mid + (size_t)i * NF + 2 * lane, ld2(a_in + (size_t)i * NF + 2 * lane) + acc);
@@ -78,14 +84,14 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
 
 // ---------------------------------------------------------------------------------------------
 // forward: equivariant messages + aggregation
-//   f_out[i][k] = f_in[i][k] + sum_e ( phi1[e] * u_e[k] + phi2[e] * f_in[j][k] )
+//   f_out[i][k] = f_in[i][k] + sum_e ( phi1[pid e] * u_e[k] + phi2[pid e] * f_in[j][k] )
 // HAS_F = false for the first layer, where force_node == 0 (newtonnet.py:143): the phi2 term vanishes.
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_F>
 __global__ void __launch_bounds__(256)
-force_fwd_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2, const float* __restrict__ geo,
-                 const int* __restrict__ row_ptr, const int* __restrict__ col, const float* __restrict__ f_in,
-                 float* __restrict__ f_out, int n_atoms) {
+force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restrict__ phi2, const float* __restrict__ geo,
+                 const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
+                 const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -96,13 +102,14 @@ force_fwd_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2,
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];  // (ux,uy,uz,r), wave-uniform
-    const float2 p1 = ld2_nt(phi1 + (size_t)e * NF + 2 * lane);
+    const size_t p = (size_t)pid[e];
+    const float2 p1 = ld2(phi1 + p * NF + 2 * lane);
     acc[0] = fma2(p1, g.x, acc[0]);
     acc[1] = fma2(p1, g.y, acc[1]);
     acc[2] = fma2(p1, g.z, acc[2]);
     if (HAS_F) {
       const int j = col[e];
-      const float2 p2 = ld2_nt(phi2 + (size_t)e * NF + 2 * lane);
+      const float2 p2 = ld2(phi2 + p * NF + 2 * lane);
 #pragma unroll
       for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
     }
@@ -112,36 +119,44 @@ force_fwd_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2,
 }
 
 // ---------------------------------------------------------------------------------------------
-// adjoint of force_fwd for receiver row i, given gf = dE/d f_out:
-//   g_phi1[e]   = sum_k gf[i][k] u_e[k]                      -> g_h12[e][0:F]   (feeds the MLP adjoint GEMMs)
-//   g_phi2[e]   = sum_k gf[i][k] * f_in[j][k]                -> g_h12[e][F:2F]
-//   g_u[e][k]   = < gf[i][k] , phi1[e] >                     (wave reduction)
-//   g_fin[i][k] = gf[i][k] + sum_{e in row i} phi2[rev e] * gf[j][k]
-//                 (the sender-side scatter  g_fin[j] += phi2[e] * gf[i]  re-indexed by the reverse edge)
+// adjoint of force_fwd for receiver row i, given gf = dE/d f_out (p = pid[e], the shared pair row):
+//   g_u[e][k]   = < gf[i][k] , phi1[p] >                                  (wave reduction, per directed edge)
+//   g_fin[i][k] = gf[i][k] + sum_{e in row i} phi2[p] * gf[j][k]
+//                 (the sender-side scatter  g_fin[j] += phi2[e] * gf[i]  seen from the receiving end of the reverse
+//                  edge, whose phi2 is the same pair row)
+//   and, written once per pair by the row of the lower endpoint (i < j), the sum of both directions' contributions
+//   to the shared phi rows -- u_(j,i) = -u_(i,j):
+//   g_phi1[p]   = sum_k (gf[i][k] - gf[j][k]) u_e[k]                      -> g_h12[p][0:F]   (feeds the MLP adjoint)
+//   g_phi2[p]   = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]     -> g_h12[p][F:2F]
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_F>
 __global__ void __launch_bounds__(256)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
-                 const int* __restrict__ rev, const float* __restrict__ f_in, float* __restrict__ g_h12,
+                 const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
                  float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  float2 gfi[3], acc[3];
+  float2 gfi[3], fi[3], acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     gfi[k] = ld2(gf + ((size_t)i * 3 + k) * NF + 2 * lane);
     acc[k] = gfi[k];
+    if (HAS_F) fi[k] = ld2(f_in + ((size_t)i * 3 + k) * NF + 2 * lane);
   }
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];
-    const float2 p1 = ld2_nt(phi1 + (size_t)e * NF + 2 * lane);
-    float2 gp1 = gfi[0] * g.x;
-    gp1 = fma2(gfi[1], g.y, gp1);
-    gp1 = fma2(gfi[2], g.z, gp1);
-    st2_nt(g_h12 + (size_t)e * 2 * NF + 2 * lane, gp1);
+    const int j = col[e];
+    const size_t p = (size_t)pid[e];
+    const bool owner = j > i;   // wave-uniform
+    const float2 p1 = ld2(phi1 + p * NF + 2 * lane);
+    float2 gfj[3];
+    if (HAS_F || owner) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gfj[k] = ld2(gf + ((size_t)j * 3 + k) * NF + 2 * lane);
+    }
     float s0 = fmaf(gfi[0].x, p1.x, gfi[0].y * p1.y);
     float s1 = fmaf(gfi[1].x, p1.x, gfi[1].y * p1.y);
     float s2 = fmaf(gfi[2].x, p1.x, gfi[2].y * p1.y);
@@ -149,17 +164,25 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) reinterpret_cast<float4*>(g_u)[e] = make_float4(s0, s1, s2, 0.f);
+    if (owner) {
+      float2 gp1 = make_float2(gfi[0].x - gfj[0].x, gfi[0].y - gfj[0].y) * g.x;
+      gp1 = fma2(make_float2(gfi[1].x - gfj[1].x, gfi[1].y - gfj[1].y), g.y, gp1);
+      gp1 = fma2(make_float2(gfi[2].x - gfj[2].x, gfi[2].y - gfj[2].y), g.z, gp1);
+      st2_nt(g_h12 + p * 2 * NF + 2 * lane, gp1);
+    }
     if (HAS_F) {
-      const int j = col[e];
-      const int r = rev[e];
-      const float2 p2r = ld2_nt(phi2 + (size_t)r * NF + 2 * lane);
-      float2 gp2 = make_float2(0.f, 0.f);
+      const float2 p2 = ld2(phi2 + p * NF + 2 * lane);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
-        acc[k] = fma2(p2r, ld2(gf + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
+      for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, gfj[k], acc[k]);
+      if (owner) {
+        float2 gp2 = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
+          gp2 = fma2(gfj[k], fi[k], gp2);
+        }
+        st2_nt(g_h12 + p * 2 * NF + NF + 2 * lane, gp2);
       }
-      st2_nt(g_h12 + (size_t)e * 2 * NF + NF + 2 * lane, gp2);
     }
   }
   if (HAS_F) {
@@ -169,17 +192,17 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// adjoint of msg_fwd for receiver row i.  g_msg[e] holds the MLP-side gradient of msg[e]; the
-// aggregation a_mid = a_in + sum msg adds g_a[i] to every message of row i:
-//   gm_e  = g_msg[e]      + g_a[i]        gm_r = g_msg[rev e] + g_a[j]
-//   g_x[e]  = < gm_e * m[i] * m[j] , d eps_e/dx >                       (wave reduction)
-//   g_m[i]  = sum_{e in row i} (gm_e + gm_r) * eps_e * m[j]
-//             (receiver term + the sender term of the reverse edge; eps_rev == eps_e since x is symmetric)
+// adjoint of msg_fwd for receiver row i.  g_msg[p] holds the MLP-side gradient of the shared pair message; the
+// aggregations a_mid[i] += msg and a_mid[j] += msg (one per directed edge) add g_a[i] + g_a[j]:
+//   G       = g_msg[p] + g_a[i] + g_a[j]                 total gradient of the pair message
+//   g_m[i]  = sum_{e in row i} G * eps_e * m[j]
+//   g_x[e]  = 1/2 < G * m[i] * m[j] , d eps_e/dx >       (wave reduction; x is shared by the two directed edges, each
+//                                                         carries half so that their sum is the pair's derivative)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, const float* __restrict__ m,
+msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
                const int2* __restrict__ xg, const float* __restrict__ table,
-               const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ rev,
+               const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
@@ -190,11 +213,9 @@ msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, c
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const int j = col[e];
-    const int r = rev[e];
     const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
     const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
-    const float2 gm_e = ld2(g_msg + (size_t)e * NF + 2 * lane) + gai;
-    const float2 gm_r = ld2(g_msg + (size_t)r * NF + 2 * lane) + gaj;
+    const float2 G = ld2(g_msg + (size_t)pid[e] * NF + 2 * lane) + gai + gaj;
     const int2 gxi = xg[e];   // wave-uniform
     float4 td[4];   // (T, D) pairs of this lane's two features, rows g0 .. g0+3 of the interleaved table
 #pragma unroll
@@ -207,10 +228,10 @@ msg_bwd_kernel(const float* __restrict__ g_msg, const float* __restrict__ g_a, c
       eps = fma2(make_float2(td[k].x, td[k].z), fw.w[k], eps);
       deps = fma2(make_float2(td[k].y, td[k].w), fw.w[k], deps);
     }
-    const float2 t = gm_e * mi * mj;
+    const float2 t = G * mi * mj;
     const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
-    if (lane == 0) g_x[e] = gx;
-    acc = fma2((gm_e + gm_r) * eps, mj, acc);
+    if (lane == 0) g_x[e] = 0.5f * gx;
+    acc = fma2(G * eps, mj, acc);
   }
   st2(g_m + (size_t)i * NF + 2 * lane, acc);
 }
@@ -420,49 +441,49 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, ROWS_PER_BLOCK); }
 
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
-                   const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
+                   const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, a_in, msg,
-                                                     a_mid, n_atoms);
+  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
+                                                     msg, a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
-                     const int* col, const float* f_in, float* f_out, int n_atoms, hipStream_t s) {
+                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, f_in, f_out, n_atoms);
+    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   else
-    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, f_in, f_out, n_atoms);
+    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
-                     const int* row_ptr, const int* col, const int* rev, const float* f_in, float* g_h12, float* g_u,
+                     const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
                      float* g_fin, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, rev, f_in, g_h12, g_u,
+    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                g_fin, n_atoms);
   else
-    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, rev, f_in, g_h12, g_u,
+    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                 g_fin, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
-                   const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
-                   int n_atoms, hipStream_t s) {
+                   const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
+                   hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
-  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, rev, g_m, g_x,
-                                                    n_atoms);
+  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col,
+                                                    pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }

@@ -536,3 +536,58 @@ extern "C" int nnhip_graph_fill_cells(const float* pos, const float* cell, int32
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
+
+// =============================================================================================
+// Undirected pairs.  The message of an edge, msg = (W_e rbf) * m[i] * m[j] (newtonnet.py:211), is symmetric under
+// i <-> j, hence so is everything the two edge MLPs compute from it (equiv_message1/2, newtonnet.py:218,222):
+// phi_k(i,j) == phi_k(j,i).  The hot path therefore evaluates msg / h / phi once per UNDIRECTED pair and lets both
+// directed edges read the same row: half the MFMA work and half the [E,128] traffic of the dominant kernels.
+//   pid[e]      pair index of directed edge e; pairs are numbered in CSR order of their upper edge (i < j), so the
+//               upper edges of a row own a contiguous run of pair rows
+//   pair_ptr[i] first pair owned by row i (exclusive scan of the number of upper edges per row)
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+pairs_count_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int n_atoms, int* __restrict__ n_upper) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  int c = 0;
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) c += (col[e] > i);
+  n_upper[i] = c;
+}
+
+template <bool UPPER>
+__global__ void __launch_bounds__(256)
+pairs_assign_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ rev,
+                    const int* __restrict__ pair_ptr, int n_atoms, int* pid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  int p = pair_ptr[i];
+  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+    if (UPPER) {
+      if (col[e] > i) pid[e] = p++;
+    } else {
+      if (col[e] < i) pid[e] = pid[rev[e]];   // the upper edge (j, i) was numbered by the previous launch
+    }
+  }
+}
+
+extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, const int32_t* rev, int32_t n_atoms,
+                                 int32_t n_edges, int32_t* pair_ptr, int32_t* pid, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms < 0 || n_edges < 0 || !pair_ptr || (n_edges && !pid)) {
+    nnhip_set_error("nnhip_graph_pairs: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  HIP_TRY(hipMemsetAsync(pair_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
+  if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  pairs_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, n_atoms, pair_ptr);
+  LAUNCH_CHECK();
+  scan_rows_kernel<<<1, 1024, 0, stream>>>(pair_ptr, n_atoms, pair_ptr);
+  LAUNCH_CHECK();
+  pairs_assign_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
+  LAUNCH_CHECK();
+  pairs_assign_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}

@@ -15,15 +15,15 @@
 // ---- pieces defined in the other translation units ---------------------------------------------------
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, hipStream_t s);
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
-                   const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
+                   const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
-                     const int* col, const float* f_in, float* f_out, int n_atoms, hipStream_t s);
+                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, hipStream_t s);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
-                     const int* row_ptr, const int* col, const int* rev, const float* f_in, float* g_h12, float* g_u,
+                     const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
                      float* g_fin, int n_atoms, hipStream_t s);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
-                   const int* row_ptr, const int* col, const int* rev, float* g_m, float* g_x,
-                   int n_atoms, hipStream_t s);
+                   const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
+                   hipStream_t s);
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
@@ -136,7 +136,8 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   (void)B;
   memset(&w, 0, sizeof(w));
   size_t off = 0;
-  const size_t nf = (size_t)N * NF * 4, ef = (size_t)E * NF * 4;
+  const size_t nf = (size_t)N * NF * 4;
+  const size_t ef = (size_t)((E + 1) / 2) * NF * 4;   // msg / h / phi / g_phi / g_msg live once per undirected pair
   w.pub.a0 = carve(off, nf);
   for (int l = 0; l < L; ++l) {
     w.pub.m[l] = carve(off, nf);
@@ -223,7 +224,7 @@ static int lin2(int pro, int epi, LinGroup g0, LinGroup g1, int lda, int ldc, in
 // ---- the hot path --------------------------------------------------------------------------------------
 extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                                    const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
-                                   const int32_t* rev, const float* geo, const int32_t* xg,
+                                   const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
                                    const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                                    size_t workspace_bytes, float* energy, float* forces, float* virial,
                                    float* atom_energy_out, float* atom_node_out, float* force_node_out,
@@ -239,6 +240,11 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     return NNHIP_E_UNSUPPORTED;
   }
   const int L = model->n_layers;
+  if (E & 1) {
+    nnhip_set_error("nnhip_energy_forces: odd edge count %d (the edge set must be symmetric)", E);
+    return NNHIP_E_INVALID;
+  }
+  const int P_ = E / 2;   // undirected pairs
   WsInternal w;
   make_layout(N, E, B, L, w);
   if (workspace_bytes < w.pub.total || (!workspace && w.pub.total)) {
@@ -308,16 +314,16 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
     TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
     // messages + invariant update
-    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
+    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
     if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
       float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mlp(MODE_FWD, false, {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), E, NF, 2 * NF, NF}, s));
+      TRY(launch_mlp(MODE_FWD, false, {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, 2 * NF, NF}, s));
       if (has_f)
         TRY(launch_mlp(MODE_FWD, false,
-                       {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), E, NF, 2 * NF, NF}, s));
+                       {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF}, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, f_in, P(w.pub.f_out[l]), N, s));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, P(w.pub.f_out[l]), N, s));
     // equiv_update + energy update
     TRY(lin1(PRO_NONE, EPI_STORE, P(w.pub.f_out[l]), NF, lp.update_w, P(w.pub.q[l]), NF, nullptr, nullptr, 0, 3 * N, s));
     TRY(launch_node_update_fwd(P(w.pub.a_mid[l]), P(w.pub.f_out[l]), P(w.pub.q[l]), N, P(w.pub.a_out[l]), s));
@@ -350,18 +356,18 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(lin1(PRO_NONE, EPI_ACC, P(w.tmp3), NF, P(w.wT[l][6]), P(w.gf_mid), NF, nullptr, nullptr, 0, 3 * N, s));
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
-    TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, rev, f_prev,
+    TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
                          P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, s));
     if (E > 0) {
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
-      float* gp = P(w.g_h12);   // [E][2F]: g_phi1 | g_phi2 written by force_bwd
+      float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
       float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mlp(MODE_BWD, false, {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), E, 2 * NF, 2 * NF, NF}, s));
+      TRY(launch_mlp(MODE_BWD, false, {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF}, s));
       if (has_f)
-        TRY(launch_mlp(MODE_BWD, true, {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), E, 2 * NF, 2 * NF, NF}, s));
+        TRY(launch_mlp(MODE_BWD, true, {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF}, s));
     }
     // message adjoint -> g_m, g_x
-    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, rev, P(w.g_m),
+    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, P(w.g_m),
                        P(w.pub.g_x) + (size_t)l * E, N, s));
     // message_nodepart adjoint: g_hn = (g_m W2) * silu'(hn) ; g_a += g_hn W0
     TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_m), NF, P(w.wT[l][1]), P(w.g_hn), NF, nullptr, P(w.pub.hn[l]), NF, N, s));

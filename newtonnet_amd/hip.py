@@ -86,7 +86,8 @@ def lib():
     L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.nnhip_workspace_bytes.restype = sz
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
-    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
+    L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
@@ -96,7 +97,7 @@ def lib():
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
-               'nnhip_graph_fill_cells', 'nnhip_mlp128'):
+               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -106,7 +107,7 @@ EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'n
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
-                    'nnhip_mlp128')
+                    'nnhip_mlp128', 'nnhip_graph_pairs')
 
 
 def _check(rc: int, what: str):
@@ -134,7 +135,7 @@ CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fa
 class Graph:
     """Neighbor list + edge embedding of one batch (device tensors)."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr')
 
 
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
@@ -185,6 +186,10 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
                                   float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
                'nnhip_graph_fill')
+    pints = torch.empty(E + N + 1, dtype=torch.int32, device=dev)
+    g.pid, g.pair_ptr = pints[:E], pints[E:]
+    _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid), st),
+           'nnhip_graph_pairs')
     nb = frequencies.numel()
     g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
     g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None     # dist_edge (tests / API)
@@ -219,7 +224,7 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
     out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
-                                 _ptr(g.rev), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,
+                                 _ptr(g.rev), _ptr(g.pid), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
                                  _ptr(out['force_node']), _stream(dev)), 'nnhip_energy_forces')

@@ -69,6 +69,8 @@ def test_intermediates_against_trace():
     N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
     lay = hip.workspace_layout(N, E, B, L)
     ws = res['workspace']
+    Pn, pid, rev = E // 2, g.pid.cpu().long(), g.rev.cpu().long()   # msg / phi live once per undirected pair
+    assert torch.equal(pid, pid[rev]) and pid.max().item() == Pn - 1 and len(torch.unique(pid)) == Pn
 
     def view(off, shape):
         n = int(np.prod(shape))
@@ -83,13 +85,14 @@ def test_intermediates_against_trace():
     close('dir', g.geo[:, :3].cpu().double(), T['u'], 1e-6)
     for l in range(L):
         close(f'm{l}', view(lay.m[l], (N, 128)), T[f'm_{l}'])
-        close(f'msg{l}', view(lay.msg[l], (E, 128)), T[f'msg_{l}'])
-        close(f'phi1{l}', view(lay.phi1[l], (E, 128)), T[f'phi1_{l}'])
+        close(f'msg{l}', view(lay.msg[l], (Pn, 128))[pid], T[f'msg_{l}'])
+        close(f'phi1{l}', view(lay.phi1[l], (Pn, 128))[pid], T[f'phi1_{l}'])
         if l > 0:
-            close(f'phi2{l}', view(lay.phi2[l], (E, 128)), T[f'phi2_{l}'])
+            close(f'phi2{l}', view(lay.phi2[l], (Pn, 128))[pid], T[f'phi2_{l}'])
         close(f'f_out{l}', view(lay.f_out[l], (N, 3, 128)), T[f'f_out_{l}'])
         close(f'a_out{l}', view(lay.a_out[l], (N, 128)), T[f'a_out_{l}'])
-        close(f'g_x{l}', view(lay.g_x + 4 * l * E, (E,)), T[f'g_x_{l}'], 2e-4)
+        gx = view(lay.g_x + 4 * l * E, (E,))
+        close(f'g_x{l}', gx + gx[rev], T[f'g_x_{l}'] + T[f'g_x_{l}'][rev], 2e-4)   # x is shared: only the pair sum is defined
         close(f'g_u{l}', view(lay.g_u + 16 * l * E, (E, 4))[:, :3], T[f'g_u_{l}'], 2e-4)
 
 

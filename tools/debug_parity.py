@@ -69,23 +69,27 @@ def run(case):
     ws = res['workspace']
     N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
     lay = hip.workspace_layout(N, E, B, L)
+    Pn = E // 2
+    pid = g.pid.cpu().long()          # edge tensors live once per undirected pair: compare row pid[e] with edge e
     report('a0', view(ws, lay.a0, (N, 128)), T['a0'])
     for l in range(L):
         print(f'  -- layer {l}')
         report('hn', view(ws, lay.hn[l], (N, 128)), T[f'hn_{l}'])
         report('m', view(ws, lay.m[l], (N, 128)), T[f'm_{l}'])
-        report('msg', view(ws, lay.msg[l], (E, 128)), T[f'msg_{l}'])
+        report('msg', view(ws, lay.msg[l], (Pn, 128))[pid], T[f'msg_{l}'])
         report('a_mid', view(ws, lay.a_mid[l], (N, 128)), T[f'a_mid_{l}'])
-        h12 = view(ws, lay.h12[l], (E, 256))
+        h12 = view(ws, lay.h12[l], (Pn, 256))[pid]
         report('h1', h12[:, :128], T[f'h1_{l}'])
-        report('phi1', view(ws, lay.phi1[l], (E, 128)), T[f'phi1_{l}'])
+        report('phi1', view(ws, lay.phi1[l], (Pn, 128))[pid], T[f'phi1_{l}'])
         if l > 0:
             report('h2', h12[:, 128:], T[f'h2_{l}'])
-            report('phi2', view(ws, lay.phi2[l], (E, 128)), T[f'phi2_{l}'])
+            report('phi2', view(ws, lay.phi2[l], (Pn, 128))[pid], T[f'phi2_{l}'])
         report('f_out', view(ws, lay.f_out[l], (N, 3, 128)), T[f'f_out_{l}'])
         report('q', view(ws, lay.q[l], (N, 3, 128)), T[f'q_{l}'])
         report('a_out', view(ws, lay.a_out[l], (N, 128)), T[f'a_out_{l}'])
-        report('g_x', view(ws, lay.g_x + 4 * l * E, (E,)), T[f'g_x_{l}'])
+        gx = view(ws, lay.g_x + 4 * l * E, (E,))
+        rev = g.rev.cpu().long()
+        report('g_x pair', gx + gx[rev], T[f'g_x_{l}'] + T[f'g_x_{l}'][rev])   # only the pair sum is defined
         report('g_u', view(ws, lay.g_u + 16 * l * E, (E, 4))[:, :3], T[f'g_u_{l}'])
     report('atom_energy', res['atom_energy'].cpu(), T['atom_energy'])
     report('energy', res['energy'].cpu(), T['energy'])
