@@ -57,7 +57,10 @@ def synthetic_box(n_atoms, n_side, seed, device):
 
 
 def algorithmic_counts(N, E, L=3, F=128):
-    """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step."""
+    """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step.
+    The edge MLPs are evaluated once per undirected pair (P = E/2 rows): the FLOP counts below are the FLOPs actually
+    executed, i.e. HALF of the reference's per-directed-edge count for those layers (phi(i,j) == phi(j,i))."""
+    P = E // 2
     edge_fwd = L * (1568 * E + 4608 * N)
     edge_bwd = L * (3136 * E + 6144 * N)
     # dense linears actually needed for energy + force (layer-0 phi2 branch is identically zero and skipped):
@@ -65,12 +68,12 @@ def algorithmic_counts(N, E, L=3, F=128):
     fl = 0
     for l in range(L):
         n_edge_mlp = 1 if l == 0 else 2
-        fwd = 2 * N + 2 * n_edge_mlp * E + 3 * N
-        bwd = 3 * N + 2 * n_edge_mlp * E + (2 * N if l > 0 else 2 * N)
+        fwd = 2 * N + 2 * n_edge_mlp * P + 3 * N
+        bwd = 3 * N + 2 * n_edge_mlp * P + 2 * N
         fl += (fwd + bwd) * 2 * F * F
     fl += (2 * N + 2 * N) * 2 * F * F
     n_mlp = sum(1 if l == 0 else 2 for l in range(L))          # fused edge-MLP launches: fwd + adjoint each
-    mlp_fl = 2 * n_mlp * 2 * E * 2 * F * F
+    mlp_fl = 2 * n_mlp * 2 * P * 2 * F * F
     return edge_fwd, edge_bwd, fl, mlp_fl
 
 

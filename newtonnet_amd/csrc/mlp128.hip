@@ -54,7 +54,12 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
   const float* w1row = w1s + r * MW_LD + 4 * h;
   const float* w2row = w2s + r * MW_LD + 4 * h;
 
-  int tile = blockIdx.x * 8 + wave;
+  // Tile -> wave map.  Waves w and w + 4 of a workgroup share a SIMD (waves are dealt to the 4 SIMDs cyclically), and the
+  // matrix pipe of a SIMD is what bounds this kernel, so the tiles are dealt to SIMDs first and to the two waves of a
+  // SIMD second: when the tile count is not a multiple of the wave count the surplus tiles land on DIFFERENT SIMDs
+  // (e.g. 4891 tiles, 1024 SIMDs: 3 + 2 on 795 of them, 2 + 2 on the rest -- not 3 + 3 on 400 and 2 + 2 elsewhere).
+  const int n_simd = gridDim.x * 4;
+  int tile = (wave >> 2) * n_simd + blockIdx.x * 4 + (wave & 3);
   const int tile_step = gridDim.x * 8;
   if (tile >= n_tiles) return;
   float4 x[16];
