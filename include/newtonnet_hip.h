@@ -93,7 +93,8 @@ typedef struct {
  * over the RECEIVER i = edge_index[0].
  *
  * nnhip_graph_count: writes row_ptr[N+1] (exclusive scan of the in-degree) and
- *   mol_ptr[B+1].  status[0] is set non-zero if `batch` is not sorted.
+ *   mol_ptr[B+1].  status is int32[1 + ceil(n_atoms/1024)]: status[0] is set non-zero if `batch` is not sorted, the rest
+ *   is scratch of the prefix scan.
  *   The caller reads E = row_ptr[N] (a device->host copy; the only sync).
  * nnhip_graph_fill: writes col[E] (sender j), rev[E] (index of the reverse
  *   edge (j,i); the edge set is symmetric), disp[E][3] = pos_i - pos_j (after
@@ -113,7 +114,7 @@ int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, 
  * pair_ptr[N+1] = first pair owned by each row.  n_edges must be even (symmetric edge set).
  * ------------------------------------------------------------------------ */
 int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, const int32_t* rev, int32_t n_atoms, int32_t n_edges,
-                      int32_t* pair_ptr, int32_t* pid, void* stream);
+                      int32_t* pair_ptr, int32_t* pid, int32_t* scan_scratch /* int32[ceil(n_atoms/1024)] */, void* stream);
 
 /* --------------------------------------------------------------------------
  * O(N) variant of the neighbor list for ONE large orthorhombic periodic box (BASELINE config 5; the reference's

@@ -409,14 +409,19 @@ head_out_kernel(const float* __restrict__ e2, const float* __restrict__ w4, cons
   if (g_e2) st2(g_e2 + (size_t)i * NF + 2 * lane, make_float2(sc * w.x * dsilu_f(h.x), sc * w.y * dsilu_f(h.y)));
 }
 
-// E_b = sum of atom energies of molecule b  (output.py:246).  fp64 accumulation, one rounding.
-__global__ void mol_energy_kernel(const float* __restrict__ atom_energy, const int* __restrict__ mol_ptr, int n_mol,
-                                  float* __restrict__ energy) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// E_b = sum of atom energies of molecule b  (output.py:246).  One wave per molecule, fp64 partial sums in a fixed
+// lane-strided order + butterfly: deterministic, one rounding at the end; a 100k-atom box no longer serialises on one
+// thread.
+__global__ void __launch_bounds__(256)
+mol_energy_kernel(const float* __restrict__ atom_energy, const int* __restrict__ mol_ptr, int n_mol,
+                  float* __restrict__ energy) {
+  const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (b >= n_mol) return;
+  const int lane = threadIdx.x & 63;
   double s = 0.0;
-  for (int i = mol_ptr[b]; i < mol_ptr[b + 1]; ++i) s += (double)atom_energy[i];
-  energy[b] = (float)s;
+  for (int i = mol_ptr[b] + lane; i < mol_ptr[b + 1]; i += 64) s += (double)atom_energy[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+  if (lane == 0) energy[b] = (float)s;
 }
 
 // out[m][n][k] = in[m][k][n] for a list of 128x128 matrices (weights for the adjoint GEMMs)
@@ -535,7 +540,7 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
   ScopedTimer t0(TC_OTHER, s);
   head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, atom_energy, g_e2);
   LAUNCH_CHECK();
-  mol_energy_kernel<<<cdiv(n_mol, 256), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
+  mol_energy_kernel<<<cdiv(n_mol, ROWS_PER_BLOCK), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
   LAUNCH_CHECK();
   return 0;
 }

@@ -129,31 +129,65 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
   if (!FILL) deg[i] = cnt;
 }
 
-// exclusive scan of deg[n] -> row_ptr[n+1]; one workgroup (n is at most a few 1e5..1e6 here)
-// (deg may alias row_ptr: every thread sums its chunk before anything is overwritten, and reads each
-// element before replacing it)
-__global__ void __launch_bounds__(1024) scan_rows_kernel(const int* deg, int n, int* row_ptr) {
-  __shared__ int part[1024];
+// exclusive scan of deg[n] -> row_ptr[n+1] in two fully parallel launches (in place is fine: deg may alias row_ptr):
+//   scan_partials_kernel: one 1024-element tile per block -> tile sum
+//   scan_apply_kernel:    every block sums the tile sums before it (<= 1024 tiles, one coalesced pass), scans its own
+//                         tile in LDS and writes the exclusive prefix; the last block also writes row_ptr[n]
+#define SCAN_TILE 1024
+__device__ __forceinline__ int block_reduce_sum_1024(int v, int* sh) {
   const int t = threadIdx.x;
-  const int chunk = (n + 1023) / 1024;
-  const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
-  int s = 0;
-  for (int k = lo; k < hi; ++k) s += deg[k];
-  part[t] = s;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  if ((t & 63) == 0) sh[t >> 6] = v;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
+  int s = 0;
+  if (t < 16) s = sh[t];
+  if (t < 64) {
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+    if (t == 0) sh[16] = s;
+  }
+  __syncthreads();
+  const int total = sh[16];
+  __syncthreads();
+  return total;
+}
+__global__ void __launch_bounds__(SCAN_TILE) scan_partials_kernel(const int* deg, int n, int* tile_sums) {
+  __shared__ int sh[17];
+  const int k = blockIdx.x * SCAN_TILE + threadIdx.x;
+  const int total = block_reduce_sum_1024(k < n ? deg[k] : 0, sh);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(SCAN_TILE) scan_apply_kernel(const int* deg, int n, const int* tile_sums, int* row_ptr) {
+  __shared__ int sh[17];
+  __shared__ int part[SCAN_TILE];
+  const int t = threadIdx.x;
+  int before = 0;
+  for (int b = t; b < (int)blockIdx.x; b += SCAN_TILE) before += tile_sums[b];
+  const int offset = block_reduce_sum_1024(before, sh);
+  const int k = blockIdx.x * SCAN_TILE + t;
+  const int d = k < n ? deg[k] : 0;
+  part[t] = d;
+  __syncthreads();
+  for (int off = 1; off < SCAN_TILE; off <<= 1) {
     const int v = (t >= off) ? part[t - off] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
-  int run = part[t] - s;  // exclusive prefix of this thread's chunk
-  for (int k = lo; k < hi; ++k) {
-    const int d = deg[k];
-    row_ptr[k] = run;
-    run += d;
+  if (k < n) row_ptr[k] = offset + part[t] - d;
+  if (k == n - 1) row_ptr[n] = offset + part[t];
+}
+// tile_sums: scratch of ceil(n / 1024) ints.  Callers pass the tail of a buffer they own (see below).
+static int launch_scan(const int* deg, int n, int* row_ptr, int* tile_sums, hipStream_t stream) {
+  const int nb = cdiv(n, SCAN_TILE);
+  if (nb > SCAN_TILE * SCAN_TILE) {
+    nnhip_set_error("scan: n = %d too large", n);
+    return NNHIP_E_UNSUPPORTED;
   }
-  if (t == 1023) row_ptr[n] = part[1023];
+  scan_partials_kernel<<<nb, SCAN_TILE, 0, stream>>>(deg, n, tile_sums);
+  LAUNCH_CHECK();
+  scan_apply_kernel<<<nb, SCAN_TILE, 0, stream>>>(deg, n, tile_sums, row_ptr);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
 }
 
 // reverse-edge index: for e = (i, j) find e' = (j, i) by binary search in row j (cols ascending)
@@ -230,7 +264,7 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
     return NNHIP_E_INVALID;
   }
   ScopedTimer tm(TC_GRAPH, stream);
-  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream));   // status[0]; status[1..] is scan scratch
   HIP_TRY(hipMemsetAsync(mol_ptr, 0, sizeof(int32_t) * (n_mol + 1), stream));
   HIP_TRY(hipMemsetAsync(row_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
   if (n_atoms == 0) return NNHIP_OK;
@@ -240,8 +274,10 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
   graph_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, cutoff, row_ptr,
                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
-  scan_rows_kernel<<<1, 1024, 0, stream>>>(row_ptr, n_atoms, row_ptr);
-  LAUNCH_CHECK();
+  {
+    const int rc = launch_scan(row_ptr, n_atoms, row_ptr, status + 1, stream);   // status[1..] = scan scratch
+    if (rc) return rc;
+  }
   return NNHIP_OK;
 }
 
@@ -458,12 +494,19 @@ static int make_grid(const float* box_len_host, float cutoff, CellGrid& g, int& 
   return NNHIP_OK;
 }
 
-// scratch: bin_of[N] | bin_cnt/bin_ptr[n_bins+1] | cursor[n_bins] | bin_atoms[N]   (int32)
+// scratch: bin_of[N] | bin_cnt/bin_ptr[n_bins+1] | cursor[n_bins] | bin_atoms[N] | scan_tmp[max(N, n_bins)/1024 + 1]   (int32)
 extern "C" size_t nnhip_graph_cells_scratch_bytes(int32_t n_atoms, const float* box_len_host, float cutoff) {
   CellGrid g;
   int n_bins;
   if (make_grid(box_len_host, cutoff, g, n_bins) != NNHIP_OK) return 0;
-  return sizeof(int32_t) * ((size_t)2 * n_atoms + 2 * (size_t)n_bins + 2);
+  return sizeof(int32_t) * ((size_t)2 * n_atoms + 2 * (size_t)n_bins + 2 + (size_t)(n_atoms > n_bins ? n_atoms : n_bins) / 1024 + 2);
+}
+
+static int* scan_tmp_of(void* scratch, int n_atoms, const float* box_len_host, float cutoff) {
+  CellGrid g;
+  int n_bins = 0;
+  make_grid(box_len_host, cutoff, g, n_bins);
+  return (int*)scratch + 2 * (size_t)n_atoms + 2 * (size_t)n_bins + 1;
 }
 
 static int cells_common(const float* pos, int n_atoms, const float* box_len_host, float cutoff, void* scratch,
@@ -480,12 +523,15 @@ static int cells_common(const float* pos, int n_atoms, const float* box_len_host
   bin_ptr = s + n_atoms;
   cursor = bin_ptr + n_bins + 1;
   bin_atoms = cursor + n_bins;
+  int* scan_tmp = bin_atoms + n_atoms;
   if (build) {
     HIP_TRY(hipMemsetAsync(bin_ptr, 0, sizeof(int) * (2 * (size_t)n_bins + 1), stream));
     cells_bin_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, n_atoms, g, bin_of, bin_ptr);
     LAUNCH_CHECK();
-    scan_rows_kernel<<<1, 1024, 0, stream>>>(bin_ptr, n_bins, bin_ptr);
-    LAUNCH_CHECK();
+    {
+      const int rc2 = launch_scan(bin_ptr, n_bins, bin_ptr, scan_tmp, stream);
+      if (rc2) return rc2;
+    }
     cells_bin_fill_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(bin_of, bin_ptr, n_atoms, cursor, bin_atoms);
     LAUNCH_CHECK();
   }
@@ -510,8 +556,10 @@ extern "C" int nnhip_graph_count_cells(const float* pos, const float* cell, int3
   cells_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cutoff,
                                                                    row_ptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
-  scan_rows_kernel<<<1, 1024, 0, stream>>>(row_ptr, n_atoms, row_ptr);
-  LAUNCH_CHECK();
+  {
+    const int rc2 = launch_scan(row_ptr, n_atoms, row_ptr, scan_tmp_of(scratch, n_atoms, box_len_host, cutoff), stream);
+    if (rc2) return rc2;
+  }
   return NNHIP_OK;
 }
 
@@ -572,9 +620,9 @@ pairs_assign_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col
 }
 
 extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, const int32_t* rev, int32_t n_atoms,
-                                 int32_t n_edges, int32_t* pair_ptr, int32_t* pid, void* stream_) {
+                                 int32_t n_edges, int32_t* pair_ptr, int32_t* pid, int32_t* scan_scratch, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_atoms < 0 || n_edges < 0 || !pair_ptr || (n_edges && !pid)) {
+  if (n_atoms < 0 || n_edges < 0 || !pair_ptr || (n_edges && (!pid || !scan_scratch))) {
     nnhip_set_error("nnhip_graph_pairs: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -583,8 +631,10 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
   ScopedTimer tm(TC_GRAPH, stream);
   pairs_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, n_atoms, pair_ptr);
   LAUNCH_CHECK();
-  scan_rows_kernel<<<1, 1024, 0, stream>>>(pair_ptr, n_atoms, pair_ptr);
-  LAUNCH_CHECK();
+  {
+    const int rc = launch_scan(pair_ptr, n_atoms, pair_ptr, scan_scratch, stream);
+    if (rc) return rc;
+  }
   pairs_assign_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
   LAUNCH_CHECK();
   pairs_assign_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);

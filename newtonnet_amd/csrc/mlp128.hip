@@ -40,12 +40,6 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* w1s = wl;
   float* w2s = wl + NF * MW_LD;
-  for (int idx = threadIdx.x; idx < NF * (NF / 4); idx += 512) {
-    const int n = idx >> 5, k4 = idx & 31;
-    *reinterpret_cast<float4*>(&w1s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W1)[idx];
-    *reinterpret_cast<float4*>(&w2s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W2)[idx];
-  }
-  __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -61,9 +55,15 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
   const int n_simd = gridDim.x * 4;
   int tile = (wave >> 2) * n_simd + blockIdx.x * 4 + (wave & 3);
   const int tile_step = gridDim.x * 8;
+  float4 x[16];   // first X fragment is requested before the weights are staged: its latency hides under the LDS fill
+  mlp_load_x(x, p.X, p.ldx, min((min(tile, n_tiles - 1) << 5) + r, p.M - 1), h);
+  for (int idx = threadIdx.x; idx < NF * (NF / 4); idx += 512) {
+    const int n = idx >> 5, k4 = idx & 31;
+    *reinterpret_cast<float4*>(&w1s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W1)[idx];
+    *reinterpret_cast<float4*>(&w2s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W2)[idx];
+  }
+  __syncthreads();
   if (tile >= n_tiles) return;
-  float4 x[16];
-  mlp_load_x(x, p.X, p.ldx, min((tile << 5) + r, p.M - 1), h);
   for (; tile < n_tiles; tile += tile_step) {
     const int e = (tile << 5) + r;           // this lane's edge (both halves of the wave share it)
     const int ec = min(e, p.M - 1);

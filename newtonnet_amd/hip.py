@@ -86,7 +86,7 @@ def lib():
     L.nnhip_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.nnhip_workspace_bytes.restype = sz
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
-    L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
@@ -151,8 +151,9 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     N, B = pos.shape[0], cell.shape[0]
     g = Graph()
     g.n_atoms, g.n_mol = N, B
-    meta = torch.empty(B + 1 + N + 1 + 1, dtype=torch.int32, device=dev)
-    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]
+    n_scan = (N + 1023) // 1024 + 1
+    meta = torch.empty(B + 1 + N + 1 + 1 + n_scan, dtype=torch.int32, device=dev)
+    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]   # status[0] + scan scratch
     st = _stream(dev)
     # One big orthorhombic periodic box -> O(N) cell-list kernels (bit-identical output to the all-pairs kernels).
     box = None
@@ -163,13 +164,13 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
             box = (C.c_float * 3)(*[float(v) for v in diag])
     if box is not None:
         scratch = torch.empty(L.nnhip_graph_cells_scratch_bytes(N, box, float(cutoff)), dtype=torch.uint8, device=dev)
-        status.zero_()
+        status[:1].zero_()
         _check(L.nnhip_graph_count_cells(_ptr(pos), _ptr(cell), N, float(cutoff), box, _ptr(scratch), _ptr(g.mol_ptr),
                                          _ptr(g.row_ptr), st), 'nnhip_graph_count_cells')
     else:
         _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
                                    _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
-    tail = meta[B + N + 1:].tolist()          # (E, status): the one device->host sync of the path
+    tail = meta[B + N + 1:B + N + 3].tolist()  # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
     if bad:
         raise ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
@@ -186,9 +187,10 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
                                   float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
                'nnhip_graph_fill')
-    pints = torch.empty(E + N + 1, dtype=torch.int32, device=dev)
-    g.pid, g.pair_ptr = pints[:E], pints[E:]
-    _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid), st),
+    pints = torch.empty(E + N + 1 + n_scan, dtype=torch.int32, device=dev)
+    g.pid, g.pair_ptr = pints[:E], pints[E:E + N + 1]
+    _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid),
+                               _ptr(pints[E + N + 1:]), st),
            'nnhip_graph_pairs')
     nb = frequencies.numel()
     g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
