@@ -95,12 +95,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} '
                          f'(WORLD_SIZE={world})')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # One process per GPU.  (BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo lets several ranks share one device: used only to
+    # exercise this launch path on a 1-GPU box.)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev if os.environ.get('BENCH_SHARE_GPU') == '1' else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')     # "nccl" is RCCL on ROCm
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from newtonnet_amd import hip
     from newtonnet_amd.models import NewtonNet
@@ -137,7 +145,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     E = int(out.edge_index.shape[1])
