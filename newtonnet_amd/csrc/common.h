@@ -112,4 +112,31 @@ struct MlpArgs {
 };
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s);
 
+// ---- row-local fused node kernels (node128.hip) -------------------------------------
+struct NodeFwdArgs {
+  const float* f;      // [N][3][F] force_node after the edge phase (f')
+  const float* a_mid;  // [N][F]
+  const float* Wu;     // [F][F]
+  float* q;            // [N][3][F] out
+  float* a_out;        // [N][F] out
+  const float *W0, *b0, *W2, *b2;  // next layer's message_nodepart (W0 == NULL: no next layer)
+  float *hn, *m;       // [N][F] out (next layer)
+  int N;
+};
+struct NodeBwdArgs {
+  const float* g_top;  // [N][F]  g_m of the upper layer (or g_e2 at the head)
+  const float* h_top;  // [N][F]  hn of the upper layer (or e1): pre-activation for silu'
+  const float *W2T, *W0T;  // transposed weights of the upper node MLP / head
+  float* g_a;          // [N][F]  running dE/d atom_node  (acc_ga: g_a += ..., else g_a = ...)
+  const float* f;      // [N][3][F] force_node of the lower layer after its edge phase
+  const float* q;      // [N][3][F]
+  const float* G_f;    // [N][3][F] dE/d f_out of the lower layer from above (NULL = 0)
+  const float* WuT;    // [F][F] transposed equiv_update of the lower layer
+  float* gf;           // [N][3][F] out
+  int N;
+  int acc_ga;
+};
+int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s);
+int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

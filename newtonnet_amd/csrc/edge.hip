@@ -364,31 +364,6 @@ __global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restr
   reinterpret_cast<float4*>(a0)[t] = reinterpret_cast<const float4*>(table + (size_t)z[i] * NF)[c];
 }
 
-// a_out = a_mid + sum_k f[k] * q[k]     (newtonnet.py:230-231, q = equiv_update(force_node))
-__global__ void node_update_fwd_kernel(const float* __restrict__ a_mid, const float* __restrict__ f,
-                                       const float* __restrict__ q, int n_atoms, float* __restrict__ a_out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n_atoms * NF) return;
-  const size_t i = t / NF, c = t % NF;
-  float v = a_mid[t];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) v = fmaf(f[(i * 3 + k) * NF + c], q[(i * 3 + k) * NF + c], v);
-  a_out[t] = v;
-}
-
-// adjoint of the update, elementwise part:  tmp[i][k] = g_a[i] * f[i][k]  (GEMM input: x W_u),
-//   gf[i][k] = g_fout[i][k] + g_a[i] * q[i][k]   (the GEMM then accumulates tmp W_u into gf)
-__global__ void node_update_bwd_kernel(const float* __restrict__ g_a, const float* __restrict__ f,
-                                       const float* __restrict__ q, const float* __restrict__ g_fout /*or NULL*/,
-                                       int n_atoms, float* __restrict__ tmp, float* __restrict__ gf) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n_atoms * 3 * NF) return;
-  const size_t i = t / (3 * NF), c = t % NF;
-  const float ga = g_a[i * NF + c];
-  tmp[t] = ga * f[t];
-  gf[t] = fmaf(ga, q[t], g_fout ? g_fout[t] : 0.f);
-}
-
 // energy head tail (output.py:98-100 last Linear, scalers.py:55-58) and the seed of the reverse sweep:
 //   eps_i = <silu(e2_i), w4> + b4;  E_i = eps_i * scale[z_i] + shift[z_i]
 //   g_e2[i] = scale[z_i] * w4 * silu'(e2_i)          (dE_b/dE_i = 1, output.py:69)
@@ -514,22 +489,6 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
 int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
   embed_kernel<<<cdiv((long)n_atoms * (NF / 4), 256), 256, 0, s>>>(z, table, n_atoms, a0);
-  LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_node_update_fwd(const float* a_mid, const float* f, const float* q, int n_atoms, float* a_out,
-                           hipStream_t s) {
-  ScopedTimer t0(TC_OTHER, s);
-  node_update_fwd_kernel<<<cdiv((long)n_atoms * NF, 256), 256, 0, s>>>(a_mid, f, q, n_atoms, a_out);
-  LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_node_update_bwd(const float* g_a, const float* f, const float* q, const float* g_fout, int n_atoms,
-                           float* tmp, float* gf, hipStream_t s) {
-  ScopedTimer t0(TC_OTHER, s);
-  node_update_bwd_kernel<<<cdiv((long)n_atoms * 3 * NF, 256), 256, 0, s>>>(g_a, f, q, g_fout, n_atoms, tmp, gf);
   LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,214 @@
+// Row-local fused node kernels (gfx950, exact fp32 MFMA): everything that happens to the node tensors BETWEEN two
+// edge phases of the path, in one launch.
+//
+// Forward boundary after the edge phase of layer l (newtonnet/models/newtonnet.py:229-231 and, for the next layer,
+// :181-185,209):
+//     q_k   = f'_k W_u^T                    k = 0,1,2          (equiv_update)
+//     a_out = a_mid + sum_k f'_k * q_k                           (energy update)
+//     hn    = a_out W_0^T + b_0 ;  m = silu(hn) W_2^T + b_2      (message_nodepart of layer l+1, if any)
+// Reverse boundary (the adjoint of the same operations, walking down):
+//     g_hn  = (g_m W_2) * silu'(hn) ;  g_a (+)= g_hn W_0          (message_nodepart adjoint of the upper layer, or the
+//                                                                  energy-head adjoint at the top)
+//     gf_k  = G_f,k + g_a * q_k + (g_a * f'_k) W_u                (update adjoint of the lower layer)
+//
+// All of it is row-local (no atom talks to another), but as separate launches it was ~20 latency-bound kernels per
+// step (a 0.7 GFLOP GEMM takes ~20 us whatever the kernel: one 256-MFMA chain per wave).  Here one 4-wave workgroup
+// owns a 32-atom tile and walks the whole chain; wave w computes output column block w of every GEMM (64-MFMA chains),
+// activations pass from one GEMM to the next through a 16.5 KiB LDS tile, and the weights come straight from L2 as
+// the MFMA A operand (transposed formulation, as in mlp128.hip: D^T[feature][atom] = W X^T; every wave of the grid
+// with the same w reads the same 16 KiB of each matrix).
+#include "common.h"
+
+#define NT_LD 132                       // LDS tile row pitch (floats): conflict-free ds_read_b128 / ds_write_b128
+#define NODE_LDS_FLOATS (32 * NT_LD)
+
+struct Tile {
+  float* xs;  // LDS [32][NT_LD]
+  int r, h, nb;
+};
+
+// block `nb` of D^T = W . X^T for the 32 rows in the LDS tile; W rows nb*32 .. nb*32+31 straight from global (L2)
+__device__ __forceinline__ f32x16 tile_gemm(const Tile& t, const float* __restrict__ W) {
+  float4 wf[16];
+  const float4* wp = reinterpret_cast<const float4*>(W + (size_t)(t.nb * 32 + t.r) * NF + 4 * t.h);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) wf[k] = wp[2 * k];  // k-slots 8k + 4h + {0..3}
+  // all 16 weight loads in flight together (hipcc would otherwise sink each one next to its MFMA group: 16 serial L2
+  // round trips per GEMM)
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const float* xr = t.xs + t.r * NT_LD + 4 * t.h;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float4 x = *reinterpret_cast<const float4*>(xr + 8 * k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].x, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].y, x.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].z, x.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].w, x.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// this lane's 16 values of column block nb (features nb*32 + (k&3) + 8 (k>>2) + 4h) of row `row`
+__device__ __forceinline__ void blk_load(float (&v)[16], const float* __restrict__ base, size_t row_off, const Tile& t) {
+  const float4* p = reinterpret_cast<const float4*>(base + row_off + t.nb * 32 + 4 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 x = p[2 * q];
+    v[4 * q] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void blk_store(const float (&v)[16], float* __restrict__ base, size_t row_off, const Tile& t) {
+  float4* p = reinterpret_cast<float4*>(base + row_off + t.nb * 32 + 4 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+__device__ __forceinline__ void blk_to_tile(const float (&v)[16], const Tile& t) {
+  float* p = t.xs + t.r * NT_LD + t.nb * 32 + 4 * t.h;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(p + 8 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+__device__ __forceinline__ void acc_to(float (&v)[16], const f32x16& a) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = a[k];
+}
+
+__global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, p.N - 1);   // clamped row for loads; stores are predicated
+  const bool live = row < p.N;
+
+  float upd[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) upd[k] = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    float x[16], qv[16];
+    blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
+    if (c) __syncthreads();            // every wave is done reading the previous tile
+    blk_to_tile(x, t);
+    __syncthreads();
+    acc_to(qv, tile_gemm(t, p.Wu));
+    if (live) blk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(x[k], qv[k], upd[k]);
+  }
+  float a[16];
+  blk_load(a, p.a_mid, (size_t)rc * NF, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] += upd[k];
+  if (live) blk_store(a, p.a_out, (size_t)row * NF, t);
+  if (!p.W0) return;
+
+  // message_nodepart of the next layer
+  __syncthreads();
+  blk_to_tile(a, t);
+  __syncthreads();
+  float hn[16], bias[16];
+  acc_to(hn, tile_gemm(t, p.W0));
+  blk_load(bias, p.b0, 0, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hn[k] += bias[k];
+  if (live) blk_store(hn, p.hn, (size_t)row * NF, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hn[k] = silu_f(hn[k]);
+  __syncthreads();
+  blk_to_tile(hn, t);
+  __syncthreads();
+  float m[16];
+  acc_to(m, tile_gemm(t, p.W2));
+  blk_load(bias, p.b2, 0, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] += bias[k];
+  if (live) blk_store(m, p.m, (size_t)row * NF, t);
+}
+
+__global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, p.N - 1);
+  const bool live = row < p.N;
+
+  float ga[16];
+  if (p.W2T) {
+    // adjoint of the upper two-layer node MLP / head:  g_hn = (g_top W2) * silu'(h_top);  g_a (+)= g_hn W0
+    float x[16], hpre[16], g[16];
+    blk_load(x, p.g_top, (size_t)rc * NF, t);
+    blk_load(hpre, p.h_top, (size_t)rc * NF, t);
+    blk_to_tile(x, t);
+    __syncthreads();
+    acc_to(g, tile_gemm(t, p.W2T));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
+    __syncthreads();
+    blk_to_tile(g, t);
+    __syncthreads();
+    acc_to(ga, tile_gemm(t, p.W0T));
+    if (p.acc_ga) {
+      float old[16];
+      blk_load(old, p.g_a, (size_t)rc * NF, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ga[k] += old[k];
+    }
+    if (live) blk_store(ga, p.g_a, (size_t)row * NF, t);
+  } else {
+    blk_load(ga, p.g_a, (size_t)rc * NF, t);
+  }
+  if (!p.WuT) return;
+
+  // adjoint of the lower layer's update:  gf_k = G_f,k + g_a * q_k + (g_a * f'_k) W_u
+  for (int c = 0; c < 3; ++c) {
+    float x[16], qv[16], out[16];
+    blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
+    blk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] *= ga[k];
+    __syncthreads();
+    blk_to_tile(x, t);
+    __syncthreads();
+    acc_to(out, tile_gemm(t, p.WuT));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qv[k], out[k]);
+    if (p.G_f) {
+      float gin[16];
+      blk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] += gin[k];
+    }
+    if (live) blk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
+  }
+}
+
+int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_LIN1, s);
+  node_fwd_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_LIN1, s);
+  node_bwd_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a);
+  LAUNCH_CHECK();
+  return 0;
+}

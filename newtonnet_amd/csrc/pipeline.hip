@@ -29,9 +29,6 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
                         float* virial, hipStream_t s);
 int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s);
-int launch_node_update_fwd(const float* a_mid, const float* f, const float* q, int n_atoms, float* a_out, hipStream_t s);
-int launch_node_update_bwd(const float* g_a, const float* f, const float* q, const float* g_fout, int n_atoms,
-                           float* tmp, float* gf, hipStream_t s);
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s);
@@ -116,9 +113,7 @@ struct WsInternal {
   size_t g_h12;                    // [E][2F] adjoint scratch (g_phi -> g_h)
   size_t g_msg;                    // [E][F]
   size_t g_m;                      // [N][F]
-  size_t g_hn;                     // [N][F]
   size_t g_e;                      // [N][F] head adjoint scratch (g_e2 then g_e1)
-  size_t tmp3;                     // [N][3][F]
   size_t g_f2;                     // [N][3][F] second g_f buffer (ping-pong)
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
@@ -163,11 +158,9 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   w.pub.g_f = carve(off, 3 * nf);
   w.g_f2 = carve(off, 3 * nf);
   w.gf_mid = carve(off, 3 * nf);
-  w.tmp3 = carve(off, 3 * nf);
   w.g_h12 = carve(off, 2 * ef);
   w.g_msg = carve(off, ef);
   w.g_m = carve(off, nf);
-  w.g_hn = carve(off, nf);
   w.g_e = carve(off, nf);
   w.g_d = carve(off, (size_t)E * 16);
   w.atom_energy = carve(off, (size_t)N * 4);
@@ -310,9 +303,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   for (int l = 0; l < L; ++l) {
     const nnhip_layer_params& lp = model->layer[l];
     const bool has_f = l > 0;
-    // message_nodepart: hn = a W0^T + b0 ; m = silu(hn) W2^T + b2
-    TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
-    TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
+    // message_nodepart: hn = a W0^T + b0 ; m = silu(hn) W2^T + b2.  (For l > 0 it was already produced by the fused
+    // node kernel that closed the previous layer.)
+    if (l == 0) {
+      TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
+      TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
+    }
     // messages + invariant update
     TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
@@ -324,9 +320,27 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
                        {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF}, s));
     }
     TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, P(w.pub.f_out[l]), N, s));
-    // equiv_update + energy update
-    TRY(lin1(PRO_NONE, EPI_STORE, P(w.pub.f_out[l]), NF, lp.update_w, P(w.pub.q[l]), NF, nullptr, nullptr, 0, 3 * N, s));
-    TRY(launch_node_update_fwd(P(w.pub.a_mid[l]), P(w.pub.f_out[l]), P(w.pub.q[l]), N, P(w.pub.a_out[l]), s));
+    // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
+    {
+      NodeFwdArgs na;
+      memset(&na, 0, sizeof(na));
+      na.f = P(w.pub.f_out[l]);
+      na.a_mid = P(w.pub.a_mid[l]);
+      na.Wu = lp.update_w;
+      na.q = P(w.pub.q[l]);
+      na.a_out = P(w.pub.a_out[l]);
+      if (l + 1 < L) {
+        const nnhip_layer_params& nx = model->layer[l + 1];
+        na.W0 = nx.node0_w;
+        na.b0 = nx.node0_b;
+        na.W2 = nx.node2_w;
+        na.b2 = nx.node2_b;
+        na.hn = P(w.pub.hn[l + 1]);
+        na.m = P(w.pub.m[l + 1]);
+      }
+      na.N = N;
+      TRY(launch_node_fwd(na, s));
+    }
     a_in = P(w.pub.a_out[l]);
     f_in = P(w.pub.f_out[l]);
   }
@@ -341,19 +355,32 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   if (!want_forces) return NNHIP_OK;
 
   // ------------------------------------------------------------------ reverse sweep
-  // head: g_e1 = (g_e2 H2) * silu'(e1) ; g_a = g_e1 H0
-  TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_e), NF, P(w.headT[1]), P(w.g_e), NF, nullptr, P(w.pub.e1), NF, N, s));
-  TRY(lin1(PRO_NONE, EPI_STORE, P(w.g_e), NF, P(w.headT[0]), P(w.pub.g_a), NF, nullptr, nullptr, 0, N, s));
-  float* g_fout = nullptr;  // dE/d force_node after the last layer is zero
+  // head adjoint (g_e1 = (g_e2 H2) * silu'(e1); g_a = g_e1 H0) + update adjoint of the last layer
+  // (gf = g_a * q + (g_a * f) W_u; dE/d force_node after the last layer is zero): one row-local launch
+  {
+    NodeBwdArgs nb;
+    memset(&nb, 0, sizeof(nb));
+    nb.g_top = P(w.g_e);
+    nb.h_top = P(w.pub.e1);
+    nb.W2T = P(w.headT[1]);
+    nb.W0T = P(w.headT[0]);
+    nb.g_a = P(w.pub.g_a);
+    nb.acc_ga = 0;
+    nb.f = P(w.pub.f_out[L - 1]);
+    nb.q = P(w.pub.q[L - 1]);
+    nb.G_f = nullptr;
+    nb.WuT = P(w.wT[L - 1][6]);
+    nb.gf = P(w.gf_mid);
+    nb.N = N;
+    TRY(launch_node_bwd(nb, s));
+  }
   float* g_fbuf[2] = {P(w.pub.g_f), P(w.g_f2)};
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const nnhip_layer_params& lp = model->layer[l];
+    (void)lp;
     const bool has_f = l > 0;
     const float* f_prev = has_f ? P(w.pub.f_out[l - 1]) : nullptr;
-    // update adjoint: gf = g_fout + g_a * q + (g_a * f) W_u
-    TRY(launch_node_update_bwd(P(w.pub.g_a), P(w.pub.f_out[l]), P(w.pub.q[l]), g_fout, N, P(w.tmp3), P(w.gf_mid), s));
-    TRY(lin1(PRO_NONE, EPI_ACC, P(w.tmp3), NF, P(w.wT[l][6]), P(w.gf_mid), NF, nullptr, nullptr, 0, 3 * N, s));
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
@@ -369,15 +396,27 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, P(w.g_m),
                        P(w.pub.g_x) + (size_t)l * E, N, s));
-    // message_nodepart adjoint: g_hn = (g_m W2) * silu'(hn) ; g_a += g_hn W0
-    TRY(lin1(PRO_NONE, EPI_DSILU, P(w.g_m), NF, P(w.wT[l][1]), P(w.g_hn), NF, nullptr, P(w.pub.hn[l]), NF, N, s));
-    TRY(lin1(PRO_NONE, EPI_ACC, P(w.g_hn), NF, P(w.wT[l][0]), P(w.pub.g_a), NF, nullptr, nullptr, 0, N, s));
-    g_fout = has_f ? g_fin : nullptr;
+    // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
+    // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
+    // message_nodepart input is the embedding of z, which does not depend on the positions.
+    if (l > 0) {
+      NodeBwdArgs nb;
+      memset(&nb, 0, sizeof(nb));
+      nb.g_top = P(w.g_m);
+      nb.h_top = P(w.pub.hn[l]);
+      nb.W2T = P(w.wT[l][1]);
+      nb.W0T = P(w.wT[l][0]);
+      nb.g_a = P(w.pub.g_a);
+      nb.acc_ga = 1;
+      nb.f = P(w.pub.f_out[l - 1]);
+      nb.q = P(w.pub.q[l - 1]);
+      nb.G_f = g_fin;   // dE/d f_out of layer l-1, produced by force_bwd of layer l just above
+      nb.WuT = P(w.wT[l - 1][6]);
+      nb.gf = P(w.gf_mid);
+      nb.N = N;
+      TRY(launch_node_bwd(nb, s));
+    }
     pp ^= 1;
-  }
-  if (virial && (!pos || !cell)) {
-    nnhip_set_error("nnhip_energy_forces: virial needs pos and cell");
-    return NNHIP_E_INVALID;
   }
   TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, pos, cell, row_ptr, col, rev, mol_ptr, N, E, B, L,
                           model->cutoff, P(w.g_d), forces, virial, s));
