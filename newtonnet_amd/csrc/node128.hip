@@ -27,15 +27,18 @@ struct Tile {
   int r, h, nb;
 };
 
-// block `nb` of D^T = W . X^T for the 32 rows in the LDS tile; W rows nb*32 .. nb*32+31 straight from global (L2)
-__device__ __forceinline__ f32x16 tile_gemm(const Tile& t, const float* __restrict__ W) {
-  float4 wf[16];
+// Weight fragment of column block `nb`: rows nb*32 .. nb*32+31 of W straight from global (L2), k-slots 8k + 4h + {0..3}.
+// Fetched one GEMM AHEAD (right after the previous GEMM's MFMAs have consumed the registers), so the L2 round trip hides
+// under the epilogue / LDS hand-over / barrier of the previous stage.
+__device__ __forceinline__ void load_w(float4 (&wf)[16], const Tile& t, const float* __restrict__ W) {
   const float4* wp = reinterpret_cast<const float4*>(W + (size_t)(t.nb * 32 + t.r) * NF + 4 * t.h);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) wf[k] = wp[2 * k];  // k-slots 8k + 4h + {0..3}
-  // all 16 weight loads in flight together (hipcc would otherwise sink each one next to its MFMA group: 16 serial L2
-  // round trips per GEMM)
-  __builtin_amdgcn_sched_barrier(0);
+  for (int k = 0; k < 16; ++k) wf[k] = wp[2 * k];
+  __builtin_amdgcn_sched_barrier(0);   // keep the 16 loads together and ahead of what follows
+}
+
+// block `nb` of D^T = W . X^T for the 32 rows in the LDS tile
+__device__ __forceinline__ f32x16 tile_gemm(const Tile& t, const float4 (&wf)[16]) {
   f32x16 acc;
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
@@ -48,6 +51,7 @@ __device__ __forceinline__ f32x16 tile_gemm(const Tile& t, const float* __restri
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].z, x.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].w, x.w, acc, 0, 0, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);
   return acc;
 }
 
@@ -90,16 +94,20 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   const int rc = min(row, p.N - 1);   // clamped row for loads; stores are predicated
   const bool live = row < p.N;
 
+  float4 wf[16];
+  load_w(wf, t, p.Wu);                 // one fetch serves the three components
   float upd[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) upd[k] = 0.f;
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     float x[16], qv[16];
     blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
     if (c) __syncthreads();            // every wave is done reading the previous tile
     blk_to_tile(x, t);
     __syncthreads();
-    acc_to(qv, tile_gemm(t, p.Wu));
+    acc_to(qv, tile_gemm(t, wf));
+    if (c == 2 && p.W0) load_w(wf, t, p.W0);
     if (live) blk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(x[k], qv[k], upd[k]);
@@ -116,7 +124,8 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   blk_to_tile(a, t);
   __syncthreads();
   float hn[16], bias[16];
-  acc_to(hn, tile_gemm(t, p.W0));
+  acc_to(hn, tile_gemm(t, wf));
+  load_w(wf, t, p.W2);
   blk_load(bias, p.b0, 0, t);
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] += bias[k];
@@ -127,7 +136,7 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   blk_to_tile(hn, t);
   __syncthreads();
   float m[16];
-  acc_to(m, tile_gemm(t, p.W2));
+  acc_to(m, tile_gemm(t, wf));
   blk_load(bias, p.b2, 0, t);
 #pragma unroll
   for (int k = 0; k < 16; ++k) m[k] += bias[k];
@@ -146,20 +155,24 @@ __global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
   const bool live = row < p.N;
 
   float ga[16];
+  float4 wf[16];
   if (p.W2T) {
     // adjoint of the upper two-layer node MLP / head:  g_hn = (g_top W2) * silu'(h_top);  g_a (+)= g_hn W0
+    load_w(wf, t, p.W2T);
     float x[16], hpre[16], g[16];
     blk_load(x, p.g_top, (size_t)rc * NF, t);
     blk_load(hpre, p.h_top, (size_t)rc * NF, t);
     blk_to_tile(x, t);
     __syncthreads();
-    acc_to(g, tile_gemm(t, p.W2T));
+    acc_to(g, tile_gemm(t, wf));
+    load_w(wf, t, p.W0T);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
     __syncthreads();
     blk_to_tile(g, t);
     __syncthreads();
-    acc_to(ga, tile_gemm(t, p.W0T));
+    acc_to(ga, tile_gemm(t, wf));
+    if (p.WuT) load_w(wf, t, p.WuT);
     if (p.acc_ga) {
       float old[16];
       blk_load(old, p.g_a, (size_t)rc * NF, t);
@@ -169,10 +182,12 @@ __global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
     if (live) blk_store(ga, p.g_a, (size_t)row * NF, t);
   } else {
     blk_load(ga, p.g_a, (size_t)rc * NF, t);
+    if (p.WuT) load_w(wf, t, p.WuT);
   }
   if (!p.WuT) return;
 
   // adjoint of the lower layer's update:  gf_k = G_f,k + g_a * q_k + (g_a * f'_k) W_u
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     float x[16], qv[16], out[16];
     blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
@@ -182,7 +197,7 @@ __global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
     __syncthreads();
     blk_to_tile(x, t);
     __syncthreads();
-    acc_to(out, tile_gemm(t, p.WuT));
+    acc_to(out, tile_gemm(t, wf));
 #pragma unroll
     for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qv[k], out[k]);
     if (p.G_f) {
