@@ -109,6 +109,8 @@ struct MlpArgs {
   float* H;         // [M][ldh]  FWD: output (pre-activation);  BWD: input (pre-activation of the forward)
   float* Y;         // [M][ldy]  stage-2 output
   int M, ldx, ldh, ldy;
+  const float* b1;  // optional biases (node MLP / energy head; forward mode, row-local small-M kernel only)
+  const float* b2;
 };
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s);
 

@@ -181,10 +181,16 @@ static int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
   return 0;
 }
 
+int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s);   // node128.hip
+
+#define MLP_WIDE_MAX_TILES 1536   // up to ~49k rows one workgroup per tile beats the persistent form (tools/bench_mlp.py)
+
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
-  ScopedTimer t1(TC_MLP, s);
+  ScopedTimer t1((a.b1 || a.b2) ? TC_LIN1 : TC_MLP, s);   // biased form = node MLP / energy head (node-level class)
+  static const int wide_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : MLP_WIDE_MAX_TILES;
+  if (cdiv(a.M, 32) <= wide_max || a.b1 || a.b2) return launch_mlp_wide(mode, accum, a, s);
   if (mode == MODE_FWD && !accum) return launch_mlp_t<MODE_FWD, false>(a, s);
   if (mode == MODE_BWD && !accum) return launch_mlp_t<MODE_BWD, false>(a, s);
   if (mode == MODE_BWD && accum) return launch_mlp_t<MODE_BWD, true>(a, s);
@@ -209,5 +215,6 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
   a.ldx = ldx;
   a.ldh = ldh;
   a.ldy = ldy;
+  a.b1 = a.b2 = nullptr;
   return launch_mlp(mode, accumulate != 0, a, (hipStream_t)stream);
 }

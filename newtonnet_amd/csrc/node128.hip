@@ -227,3 +227,78 @@ int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
   LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M form of the fused edge MLP (same contract as mlp128.hip:mlp128_kernel, same MlpArgs): one 4-wave workgroup
+// per 32-row tile, wave w = column block w of both stages, weights from L2, hidden tile through LDS.  The persistent
+// kernel costs one 512-MFMA chain plus a 132 KiB LDS fill even for a single tile (~35 us); this one runs two 64-MFMA
+// chains (~10 us).  Used for the single-molecule / MD-loop regime (MLAseCalculator, ase_interface.py:52-81).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, bool ACCUM>
+__global__ void __launch_bounds__(256) mlp128_wide_kernel(const MlpArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, p.M - 1);
+  const bool live = row < p.M;
+
+  float4 wf[16];
+  load_w(wf, t, p.W1);
+  float x[16], hv[16], hin[16];
+  blk_load(x, p.X, (size_t)rc * p.ldx, t);
+  if (MODE == MODE_BWD) blk_load(hin, p.H, (size_t)rc * p.ldh, t);
+  blk_to_tile(x, t);
+  __syncthreads();
+  acc_to(hv, tile_gemm(t, wf));
+  load_w(wf, t, p.W2);
+  if (MODE == MODE_FWD) {
+    if (p.b1) {
+      float b[16];
+      blk_load(b, p.b1, 0, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) hv[k] += b[k];
+    }
+    if (live) blk_store(hv, p.H, (size_t)row * p.ldh, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = silu_f(hv[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
+  }
+  __syncthreads();
+  blk_to_tile(hv, t);
+  __syncthreads();
+  float y[16];
+  acc_to(y, tile_gemm(t, wf));
+  if (MODE == MODE_FWD && p.b2) {
+    float b[16];
+    blk_load(b, p.b2, 0, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += b[k];
+  }
+  if (ACCUM) {
+    float yold[16];
+    blk_load(yold, p.Y, (size_t)rc * p.ldy, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += yold[k];
+  }
+  if (live) blk_store(y, p.Y, (size_t)row * p.ldy, t);
+}
+
+int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
+  const int n_tiles = cdiv(a.M, 32);
+  if (mode == MODE_FWD && !accum)
+    mlp128_wide_kernel<MODE_FWD, false><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_BWD && !accum)
+    mlp128_wide_kernel<MODE_BWD, false><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_BWD && accum)
+    mlp128_wide_kernel<MODE_BWD, true><<<n_tiles, 256, 0, s>>>(a);
+  else
+    return NNHIP_E_INVALID;
+  LAUNCH_CHECK();
+  return 0;
+}

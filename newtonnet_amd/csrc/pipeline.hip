@@ -185,29 +185,6 @@ extern "C" int nnhip_workspace_layout(int32_t N, int32_t E, int32_t B, int32_t L
   return NNHIP_OK;
 }
 
-// ---- linear helpers ----------------------------------------------------------------------------------
-static int lin1(int pro, int epi, const float* A, int lda, const float* W, float* C, int ldc, const float* bias,
-                const float* H, int ldh, int M, hipStream_t s) {
-  LinArgs a;
-  memset(&a, 0, sizeof(a));
-  a.g[0] = {A, W, C, bias, H};
-  a.M = M;
-  a.lda = lda;
-  a.ldc = ldc;
-  a.ldh = ldh;
-  return launch_lin(pro, epi, a, 1, s);
-}
-static int lin2(int pro, int epi, LinGroup g0, LinGroup g1, int lda, int ldc, int ldh, int M, hipStream_t s) {
-  LinArgs a;
-  memset(&a, 0, sizeof(a));
-  a.g[0] = g0;
-  a.g[1] = g1;
-  a.M = M;
-  a.lda = lda;
-  a.ldc = ldc;
-  a.ldh = ldh;
-  return launch_lin(pro, epi, a, 2, s);
-}
 #define TRY(x)            \
   do {                    \
     int _r = (x);         \
@@ -305,10 +282,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     const bool has_f = l > 0;
     // message_nodepart: hn = a W0^T + b0 ; m = silu(hn) W2^T + b2.  (For l > 0 it was already produced by the fused
     // node kernel that closed the previous layer.)
-    if (l == 0) {
-      TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, lp.node0_w, P(w.pub.hn[l]), NF, lp.node0_b, nullptr, 0, N, s));
-      TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.hn[l]), NF, lp.node2_w, P(w.pub.m[l]), NF, lp.node2_b, nullptr, 0, N, s));
-    }
+    if (l == 0)
+      TRY(launch_mlp(MODE_FWD, false,
+                     {a_in, lp.node0_w, lp.node2_w, P(w.pub.hn[l]), P(w.pub.m[l]), N, NF, NF, NF, lp.node0_b, lp.node2_b}, s));
     // messages + invariant update
     TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
@@ -345,8 +321,8 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     f_in = P(w.pub.f_out[l]);
   }
   // energy head
-  TRY(lin1(PRO_NONE, EPI_BIAS, a_in, NF, model->head0_w, P(w.pub.e1), NF, model->head0_b, nullptr, 0, N, s));
-  TRY(lin1(PRO_SILU, EPI_BIAS, P(w.pub.e1), NF, model->head2_w, P(w.pub.e2), NF, model->head2_b, nullptr, 0, N, s));
+  TRY(launch_mlp(MODE_FWD, false, {a_in, model->head0_w, model->head2_w, P(w.pub.e1), P(w.pub.e2), N, NF, NF, NF,
+                                   model->head0_b, model->head2_b}, s));
   float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
   TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
                       atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
