@@ -220,6 +220,18 @@ int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const float* W2, 
                  int32_t ldy, int32_t M, int32_t mode, int32_t accumulate, void* stream);
 
 /* --------------------------------------------------------------------------
+ * direct_force head.
+ * Replaces: DirectForceOutput.forward (newtonnet/models/output.py:115-132) + ScaleShift (scalers.py:55-56):
+ *   d = Linear(silu(Linear(silu(Linear(atom_node)))));  out[i][k] = scale[z_i] * < d[i], force_node[i][k] >
+ * w0/w2/w4: output_layers.k.layers.{0,2,4}.weight [F][F], b0/b2/b4 biases [F]; scale: scalers.k.scale.weight [119]
+ * (NULL = 1).  atom_node [N][F] and force_node [N][3][F] are the outputs of nnhip_energy_forces.
+ * scratch: 3 * n_atoms * F floats.
+ * ------------------------------------------------------------------------ */
+int nnhip_direct_force(const float* atom_node, const float* force_node, const int64_t* z, const float* w0, const float* b0,
+                       const float* w2, const float* b2, const float* w4, const float* b4, const float* scale,
+                       int32_t n_atoms, float* scratch, float* out, void* stream);
+
+/* --------------------------------------------------------------------------
  * Differentiable building blocks of the train-mode forward (both are linear maps and each other's adjoints, so
  * torch.autograd can differentiate through them twice: force-loss training, output.py:66-73 + trainer.py:307-309).
  * Replaces: torch_geometric.utils.scatter(..., reduce='sum') (newtonnet.py:214,226; output.py:246) and the

@@ -17,6 +17,8 @@
 // activations pass from one GEMM to the next through a 16.5 KiB LDS tile, and the weights come straight from L2 as
 // the MFMA A operand (transposed formulation, as in mlp128.hip: D^T[feature][atom] = W X^T; every wave of the grid
 // with the same w reads the same 16 KiB of each matrix).
+#include <string.h>
+
 #include "common.h"
 
 #define NT_LD 132                       // LDS tile row pitch (floats): conflict-free ds_read_b128 / ds_write_b128
@@ -301,4 +303,66 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
     return NNHIP_E_INVALID;
   LAUNCH_CHECK();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// direct_force head (newtonnet/models/output.py:115-132, scalers.py:55-56):
+//   d = Linear(silu(Linear(silu(Linear(atom_node)))))  [N][F];   force[i][k] = scale[z_i] * < d[i] , force_node[i][k] >
+// The first two linears run in the row-local MLP kernel above (biased form), the third in lin128; this is the tail.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+direct_force_tail_kernel(const float* __restrict__ d, const float* __restrict__ force_node, const float* __restrict__ scale,
+                         const int64_t* __restrict__ z, int n_atoms, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float2 dv = ld2(d + (size_t)i * NF + 2 * lane);
+  float s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float2 f = ld2(force_node + ((size_t)i * 3 + k) * NF + 2 * lane);
+    s[k] = wave_sum(fmaf(dv.x, f.x, dv.y * f.y));
+  }
+  if (lane == 0) {
+    const float sc = scale ? scale[z[i]] : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = s[k] * sc;
+  }
+}
+
+extern "C" int nnhip_direct_force(const float* atom_node, const float* force_node, const int64_t* z, const float* w0,
+                                  const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
+                                  const float* scale, int32_t n_atoms, float* scratch, float* out, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (!atom_node || !force_node || !z || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !scratch || !out || n_atoms < 0) {
+    nnhip_set_error("nnhip_direct_force: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0) return NNHIP_OK;
+  float* e1 = scratch;
+  float* e2 = scratch + (size_t)n_atoms * NF;
+  float* d = scratch + 2 * (size_t)n_atoms * NF;
+  MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = atom_node;
+  a.W1 = w0;
+  a.W2 = w2;
+  a.H = e1;
+  a.Y = e2;
+  a.M = n_atoms;
+  a.ldx = a.ldh = a.ldy = NF;
+  a.b1 = b0;
+  a.b2 = b2;
+  int rc = launch_mlp(MODE_FWD, false, a, s);
+  if (rc) return rc;
+  LinArgs l;
+  memset(&l, 0, sizeof(l));
+  l.g[0] = {e2, w4, d, b4, nullptr};
+  l.M = n_atoms;
+  l.lda = l.ldc = NF;
+  rc = launch_lin(PRO_SILU, EPI_BIAS, l, 1, s);
+  if (rc) return rc;
+  direct_force_tail_kernel<<<cdiv(n_atoms, 4), 256, 0, s>>>(d, force_node, scale, z, n_atoms, out);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
 }

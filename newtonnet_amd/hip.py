@@ -91,13 +91,14 @@ def lib():
                                       vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
+    L.nnhip_direct_force.argtypes = [vp] * 10 + [i32, vp, vp, vp]
     L.nnhip_segment_sum.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
-               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs'):
+               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -107,7 +108,7 @@ EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'n
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
-                    'nnhip_mlp128', 'nnhip_graph_pairs')
+                    'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force')
 
 
 def _check(rc: int, what: str):
@@ -261,6 +262,18 @@ def mlp128(X: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, H: torch.Tensor,
     _check(lib().nnhip_mlp128(_ptr(X), X.stride(0), _ptr(W1), _ptr(W2), _ptr(H), H.stride(0), _ptr(Y), Y.stride(0), M,
                               mode, 1 if accumulate else 0, _stream(X.device)), 'nnhip_mlp128')
     return Y
+
+
+def direct_force(atom_node: torch.Tensor, force_node: torch.Tensor, z: torch.Tensor, head, scale) -> torch.Tensor:
+    """direct_force head (output.py:115-132): head = nn.Sequential(Linear, act, Linear, act, Linear); scale [119,1] or None."""
+    N = atom_node.shape[0]
+    out = torch.empty(N, 3, dtype=torch.float32, device=atom_node.device)
+    scratch = torch.empty(3 * max(N, 1) * NNHIP_F, dtype=torch.float32, device=atom_node.device)
+    _check(lib().nnhip_direct_force(_ptr(atom_node), _ptr(force_node), _ptr(z), _ptr(head[0].weight), _ptr(head[0].bias),
+                                    _ptr(head[2].weight), _ptr(head[2].bias), _ptr(head[4].weight), _ptr(head[4].bias),
+                                    _ptr(scale), N, _ptr(scratch), _ptr(out), _stream(atom_node.device)),
+           'nnhip_direct_force')
+    return out
 
 
 def segment_sum(x: torch.Tensor, row_ptr: torch.Tensor, n_rows: int) -> torch.Tensor:

@@ -142,7 +142,7 @@ class NewtonNet(nn.Module):
         if 'energy' not in keys:
             raise NotImplementedError("the HIP hot path needs the 'energy' head (output_properties)")
         for key in keys:
-            if key not in ('energy', 'gradient_force', 'virial', 'stress'):
+            if key not in ('energy', 'gradient_force', 'direct_force', 'virial', 'stress'):
                 raise NotImplementedError(f"output property '{key}' is outside the MI355X hot path")
         deriv_layers = [ol for ol in self.output_layers if isinstance(ol, DerivativeProperty)]
         train_graph = any(ol.create_graph for ol in deriv_layers) and torch.is_grad_enabled()
@@ -183,6 +183,13 @@ class NewtonNet(nn.Module):
                 outputs.virial = res['virial']
             elif key == 'stress':
                 outputs.stress = -res['virial'] / cell.det().view(-1, 1, 1)
+            elif key == 'direct_force':
+                k = keys.index('direct_force')
+                sc = self.scalers[k].scale
+                with torch.no_grad():
+                    outputs.direct_force = hip.direct_force(res['atom_node'], res['force_node'], zc,
+                                                            self.output_layers[k].layers,
+                                                            sc.weight if sc is not None else None)
         return outputs
 
     # ------------------------------------------------------------------------------------------
@@ -191,8 +198,8 @@ class NewtonNet(nn.Module):
         (trainer.py:301-313).  Built from twice-differentiable HIP primitives, see newtonnet_amd/train_ops.py."""
         from newtonnet_amd import train_ops
         for key in keys:
-            if key not in ('energy', 'gradient_force'):
-                raise NotImplementedError(f"train-mode forward supports energy / gradient_force (got '{key}')")
+            if key not in ('energy', 'gradient_force', 'direct_force'):
+                raise NotImplementedError(f"train-mode forward supports energy / gradient_force / direct_force (got '{key}')")
         self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
         if not pos.requires_grad:
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
@@ -205,4 +212,12 @@ class NewtonNet(nn.Module):
                                               retain_graph=True)
             outputs.pos_grad = pos_grad
             outputs.gradient_force = -pos_grad
+        if 'direct_force' in keys:      # output.py:130-132 + scalers.py:55-56, plain differentiable torch
+            k = keys.index('direct_force')
+            head = self.output_layers[k].layers
+            d = head[4](torch.nn.functional.silu(head[2](torch.nn.functional.silu(head[0](atom_node)))))
+            df = (d.unsqueeze(1) * force_node).sum(dim=-1)
+            if self.scalers[k].scale is not None:
+                df = df * self.scalers[k].scale(z)
+            outputs.direct_force = df
         return outputs

@@ -7,7 +7,7 @@ csrc/edge.hip:head_out_kernel; the gradient force is the analytic reverse sweep 
 """
 from torch import nn
 
-SUPPORTED = ('energy', 'gradient_force', 'virial', 'stress')
+SUPPORTED = ('energy', 'gradient_force', 'direct_force', 'virial', 'stress')
 
 
 def get_output_by_string(key, n_features=None, activation=None):
@@ -19,9 +19,11 @@ def get_output_by_string(key, n_features=None, activation=None):
         return VirialOutput()
     if key == 'stress':
         return StressOutput()
-    if key in ('direct_force', 'hessian', 'charge', 'bec'):
+    if key == 'direct_force':
+        return DirectForceOutput(n_features, activation)
+    if key in ('hessian', 'charge', 'bec'):
         raise NotImplementedError(
-            f'Output type {key} is outside the MI355X hot path (energy / gradient_force / virial / stress); '
+            f'Output type {key} is outside the MI355X hot path (energy / gradient_force / direct_force / virial / stress); '
             f'see DESIGN.md "out of scope"')
     raise NotImplementedError(f'Output type {key} is not implemented yet')
 
@@ -59,6 +61,17 @@ class EnergyOutput(DirectProperty):
             nn.Linear(n_features, n_features), activation,
             nn.Linear(n_features, n_features), activation,
             nn.Linear(n_features, 1))
+
+
+class DirectForceOutput(DirectProperty):
+    """force = sum_f MLP3(atom_node)[f] * force_node[:, :, f]  (output.py:115-132); keys layers.{0,2,4}.{weight,bias}.
+    Runs in nnhip_direct_force (csrc/node128.hip)."""
+    def __init__(self, n_features, activation):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Linear(n_features, n_features), activation,
+            nn.Linear(n_features, n_features), activation,
+            nn.Linear(n_features, n_features))
 
 
 class GradientForceOutput(DerivativeProperty):

@@ -42,11 +42,14 @@ sys.dont_write_bytecode = True
 # ----------------------------------------------------------------------------
 def _install_shims():
     def scatter(src, index, dim=0, dim_size=None, reduce='sum'):
-        assert reduce == 'sum' and dim == 0
+        assert reduce in ('sum', 'mean') and dim == 0     # 'mean' only in the data statistics (loader.py:224)
         if dim_size is None:
             dim_size = int(index.max()) + 1 if index.numel() else 0
-        out = src.new_zeros((dim_size,) + tuple(src.shape[1:]))
-        return out.index_add_(0, index, src)
+        out = src.new_zeros((dim_size,) + tuple(src.shape[1:])).index_add_(0, index, src)
+        if reduce == 'mean':
+            cnt = src.new_zeros(dim_size).index_add_(0, index, torch.ones_like(index, dtype=src.dtype)).clamp(min=1)
+            out = out / cnt.reshape((-1,) + (1,) * (src.dim() - 1))
+        return out
 
     tg = types.ModuleType('torch_geometric')
     tgu = types.ModuleType('torch_geometric.utils')
@@ -306,5 +309,65 @@ def main():
     print('K2', final['test_energy_mae'], final['test_gradient_force_mae'])
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+# ----------------------------------------------------------------------------
+# "next" rows of SURVEY.md 8(f): direct_force head (output.py:115-132) and per-element statistics (loader.py:197-230)
+# ----------------------------------------------------------------------------
+def main_extra():
+    NewtonNet = import_reference()
+    train = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_train/raw/aspirin_ccsd-train.xyz', 64)
+    z_asp = torch.tensor(train[0][0], dtype=torch.long)
+
+    # ---- direct_force head: seeded reference model with ['energy', 'gradient_force', 'direct_force']
+    torch.manual_seed(1)
+    model = NewtonNet(output_properties=['energy', 'gradient_force', 'direct_force'])
+    model.to(torch.float64)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.eval()
+    B = 4
+    z = z_asp.repeat(B)
+    pos = torch.tensor(np.concatenate([f[1] for f in train[:B]]), dtype=torch.float64)
+    batch = torch.repeat_interleave(torch.arange(B), 21)
+    cell = torch.zeros(B, 3, 3, dtype=torch.float64)
+    out = model(z, pos.clone(), cell, batch)
+    np.savez_compressed(f'{OUT}/case_direct_force.npz', z=z.numpy(), pos=pos.numpy(), cell=cell.numpy(), batch=batch.numpy(),
+                        energy=out.energy.detach().numpy(), forces=out.gradient_force.detach().numpy(),
+                        direct_force=out.direct_force.detach().numpy(),
+                        **{'sd.' + k: v.float().numpy() for k, v in sd.items()})
+    print('direct_force', out.direct_force.shape, float(out.direct_force.abs().max()))
+
+    # ---- MolecularStatistics on the first 64 train frames (loader.py:197-230); the class needs only torch + scatter,
+    # but its module imports ase / torch_geometric.data at import time -> provide empty stand-ins for the import
+    for name in ('ase', 'ase.io', 'tqdm', 'torch_geometric.data'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['ase'].units = types.SimpleNamespace(kcal=1.0, mol=1.0, kJ=1.0, __setattr__=lambda *a: None)
+    sys.modules['ase.io'].read = None
+    sys.modules['tqdm'].tqdm = lambda x, **k: x
+    for cls in ('Dataset', 'InMemoryDataset', 'Data'):
+        setattr(sys.modules['torch_geometric.data'], cls, type(cls, (), {}))
+    units = types.ModuleType('ase.units')
+    units.kcal = units.mol = units.kJ = 1.0
+    sys.modules['ase'].units = units
+    sys.modules['ase.units'] = units
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_loader', f'{REF}/newtonnet/data/loader.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n = 64
+    data = types.SimpleNamespace(
+        z=z_asp.repeat(n), batch=torch.repeat_interleave(torch.arange(n), 21),
+        energy=torch.tensor([f[2] for f in train[:n]], dtype=torch.float64),
+        force=torch.tensor(np.concatenate([f[3] for f in train[:n]]), dtype=torch.float64))
+    stats = mod.MolecularStatistics()(data)
+    np.savez_compressed(f'{OUT}/case_statistics.npz', z=data.z.numpy(), batch=data.batch.numpy(), energy=data.energy.numpy(),
+                        force=data.force.numpy(), energy_shift=stats['energy']['shift'].numpy(),
+                        energy_scale=stats['energy']['scale'].numpy(), force_scale=stats['force']['scale'].numpy())
+    print('stats shift', stats['energy']['shift'][[1, 6, 8]], 'scale', stats['energy']['scale'][[1, 6, 8]])
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'extra':
+    main_extra()

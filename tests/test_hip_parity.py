@@ -310,3 +310,26 @@ def test_large_nonperiodic_cluster_and_high_degree_rows():
     assert np.all(np.abs(e - want['energy'].numpy()) <= np.maximum(util.energy_tol(want['energy'].numpy()), 2e-5 * np.abs(e)))
     fs = max(1.0, want['forces'].abs().max().item() / 5.0)
     check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), fs)
+
+
+def test_direct_force_head():
+    """direct_force head (output.py:115-132) against the reference's own output (tests/golden/case_direct_force.npz)."""
+    from newtonnet_amd.models import NewtonNet
+    c = util.load_npz('case_direct_force.npz')
+    sd = {k[3:]: torch.from_numpy(v) for k, v in c.items() if k.startswith('sd.')}
+    model = NewtonNet(output_properties=['energy', 'gradient_force', 'direct_force'])
+    model.load_state_dict(sd)
+    model = model.to('cuda')
+    model.eval()
+    z, pos, cell, batch = (torch.from_numpy(c[k]) for k in ('z', 'pos', 'cell', 'batch'))
+    out = model(z.cuda(), pos.float().cuda(), cell.float().cuda(), batch.cuda())
+    assert out.direct_force.shape == (84, 3)
+    np.testing.assert_allclose(out.direct_force.cpu().numpy(), c['direct_force'], rtol=2e-4, atol=2e-6)
+    check_forces(out.gradient_force.cpu().numpy(), c['forces'])
+    assert np.all(np.abs(out.energy.cpu().numpy() - c['energy']) <= util.energy_tol(c['energy']))
+    # train mode: same value, differentiable
+    model.train()
+    p = pos.float().cuda().requires_grad_(True)
+    o2 = model(z.cuda(), p, cell.float().cuda(), batch.cuda())
+    assert o2.direct_force.requires_grad
+    np.testing.assert_allclose(o2.direct_force.detach().cpu().numpy(), c['direct_force'], rtol=2e-4, atol=2e-6)

@@ -86,3 +86,14 @@ def test_candidate_pair_order_unsorted_batch():
     batch = torch.tensor([1, 0, 1, 0, 2])
     p = ref.candidate_pairs(batch).numpy()
     assert p.T.tolist() == [[1, 3], [3, 1], [0, 2], [2, 0]]
+
+
+def test_direct_force_head_pinned():
+    """Oracle's direct_force head against the reference's own output for the same weights (gen_golden.py extra)."""
+    c = util.load_npz('case_direct_force.npz')
+    sd = {k[3:]: torch.from_numpy(v).double() for k, v in c.items() if k.startswith('sd.')}
+    z, pos, cell, batch = (torch.from_numpy(c[k]) for k in ('z', 'pos', 'cell', 'batch'))
+    out = ref.energy_forces(sd, z, pos.double(), cell.double(), batch)
+    df = ref.direct_force_head(sd, 2, out['atom_node'], out['force_node'], z)
+    np.testing.assert_allclose(df.numpy(), c['direct_force'], rtol=1e-4, atol=1e-6)      # reference ran in fp32
+    np.testing.assert_allclose(out['forces'].numpy(), c['forces'], atol=5e-5)
