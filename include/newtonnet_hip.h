@@ -175,8 +175,8 @@ typedef struct {
   size_t phi1[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t phi2[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */
-  size_t a_out[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the layer */
-  size_t f_out[NNHIP_MAX_LAYERS];  /* [N][3][F] force_node after the layer */
+  size_t a_out[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the layer (last layer: only when atom_node == NULL) */
+  size_t f_out[NNHIP_MAX_LAYERS];  /* [N][3][F] force_node after the layer (last layer: only when force_node == NULL) */
   size_t q[NNHIP_MAX_LAYERS];      /* [N][3][F] equiv_update(force_node) */
   size_t a0;                       /* [N][F]   embedded atom_node */
   size_t e1, e2;                   /* [N][F]   head hidden pre-activations */

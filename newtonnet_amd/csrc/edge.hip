@@ -21,6 +21,32 @@
 
 #define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
 
+// Compile-time ablations for tools/ablate_edge.sh (WRONG results; the shipped build defines none of them):
+//   EDGE_ABL_SELF   gather the sender rows from row i instead of j (always cache-hot)
+//   EDGE_ABL_PAIR   read the pair rows (phi / g_msg) from row i & 1023 instead of pid[e]
+//   EDGE_ABL_TABLE  read the filter table at row 0
+//   EDGE_ABL_STORE  drop the pair-row stores
+#ifdef EDGE_ABL_SELF
+#define ABL_J(j, i) (i)
+#else
+#define ABL_J(j, i) (j)
+#endif
+#ifdef EDGE_ABL_PAIR
+#define ABL_P(p, i) ((i) & 1023)
+#else
+#define ABL_P(p, i) (p)
+#endif
+#ifdef EDGE_ABL_TABLE
+#define ABL_G(g) ((g) & 0)
+#else
+#define ABL_G(g) (g)
+#endif
+#ifdef EDGE_ABL_STORE
+#define ABL_ST(c) ((c) && n_atoms < 0)
+#else
+#define ABL_ST(c) (c)
+#endif
+
 __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
   const int tile = xcd_tile(blockIdx.x, n_rows_padded_blocks);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,14 +95,14 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
     const int j = col[e];
     const int2 gx = xg[e];   // wave-uniform
     float2 t[4];
-    filter_rows(table, gx.x, lane, t);
-    const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
+    filter_rows(table, ABL_G(gx.x), lane, t);
+    const float2 mj = ld2(m + (size_t)ABL_J(j, i) * NF + 2 * lane);
     const FilterW fw = filter_weights(__int_as_float(gx.y));
     float2 eps = t[0] * fw.w[0];
 #pragma unroll
     for (int k = 1; k < 4; ++k) eps = fma2(t[k], fw.w[k], eps);
     const float2 v = eps * mi * mj;
-    if (j > i) st2(msg + (size_t)pid[e] * NF + 2 * lane, v);   // the lower endpoint writes the shared pair row
+    if (ABL_ST(j > i)) st2(msg + (size_t)pid[e] * NF + 2 * lane, v);   // the lower endpoint writes the shared pair row
     acc = acc + v;
   }
   st2(a_mid + (size_t)i * NF + 2 * lane, ld2(a_in + (size_t)i * NF + 2 * lane) + acc);
@@ -102,13 +128,13 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];  // (ux,uy,uz,r), wave-uniform
-    const size_t p = (size_t)pid[e];
+    const size_t p = (size_t)ABL_P(pid[e], i);
     const float2 p1 = ld2(phi1 + p * NF + 2 * lane);
     acc[0] = fma2(p1, g.x, acc[0]);
     acc[1] = fma2(p1, g.y, acc[1]);
     acc[2] = fma2(p1, g.z, acc[2]);
     if (HAS_F) {
-      const int j = col[e];
+      const int j = ABL_J(col[e], i);
       const float2 p2 = ld2(phi2 + p * NF + 2 * lane);
 #pragma unroll
       for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
@@ -148,10 +174,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
     const float4 g = reinterpret_cast<const float4*>(geo)[e];
-    const int j = col[e];
+    const int jj = col[e];
+    const int j = ABL_J(jj, i);
     const size_t p = (size_t)pid[e];
-    const bool owner = j > i;   // wave-uniform
-    const float2 p1 = ld2(phi1 + p * NF + 2 * lane);
+    const bool owner = jj > i;   // wave-uniform
+    const float2 p1 = ld2(phi1 + (size_t)ABL_P(p, i) * NF + 2 * lane);
     float2 gfj[3];
     if (HAS_F || owner) {
 #pragma unroll
@@ -168,10 +195,10 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
       float2 gp1 = make_float2(gfi[0].x - gfj[0].x, gfi[0].y - gfj[0].y) * g.x;
       gp1 = fma2(make_float2(gfi[1].x - gfj[1].x, gfi[1].y - gfj[1].y), g.y, gp1);
       gp1 = fma2(make_float2(gfi[2].x - gfj[2].x, gfi[2].y - gfj[2].y), g.z, gp1);
-      st2_nt(g_h12 + p * 2 * NF + 2 * lane, gp1);
+      if (ABL_ST(true)) st2_nt(g_h12 + p * 2 * NF + 2 * lane, gp1);
     }
     if (HAS_F) {
-      const float2 p2 = ld2(phi2 + p * NF + 2 * lane);
+      const float2 p2 = ld2(phi2 + (size_t)ABL_P(p, i) * NF + 2 * lane);
 #pragma unroll
       for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, gfj[k], acc[k]);
       if (owner) {
@@ -181,7 +208,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
           gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
           gp2 = fma2(gfj[k], fi[k], gp2);
         }
-        st2_nt(g_h12 + p * 2 * NF + NF + 2 * lane, gp2);
+        if (ABL_ST(true)) st2_nt(g_h12 + p * 2 * NF + NF + 2 * lane, gp2);
       }
     }
   }
@@ -196,8 +223,9 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 // aggregations a_mid[i] += msg and a_mid[j] += msg (one per directed edge) add g_a[i] + g_a[j]:
 //   G       = g_msg[p] + g_a[i] + g_a[j]                 total gradient of the pair message
 //   g_m[i]  = sum_{e in row i} G * eps_e * m[j]
-//   g_x[e]  = 1/2 < G * m[i] * m[j] , d eps_e/dx >       (wave reduction; x is shared by the two directed edges, each
-//                                                         carries half so that their sum is the pair's derivative)
+//   g_x[e]  = < G * m[i] * m[j] , d eps_e/dx >  for j > i, 0 for j < i   (wave reduction; x is shared by the two
+//             directed edges and only their sum enters the force, so the pair's owner carries all of it and the
+//             other direction skips the derivative table)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
@@ -212,25 +240,36 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   float2 acc = make_float2(0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
-    const int j = col[e];
+    const int j = ABL_J(col[e], i);
     const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
     const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
-    const float2 G = ld2(g_msg + (size_t)pid[e] * NF + 2 * lane) + gai + gaj;
+    const float2 G = ld2(g_msg + (size_t)ABL_P(pid[e], i) * NF + 2 * lane) + gai + gaj;
     const int2 gxi = xg[e];   // wave-uniform
-    float4 td[4];   // (T, D) pairs of this lane's two features, rows g0 .. g0+3 of the interleaved table
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      td[k] = *reinterpret_cast<const float4*>(table + (size_t)FT_ROWS * NF + ((size_t)(gxi.x + k) * NF + 2 * lane) * 2);
     const FilterW fw = filter_weights(__int_as_float(gxi.y));
-    float2 eps = make_float2(td[0].x, td[0].z) * fw.w[0], deps = make_float2(td[0].y, td[0].w) * fw.w[0];
+    float2 eps;
+    if (col[e] > i) {   // wave-uniform: the pair's owner also evaluates d eps/dx and carries the pair's whole g_x
+      float4 td[4];   // (T, D) pairs of this lane's two features, rows g0 .. g0+3 of the interleaved table
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      eps = fma2(make_float2(td[k].x, td[k].z), fw.w[k], eps);
-      deps = fma2(make_float2(td[k].y, td[k].w), fw.w[k], deps);
+      for (int k = 0; k < 4; ++k)
+        td[k] = *reinterpret_cast<const float4*>(table + (size_t)FT_ROWS * NF + ((size_t)(ABL_G(gxi.x) + k) * NF + 2 * lane) * 2);
+      eps = make_float2(td[0].x, td[0].z) * fw.w[0];
+      float2 deps = make_float2(td[0].y, td[0].w) * fw.w[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        eps = fma2(make_float2(td[k].x, td[k].z), fw.w[k], eps);
+        deps = fma2(make_float2(td[k].y, td[k].w), fw.w[k], deps);
+      }
+      const float2 t = G * mi * mj;
+      const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
+      if (lane == 0) g_x[e] = gx;
+    } else {
+      float2 t4[4];
+      filter_rows(table, ABL_G(gxi.x), lane, t4);
+      eps = t4[0] * fw.w[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) eps = fma2(t4[k], fw.w[k], eps);
+      if (lane == 0) g_x[e] = 0.f;
     }
-    const float2 t = G * mi * mj;
-    const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
-    if (lane == 0) g_x[e] = 0.5f * gx;
     acc = fma2(G * eps, mj, acc);
   }
   st2(g_m + (size_t)i * NF + 2 * lane, acc);

@@ -27,6 +27,16 @@ __global__ void mol_ptr_kernel(const int64_t* __restrict__ batch, int n_atoms, i
     for (long k = b + 1; k <= n_mol; ++k) mol_ptr[k] = n_atoms;
 }
 
+// One launch instead of three memsets (each memset of an odd length is two fill dispatches): status[0] = 0,
+// mol_ptr[0..n_mol] = 0 (so that an invalid batch vector leaves empty, in-bounds molecule extents) and row_ptr = 0.
+__global__ void graph_init_kernel(int* __restrict__ status, int* __restrict__ mol_ptr, int n_mol1,
+                                  int* __restrict__ row_ptr, int n_atoms1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) status[0] = 0;
+  if (i < n_mol1) mol_ptr[i] = 0;
+  if (i < n_atoms1) row_ptr[i] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pair predicate shared by the count and fill passes (must be bit-identical in both)
 // ---------------------------------------------------------------------------------------------
@@ -94,12 +104,16 @@ __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float x
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
-                  const int* __restrict__ mol_ptr, int n_atoms, float cutoff, int* __restrict__ deg,
+                  const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cutoff, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
                   float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
   const long b = batch[i];
+  if (b < 0 || b >= n_mol) {   // flagged by mol_ptr_kernel; keep every access in bounds
+    if (!FILL) deg[i] = 0;
+    return;
+  }
   const int s = mol_ptr[b], e = mol_ptr[b + 1];
   const CellInfo ci = load_cell(cell, b);
   const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
@@ -264,14 +278,16 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
     return NNHIP_E_INVALID;
   }
   ScopedTimer tm(TC_GRAPH, stream);
-  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int32_t), stream));   // status[0]; status[1..] is scan scratch
-  HIP_TRY(hipMemsetAsync(mol_ptr, 0, sizeof(int32_t) * (n_mol + 1), stream));
-  HIP_TRY(hipMemsetAsync(row_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
+  {  // status[0]; status[1..] is scan scratch
+    const int n_init = (n_mol > n_atoms ? n_mol : n_atoms) + 1;
+    graph_init_kernel<<<cdiv(n_init, 256), 256, 0, stream>>>(status, mol_ptr, n_mol + 1, row_ptr, n_atoms + 1);
+    LAUNCH_CHECK();
+  }
   if (n_atoms == 0) return NNHIP_OK;
   mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status);
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
-  graph_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, cutoff, row_ptr,
+  graph_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, row_ptr,
                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
   {
@@ -285,7 +301,6 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
                                 const int32_t* row_ptr, int32_t n_atoms, int32_t n_mol, int32_t n_edges, float cutoff,
                                 int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  (void)n_mol;
   if (n_atoms < 0 || n_edges < 0) {
     nnhip_set_error("nnhip_graph_fill: bad arguments");
     return NNHIP_E_INVALID;
@@ -293,7 +308,7 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
   // `rev` doubles as the receiver-of-edge scratch during the fill; edge_rev_kernel then replaces it in place
-  graph_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, cutoff, nullptr,
+  graph_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, nullptr,
                                                                   row_ptr, col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
@@ -626,9 +641,11 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
     nnhip_set_error("nnhip_graph_pairs: bad arguments");
     return NNHIP_E_INVALID;
   }
-  HIP_TRY(hipMemsetAsync(pair_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
-  if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
-  ScopedTimer tm(TC_GRAPH, stream);
+  if (n_atoms == 0 || n_edges == 0) {
+    HIP_TRY(hipMemsetAsync(pair_ptr, 0, sizeof(int32_t) * (n_atoms + 1), stream));
+    return NNHIP_OK;
+  }
+  ScopedTimer tm(TC_GRAPH, stream);   // pairs_count + the scan write every pair_ptr entry
   pairs_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, n_atoms, pair_ptr);
   LAUNCH_CHECK();
   {

@@ -277,6 +277,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   TRY(launch_embed(z, model->node_embedding, N, P(w.pub.a0), s));
   const float* a_in = P(w.pub.a0);
   const float* f_in = nullptr;  // force_node == 0 entering the first layer (newtonnet.py:143)
+  // the last layer writes atom_node / force_node straight into the caller's output arrays when they are given
+  auto A_OUT = [&](int l) { return (l == L - 1 && atom_node_out) ? atom_node_out : P(w.pub.a_out[l]); };
+  auto F_OUT = [&](int l) { return (l == L - 1 && force_node_out) ? force_node_out : P(w.pub.f_out[l]); };
   for (int l = 0; l < L; ++l) {
     const nnhip_layer_params& lp = model->layer[l];
     const bool has_f = l > 0;
@@ -295,16 +298,16 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
         TRY(launch_mlp(MODE_FWD, false,
                        {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF}, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, P(w.pub.f_out[l]), N, s));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, s));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
       memset(&na, 0, sizeof(na));
-      na.f = P(w.pub.f_out[l]);
+      na.f = F_OUT(l);
       na.a_mid = P(w.pub.a_mid[l]);
       na.Wu = lp.update_w;
       na.q = P(w.pub.q[l]);
-      na.a_out = P(w.pub.a_out[l]);
+      na.a_out = A_OUT(l);
       if (l + 1 < L) {
         const nnhip_layer_params& nx = model->layer[l + 1];
         na.W0 = nx.node0_w;
@@ -317,8 +320,8 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       na.N = N;
       TRY(launch_node_fwd(na, s));
     }
-    a_in = P(w.pub.a_out[l]);
-    f_in = P(w.pub.f_out[l]);
+    a_in = A_OUT(l);
+    f_in = F_OUT(l);
   }
   // energy head
   TRY(launch_mlp(MODE_FWD, false, {a_in, model->head0_w, model->head2_w, P(w.pub.e1), P(w.pub.e2), N, NF, NF, NF,
@@ -326,8 +329,6 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
   TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
                       atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
-  if (atom_node_out) HIP_TRY(hipMemcpyAsync(atom_node_out, a_in, (size_t)N * NF * 4, hipMemcpyDeviceToDevice, s));
-  if (force_node_out) HIP_TRY(hipMemcpyAsync(force_node_out, f_in, (size_t)N * 3 * NF * 4, hipMemcpyDeviceToDevice, s));
   if (!want_forces) return NNHIP_OK;
 
   // ------------------------------------------------------------------ reverse sweep
@@ -342,7 +343,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nb.W0T = P(w.headT[0]);
     nb.g_a = P(w.pub.g_a);
     nb.acc_ga = 0;
-    nb.f = P(w.pub.f_out[L - 1]);
+    nb.f = F_OUT(L - 1);
     nb.q = P(w.pub.q[L - 1]);
     nb.G_f = nullptr;
     nb.WuT = P(w.wT[L - 1][6]);
@@ -356,7 +357,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     const nnhip_layer_params& lp = model->layer[l];
     (void)lp;
     const bool has_f = l > 0;
-    const float* f_prev = has_f ? P(w.pub.f_out[l - 1]) : nullptr;
+    const float* f_prev = has_f ? F_OUT(l - 1) : nullptr;
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
@@ -384,7 +385,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       nb.W0T = P(w.wT[l][0]);
       nb.g_a = P(w.pub.g_a);
       nb.acc_ga = 1;
-      nb.f = P(w.pub.f_out[l - 1]);
+      nb.f = F_OUT(l - 1);
       nb.q = P(w.pub.q[l - 1]);
       nb.G_f = g_fin;   // dE/d f_out of layer l-1, produced by force_bwd of layer l just above
       nb.WuT = P(w.wT[l - 1][6]);

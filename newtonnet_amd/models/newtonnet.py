@@ -152,13 +152,18 @@ class NewtonNet(nn.Module):
 
         emb = self.embedding_layers
         # the reference marks the caller's tensor (newtonnet.py:150-152); kept for API parity
-        displacement = torch.eye(3, dtype=pos.dtype, device=pos.device).repeat(cell.shape[0], 1, 1)
-        if emb.requires_dr and pos.is_leaf and pos.is_floating_point():
+        mark = emb.requires_dr and pos.is_leaf and pos.is_floating_point()
+        if mark:
             pos.requires_grad = True
-            displacement.requires_grad = True
+
+        def make_displacement():
+            d = torch.eye(3, dtype=pos.dtype, device=pos.device).repeat(cell.shape[0], 1, 1)
+            if mark:
+                d.requires_grad = True
+            return d
 
         if train_graph:
-            return self._forward_train(z, pos, cell, batch, keys, energy_idx, displacement)
+            return self._forward_train(z, pos, cell, batch, keys, energy_idx, make_displacement())
 
         with torch.no_grad():
             model = self._hip_model(energy_idx)
@@ -169,11 +174,12 @@ class NewtonNet(nn.Module):
                                     want_virial=want_virial)
 
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
-                                  edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
+                                  edge_index=g.edge_index, cell=cell, batch=batch)
+        outputs.lazy('displacement', make_displacement)
         if want_forces:
-            outputs.pos_grad = -res['forces']
+            outputs.lazy('pos_grad', lambda: -res['forces'])
             if want_virial:
-                outputs.displacement_grad = -res['virial']
+                outputs.lazy('displacement_grad', lambda: -res['virial'])
         for key in keys:
             if key == 'energy':
                 outputs.energy = res['energy']

@@ -37,10 +37,25 @@ def get_aggregator_by_string(key):
 
 
 class CustomOutputSet:
-    """Attribute bag returned by NewtonNet.forward (output.py:51-54)."""
+    """Attribute bag returned by NewtonNet.forward (output.py:51-54).
+
+    `lazy(name, thunk)` registers an attribute that is materialised on first access: the eval-mode hot path uses it for
+    the by-products the reference's autograd leaves in the bag (`pos_grad`, `displacement`, `displacement_grad`), so a
+    step that never looks at them launches no kernels for them."""
     def __init__(self, **outputs):
         for key, value in outputs.items():
             setattr(self, key, value)
+
+    def lazy(self, name, thunk):
+        self.__dict__.setdefault('_lazy', {})[name] = thunk
+
+    def __getattr__(self, name):          # only reached when normal lookup fails
+        lazy = self.__dict__.get('_lazy')
+        if lazy is not None and name in lazy:
+            value = lazy.pop(name)()
+            setattr(self, name, value)
+            return value
+        raise AttributeError(name)
 
 
 class DirectProperty(nn.Module):

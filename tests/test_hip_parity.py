@@ -64,9 +64,13 @@ def test_intermediates_against_trace():
     g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0,
                         model.embedding_layers.edge_embedding.embedding.frequencies, want_rbf=True)
     assert np.array_equal(g.edge_index.cpu().numpy(), T['edge_index'].numpy())
-    res = hip.energy_forces(m, z.cuda(), pos.cuda(), cell.cuda(), g)
+    # want_nodes=False keeps the last layer's atom_node / force_node in the workspace (otherwise they are written straight
+    # into the output arrays); the second call checks that direct form
+    res = hip.energy_forces(m, z.cuda(), pos.cuda(), cell.cuda(), g, want_nodes=False)
+    res_n = hip.energy_forces(m, z.cuda(), pos.cuda(), cell.cuda(), g, want_nodes=True)
     torch.cuda.synchronize()
     N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
+    assert torch.equal(res_n['forces'], res['forces']) and torch.equal(res_n['energy'], res['energy'])
     lay = hip.workspace_layout(N, E, B, L)
     ws = res['workspace']
     Pn, pid, rev = E // 2, g.pid.cpu().long(), g.rev.cpu().long()   # msg / phi live once per undirected pair
@@ -91,6 +95,9 @@ def test_intermediates_against_trace():
             close(f'phi2{l}', view(lay.phi2[l], (Pn, 128))[pid], T[f'phi2_{l}'])
         close(f'f_out{l}', view(lay.f_out[l], (N, 3, 128)), T[f'f_out_{l}'])
         close(f'a_out{l}', view(lay.a_out[l], (N, 128)), T[f'a_out_{l}'])
+        if l == L - 1:
+            assert torch.equal(res_n['atom_node'].cpu().double(), view(lay.a_out[l], (N, 128)))
+            assert torch.equal(res_n['force_node'].cpu().double(), view(lay.f_out[l], (N, 3, 128)))
         gx = view(lay.g_x + 4 * l * E, (E,))
         close(f'g_x{l}', gx + gx[rev], T[f'g_x_{l}'] + T[f'g_x_{l}'][rev], 2e-4)   # x is shared: only the pair sum is defined
         close(f'g_u{l}', view(lay.g_u + 16 * l * E, (E, 4))[:, :3], T[f'g_u_{l}'], 2e-4)

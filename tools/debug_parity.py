@@ -64,7 +64,7 @@ def run(case):
     report('dir', g.geo[:, :3].cpu(), T['u'])
     report('r', g.geo[:, 3].cpu(), T['r'])
     report('rbf', g.rbf.cpu(), T['rbf'])
-    res = hip.energy_forces(m, zc, pc, cc, g, want_forces=True, want_virial=True)
+    res = hip.energy_forces(m, zc, pc, cc, g, want_forces=True, want_virial=True, want_nodes=False)
     torch.cuda.synchronize()
     ws = res['workspace']
     N, E, B, L = g.n_atoms, g.n_edges, g.n_mol, m.n_layers
