@@ -112,7 +112,13 @@ struct MlpArgs {
   const float* b1;  // optional biases (node MLP / energy head; forward mode, row-local small-M kernel only)
   const float* b2;
 };
+struct MlpPair {      // up to two MLPs over the same M rows, run back to back by one persistent launch (mlp128.hip)
+  MlpArgs a[2];
+  int n;
+  int accum[2];       // stage-2 output is added to Y instead of overwriting it
+};
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s);
+int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s);
 
 // ---- row-local fused node kernels (node128.hip) -------------------------------------
 struct NodeFwdArgs {

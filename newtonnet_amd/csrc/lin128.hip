@@ -99,10 +99,17 @@ __global__ void __launch_bounds__(256, 2) lin128_kernel(const LinArgs p) {
   const LinGroup G = p.g[blockIdx.y];
 
   // stage W (coalesced 16-B loads; each 8-lane group writes one contiguous 128-B run of an LDS row)
-  for (int idx = threadIdx.x; idx < NF * (NF / 4); idx += 256) {
-    const int n = idx >> 5, k4 = idx & 31;
-    const float4 v = reinterpret_cast<const float4*>(G.W)[idx];
-    *reinterpret_cast<float4*>(&wlds[n * W_LD + k4 * 4]) = v;
+  {  // all 16 requests in flight before the first LDS write (a rolled load -> store loop serializes 16 L2 round trips)
+    float4 wv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wv[q] = reinterpret_cast<const float4*>(G.W)[threadIdx.x + 256 * q];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = threadIdx.x + 256 * q;
+      const int n = idx >> 5, k4 = idx & 31;
+      *reinterpret_cast<float4*>(&wlds[n * W_LD + k4 * 4]) = wv[q];
+    }
   }
   __syncthreads();
 

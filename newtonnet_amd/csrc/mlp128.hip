@@ -35,16 +35,38 @@ __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int 
   for (int t = 0; t < 16; ++t) x[t] = xp[2 * t];  // features 8t + 4h + {0..3}
 }
 
-template <int MODE, bool ACCUM>
-__global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
+// Stage both weight matrices of one MLP: all 16 requests of a thread are in flight before the first LDS write.
+// (Macros, not functions: the fragments must stay in registers.)
+#define MLP_W_LD(q, W1p, W2p)                                                                   \
+  const float4 w1v##q = reinterpret_cast<const float4*>(W1p)[threadIdx.x + 512 * q];             \
+  const float4 w2v##q = reinterpret_cast<const float4*>(W2p)[threadIdx.x + 512 * q];
+#define MLP_W_ST(q)                                                                              \
+  *reinterpret_cast<float4*>(&w1s[((threadIdx.x + 512 * q) >> 5) * MW_LD + (threadIdx.x & 31) * 4]) = w1v##q; \
+  *reinterpret_cast<float4*>(&w2s[((threadIdx.x + 512 * q) >> 5) * MW_LD + (threadIdx.x & 31) * 4]) = w2v##q;
+#define MLP_W_REQUEST(W1p, W2p)                                                                  \
+  MLP_W_LD(0, W1p, W2p) MLP_W_LD(1, W1p, W2p) MLP_W_LD(2, W1p, W2p) MLP_W_LD(3, W1p, W2p)        \
+  MLP_W_LD(4, W1p, W2p) MLP_W_LD(5, W1p, W2p) MLP_W_LD(6, W1p, W2p) MLP_W_LD(7, W1p, W2p)        \
+  __builtin_amdgcn_sched_barrier(0);
+#define MLP_W_COMMIT() MLP_W_ST(0) MLP_W_ST(1) MLP_W_ST(2) MLP_W_ST(3) MLP_W_ST(4) MLP_W_ST(5) MLP_W_ST(6) MLP_W_ST(7)
+
+// One launch runs P.n (1 or 2) MLPs of the same row count back to back ("phases": phi1 then phi2, or the two adjoint
+// terms of g_msg).  A launch costs ~15 us before the matrix pipes are busy (every wave's first X tile -- 33 MB -- and
+// 256 copies of the weights are requested at once) and the same again in stragglers at the end; the second phase only
+// restages the weights (L2 hits, the next X tile is already in flight) and reuses the running pipeline.
+template <int MODE, bool ACCUM_LAST>   // ACCUM_LAST: the last phase adds its result to Y (P.accum is checked by the host)
+__global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* w1s = wl;
   float* w2s = wl + NF * MW_LD;
 
+#ifdef MLP_CLOCK_DEBUG
+  const long long dbg_wstart = wall_clock64();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int n_tiles = (p.M + 31) >> 5;
+  const int M = P.a[0].M;
+  const int n_tiles = (M + 31) >> 5;
   const float* w1row = w1s + r * MW_LD + 4 * h;
   const float* w2row = w2s + r * MW_LD + 4 * h;
 
@@ -53,21 +75,46 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
   // SIMD second: when the tile count is not a multiple of the wave count the surplus tiles land on DIFFERENT SIMDs
   // (e.g. 4891 tiles, 1024 SIMDs: 3 + 2 on 795 of them, 2 + 2 on the rest -- not 3 + 3 on 400 and 2 + 2 elsewhere).
   const int n_simd = gridDim.x * 4;
-  int tile = (wave >> 2) * n_simd + blockIdx.x * 4 + (wave & 3);
+  const int tile0 = (wave >> 2) * n_simd + blockIdx.x * 4 + (wave & 3);
   const int tile_step = gridDim.x * 8;
-  float4 x[16];   // first X fragment is requested before the weights are staged: its latency hides under the LDS fill
-  mlp_load_x(x, p.X, p.ldx, min((min(tile, n_tiles - 1) << 5) + r, p.M - 1), h);
-  for (int idx = threadIdx.x; idx < NF * (NF / 4); idx += 512) {
-    const int n = idx >> 5, k4 = idx & 31;
-    *reinterpret_cast<float4*>(&w1s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W1)[idx];
-    *reinterpret_cast<float4*>(&w2s[n * MW_LD + k4 * 4]) = reinterpret_cast<const float4*>(p.W2)[idx];
+  float4 x[16];
+  {
+    // weights first (L2 hits, returned first by the in-order vmcnt queue), then this wave's first X fragment: the LDS fill
+    // and the barrier only wait for the weights, and stage 1 starts consuming X as its 16 pieces arrive
+    MLP_W_REQUEST(P.a[0].W1, P.a[0].W2)
+    mlp_load_x(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
+    __builtin_amdgcn_sched_barrier(0);
+    MLP_W_COMMIT()
   }
   __syncthreads();
-  if (tile >= n_tiles) return;
-  for (; tile < n_tiles; tile += tile_step) {
+#ifdef MLP_CLOCK_DEBUG   // tooling: shader clock vs the 100 MHz wall clock over the tile loop of one wave
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+  int dbg_tiles = 0;
+#endif
+  for (int ph = 0; ph < P.n; ++ph) {
+    // per-phase arguments picked with selects (indexing the kernel-argument array with `ph` would spill it to scratch)
+    struct { const float* X; float* H; float* Y; int ldx, ldh, ldy; } p;
+    p.X = ph ? P.a[1].X : P.a[0].X;
+    p.H = ph ? P.a[1].H : P.a[0].H;
+    p.Y = ph ? P.a[1].Y : P.a[0].Y;
+    p.ldx = ph ? P.a[1].ldx : P.a[0].ldx;
+    p.ldh = ph ? P.a[1].ldh : P.a[0].ldh;
+    p.ldy = ph ? P.a[1].ldy : P.a[0].ldy;
+    const bool accum = ACCUM_LAST && ph == P.n - 1;            // uniform
+    const bool more = ph + 1 < P.n;                            // (P.n <= 2: a following phase is always a[1])
+    if (ph > 0) {
+      __syncthreads();                     // every wave is done with the previous phase's weights
+      MLP_W_REQUEST(P.a[1].W1, P.a[1].W2)
+      MLP_W_COMMIT()
+      __syncthreads();
+    }
+  for (int tile = tile0; tile < n_tiles; tile += tile_step) {
+#ifdef MLP_CLOCK_DEBUG
+    ++dbg_tiles;
+#endif
     const int e = (tile << 5) + r;           // this lane's edge (both halves of the wave share it)
-    const int ec = min(e, p.M - 1);
-    const bool live = e < p.M;
+    const int ec = min(e, M - 1);
+    const bool live = e < M;
     float hs[4][16];                         // stage-1 result -> activation, feature nb*32 + (k&3) + 8(k>>2) + 4h
 
     // ---------------- stage 1: H^T = W1 . X^T  (4 blocks of 32 features)
@@ -83,16 +130,22 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[k] = 0.f;
       const float* wr = w1row + nb * 32 * MW_LD;
-      float4 a = *reinterpret_cast<const float4*>(wr);
+      // A fragments come from LDS two k-groups ahead of their use; the sched_group_barrier pairs pin the order
+      // "1 ds_read, 4 MFMA" (left alone, the compiler sinks each read to just before its first use).
+      float4 a0 = *reinterpret_cast<const float4*>(wr), a1 = *reinterpret_cast<const float4*>(wr + 8);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        float4 an;
-        if (t < 15) an = *reinterpret_cast<const float4*>(wr + 8 * (t + 1));
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, x[t].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, x[t].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, x[t].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, x[t].w, acc, 0, 0, 0);
-        if (t < 15) a = an;
+        float4 a2;
+        if (t < 14) a2 = *reinterpret_cast<const float4*>(wr + 8 * (t + 2));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, x[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, x[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, x[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, x[t].w, acc, 0, 0, 0);
+        a0 = a1;
+        if (t < 14) a1 = a2;
+        if (t < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (MODE == MODE_FWD) {
@@ -114,11 +167,15 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
       }
     }
 
-    // X of the NEXT tile: its registers are dead now; stage 2 (256 MFMAs) hides the latency.  (asm volatile pins the
-    // request here, ahead of this tile's stage-2 stores in the in-order vmcnt queue.)
+    // X of the NEXT tile (of this phase, or the first tile of the next phase): its registers are dead now; stage 2
+    // (256 MFMAs) hides the latency.  (The sched_barrier pins the request here, ahead of this tile's stage-2 stores in
+    // the in-order vmcnt queue.)
     {
-      const int nrow = min((min(tile + tile_step, n_tiles - 1) << 5) + r, p.M - 1);
-      mlp_load_x(x, p.X, p.ldx, nrow, h);
+      const bool last = tile + tile_step >= n_tiles;
+      const float* xn = (last && more) ? P.a[1].X : p.X;
+      const int ldn = (last && more) ? P.a[1].ldx : p.ldx;
+      const int nt = last ? tile0 : tile + tile_step;
+      mlp_load_x(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
       __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -126,25 +183,29 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
 #pragma unroll
     for (int nb2 = 0; nb2 < 4; ++nb2) {
       float4 yold[4];
-      if (ACCUM) {
+      if (ACCUM_LAST) {
         const float4* yp = reinterpret_cast<const float4*>(p.Y + (size_t)ec * p.ldy + nb2 * 32 + 4 * h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) yold[q] = yp[2 * q];
+        for (int q = 0; q < 4; ++q) yold[q] = accum ? yp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       f32x16 acc;
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[k] = 0.f;
       const float* wr = w2row + nb2 * 32 * MW_LD;
-      float4 a = *reinterpret_cast<const float4*>(wr);
+      float4 a0 = *reinterpret_cast<const float4*>(wr), a1 = *reinterpret_cast<const float4*>(wr + 8);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int T = 0; T < 16; ++T) {  // k-group T: features (T>>2)*32 + 8 (T&3) + 4h + {0..3} = hs[T>>2][4 (T&3) + c]
-        float4 an;
-        if (T < 15) an = *reinterpret_cast<const float4*>(wr + 8 * (T + 1));
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, hs[T >> 2][4 * (T & 3) + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, hs[T >> 2][4 * (T & 3) + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, hs[T >> 2][4 * (T & 3) + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, hs[T >> 2][4 * (T & 3) + 3], acc, 0, 0, 0);
-        if (T < 15) a = an;
+        float4 a2;
+        if (T < 14) a2 = *reinterpret_cast<const float4*>(wr + 8 * (T + 2));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, hs[T >> 2][4 * (T & 3) + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, hs[T >> 2][4 * (T & 3) + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, hs[T >> 2][4 * (T & 3) + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, hs[T >> 2][4 * (T & 3) + 3], acc, 0, 0, 0);
+        a0 = a1;
+        if (T < 14) a1 = a2;
+        if (T < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (live) {
@@ -152,7 +213,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-          if (ACCUM) {
+          if (ACCUM_LAST) {
             v.x += yold[q].x;
             v.y += yold[q].y;
             v.z += yold[q].z;
@@ -163,20 +224,29 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpArgs p) {
       }
     }
   }
+  }
+#ifdef MLP_CLOCK_DEBUG
+  if ((blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255) && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 7)) {
+    const long long wend = wall_clock64();
+    const long long dc = clock64() - dbg_c0, dw = wend - dbg_w0;
+    printf("mlp128 mode %d blk %3d w%d: start %lld  staged +%.2f us  loop %.2f us (%d tiles, %.3f GHz)  end %lld\n", MODE,
+           (int)blockIdx.x, wave, dbg_wstart, (dbg_w0 - dbg_wstart) / 100.0, dw / 100.0, dbg_tiles, dc / (dw * 10.0), wend);
+  }
+#endif
 }
 
-template <int MODE, bool ACCUM>
-static int launch_mlp_t(const MlpArgs& a, hipStream_t s) {
+template <int MODE, bool ACCUM_LAST>
+static int launch_mlp_t(const MlpPair& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 MLP_LDS_BYTES));
     attr_set = true;
   }
-  const int n_tiles = (a.M + 31) / 32;
+  const int n_tiles = (a.a[0].M + 31) / 32;
   int blocks = cdiv(n_tiles, 8);
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU (135 KiB of LDS each)
-  mlp128_kernel<MODE, ACCUM><<<blocks, 512, MLP_LDS_BYTES, s>>>(a);
+  mlp128_kernel<MODE, ACCUM_LAST><<<blocks, 512, MLP_LDS_BYTES, s>>>(a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -185,17 +255,55 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s);   //
 
 #define MLP_WIDE_MAX_TILES 1536   // up to ~49k rows one workgroup per tile beats the persistent form (tools/bench_mlp.py)
 
+static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipStream_t s) {
+  if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false>(P, s);
+  if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false>(P, s);
+  if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true>(P, s);
+  nnhip_set_error("launch_mlp: unsupported mode %d/%d", mode, (int)accum_last);
+  return NNHIP_E_INVALID;
+}
+
+static bool mlp_use_wide(const MlpArgs& a) {
+  static const int wide_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : MLP_WIDE_MAX_TILES;
+  return cdiv(a.M, 32) <= wide_max || a.b1 || a.b2;
+}
+
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1((a.b1 || a.b2) ? TC_LIN1 : TC_MLP, s);   // biased form = node MLP / energy head (node-level class)
-  static const int wide_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : MLP_WIDE_MAX_TILES;
-  if (cdiv(a.M, 32) <= wide_max || a.b1 || a.b2) return launch_mlp_wide(mode, accum, a, s);
-  if (mode == MODE_FWD && !accum) return launch_mlp_t<MODE_FWD, false>(a, s);
-  if (mode == MODE_BWD && !accum) return launch_mlp_t<MODE_BWD, false>(a, s);
-  if (mode == MODE_BWD && accum) return launch_mlp_t<MODE_BWD, true>(a, s);
-  nnhip_set_error("launch_mlp: unsupported mode %d/%d", mode, (int)accum);
-  return NNHIP_E_INVALID;
+  if (mlp_use_wide(a)) return launch_mlp_wide(mode, accum, a, s);
+  if (mode != MODE_FWD && mode != MODE_BWD) {
+    nnhip_set_error("launch_mlp: unsupported mode %d", mode);
+    return NNHIP_E_INVALID;
+  }
+  MlpPair P;
+  P.a[0] = P.a[1] = a;
+  P.n = 1;
+  P.accum[0] = P.accum[1] = accum ? 1 : 0;
+  return launch_mlp_dispatch(mode, accum, P, s);
+}
+
+// Two MLPs over the same rows in one persistent launch (phi1 | phi2 forward; the two terms of g_msg in the adjoint).
+int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s) {
+  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0) {   // only the last phase may accumulate
+    nnhip_set_error("launch_mlp_pair: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (a0.M <= 0) return 0;
+  if (mlp_use_wide(a0) || mlp_use_wide(a1)) {
+    const int rc = launch_mlp(mode, accum0, a0, s);
+    return rc ? rc : launch_mlp(mode, accum1, a1, s);
+  }
+  ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_MLP, s);
+  MlpPair P;
+  P.a[0] = a0;
+  P.a[1] = a1;
+  P.n = 2;
+  P.accum[0] = accum0 ? 1 : 0;
+  P.accum[1] = accum1 ? 1 : 0;
+  return launch_mlp_dispatch(mode, accum1, P, s);
 }
 
 // C ABI (include/newtonnet_hip.h)

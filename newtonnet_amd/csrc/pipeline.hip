@@ -293,10 +293,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
     if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
       float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mlp(MODE_FWD, false, {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, 2 * NF, NF}, s));
+      const MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, 2 * NF, NF};
+      const MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF};
       if (has_f)
-        TRY(launch_mlp(MODE_FWD, false,
-                       {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF}, s));
+        TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
+      else
+        TRY(launch_mlp(MODE_FWD, false, m1, s));
     }
     TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, s));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
@@ -366,9 +368,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
       float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mlp(MODE_BWD, false, {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF}, s));
+      const MlpArgs m1 = {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
+      const MlpArgs m2 = {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
       if (has_f)
-        TRY(launch_mlp(MODE_BWD, true, {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF}, s));
+        TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
+      else
+        TRY(launch_mlp(MODE_BWD, false, m1, s));
     }
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, P(w.g_m),
