@@ -33,6 +33,7 @@ extern "C" {
 #define NNHIP_F 128
 #define NNHIP_NB 20
 #define NNHIP_MAX_LAYERS 8
+#define NNHIP_N_ELEMENTS 119 /* rows of node_embedding / scale / shift (z = 0..118) */
 
 enum {
   NNHIP_OK = 0,
@@ -175,6 +176,7 @@ typedef struct {
   size_t phi1[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t phi2[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */
+  /* hn[0] is not written: layer 0's message_nodepart is evaluated per element (its adjoint is never needed) */
   size_t a_out[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the layer (last layer: only when atom_node == NULL) */
   size_t f_out[NNHIP_MAX_LAYERS];  /* [N][3][F] force_node after the layer (last layer: only when force_node == NULL) */
   size_t q[NNHIP_MAX_LAYERS];      /* [N][3][F] equiv_update(force_node) */

@@ -39,17 +39,34 @@ struct ScopedTimer {
 
 // ---- device helpers ----------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (about 1 ulp each): well inside the fp32 tolerance of the path
+#ifdef ABL_NO_SILU   // tooling only (wrong results): price the activation's VALU work
+__device__ __forceinline__ float sigmoid_f(float x) { return 0.5f + 0.25f * x; }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float dsilu_f(float x) {
   const float s = sigmoid_f(x);
   return s * (1.0f + x * (1.0f - s));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// Wave-wide sum on the DPP path (register-to-register cross-lane moves, a few cycles each; __shfl_xor compiles to
+// ds_bpermute_b32, an LDS-pipe round trip of ~100 cycles per step, and six of those in a row were a third of the per-edge
+// latency chain of the message / force adjoints).  quad_perm swaps -> row_half_mirror -> row_mirror leave the 16-lane row
+// sums in every lane; row_bcast15 / row_bcast31 (gfx9 DPP) fold the four rows into lane 63.
+#define NN_DPP_ADD(v, ctrl, row_mask)                                                                            \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xF, false))
+__device__ __forceinline__ float wave_sum_lane63(float v) {   // the total is valid in lane 63 only
+  NN_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+  NN_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  NN_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+  NN_DPP_ADD(v, 0x140, 0xF);   // row_mirror
+  NN_DPP_ADD(v, 0x142, 0xA);   // row_bcast15 into rows 1 and 3
+  NN_DPP_ADD(v, 0x143, 0xC);   // row_bcast31 into rows 2 and 3
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {          // the total in every lane (as a scalar broadcast)
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
 }
 
 // Block b is observed to run on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every XCD a

@@ -227,6 +227,9 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 //             directed edges and only their sum enters the force, so the pair's owner carries all of it and the
 //             other direction skips the derivative table)
 // ---------------------------------------------------------------------------------------------
+// NEED_GM = false for the first layer: its m = message_nodepart(Embedding[z]) does not depend on the positions, so g_m is
+// never used and the rows only visit the pairs they own (for g_x).
+template <bool NEED_GM>
 __global__ void __launch_bounds__(256)
 msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
                const int2* __restrict__ xg, const float* __restrict__ table,
@@ -240,6 +243,10 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   float2 acc = make_float2(0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   for (int e = beg; e < end; ++e) {
+    if (!NEED_GM && col[e] < i) {   // wave-uniform
+      if (lane == 0) g_x[e] = 0.f;
+      continue;
+    }
     const int j = ABL_J(col[e], i);
     const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
     const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
@@ -270,9 +277,9 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
       for (int k = 1; k < 4; ++k) eps = fma2(t4[k], fw.w[k], eps);
       if (lane == 0) g_x[e] = 0.f;
     }
-    acc = fma2(G * eps, mj, acc);
+    if (NEED_GM) acc = fma2(G * eps, mj, acc);
   }
-  st2(g_m + (size_t)i * NF + 2 * lane, acc);
+  if (NEED_GM) st2(g_m + (size_t)i * NF + 2 * lane, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,12 +402,17 @@ virial_kernel(const float* __restrict__ g_d, const float* __restrict__ disp, con
 // node-level elementwise pieces (N x F; an order of magnitude less traffic than the edge tensors)
 // ---------------------------------------------------------------------------------------------
 // atom_node = Embedding[z]   (newtonnet.py:142)
-__global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restrict__ table, int n_atoms,
-                             float* __restrict__ a0) {
+// and, in the same pass, the first layer's m = message_nodepart(Embedding[z]) looked up from its per-element table
+// (pipeline.hip evaluates that MLP on the 119 embedding rows instead of the N atom rows)
+__global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restrict__ table,
+                             const float* __restrict__ m_table, int n_atoms, float* __restrict__ a0,
+                             float* __restrict__ m0) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
   if (t >= (size_t)n_atoms * (NF / 4)) return;
   const int i = (int)(t / (NF / 4)), c = (int)(t % (NF / 4));
-  reinterpret_cast<float4*>(a0)[t] = reinterpret_cast<const float4*>(table + (size_t)z[i] * NF)[c];
+  const size_t zi = (size_t)z[i];
+  reinterpret_cast<float4*>(a0)[t] = reinterpret_cast<const float4*>(table + zi * NF)[c];
+  reinterpret_cast<float4*>(m0)[t] = reinterpret_cast<const float4*>(m_table + zi * NF)[c];
 }
 
 // energy head tail (output.py:98-100 last Linear, scalers.py:55-58) and the seed of the reverse sweep:
@@ -498,11 +510,15 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
 
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
-                   hipStream_t s) {
+                   bool need_gm, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
-  msg_bwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col,
-                                                    pid, g_m, g_x, n_atoms);
+  if (need_gm)
+    msg_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+                                                            row_ptr, col, pid, g_m, g_x, n_atoms);
+  else
+    msg_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+                                                             row_ptr, col, pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -525,9 +541,10 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
   return 0;
 }
 
-int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s) {
+int launch_embed(const int64_t* z, const float* table, const float* m_table, int n_atoms, float* a0, float* m0,
+                 hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
-  embed_kernel<<<cdiv((long)n_atoms * (NF / 4), 256), 256, 0, s>>>(z, table, n_atoms, a0);
+  embed_kernel<<<cdiv((long)n_atoms * (NF / 4), 256), 256, 0, s>>>(z, table, m_table, n_atoms, a0, m0);
   LAUNCH_CHECK();
   return 0;
 }

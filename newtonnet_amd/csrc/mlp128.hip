@@ -149,7 +149,11 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (MODE == MODE_FWD) {
+#ifdef ABL_NO_STORE   // tooling only
+        if (live && M < 0) {
+#else
         if (live) {
+#endif
           float4* hp = reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
 #pragma unroll
           for (int q = 0; q < 4; ++q) hp[2 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -208,7 +212,11 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef ABL_NO_STORE
+      if (live && M < 0) {
+#else
       if (live) {
+#endif
         float4* yp = reinterpret_cast<float4*>(p.Y + (size_t)e * p.ldy + nb2 * 32 + 4 * h);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

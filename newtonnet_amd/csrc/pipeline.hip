@@ -22,13 +22,14 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
                      float* g_fin, int n_atoms, hipStream_t s);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
-                   const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
+                   const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm,
                    hipStream_t s);
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
                         float* virial, hipStream_t s);
-int launch_embed(const int64_t* z, const float* table, int n_atoms, float* a0, hipStream_t s);
+int launch_embed(const int64_t* z, const float* table, const float* m_table, int n_atoms, float* a0, float* m0,
+                 hipStream_t s);
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s);
@@ -110,6 +111,7 @@ struct WsInternal {
   nnhip_ws_layout pub;
   size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
   size_t headT[2];                 // head0^T, head2^T
+  size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
   size_t g_h12;                    // [E][2F] adjoint scratch (g_phi -> g_h)
   size_t g_msg;                    // [E][F]
   size_t g_m;                      // [N][F]
@@ -148,6 +150,8 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
     for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
     w.ftab[l] = carve(off, (size_t)3 * FT_ROWS * NF * 4);
   }
+  w.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
+  w.m_tab = carve(off, (size_t)128 * NF * 4);
   w.headT[0] = carve(off, NF * NF * 4);
   w.headT[1] = carve(off, NF * NF * 4);
   w.pub.e1 = carve(off, nf);
@@ -274,7 +278,15 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   }
 
   // ------------------------------------------------------------------ forward sweep
-  TRY(launch_embed(z, model->node_embedding, N, P(w.pub.a0), s));
+  // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
+  // atoms' rows up, instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is not kept: its
+  // adjoint is never needed, the embedding does not depend on the positions.)
+  {
+    const nnhip_layer_params& l0 = model->layer[0];
+    TRY(launch_mlp(MODE_FWD, false, {model->node_embedding, l0.node0_w, l0.node2_w, P(w.hn_tab), P(w.m_tab), NNHIP_N_ELEMENTS,
+                                     NF, NF, NF, l0.node0_b, l0.node2_b}, s));
+    TRY(launch_embed(z, model->node_embedding, P(w.m_tab), N, P(w.pub.a0), P(w.pub.m[0]), s));
+  }
   const float* a_in = P(w.pub.a0);
   const float* f_in = nullptr;  // force_node == 0 entering the first layer (newtonnet.py:143)
   // the last layer writes atom_node / force_node straight into the caller's output arrays when they are given
@@ -283,11 +295,8 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   for (int l = 0; l < L; ++l) {
     const nnhip_layer_params& lp = model->layer[l];
     const bool has_f = l > 0;
-    // message_nodepart: hn = a W0^T + b0 ; m = silu(hn) W2^T + b2.  (For l > 0 it was already produced by the fused
-    // node kernel that closed the previous layer.)
-    if (l == 0)
-      TRY(launch_mlp(MODE_FWD, false,
-                     {a_in, lp.node0_w, lp.node2_w, P(w.pub.hn[l]), P(w.pub.m[l]), N, NF, NF, NF, lp.node0_b, lp.node2_b}, s));
+    // message_nodepart (hn = a W0^T + b0 ; m = silu(hn) W2^T + b2) was produced by the fused node kernel that closed the
+    // previous layer (by the per-element table for l = 0)
     // messages + invariant update
     TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
@@ -377,7 +386,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     }
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, P(w.g_m),
-                       P(w.pub.g_x) + (size_t)l * E, N, s));
+                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s));
     // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
     // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
     // message_nodepart input is the embedding of z, which does not depend on the positions.
