@@ -8,7 +8,9 @@
 #define NF NNHIP_F    // 128 features: one wave = 64 lanes x float2
 #define NB NNHIP_NB   // 20 radial basis functions
 #define WAVE 64
+#ifndef FT_G
 #define FT_G 4096            // radial-filter table: intervals on x = r/cutoff in [0, 1)
+#endif
 #define FT_ROWS (FT_G + 3)   // rows for x_g = (g - 1) / FT_G  (4-point stencil at both ends)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,6 +67,14 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {   // the total is va
   NN_DPP_ADD(v, 0x143, 0xC);   // row_bcast31 into rows 2 and 3
   return v;
 }
+__device__ __forceinline__ float half_sum_top(float v) {      // sums of lanes 0-31 / 32-63, valid in lanes 31 / 63 only
+  NN_DPP_ADD(v, 0xB1, 0xF);
+  NN_DPP_ADD(v, 0x4E, 0xF);
+  NN_DPP_ADD(v, 0x141, 0xF);
+  NN_DPP_ADD(v, 0x140, 0xF);
+  NN_DPP_ADD(v, 0x142, 0xA);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {          // the total in every lane (as a scalar broadcast)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
 }
@@ -77,6 +87,40 @@ __device__ __forceinline__ int xcd_tile(int b, int n_blocks) {
   const int x = b & 7, k = b >> 3;
   const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + k;
+}
+
+// 16-byte row pieces.  The texture addresser spends ~16 cycles on a wave64 vector-memory instruction whatever its width
+// (PMC: TA_BUSY 90-100 % in the edge kernels while they moved 8 bytes per lane), so the edge kernels use float4 per lane.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 w;
+  w.x = v.x;
+  w.y = v.y;
+  w.z = v.z;
+  w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<v4*>(p));
+}
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
+  return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+// lanes 0-31 receive the value held by lane + 32 (folding the two half-wave partial sums of a row)
+__device__ __forceinline__ float4 upper_half(float4 v) {
+  return make_float4(__shfl_down(v.x, 32, WAVE), __shfl_down(v.y, 32, WAVE), __shfl_down(v.z, 32, WAVE), __shfl_down(v.w, 32, WAVE));
 }
 
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }

@@ -7,9 +7,10 @@
 // (newtonnet/models/output.py:66-73)                                                      -> *_bwd_kernel
 //
 // Layout / mapping: the edge list is a CSR over the receiver i (graph.hip).  One 64-lane wavefront owns
-// one receiver row; lane l holds features 2l, 2l+1, so every [F]=128-float row access is one fully
-// coalesced 512-byte transaction and the per-row sums live in registers: deterministic segmented
-// reductions, no float atomics.  Sender-side scatters of the adjoint are turned into receiver-side
+// one receiver row and walks its edges two at a time: the lower half-wave takes the even edge, the upper half the odd
+// one, and lane l of a half holds features 4l .. 4l+3, so every [F]=128-float row access is a 16-byte-per-lane
+// instruction covering two 512-byte rows (the texture addresser charges per instruction, not per byte).  The per-row
+// sums live in registers (the two halves are folded once per row): deterministic segmented reductions, no float atomics.  Sender-side scatters of the adjoint are turned into receiver-side
 // gathers (the edge set is symmetric).  Per-edge scalars (col, dir, table position) are wave-uniform and come
 // in through the scalar cache.  HBM-bound: no MFMA here.
 //
@@ -54,7 +55,7 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
 }
 
 // Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx by cubic interpolation of
-// per-layer tables T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 4096 intervals,
+// per-layer table planes T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 4096 intervals,
 // built in fp64 on every call).  Evaluating the 20-term contraction per (edge, feature) on the VALU was the
 // bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the tables turn it into
 // coalesced 512-B L2 reads and a handful of FMAs.  Interpolation error ~ h^4 |d4f/dx4| / 24 ~ 1e-9 relative
@@ -71,9 +72,43 @@ __device__ __forceinline__ FilterW filter_weights(float u) {
   f.w[3] = up1 * u * um1 * (1.f / 6.f);
   return f;
 }
-__device__ __forceinline__ void filter_rows(const float* __restrict__ table, int g0, int lane, float2 (&t)[4]) {
+__device__ __forceinline__ float4 filter_value(const float* __restrict__ table, int g0, int c4, const FilterW& fw) {
+  float4 t[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = ld2(table + (size_t)(g0 + k) * NF + 2 * lane);
+  for (int k = 0; k < 4; ++k) t[k] = ld4(table + (size_t)(g0 + k) * NF + c4);
+  float4 eps = mul4(t[0], fw.w[0]);
+#pragma unroll
+  for (int k = 1; k < 4; ++k) eps = fma4(t[k], fw.w[k], eps);
+  return eps;
+}
+// value and derivative: the derivative plane follows the value plane
+__device__ __forceinline__ void filter_value_deriv(const float* __restrict__ table, int g0, int c4, const FilterW& fw,
+                                                   float4& eps, float4& deps) {
+  const float* dt = table + (size_t)FT_ROWS * NF;
+  float4 t[4], d[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t[k] = ld4(table + (size_t)(g0 + k) * NF + c4);
+    d[k] = ld4(dt + (size_t)(g0 + k) * NF + c4);
+  }
+  eps = mul4(t[0], fw.w[0]);
+  deps = mul4(d[0], fw.w[0]);
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    eps = fma4(t[k], fw.w[k], eps);
+    deps = fma4(d[k], fw.w[k], deps);
+  }
+}
+
+// First edge of row i whose sender is above i (cols ascend within a row: [beg, mid) are the pairs owned by the other
+// endpoint, [mid, end) the pairs this row owns).  One coalesced read of the row's cols per 64 edges.
+__device__ __forceinline__ int row_mid(const int* __restrict__ col, int beg, int end, int i, int lane) {
+  int mid = beg;
+  for (int e = beg; e < end; e += 64) {
+    const bool below = (e + lane < end) && col[e + lane] < i;
+    mid += __popcll(__ballot(below));
+  }
+  return mid;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -88,24 +123,31 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
-  float2 acc = make_float2(0.f, 0.f);
+  const int c4 = 4 * (lane & 31);
+  const bool hi = lane >= 32;
+  const float4 mi = ld4(m + (size_t)i * NF + c4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; ++e) {
-    const int j = col[e];
-    const int2 gx = xg[e];   // wave-uniform
-    float2 t[4];
-    filter_rows(table, ABL_G(gx.x), lane, t);
-    const float2 mj = ld2(m + (size_t)ABL_J(j, i) * NF + 2 * lane);
-    const FilterW fw = filter_weights(__int_as_float(gx.y));
-    float2 eps = t[0] * fw.w[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) eps = fma2(t[k], fw.w[k], eps);
-    const float2 v = eps * mi * mj;
-    if (ABL_ST(j > i)) st2(msg + (size_t)pid[e] * NF + 2 * lane, v);   // the lower endpoint writes the shared pair row
-    acc = acc + v;
+  for (int e = beg; e < end; e += 2) {
+    const int e1 = min(e + 1, end - 1);
+    const int j0 = col[e], j1 = col[e1];
+    const int2 gx0 = xg[e], gx1 = xg[e1];   // wave-uniform
+    const int jj = hi ? j1 : j0;
+    const int2 gx = hi ? gx1 : gx0;
+    if (!hi || e + 1 < end) {
+      const FilterW fw = filter_weights(__int_as_float(gx.y));
+      const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
+      const float4 mj = ld4(m + (size_t)ABL_J(jj, i) * NF + c4);
+      const float4 v = mul4(mul4(eps, mi), mj);
+      if (ABL_ST(jj > i)) {   // the lower endpoint writes the shared pair row
+        const int p0 = pid[e], p1 = pid[e1];
+        st4(msg + (size_t)(hi ? p1 : p0) * NF + c4, v);
+      }
+      acc = add4(acc, v);
+    }
   }
-  st2(a_mid + (size_t)i * NF + 2 * lane, ld2(a_in + (size_t)i * NF + 2 * lane) + acc);
+  acc = add4(acc, upper_half(acc));
+  if (!hi) st4(a_mid + (size_t)i * NF + c4, add4(ld4(a_in + (size_t)i * NF + c4), acc));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,27 +163,39 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  float2 acc[3];
+  const int c4 = 4 * (lane & 31);          // this lane's four features
+  const bool hi = lane >= 32;              // upper half-wave: the odd edge of each pair of edges
+  float4 acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    acc[k] = HAS_F ? ld2(f_in + ((size_t)i * 3 + k) * NF + 2 * lane) : make_float2(0.f, 0.f);
+    acc[k] = (HAS_F && !hi) ? ld4(f_in + ((size_t)i * 3 + k) * NF + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; ++e) {
-    const float4 g = reinterpret_cast<const float4*>(geo)[e];  // (ux,uy,uz,r), wave-uniform
-    const size_t p = (size_t)ABL_P(pid[e], i);
-    const float2 p1 = ld2(phi1 + p * NF + 2 * lane);
-    acc[0] = fma2(p1, g.x, acc[0]);
-    acc[1] = fma2(p1, g.y, acc[1]);
-    acc[2] = fma2(p1, g.z, acc[2]);
-    if (HAS_F) {
-      const int j = ABL_J(col[e], i);
-      const float2 p2 = ld2(phi2 + p * NF + 2 * lane);
+  for (int e = beg; e < end; e += 2) {
+    const int e1 = min(e + 1, end - 1);    // (clamped; the odd half is masked off when the row has no edge e + 1)
+    const float4 g0 = reinterpret_cast<const float4*>(geo)[e];   // (ux,uy,uz,r), wave-uniform
+    const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
+    const int p0 = pid[e], p1 = pid[e1];
+    const float4 g = hi ? g1 : g0;
+    const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
+    if (!hi || e + 1 < end) {
+      const float4 v1 = ld4(phi1 + p * NF + c4);
+      acc[0] = fma4(v1, g.x, acc[0]);
+      acc[1] = fma4(v1, g.y, acc[1]);
+      acc[2] = fma4(v1, g.z, acc[2]);
+      if (HAS_F) {
+        const int j0 = col[e], j1 = col[e1];
+        const int j = ABL_J(hi ? j1 : j0, i);
+        const float4 v2 = ld4(phi2 + p * NF + c4);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), acc[k]);
+        for (int k = 0; k < 3; ++k) acc[k] = fma4(v2, ld4(f_in + ((size_t)j * 3 + k) * NF + c4), acc[k]);
+      }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) st2(f_out + ((size_t)i * 3 + k) * NF + 2 * lane, acc[k]);
+  for (int k = 0; k < 3; ++k) {
+    const float4 o = add4(acc[k], upper_half(acc[k]));
+    if (!hi) st4(f_out + ((size_t)i * 3 + k) * NF + c4, o);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,57 +218,85 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  float2 gfi[3], fi[3], acc[3];
+  const int c4 = 4 * (lane & 31);
+  const bool hi = lane >= 32;
+  float4 gfi[3], fi[3], acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    gfi[k] = ld2(gf + ((size_t)i * 3 + k) * NF + 2 * lane);
-    acc[k] = gfi[k];
-    if (HAS_F) fi[k] = ld2(f_in + ((size_t)i * 3 + k) * NF + 2 * lane);
+    gfi[k] = ld4(gf + ((size_t)i * 3 + k) * NF + c4);
+    acc[k] = hi ? make_float4(0.f, 0.f, 0.f, 0.f) : gfi[k];
+    if (HAS_F) fi[k] = ld4(f_in + ((size_t)i * 3 + k) * NF + c4);
   }
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; ++e) {
-    const float4 g = reinterpret_cast<const float4*>(geo)[e];
-    const int jj = col[e];
-    const int j = ABL_J(jj, i);
-    const size_t p = (size_t)pid[e];
-    const bool owner = jj > i;   // wave-uniform
-    const float2 p1 = ld2(phi1 + (size_t)ABL_P(p, i) * NF + 2 * lane);
-    float2 gfj[3];
-    if (HAS_F || owner) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) gfj[k] = ld2(gf + ((size_t)j * 3 + k) * NF + 2 * lane);
-    }
-    float s0 = fmaf(gfi[0].x, p1.x, gfi[0].y * p1.y);
-    float s1 = fmaf(gfi[1].x, p1.x, gfi[1].y * p1.y);
-    float s2 = fmaf(gfi[2].x, p1.x, gfi[2].y * p1.y);
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (lane == 0) reinterpret_cast<float4*>(g_u)[e] = make_float4(s0, s1, s2, 0.f);
-    if (owner) {
-      float2 gp1 = make_float2(gfi[0].x - gfj[0].x, gfi[0].y - gfj[0].y) * g.x;
-      gp1 = fma2(make_float2(gfi[1].x - gfj[1].x, gfi[1].y - gfj[1].y), g.y, gp1);
-      gp1 = fma2(make_float2(gfi[2].x - gfj[2].x, gfi[2].y - gfj[2].y), g.z, gp1);
-      if (ABL_ST(true)) st2_nt(g_h12 + p * 2 * NF + 2 * lane, gp1);
-    }
-    if (HAS_F) {
-      const float2 p2 = ld2(phi2 + (size_t)ABL_P(p, i) * NF + 2 * lane);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) acc[k] = fma2(p2, gfj[k], acc[k]);
-      if (owner) {
-        float2 gp2 = make_float2(0.f, 0.f);
+  const int mid = row_mid(col, beg, end, i, lane);
+  // [beg, mid): pairs owned by the other endpoint -- g_u and the phi2 gather only
+  for (int e = beg; e < mid; e += 2) {
+    const int e1 = min(e + 1, mid - 1);
+    const int p0 = pid[e], p1 = pid[e1];
+    const int eh = hi ? e1 : e;
+    const size_t p = (size_t)(hi ? p1 : p0);
+    if (!hi || e + 1 < mid) {
+      const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
+      float4 gfj[3];
+      if (HAS_F) {
+        const int j0 = col[e], j1 = col[e1];
+        const int j = ABL_J(hi ? j1 : j0, i);
+        const float4 v2 = ld4(phi2 + (size_t)ABL_P(p, i) * NF + c4);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          gp2 = fma2(gfi[k], ld2(f_in + ((size_t)j * 3 + k) * NF + 2 * lane), gp2);
-          gp2 = fma2(gfj[k], fi[k], gp2);
+          gfj[k] = ld4(gf + ((size_t)j * 3 + k) * NF + c4);
+          acc[k] = fma4(v2, gfj[k], acc[k]);
         }
-        if (ABL_ST(true)) st2_nt(g_h12 + p * 2 * NF + NF + 2 * lane, gp2);
       }
+      const float s0 = half_sum_top(dot4(gfi[0], v1));
+      const float s1 = half_sum_top(dot4(gfi[1], v1));
+      const float s2 = half_sum_top(dot4(gfi[2], v1));
+      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
+    }
+  }
+  // [mid, end): pairs this row owns -- additionally the adjoints of the shared phi rows
+  for (int e = mid; e < end; e += 2) {
+    const int e1 = min(e + 1, end - 1);
+    const int p0 = pid[e], p1 = pid[e1];
+    const int j0 = col[e], j1 = col[e1];
+    const float4 g0 = reinterpret_cast<const float4*>(geo)[e];
+    const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
+    const int eh = hi ? e1 : e;
+    const size_t p = (size_t)(hi ? p1 : p0);
+    const int j = ABL_J(hi ? j1 : j0, i);
+    const float4 g = hi ? g1 : g0;
+    if (!hi || e + 1 < end) {
+      const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
+      float4 gfj[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gfj[k] = ld4(gf + ((size_t)j * 3 + k) * NF + c4);
+      float4 gp1 = mul4(sub4(gfi[0], gfj[0]), g.x);
+      gp1 = fma4(sub4(gfi[1], gfj[1]), g.y, gp1);
+      gp1 = fma4(sub4(gfi[2], gfj[2]), g.z, gp1);
+      if (ABL_ST(true)) st4_nt(g_h12 + p * 2 * NF + c4, gp1);
+      if (HAS_F) {
+        const float4 v2 = ld4(phi2 + (size_t)ABL_P(p, i) * NF + c4);
+        float4 gp2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acc[k] = fma4(v2, gfj[k], acc[k]);
+          gp2 = fma4(gfi[k], ld4(f_in + ((size_t)j * 3 + k) * NF + c4), gp2);
+          gp2 = fma4(gfj[k], fi[k], gp2);
+        }
+        if (ABL_ST(true)) st4_nt(g_h12 + p * 2 * NF + NF + c4, gp2);
+      }
+      const float s0 = half_sum_top(dot4(gfi[0], v1));
+      const float s1 = half_sum_top(dot4(gfi[1], v1));
+      const float s2 = half_sum_top(dot4(gfi[2], v1));
+      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
     }
   }
   if (HAS_F) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) st2(g_fin + ((size_t)i * 3 + k) * NF + 2 * lane, acc[k]);
+    for (int k = 0; k < 3; ++k) {
+      const float4 o = add4(acc[k], upper_half(acc[k]));
+      if (!hi) st4(g_fin + ((size_t)i * 3 + k) * NF + c4, o);
+    }
   }
 }
 
@@ -238,48 +320,60 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  const float2 mi = ld2(m + (size_t)i * NF + 2 * lane);
-  const float2 gai = ld2(g_a + (size_t)i * NF + 2 * lane);
-  float2 acc = make_float2(0.f, 0.f);
+  const int c4 = 4 * (lane & 31);
+  const bool hi = lane >= 32;
+  const float4 mi = ld4(m + (size_t)i * NF + c4);
+  const float4 gai = ld4(g_a + (size_t)i * NF + c4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; ++e) {
-    if (!NEED_GM && col[e] < i) {   // wave-uniform
-      if (lane == 0) g_x[e] = 0.f;
-      continue;
-    }
-    const int j = ABL_J(col[e], i);
-    const float2 mj = ld2(m + (size_t)j * NF + 2 * lane);
-    const float2 gaj = ld2(g_a + (size_t)j * NF + 2 * lane);
-    const float2 G = ld2(g_msg + (size_t)ABL_P(pid[e], i) * NF + 2 * lane) + gai + gaj;
-    const int2 gxi = xg[e];   // wave-uniform
-    const FilterW fw = filter_weights(__int_as_float(gxi.y));
-    float2 eps;
-    if (col[e] > i) {   // wave-uniform: the pair's owner also evaluates d eps/dx and carries the pair's whole g_x
-      float4 td[4];   // (T, D) pairs of this lane's two features, rows g0 .. g0+3 of the interleaved table
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        td[k] = *reinterpret_cast<const float4*>(table + (size_t)FT_ROWS * NF + ((size_t)(ABL_G(gxi.x) + k) * NF + 2 * lane) * 2);
-      eps = make_float2(td[0].x, td[0].z) * fw.w[0];
-      float2 deps = make_float2(td[0].y, td[0].w) * fw.w[0];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) {
-        eps = fma2(make_float2(td[k].x, td[k].z), fw.w[k], eps);
-        deps = fma2(make_float2(td[k].y, td[k].w), fw.w[k], deps);
+  const int mid = row_mid(col, beg, end, i, lane);
+  for (int e = beg + lane; e < mid; e += 64) g_x[e] = 0.f;   // the pair's owner carries all of g_x
+  if (NEED_GM) {
+    // [beg, mid): pairs owned by the other endpoint -- value table only
+    for (int e = beg; e < mid; e += 2) {
+      const int e1 = min(e + 1, mid - 1);
+      const int j0 = col[e], j1 = col[e1];
+      const int p0 = pid[e], p1 = pid[e1];
+      const int2 gx0 = xg[e], gx1 = xg[e1];
+      const int j = ABL_J(hi ? j1 : j0, i);
+      const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
+      const int2 gx = hi ? gx1 : gx0;
+      if (!hi || e + 1 < mid) {
+        const float4 mj = ld4(m + (size_t)j * NF + c4);
+        const float4 gaj = ld4(g_a + (size_t)j * NF + c4);
+        const float4 G = add4(add4(ld4(g_msg + p * NF + c4), gai), gaj);
+        const FilterW fw = filter_weights(__int_as_float(gx.y));
+        const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
+        acc = fma4(mul4(G, eps), mj, acc);
       }
-      const float2 t = G * mi * mj;
-      const float gx = wave_sum(fmaf(t.x, deps.x, t.y * deps.y));
-      if (lane == 0) g_x[e] = gx;
-    } else {
-      float2 t4[4];
-      filter_rows(table, ABL_G(gxi.x), lane, t4);
-      eps = t4[0] * fw.w[0];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) eps = fma2(t4[k], fw.w[k], eps);
-      if (lane == 0) g_x[e] = 0.f;
     }
-    if (NEED_GM) acc = fma2(G * eps, mj, acc);
   }
-  if (NEED_GM) st2(g_m + (size_t)i * NF + 2 * lane, acc);
+  // [mid, end): pairs this row owns -- value and derivative, g_x
+  for (int e = mid; e < end; e += 2) {
+    const int e1 = min(e + 1, end - 1);
+    const int j0 = col[e], j1 = col[e1];
+    const int p0 = pid[e], p1 = pid[e1];
+    const int2 gx0 = xg[e], gx1 = xg[e1];
+    const int j = ABL_J(hi ? j1 : j0, i);
+    const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
+    const int2 gx = hi ? gx1 : gx0;
+    const int eh = hi ? e1 : e;
+    if (!hi || e + 1 < end) {
+      const float4 mj = ld4(m + (size_t)j * NF + c4);
+      const float4 gaj = ld4(g_a + (size_t)j * NF + c4);
+      const float4 G = add4(add4(ld4(g_msg + p * NF + c4), gai), gaj);
+      const FilterW fw = filter_weights(__int_as_float(gx.y));
+      float4 eps, deps;
+      filter_value_deriv(table, ABL_G(gx.x), c4, fw, eps, deps);
+      const float gxs = half_sum_top(dot4(mul4(mul4(G, mi), mj), deps));
+      if ((lane & 31) == 31) g_x[eh] = gxs;
+      if (NEED_GM) acc = fma4(mul4(G, eps), mj, acc);
+    }
+  }
+  if (NEED_GM) {
+    acc = add4(acc, upper_half(acc));
+    if (!hi) st4(g_m + (size_t)i * NF + c4, acc);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -320,9 +320,9 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
 //   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)          (values)
 //   D[g][f] = sum_n W_e[f][n] d rbf_n/dx (x_g)    (derivatives, tabulated separately: differentiating the fp32 value
 //             table would amplify its rounding by FT_G)
-// stored as table[0 .. FT_ROWS)[F] = T (forward kernel) followed by an interleaved copy [FT_ROWS][F][2] = (T, D) pairs, so
-// that the adjoint kernel gets both with one 16-byte load per lane and row.  The message kernels interpolate both with
-// the same 4-point cubic weights (edge.hip).
+// stored as two planes, table[0 .. FT_ROWS)[F] = T followed by [FT_ROWS][F] = D: with four features per lane every
+// row read of either plane is one coalesced 16-byte-per-lane instruction.  The message kernels interpolate both with the
+// same 4-point cubic weights (edge.hip).
 struct FilterTableArgs {
   const float* edge_w[NNHIP_MAX_LAYERS];
   float* table[NNHIP_MAX_LAYERS];
@@ -359,8 +359,7 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
     dacc += (double)we[n] * drb[n];
   }
   a.table[l][(size_t)g * NF + threadIdx.x] = (float)acc;
-  float2* td = reinterpret_cast<float2*>(a.table[l] + (size_t)FT_ROWS * NF);
-  td[(size_t)g * NF + threadIdx.x] = make_float2((float)acc, (float)dacc);
+  a.table[l][(size_t)(FT_ROWS + g) * NF + threadIdx.x] = (float)dacc;
 }
 
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq,

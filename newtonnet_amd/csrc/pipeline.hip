@@ -120,7 +120,7 @@ struct WsInternal {
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
   size_t atom_energy;              // [N]
-  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values + [FT_ROWS][F][2] (value, d/dx)
+  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values, then [FT_ROWS][F] d/dx
 };
 
 static size_t carve(size_t& off, size_t bytes) {
@@ -148,7 +148,7 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
     w.pub.f_out[l] = carve(off, 3 * nf);
     w.pub.q[l] = carve(off, 3 * nf);
     for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
-    w.ftab[l] = carve(off, (size_t)3 * FT_ROWS * NF * 4);
+    w.ftab[l] = carve(off, (size_t)2 * FT_ROWS * NF * 4);
   }
   w.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
   w.m_tab = carve(off, (size_t)128 * NF * 4);
