@@ -9,7 +9,7 @@
 #define NB NNHIP_NB   // 20 radial basis functions
 #define WAVE 64
 #ifndef FT_G
-#define FT_G 4096            // radial-filter table: intervals on x = r/cutoff in [0, 1)
+#define FT_G 2048            // radial-filter table: intervals on x = r/cutoff in [0, 1)
 #endif
 #define FT_ROWS (FT_G + 3)   // rows for x_g = (g - 1) / FT_G  (4-point stencil at both ends)
 

@@ -18,6 +18,8 @@
 // so they are stored once per undirected pair p = pid[e] ([P = E/2][128] arrays).  The row of the LOWER endpoint owns
 // the pair (its upper edges i < j map to a contiguous run of pair rows) and is the only writer of msg[p] and
 // g_phi[p]; both endpoints read.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
@@ -55,11 +57,13 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
 }
 
 // Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx by cubic interpolation of
-// per-layer table planes T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 4096 intervals,
+// per-layer table planes T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 2048 intervals,
 // built in fp64 on every call).  Evaluating the 20-term contraction per (edge, feature) on the VALU was the
 // bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the tables turn it into
-// coalesced 512-B L2 reads and a handful of FMAs.  Interpolation error ~ h^4 |d4f/dx4| / 24 ~ 1e-9 relative
-// (h = 1/4096, fourth derivative ~ (20 pi)^4): far below fp32 eps for both tables.
+// coalesced row reads from L2 and a handful of FMAs.  Interpolation error ~ h^4 |d4f/dx4| / 24 ~ 2e-8 relative
+// (h = 1/2048, fourth derivative ~ (20 pi)^4): below the fp32 rounding of the table entries themselves -- measured
+// against fp64 evaluation the value / derivative errors are 4e-8 / 5e-8 of the maximum at 2048 and at 4096 intervals
+// alike (1.4e-7 / 2.5e-7 at 1024), so 2048 is the smallest table that costs nothing; it keeps T + D of a layer at 2 MB.
 struct FilterW {
   float w[4];   // value weights at nodes -1, 0, 1, 2
 };
@@ -564,12 +568,17 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // host-side launchers (used by pipeline.hip)
 // ---------------------------------------------------------------------------------------------
 static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, ROWS_PER_BLOCK); }
+// tooling: NNHIP_EDGE_LDS=<bytes> attaches unused dynamic LDS to the edge kernels to cap their occupancy
+static inline size_t edge_lds() {
+  static const size_t v = getenv("NNHIP_EDGE_LDS") ? (size_t)atol(getenv("NNHIP_EDGE_LDS")) : 0;
+  return v;
+}
 
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<<<row_blocks(n_atoms), 256, 0, s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
+  msg_fwd_kernel<<<row_blocks(n_atoms), 256, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
                                                      msg, a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
@@ -580,9 +589,9 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   else
-    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -593,10 +602,10 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                g_fin, n_atoms);
   else
-    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                 g_fin, n_atoms);
   LAUNCH_CHECK();
   return 0;
@@ -608,10 +617,10 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   if (need_gm)
-    msg_bwd_kernel<true><<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                             row_ptr, col, pid, g_m, g_x, n_atoms);
   else
-    msg_bwd_kernel<false><<<row_blocks(n_atoms), 256, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                              row_ptr, col, pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;

@@ -45,13 +45,22 @@ __device__ __forceinline__ f32x16 tile_gemm(const Tile& t, const float4 (&wf)[16
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.f;
   const float* xr = t.xs + t.r * NT_LD + 4 * t.h;
+  // B fragments come from LDS two k-groups ahead of their use ("1 ds_read, 4 MFMA" pinned with sched_group_barrier; left
+  // alone the compiler sinks each read to just before its MFMAs and the chain stalls for the LDS latency 16 times)
+  float4 x0 = *reinterpret_cast<const float4*>(xr), x1 = *reinterpret_cast<const float4*>(xr + 8);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const float4 x = *reinterpret_cast<const float4*>(xr + 8 * k);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].x, x.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].y, x.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].z, x.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].w, x.w, acc, 0, 0, 0);
+    float4 x2;
+    if (k < 14) x2 = *reinterpret_cast<const float4*>(xr + 8 * (k + 2));
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].x, x0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].y, x0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].z, x0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[k].w, x0.w, acc, 0, 0, 0);
+    x0 = x1;
+    if (k < 14) x1 = x2;
+    if (k < 14) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
   }
   __builtin_amdgcn_sched_barrier(0);
   return acc;
