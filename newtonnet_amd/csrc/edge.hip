@@ -635,7 +635,7 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
     edge_gd_kernel<<<cdiv(n_edges, 256), 256, 0, s>>>(g_x, g_u, geo, n_edges, n_layers, 1.0f / cutoff, g_d);
     LAUNCH_CHECK();
   }
-  force_out_kernel<<<cdiv(n_atoms, 256), 256, 0, s>>>(g_d, row_ptr, rev, n_atoms, forces);
+  force_out_kernel<<<cdiv(n_atoms, 64), 64, 0, s>>>(g_d, row_ptr, rev, n_atoms, forces);
   LAUNCH_CHECK();
   if (virial) {
     virial_kernel<<<n_mol, 64, 0, s>>>(g_d, disp, pos, cell, row_ptr, col, mol_ptr, n_mol, virial);

@@ -101,17 +101,20 @@ __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float x
   return sqrtf(r2);
 }
 
+// One wavefront per receiver atom i; the lanes test 64 candidate senders j at a time and a ballot + prefix popcount
+// keeps the edges in ascending j (the reference's order) without any serial loop over the molecule.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
                   const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cutoff, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
                   float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
   const long b = batch[i];
   if (b < 0 || b >= n_mol) {   // flagged by mol_ptr_kernel; keep every access in bounds
-    if (!FILL) deg[i] = 0;
+    if (!FILL && lane == 0) deg[i] = 0;
     return;
   }
   const int s = mol_ptr[b], e = mol_ptr[b + 1];
@@ -119,28 +122,34 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
   const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
   int cnt = 0;
   int w = FILL ? row_ptr[i] : 0;
-  for (int j = s; j < e; ++j) {
-    if (j == i) continue;
-    float dx, dy, dz;
-    const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
-    if (r < cutoff) {
-      if (FILL) {
-        col[w] = j;
-        erow[w] = i;
-        disp[3 * (long)w] = dx;
-        disp[3 * (long)w + 1] = dy;
-        disp[3 * (long)w + 2] = dz;
+  for (int j0 = s; j0 < e; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (j < e && j != i) {
+      const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
+      hit = r < cutoff;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (FILL) {
+      if (hit) {
+        const int o = w + __popcll(mask & ((1ull << lane) - 1ull));
+        col[o] = j;
+        erow[o] = i;
+        disp[3 * (long)o] = dx;
+        disp[3 * (long)o + 1] = dy;
+        disp[3 * (long)o + 2] = dz;
         if (edge_index) {
-          edge_index[w] = i;
-          edge_index[(long)n_edges + w] = j;
+          edge_index[o] = i;
+          edge_index[(long)n_edges + o] = j;
         }
-        ++w;
-      } else {
-        ++cnt;
       }
+      w += __popcll(mask);
+    } else {
+      cnt += __popcll(mask);
     }
   }
-  if (!FILL) deg[i] = cnt;
+  if (!FILL && lane == 0) deg[i] = cnt;
 }
 
 // exclusive scan of deg[n] -> row_ptr[n+1] in two fully parallel launches (in place is fine: deg may alias row_ptr):
@@ -287,7 +296,7 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
   mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status);
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
-  graph_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, row_ptr,
+  graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, row_ptr,
                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
   {
@@ -308,7 +317,7 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
   // `rev` doubles as the receiver-of-edge scratch during the fill; edge_rev_kernel then replaces it in place
-  graph_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, nullptr,
+  graph_rows_kernel<true><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, nullptr,
                                                                   row_ptr, col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
@@ -617,19 +626,18 @@ pairs_count_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col,
   n_upper[i] = c;
 }
 
-template <bool UPPER>
+// pid in closed form, one pass: the pairs owned by row r are numbered pair_ptr[r] .. pair_ptr[r+1]) in the order of r's
+// upper edges, which are the LAST n_upper(r) edges of the row (cols ascend).  So the upper edge at position e of row r
+// has pid = pair_ptr[r+1] - (row_ptr[r+1] - e), and a lower edge (i, j), j < i, takes the number of its reverse (j, i).
 __global__ void __launch_bounds__(256)
 pairs_assign_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ rev,
-                    const int* __restrict__ pair_ptr, int n_atoms, int* pid) {
+                    const int* __restrict__ pair_ptr, int n_atoms, int* __restrict__ pid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
-  int p = pair_ptr[i];
-  for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
-    if (UPPER) {
-      if (col[e] > i) pid[e] = p++;
-    } else {
-      if (col[e] < i) pid[e] = pid[rev[e]];   // the upper edge (j, i) was numbered by the previous launch
-    }
+  const int end = row_ptr[i + 1], pend = pair_ptr[i + 1];
+  for (int e = row_ptr[i]; e < end; ++e) {
+    const int j = col[e];
+    pid[e] = (j > i) ? pend - (end - e) : pair_ptr[j + 1] - (row_ptr[j + 1] - rev[e]);
   }
 }
 
@@ -645,15 +653,13 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
     return NNHIP_OK;
   }
   ScopedTimer tm(TC_GRAPH, stream);   // pairs_count + the scan write every pair_ptr entry
-  pairs_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, n_atoms, pair_ptr);
+  pairs_count_kernel<<<cdiv(n_atoms, 64), 64, 0, stream>>>(row_ptr, col, n_atoms, pair_ptr);
   LAUNCH_CHECK();
   {
     const int rc = launch_scan(pair_ptr, n_atoms, pair_ptr, scan_scratch, stream);
     if (rc) return rc;
   }
-  pairs_assign_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
-  LAUNCH_CHECK();
-  pairs_assign_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
+  pairs_assign_kernel<<<cdiv(n_atoms, 64), 64, 0, stream>>>(row_ptr, col, rev, pair_ptr, n_atoms, pid);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
