@@ -64,6 +64,8 @@ typedef struct {
   const float* eq2_0_w;  /* ...equiv_message2.0.weight   [F][F] */
   const float* eq2_2_w;  /* ...equiv_message2.2.weight   [F][F] */
   const float* update_w; /* ...equiv_update.weight       [F][F] */
+  const float* ln_w;     /* ...layer_norm.weight         [F]  (NULL with ln_b: layer_norm=False, newtonnet.py:202-205) */
+  const float* ln_b;     /* ...layer_norm.bias           [F] */
 } nnhip_layer_params;
 
 typedef struct {

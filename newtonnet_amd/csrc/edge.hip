@@ -513,6 +513,42 @@ __global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restr
   reinterpret_cast<float4*>(m0)[t] = reinterpret_cast<const float4*>(m_table + zi * NF)[c];
 }
 
+// LayerNorm over the 128 features of atom_node at the end of an interaction layer (nn.LayerNorm(n_features), eps 1e-5,
+// newtonnet.py:202-205,228-231), in place, keeping x_hat and 1/sigma for the adjoint:
+//   x_hat = (x - mean) / sqrt(var + eps);  y = x_hat * gamma + beta
+//   dE/dx = (1/sigma) (g' - mean(g') - x_hat mean(g' x_hat)),   g' = dE/dy * gamma
+__global__ void __launch_bounds__(256)
+layer_norm_fwd_kernel(float* __restrict__ a /*in: pre-norm, out: normalised*/, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, int n_atoms, float* __restrict__ xhat, float* __restrict__ rstd) {
+  const int i = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float2 x = ld2(a + (size_t)i * NF + 2 * lane);
+  const float mean = wave_sum(x.x + x.y) * (1.0f / NF);
+  const float dx = x.x - mean, dy = x.y - mean;
+  const float var = wave_sum(fmaf(dx, dx, dy * dy)) * (1.0f / NF);
+  const float rs = 1.0f / sqrtf(var + 1e-5f);
+  const float2 xh = make_float2(dx * rs, dy * rs);
+  const float2 g = ld2(gamma + 2 * lane), b = ld2(beta + 2 * lane);
+  st2(xhat + (size_t)i * NF + 2 * lane, xh);
+  st2(a + (size_t)i * NF + 2 * lane, make_float2(fmaf(xh.x, g.x, b.x), fmaf(xh.y, g.y, b.y)));
+  if (lane == 0) rstd[i] = rs;
+}
+__global__ void __launch_bounds__(256)
+layer_norm_bwd_kernel(float* __restrict__ g_a /*in: dE/dy, out: dE/dx*/, const float* __restrict__ gamma,
+                      const float* __restrict__ xhat, const float* __restrict__ rstd, int n_atoms) {
+  const int i = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float2 g = ld2(g_a + (size_t)i * NF + 2 * lane), w = ld2(gamma + 2 * lane);
+  const float2 xh = ld2(xhat + (size_t)i * NF + 2 * lane);
+  const float2 gp = make_float2(g.x * w.x, g.y * w.y);
+  const float m1 = wave_sum(gp.x + gp.y) * (1.0f / NF);
+  const float m2 = wave_sum(fmaf(gp.x, xh.x, gp.y * xh.y)) * (1.0f / NF);
+  const float rs = rstd[i];
+  st2(g_a + (size_t)i * NF + 2 * lane, make_float2(rs * (gp.x - m1 - xh.x * m2), rs * (gp.y - m1 - xh.y * m2)));
+}
+
 // energy head tail (output.py:98-100 last Linear, scalers.py:55-58) and the seed of the reverse sweep:
 //   eps_i = <silu(e2_i), w4> + b4;  E_i = eps_i * scale[z_i] + shift[z_i]
 //   g_e2[i] = scale[z_i] * w4 * silu'(e2_i)          (dE_b/dE_i = 1, output.py:69)
@@ -641,6 +677,21 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
     virial_kernel<<<n_mol, 64, 0, s>>>(g_d, disp, pos, cell, row_ptr, col, mol_ptr, n_mol, virial);
     LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int launch_layer_norm_fwd(float* a, const float* gamma, const float* beta, int n_atoms, float* xhat, float* rstd,
+                          hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  layer_norm_fwd_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(a, gamma, beta, n_atoms, xhat, rstd);
+  LAUNCH_CHECK();
+  return 0;
+}
+int launch_layer_norm_bwd(float* g_a, const float* gamma, const float* xhat, const float* rstd, int n_atoms,
+                          hipStream_t s) {
+  ScopedTimer t0(TC_OTHER, s);
+  layer_norm_bwd_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(g_a, gamma, xhat, rstd, n_atoms);
+  LAUNCH_CHECK();
   return 0;
 }
 

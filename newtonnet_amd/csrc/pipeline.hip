@@ -28,6 +28,10 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
                         float* virial, hipStream_t s);
+int launch_layer_norm_fwd(float* a, const float* gamma, const float* beta, int n_atoms, float* xhat, float* rstd,
+                          hipStream_t s);
+int launch_layer_norm_bwd(float* g_a, const float* gamma, const float* xhat, const float* rstd, int n_atoms,
+                          hipStream_t s);
 int launch_embed(const int64_t* z, const float* table, const float* m_table, int n_atoms, float* a0, float* m0,
                  hipStream_t s);
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
@@ -112,6 +116,8 @@ struct WsInternal {
   size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
   size_t headT[2];                 // head0^T, head2^T
   size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
+  size_t xhat[NNHIP_MAX_LAYERS];   // [N][F] normalised atom_node of each layer (layer_norm=True only)
+  size_t rstd[NNHIP_MAX_LAYERS];   // [N]    1/sigma of each row
   size_t g_h12;                    // [E][2F] adjoint scratch (g_phi -> g_h)
   size_t g_msg;                    // [E][F]
   size_t g_m;                      // [N][F]
@@ -149,6 +155,10 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
     w.pub.q[l] = carve(off, 3 * nf);
     for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
     w.ftab[l] = carve(off, (size_t)2 * FT_ROWS * NF * 4);
+  }
+  for (int l = 0; l < L; ++l) {
+    w.xhat[l] = carve(off, nf);
+    w.rstd[l] = carve(off, (size_t)N * 4);
   }
   w.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
   w.m_tab = carve(off, (size_t)128 * NF * 4);
@@ -214,6 +224,11 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     return NNHIP_E_UNSUPPORTED;
   }
   const int L = model->n_layers;
+  for (int l = 0; l < L; ++l)
+    if ((model->layer[l].ln_w == nullptr) != (model->layer[l].ln_b == nullptr)) {
+      nnhip_set_error("nnhip_energy_forces: layer %d has only one of layer_norm.weight / .bias", l);
+      return NNHIP_E_INVALID;
+    }
   if (E & 1) {
     nnhip_set_error("nnhip_energy_forces: odd edge count %d (the edge set must be symmetric)", E);
     return NNHIP_E_INVALID;
@@ -319,7 +334,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       na.Wu = lp.update_w;
       na.q = P(w.pub.q[l]);
       na.a_out = A_OUT(l);
-      if (l + 1 < L) {
+      if (l + 1 < L && !lp.ln_w) {
         const nnhip_layer_params& nx = model->layer[l + 1];
         na.W0 = nx.node0_w;
         na.b0 = nx.node0_b;
@@ -330,6 +345,14 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       }
       na.N = N;
       TRY(launch_node_fwd(na, s));
+    }
+    if (lp.ln_w) {   // layer_norm=True (newtonnet.py:228-231): normalise in place, then the next message_nodepart unfused
+      TRY(launch_layer_norm_fwd(A_OUT(l), lp.ln_w, lp.ln_b, N, P(w.xhat[l]), P(w.rstd[l]), s));
+      if (l + 1 < L) {
+        const nnhip_layer_params& nx = model->layer[l + 1];
+        TRY(launch_mlp(MODE_FWD, false, {A_OUT(l), nx.node0_w, nx.node2_w, P(w.pub.hn[l + 1]), P(w.pub.m[l + 1]), N, NF, NF,
+                                         NF, nx.node0_b, nx.node2_b}, s));
+      }
     }
     a_in = A_OUT(l);
     f_in = F_OUT(l);
@@ -360,6 +383,14 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nb.WuT = P(w.wT[L - 1][6]);
     nb.gf = P(w.gf_mid);
     nb.N = N;
+    const nnhip_layer_params& top = model->layer[L - 1];
+    if (top.ln_w) {   // the LayerNorm adjoint sits between the head adjoint and the update adjoint: three launches
+      NodeBwdArgs head = nb;
+      head.WuT = nullptr;
+      TRY(launch_node_bwd(head, s));
+      TRY(launch_layer_norm_bwd(P(w.pub.g_a), top.ln_w, P(w.xhat[L - 1]), P(w.rstd[L - 1]), N, s));
+      nb.W2T = nullptr;
+    }
     TRY(launch_node_bwd(nb, s));
   }
   float* g_fbuf[2] = {P(w.pub.g_f), P(w.g_f2)};
@@ -405,6 +436,14 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       nb.WuT = P(w.wT[l - 1][6]);
       nb.gf = P(w.gf_mid);
       nb.N = N;
+      const nnhip_layer_params& below = model->layer[l - 1];
+      if (below.ln_w) {
+        NodeBwdArgs mlp = nb;
+        mlp.WuT = nullptr;
+        TRY(launch_node_bwd(mlp, s));
+        TRY(launch_layer_norm_bwd(P(w.pub.g_a), below.ln_w, P(w.xhat[l - 1]), P(w.rstd[l - 1]), N, s));
+        nb.W2T = nullptr;
+      }
       TRY(launch_node_bwd(nb, s));
     }
     pp ^= 1;

@@ -29,7 +29,7 @@ _fp = C.POINTER(C.c_float)
 
 class LayerParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('node0_w', 'node0_b', 'node2_w', 'node2_b', 'edge_w', 'eq1_0_w', 'eq1_2_w',
-                                         'eq2_0_w', 'eq2_2_w', 'update_w')]
+                                         'eq2_0_w', 'eq2_2_w', 'update_w', 'ln_w', 'ln_b')]
 
 
 class Model(C.Structure):

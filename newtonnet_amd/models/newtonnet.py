@@ -94,8 +94,6 @@ class NewtonNet(nn.Module):
                                       f'1..{hip.NNHIP_MAX_LAYERS} interactions (got {F}, {nb}, {L})')
         if self.activation_name not in HIP_FUSED:
             raise NotImplementedError(f"HIP kernels fuse SiLU only (activation='{self.activation_name}')")
-        if any(il.layer_norm is not None for il in self.interaction_layers):
-            raise NotImplementedError('layer_norm=True is not on the HIP hot path (reference default is False)')
 
         def p(t):
             if t.dtype != torch.float32 or not t.is_cuda:
@@ -118,6 +116,10 @@ class NewtonNet(nn.Module):
             lp.eq1_0_w, lp.eq1_2_w = p(il.equiv_message1[0].weight), p(il.equiv_message1[2].weight)
             lp.eq2_0_w, lp.eq2_2_w = p(il.equiv_message2[0].weight), p(il.equiv_message2[2].weight)
             lp.update_w = p(il.equiv_update.weight)
+            if il.layer_norm is not None:      # newtonnet.py:202-205,228-231 (eps = nn.LayerNorm default 1e-5)
+                if abs(il.layer_norm.eps - 1e-5) > 0 or not il.layer_norm.elementwise_affine:
+                    raise NotImplementedError('HIP path implements nn.LayerNorm(n_features) with its default eps / affine')
+                lp.ln_w, lp.ln_b = p(il.layer_norm.weight), p(il.layer_norm.bias)
         head = self.output_layers[energy_idx].layers
         m.head0_w, m.head0_b = p(head[0].weight), p(head[0].bias)
         m.head2_w, m.head2_b = p(head[2].weight), p(head[2].bias)

@@ -114,6 +114,8 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int):
             eq = eq + _mlp(il.equiv_message2, msg).unsqueeze(1) * Gather.apply(f, eg, 'col')
         f = f + SegmentSum.apply(eq.contiguous(), eg)
         a = a + (f * _lin(f, il.equiv_update.weight)).sum(dim=1)
+        if il.layer_norm is not None:          # newtonnet.py:228-231
+            a = il.layer_norm(a)
 
     head = model.output_layers[energy_idx].layers
     e = _lin(Fn.silu(_lin(Fn.silu(_lin(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),

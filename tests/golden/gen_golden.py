@@ -369,5 +369,39 @@ def main_extra():
     print('stats shift', stats['energy']['shift'][[1, 6, 8]], 'scale', stats['energy']['scale'][[1, 6, 8]])
 
 
+def main_layernorm():
+    """layer_norm=True (newtonnet.py:202-205,228-231): seeded reference model with non-trivial LayerNorm affine parameters;
+    weights are rounded to fp32 first so the fp64 reference run uses exactly the values stored in the fixture."""
+    NewtonNet = import_reference()
+    train = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_train/raw/aspirin_ccsd-train.xyz', 8)
+    torch.manual_seed(2)
+    model = NewtonNet(layer_norm=True, output_properties=['energy', 'gradient_force'])
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if 'layer_norm.weight' in name:
+                prm.add_(0.2 * torch.randn(prm.shape, generator=g))
+            if 'layer_norm.bias' in name:
+                prm.add_(0.1 * torch.randn(prm.shape, generator=g))
+    model.to(torch.float32)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(torch.float64)
+    model.eval()
+    B = 4
+    z = torch.tensor(train[0][0], dtype=torch.long).repeat(B)
+    pos = torch.tensor(np.concatenate([f[1] for f in train[:B]]), dtype=torch.float64)
+    batch = torch.repeat_interleave(torch.arange(B), 21)
+    cell = torch.zeros(B, 3, 3, dtype=torch.float64)
+    out = model(z, pos.clone(), cell, batch)
+    np.savez_compressed(f'{OUT}/case_layernorm.npz', z=z.numpy(), pos=pos.numpy(), cell=cell.numpy(), batch=batch.numpy(),
+                        energy=out.energy.detach().numpy(), forces=out.gradient_force.detach().numpy(),
+                        atom_node=out.atom_node.detach().numpy(),
+                        **{'sd.' + k: v.float().numpy() for k, v in sd.items()})
+    print('layernorm', float(out.energy.abs().max()), float(out.gradient_force.abs().max()),
+          [k for k in sd if 'layer_norm' in k][:2])
+
+
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'extra':
     main_extra()
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'layernorm':
+    main_layernorm()

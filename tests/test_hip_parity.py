@@ -340,3 +340,25 @@ def test_direct_force_head():
     o2 = model(z.cuda(), p, cell.float().cuda(), batch.cuda())
     assert o2.direct_force.requires_grad
     np.testing.assert_allclose(o2.direct_force.detach().cpu().numpy(), c['direct_force'], rtol=2e-4, atol=2e-6)
+
+
+def test_layer_norm_model():
+    """layer_norm=True through the HIP path (LayerNorm forward + adjoint kernels between the node launches) against the
+    reference's own fp64 output (tests/golden/case_layernorm.npz); eval and train mode."""
+    from newtonnet_amd.models import NewtonNet
+    c = util.load_npz('case_layernorm.npz')
+    sd = {k[3:]: torch.from_numpy(v) for k, v in c.items() if k.startswith('sd.')}
+    model = NewtonNet(layer_norm=True, output_properties=['energy', 'gradient_force'])
+    model.load_state_dict(sd)
+    model = model.to('cuda')
+    model.eval()
+    z, pos, cell, batch = (torch.from_numpy(c[k]) for k in ('z', 'pos', 'cell', 'batch'))
+    out = model(z.cuda(), pos.float().cuda(), cell.float().cuda(), batch.cuda())
+    check_forces(out.gradient_force.cpu().numpy(), c['forces'])
+    assert np.all(np.abs(out.energy.cpu().numpy() - c['energy']) <= util.energy_tol(c['energy']))
+    np.testing.assert_allclose(out.atom_node.cpu().numpy(), c['atom_node'], rtol=0, atol=2e-5)
+    model.train()
+    p = pos.float().cuda().requires_grad_(True)
+    o2 = model(z.cuda(), p, cell.float().cuda(), batch.cuda())
+    check_forces(o2.gradient_force.detach().cpu().numpy(), c['forces'])
+    assert o2.gradient_force.requires_grad

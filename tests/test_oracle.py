@@ -97,3 +97,16 @@ def test_direct_force_head_pinned():
     df = ref.direct_force_head(sd, 2, out['atom_node'], out['force_node'], z)
     np.testing.assert_allclose(df.numpy(), c['direct_force'], rtol=1e-4, atol=1e-6)      # reference ran in fp32
     np.testing.assert_allclose(out['forces'].numpy(), c['forces'], atol=5e-5)
+
+
+def test_layer_norm_pinned():
+    """layer_norm=True (newtonnet.py:202-205,228-231): the oracle against the reference's own fp64 output for the fp32 weights
+    stored in the fixture (gen_golden.py layernorm)."""
+    c = util.load_npz('case_layernorm.npz')
+    sd = {k[3:]: torch.from_numpy(v).double() for k, v in c.items() if k.startswith('sd.')}
+    assert 'interaction_layers.0.layer_norm.weight' in sd
+    z, pos, cell, batch = (torch.from_numpy(c[k]) for k in ('z', 'pos', 'cell', 'batch'))
+    out = ref.energy_forces(sd, z, pos.double(), cell.double(), batch)
+    np.testing.assert_allclose(out['energy'].numpy(), c['energy'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out['forces'].numpy(), c['forces'], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out['atom_node'].numpy(), c['atom_node'], rtol=0, atol=1e-12)
