@@ -135,6 +135,16 @@ int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms,
                            float* disp, int64_t* edge_index, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Verlet-skin reuse of a neighbor list in an MD loop (caller: MLAseCalculator.calculate,
+ * newtonnet/utils/ase_interface.py:52-81, which rebuilds the O(N^2) graph every step).
+ * nnhip_edge_disp: disp[e] = pos_i - pos_j (+ the reference's single-image shift) for the edges of a list built
+ *   earlier with cutoff + skin (edge_index[2][E] int64 from nnhip_graph_fill).  nnhip_edge_embed with the real cutoff
+ *   then points candidates with r >= cutoff at all-zero filter rows, so they contribute exactly nothing.
+ * ------------------------------------------------------------------------ */
+int nnhip_edge_disp(const float* pos, const float* cell, const int64_t* batch, const int64_t* edge_index, int32_t n_edges,
+                    float* disp, void* stream);
+
+/* --------------------------------------------------------------------------
  * Edge embedding.
  * Replaces: ScaledNorm.forward (representations.py:118-133), PolynomialCutoff
  *   p=9 (:155-171), RadialBesselLayer.forward (:223-235) and their product (:41).

@@ -11,7 +11,9 @@
 #ifndef FT_G
 #define FT_G 2048            // radial-filter table: intervals on x = r/cutoff in [0, 1)
 #endif
-#define FT_ROWS (FT_G + 3)   // rows for x_g = (g - 1) / FT_G  (4-point stencil at both ends)
+#define FT_ROWS (FT_G + 7)   // rows for x_g = (g - 1) / FT_G (4-point stencil at both ends) + 4 all-zero rows: the stencil of
+                            // a candidate edge at or beyond the cutoff (Verlet-skin lists, nnhip_edge_disp) points there
+#define FT_ZERO_ROW (FT_G + 3)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -257,7 +257,9 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, con
     const double t = x * (double)FT_G;
     int g0 = (int)floor(t);
     g0 = g0 < 0 ? 0 : (g0 > FT_G - 1 ? FT_G - 1 : g0);
-    xg[e] = make_int2(g0, __float_as_int((float)(t - (double)g0)));
+    // x >= 1 only occurs for the candidates of a skin list that are outside the cutoff right now (the exact list holds
+    // r < cutoff): their filter and its derivative are exactly zero, so they drop out of every sum
+    xg[e] = (x >= 1.0) ? make_int2(FT_ZERO_ROW, 0) : make_int2(g0, __float_as_int((float)(t - (double)g0)));
   }
   if (!rbf) return;
   const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
@@ -340,6 +342,11 @@ struct FilterTableArgs {
 __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
   __shared__ double rb[NB], drb[NB];
   const int g = blockIdx.x, l = blockIdx.y;
+  if (g >= FT_ZERO_ROW) {   // the all-zero rows behind the table proper
+    a.table[l][(size_t)g * NF + threadIdx.x] = 0.f;
+    a.table[l][(size_t)(FT_ROWS + g) * NF + threadIdx.x] = 0.f;
+    return;
+  }
   const double x = (double)(g - 1) / (double)FT_G;
   if (threadIdx.x < NB) {
     const double w = (double)a.freq[threadIdx.x];
@@ -383,6 +390,37 @@ int launch_filter_tables(const float* const* edge_w, float* const* tables, int n
   filter_table_kernel<<<dim3(FT_ROWS, n_layers), NF, 0, s>>>(a);
   LAUNCH_CHECK();
   return 0;
+}
+
+// Displacements of a FIXED candidate list at new positions (Verlet-skin reuse in an MD loop: the list was built with
+// cutoff + skin, nnhip_edge_embed then zeroes the candidates that are outside the cutoff at this step).  Same pair_disp as
+// the list builders, so an edge that is in the exact list gets the identical displacement.
+__global__ void __launch_bounds__(256)
+edge_disp_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
+                 const int64_t* __restrict__ edge_index, int n_edges, float* __restrict__ disp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const long i = edge_index[e], j = edge_index[(long)n_edges + e];
+  const CellInfo ci = load_cell(cell, batch[i]);
+  float dx, dy, dz;
+  pair_disp(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
+  disp[3 * (long)e] = dx;
+  disp[3 * (long)e + 1] = dy;
+  disp[3 * (long)e + 2] = dz;
+}
+
+extern "C" int nnhip_edge_disp(const float* pos, const float* cell, const int64_t* batch, const int64_t* edge_index,
+                               int32_t n_edges, float* disp, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_edges < 0 || (n_edges && (!pos || !cell || !batch || !edge_index || !disp))) {
+    nnhip_set_error("nnhip_edge_disp: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  edge_disp_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(pos, cell, batch, edge_index, n_edges, disp);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
 }
 
 extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,

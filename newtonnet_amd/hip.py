@@ -79,6 +79,7 @@ def lib():
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, vp]
+    L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
     L.nnhip_graph_cells_scratch_bytes.restype = sz
     L.nnhip_graph_count_cells.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp]
@@ -98,7 +99,7 @@ def lib():
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
-               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force'):
+               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -108,7 +109,7 @@ EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'n
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
-                    'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force')
+                    'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp')
 
 
 def _check(rc: int, what: str):
@@ -203,6 +204,23 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     return g
 
 
+def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
+                  frequencies: torch.Tensor) -> Graph:
+    """Re-evaluate the geometry of an existing (candidate) list at new positions, in place and without any host sync:
+    disp, geo and the filter-table positions xg.  `g` must have been built with want_edge_index=True and a cutoff of at
+    least `cutoff` (cutoff + skin for Verlet reuse); candidates outside `cutoff` get all-zero filter rows."""
+    L = lib()
+    if g.edge_index is None:
+        raise ValueError('refresh_graph needs a graph built with want_edge_index=True')
+    st = _stream(pos.device)
+    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    E = g.n_edges
+    _check(L.nnhip_edge_disp(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.edge_index), E, _ptr(g.disp), st), 'nnhip_edge_disp')
+    _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(),
+                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), st), 'nnhip_edge_embed')
+    return g
+
+
 def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
     out = WsLayout()
     _check(lib().nnhip_workspace_layout(N, E, B, n_layers, C.byref(out)), 'nnhip_workspace_layout')
@@ -210,21 +228,25 @@ def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
 
 
 def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
-                  want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None):
-    """Run the whole hot path.  Returns dict(energy, forces, virial, atom_energy, atom_node, force_node, workspace)."""
+                  want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None,
+                  out: Optional[dict] = None):
+    """Run the whole hot path.  Returns dict(energy, forces, virial, atom_energy, atom_node, force_node, workspace).
+    `out` = the dict of a previous call with the same sizes: its tensors are reused (static addresses for graph capture)."""
     L = lib()
     dev = z.device
     N, E, B = g.n_atoms, g.n_edges, g.n_mol
     need = L.nnhip_workspace_bytes(N, E, B, model.n_layers)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-    out = dict(workspace=workspace)
-    out['energy'] = torch.empty(B, dtype=torch.float32, device=dev)
-    out['forces'] = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_forces else None
-    out['virial'] = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if (want_virial and want_forces) else None
-    out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
-    out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
-    out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    if out is None:
+        out = dict()
+        out['energy'] = torch.empty(B, dtype=torch.float32, device=dev)
+        out['forces'] = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_forces else None
+        out['virial'] = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if (want_virial and want_forces) else None
+        out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
+        out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+        out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    out['workspace'] = workspace
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
                                  _ptr(g.rev), _ptr(g.pid), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,

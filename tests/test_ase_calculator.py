@@ -64,3 +64,69 @@ def test_calculator_K1_single_and_list():
     assert calc.results['energy'].shape == (16,) and calc.results['forces'].shape == (16, 21, 3)
     assert np.all(np.abs(calc.results['energy'] - k['energy'][:16]) <= util.energy_tol(k['energy'][:16]))
     assert np.abs(calc.results['forces'] - k['forces'][:16]).max() < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('capture', [True, False])
+def test_md_loop_path_follows_K1_trajectory(capture):
+    """MD-loop path (Verlet-skin list reuse + HIP-graph replay): all 201 frames of the authors' trajectory, one calculate()
+    per frame like simulate.py's dynamics loop, against their stored energies / forces (K1)."""
+    from newtonnet_amd.utils import MLAseCalculator
+    k = util.load_npz('kat_md_traj.npz')
+    calc = MLAseCalculator(os.path.join(util.GOLDEN, 'ckpt_state.npz'), properties=['energy', 'forces'],
+                           precision='single', device='cuda', skin=0.5, capture=capture)
+    exact = MLAseCalculator(os.path.join(util.GOLDEN, 'ckpt_state.npz'), properties=['energy', 'forces'],
+                            precision='single', device='cuda', skin=0.0)
+    for t in range(len(k['positions'])):
+        calc.calculate(FakeAtoms(k['numbers'], k['positions'][t]))
+        assert abs(float(calc.results['energy']) - k['energy'][t]) <= util.energy_tol(k['energy'][t:t + 1])[0]
+        assert np.abs(calc.results['forces'] - k['forces'][t]).max() < 5e-5
+        if t % 40 == 0:     # and against the exact-list path of this package: identical up to fp32 summation order
+            exact.calculate(FakeAtoms(k['numbers'], k['positions'][t]))
+            assert np.abs(calc.results['forces'] - exact.results['forces']).max() < 2e-6
+            assert abs(float(calc.results['energy']) - float(exact.results['energy'])) <= 4e-3
+    assert calc.md_stats['steps'] == 201 and (calc._md['graph'] is not None) == capture
+    # The stored frames are 100 MD steps apart (every frame moves some atom by more than skin / 2: a rebuild each time).
+    # Fine-grained motion -- 60 interpolated steps between consecutive frames -- must reuse the list and still agree with
+    # the exact-list path at every step.
+    before = calc.md_stats['rebuilds']
+    for t in (0, 57):
+        for sub in range(60):
+            w = sub / 60.0
+            a = FakeAtoms(k['numbers'], (1 - w) * k['positions'][t] + w * k['positions'][t + 1])
+            calc.calculate(a)
+            if sub % 6 == 0:
+                exact.calculate(a)
+                assert np.abs(calc.results['forces'] - exact.results['forces']).max() < 2e-6
+                assert abs(float(calc.results['energy']) - float(exact.results['energy'])) <= 4e-3
+    assert 2 <= calc.md_stats['rebuilds'] - before <= 30                           # 120 steps, a handful of rebuilds
+
+
+@pytest.mark.gpu
+def test_md_loop_path_periodic_with_stress():
+    """Periodic box drifting through the cell boundary: wrapped positions jump by a lattice vector while the skin criterion
+    follows the unwrapped ones; energy / forces / stress must match the exact-list path at every step."""
+    from newtonnet_amd.models import NewtonNet
+    from newtonnet_amd.utils import MLAseCalculator
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    n, box = 64, 9.5
+    grid = np.stack(np.meshgrid(*[np.arange(4)] * 3, indexing='ij'), -1).reshape(-1, 3) * (box / 4)
+    pos = grid + rng.normal(0, 0.15, grid.shape)
+    numbers = rng.choice([1, 6, 8], n)
+    cell = np.diag([box] * 3)
+    vel = rng.normal(0, 0.02, pos.shape) + np.array([0.05, 0.0, 0.0])     # net drift: atoms cross the boundary
+    def make(skin):
+        torch.manual_seed(5)
+        m = NewtonNet(output_properties=['energy', 'gradient_force', 'stress'])
+        return MLAseCalculator(m, properties=['energy', 'forces', 'stress'], device='cuda', skin=skin)
+    fast, exact = make(0.6), make(0.0)
+    for step in range(30):
+        a = FakeAtoms(numbers, pos + step * vel, cell=cell, pbc=(True, True, True))
+        fast.calculate(a)
+        exact.calculate(a)
+        assert np.abs(fast.results['forces'] - exact.results['forces']).max() < 5e-6
+        assert abs(float(fast.results['energy']) - float(exact.results['energy'])) < 1e-4
+        assert fast.results['stress'].shape == (6,)
+        assert np.abs(fast.results['stress'] - exact.results['stress']).max() < 1e-6
+    assert 1 <= fast.md_stats['rebuilds'] < 15

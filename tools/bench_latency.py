@@ -32,3 +32,20 @@ for B in (1, 8, 64):
     for _ in range(n): m = model._hip_model(0)
     tm = (time.perf_counter() - t0) / n
     print(f'B={B:3d}: full step {dt*1e6:8.1f} us | build_graph {tg*1e6:7.1f} | energy_forces {te*1e6:7.1f} | _hip_model {tm*1e6:6.1f}', flush=True)
+
+# ---- the calculator's MD-loop path (one structure per calculate(), positions change a little every step)
+from newtonnet_amd.utils import MLAseCalculator
+from tests.test_ase_calculator import FakeAtoms
+z, pos, cell, batch = bench.synthetic_aspirin(1, 0, 'cpu')
+numbers, p0 = z.numpy(), pos.double().numpy()
+rng = np.random.default_rng(0)
+vel = rng.normal(0, 0.004, p0.shape)
+for label, kw in (('exact list every step (skin=0)', dict(skin=0.0)), ('skin list, direct launches', dict(skin=0.5, capture=False)),
+                  ('skin list + HIP graph replay', dict(skin=0.5, capture=True))):
+    calc = MLAseCalculator(model, properties=['energy', 'forces'], device='cuda', **kw)
+    for s in range(30): calc.calculate(FakeAtoms(numbers, p0 + s * vel))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n = 400
+    for s in range(n): calc.calculate(FakeAtoms(numbers, p0 + (30 + s) * vel))
+    dt = (time.perf_counter() - t0) / n
+    print(f'calculator, {label:34s}: {dt*1e6:7.1f} us/step   {calc.md_stats}', flush=True)
