@@ -110,21 +110,29 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   float upd[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) upd[k] = 0.f;
+  // Operands of the NEXT stage are requested before each GEMM (the sched_barrier at the top of tile_gemm keeps them
+  // ahead of its MFMAs): all workgroups of the grid start together and walk the chain in lockstep, so a load issued only
+  // when it is needed is exposed on every CU at the same time.
+  float xa[16], xb[16], a[16];
+  blk_load(xa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float x[16], qv[16];
-    blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
+    float (&cur)[16] = (c & 1) ? xb : xa;
+    float (&nxt)[16] = (c & 1) ? xa : xb;
+    float qv[16];
     if (c) __syncthreads();            // every wave is done reading the previous tile
-    blk_to_tile(x, t);
+    blk_to_tile(cur, t);
     __syncthreads();
+    if (c < 2)
+      blk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
+    else
+      blk_load(a, p.a_mid, (size_t)rc * NF, t);
     acc_to(qv, tile_gemm(t, wf));
     if (c == 2 && p.W0) load_w(wf, t, p.W0);
     if (live) blk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) upd[k] = fmaf(x[k], qv[k], upd[k]);
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
-  float a[16];
-  blk_load(a, p.a_mid, (size_t)rc * NF, t);
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] += upd[k];
   if (live) blk_store(a, p.a_out, (size_t)row * NF, t);
@@ -134,23 +142,23 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   __syncthreads();
   blk_to_tile(a, t);
   __syncthreads();
-  float hn[16], bias[16];
+  float hn[16], b0v[16], b2v[16];
+  blk_load(b0v, p.b0, 0, t);
   acc_to(hn, tile_gemm(t, wf));
   load_w(wf, t, p.W2);
-  blk_load(bias, p.b0, 0, t);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) hn[k] += bias[k];
+  for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
   if (live) blk_store(hn, p.hn, (size_t)row * NF, t);
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] = silu_f(hn[k]);
   __syncthreads();
   blk_to_tile(hn, t);
   __syncthreads();
+  blk_load(b2v, p.b2, 0, t);
   float m[16];
   acc_to(m, tile_gemm(t, wf));
-  blk_load(bias, p.b2, 0, t);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) m[k] += bias[k];
+  for (int k = 0; k < 16; ++k) m[k] += b2v[k];
   if (live) blk_store(m, p.m, (size_t)row * NF, t);
 }
 
@@ -198,22 +206,26 @@ __global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
   if (!p.WuT) return;
 
   // adjoint of the lower layer's update:  gf_k = G_f,k + g_a * q_k + (g_a * f'_k) W_u
+  // (the next component's f, q and G_f are requested before each GEMM, see node_fwd_kernel)
+  float fa[16], fb[16];
+  blk_load(fa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float x[16], qv[16], out[16];
-    blk_load(x, p.f, ((size_t)rc * 3 + c) * NF, t);
-    blk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+    float (&cur)[16] = (c & 1) ? fb : fa;
+    float (&nxt)[16] = (c & 1) ? fa : fb;
+    float out[16], qv[16], gin[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] *= ga[k];
+    for (int k = 0; k < 16; ++k) cur[k] *= ga[k];
     __syncthreads();
-    blk_to_tile(x, t);
+    blk_to_tile(cur, t);
     __syncthreads();
+    if (c < 2) blk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
+    blk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);              // consumed after the GEMM: hidden under it
+    if (p.G_f) blk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
     acc_to(out, tile_gemm(t, wf));
 #pragma unroll
     for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qv[k], out[k]);
     if (p.G_f) {
-      float gin[16];
-      blk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
 #pragma unroll
       for (int k = 0; k < 16; ++k) out[k] += gin[k];
     }
