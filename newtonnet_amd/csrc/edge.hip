@@ -20,9 +20,32 @@
 // g_phi[p]; both endpoints read.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
+
+// Cache-policy switches (streaming = non-temporal), kept for A/B timing (-DEDGE_NT_x=1).  Measured on config 2: streaming
+// the non-owning endpoint's read of a pair row COSTS 10-20 % in force_fwd / force_bwd / msg_bwd (those reads do hit in L2
+// often enough), and streaming the msg store only moves time from msg_fwd to the MLP kernel -- so all four are off.  (The
+// one hint that pays is in mlp128.hip: the hidden pre-activations, written once and read once much later.)
+#ifndef EDGE_NT_MSG
+#define EDGE_NT_MSG 0
+#endif
+#ifndef EDGE_NT_PHI_FWD
+#define EDGE_NT_PHI_FWD 0
+#endif
+#ifndef EDGE_NT_PHI_BWD
+#define EDGE_NT_PHI_BWD 0
+#endif
+#ifndef EDGE_NT_GMSG
+#define EDGE_NT_GMSG 0
+#endif
+template <bool NT>
+__device__ __forceinline__ float4 ld4p(const float* p) {
+  return NT ? ld4_nt(p) : ld4(p);
+}
 
 // Compile-time ablations for tools/ablate_edge.sh (WRONG results; the shipped build defines none of them):
 //   EDGE_ABL_SELF   gather the sender rows from row i instead of j (always cache-hot)
@@ -145,7 +168,10 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
       const float4 v = mul4(mul4(eps, mi), mj);
       if (ABL_ST(jj > i)) {   // the lower endpoint writes the shared pair row
         const int p0 = pid[e], p1 = pid[e1];
-        st4(msg + (size_t)(hi ? p1 : p0) * NF + c4, v);
+        if (EDGE_NT_MSG)
+          st4_nt(msg + (size_t)(hi ? p1 : p0) * NF + c4, v);
+        else
+          st4(msg + (size_t)(hi ? p1 : p0) * NF + c4, v);
       }
       acc = add4(acc, v);
     }
@@ -174,27 +200,32 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
   for (int k = 0; k < 3; ++k)
     acc[k] = (HAS_F && !hi) ? ld4(f_in + ((size_t)i * 3 + k) * NF + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; e += 2) {
-    const int e1 = min(e + 1, end - 1);    // (clamped; the odd half is masked off when the row has no edge e + 1)
-    const float4 g0 = reinterpret_cast<const float4*>(geo)[e];   // (ux,uy,uz,r), wave-uniform
-    const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
-    const int p0 = pid[e], p1 = pid[e1];
-    const float4 g = hi ? g1 : g0;
-    const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
-    if (!hi || e + 1 < end) {
-      const float4 v1 = ld4(phi1 + p * NF + c4);
-      acc[0] = fma4(v1, g.x, acc[0]);
-      acc[1] = fma4(v1, g.y, acc[1]);
-      acc[2] = fma4(v1, g.z, acc[2]);
-      if (HAS_F) {
-        const int j0 = col[e], j1 = col[e1];
-        const int j = ABL_J(hi ? j1 : j0, i);
-        const float4 v2 = ld4(phi2 + p * NF + c4);
+  const int mid = row_mid(col, beg, end, i, lane);
+  auto run = [&](const int rb, const int re, auto nt) {   // nt: stream the pair rows (the other endpoint owns them)
+    for (int e = rb; e < re; e += 2) {
+      const int e1 = min(e + 1, re - 1);    // (clamped; the odd half is masked off when the range has no edge e + 1)
+      const float4 g0 = reinterpret_cast<const float4*>(geo)[e];   // (ux,uy,uz,r), wave-uniform
+      const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
+      const int p0 = pid[e], p1 = pid[e1];
+      const float4 g = hi ? g1 : g0;
+      const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
+      if (!hi || e + 1 < re) {
+        const float4 v1 = ld4p<decltype(nt)::value>(phi1 + p * NF + c4);
+        acc[0] = fma4(v1, g.x, acc[0]);
+        acc[1] = fma4(v1, g.y, acc[1]);
+        acc[2] = fma4(v1, g.z, acc[2]);
+        if (HAS_F) {
+          const int j0 = col[e], j1 = col[e1];
+          const int j = ABL_J(hi ? j1 : j0, i);
+          const float4 v2 = ld4p<decltype(nt)::value>(phi2 + p * NF + c4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] = fma4(v2, ld4(f_in + ((size_t)j * 3 + k) * NF + c4), acc[k]);
+          for (int k = 0; k < 3; ++k) acc[k] = fma4(v2, ld4(f_in + ((size_t)j * 3 + k) * NF + c4), acc[k]);
+        }
       }
     }
-  }
+  };
+  run(beg, mid, std::integral_constant<bool, EDGE_NT_PHI_FWD != 0>());
+  run(mid, end, std::false_type());
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float4 o = add4(acc[k], upper_half(acc[k]));
@@ -240,12 +271,12 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const int eh = hi ? e1 : e;
     const size_t p = (size_t)(hi ? p1 : p0);
     if (!hi || e + 1 < mid) {
-      const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
+      const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
       float4 gfj[3];
       if (HAS_F) {
         const int j0 = col[e], j1 = col[e1];
         const int j = ABL_J(hi ? j1 : j0, i);
-        const float4 v2 = ld4(phi2 + (size_t)ABL_P(p, i) * NF + c4);
+        const float4 v2 = ld4p<EDGE_NT_PHI_BWD != 0>(phi2 + (size_t)ABL_P(p, i) * NF + c4);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           gfj[k] = ld4(gf + ((size_t)j * 3 + k) * NF + c4);
@@ -345,7 +376,7 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
       if (!hi || e + 1 < mid) {
         const float4 mj = ld4(m + (size_t)j * NF + c4);
         const float4 gaj = ld4(g_a + (size_t)j * NF + c4);
-        const float4 G = add4(add4(ld4(g_msg + p * NF + c4), gai), gaj);
+        const float4 G = add4(add4(ld4p<EDGE_NT_GMSG != 0>(g_msg + p * NF + c4), gai), gaj);
         const FilterW fw = filter_weights(__int_as_float(gx.y));
         const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
         acc = fma4(mul4(G, eps), mj, acc);

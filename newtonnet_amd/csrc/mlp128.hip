@@ -26,6 +26,9 @@
 
 #include "common.h"
 
+#ifndef MLP_NT_H
+#define MLP_NT_H 1   // hidden pre-activations bypass the caches (streaming): they would only evict phi / msg
+#endif
 #define MW_LD 132
 #define MLP_LDS_BYTES (2 * NF * MW_LD * 4)
 
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
       if (MODE == MODE_BWD) {  // forward pre-activation of this block, same fragment layout as the stores below
         const float4* hp = reinterpret_cast<const float4*>(p.H + (size_t)ec * p.ldh + nb * 32 + 4 * h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hin[q] = hp[2 * q];
+        for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_H ? ld4_nt(reinterpret_cast<const float*>(hp + 2 * q)) : hp[2 * q];
       }
       f32x16 acc;
 #pragma unroll
@@ -156,7 +159,13 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
 #endif
           float4* hp = reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) hp[2 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+          for (int q = 0; q < 4; ++q) {
+            const float4 hv = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            if (MLP_NT_H)
+              st4_nt(reinterpret_cast<float*>(hp + 2 * q), hv);   // written once, read once by the adjoint much later
+            else
+              hp[2 * q] = hv;
+          }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) hs[nb][k] = silu_f(acc[k]);
