@@ -32,10 +32,15 @@
 #define MW_LD 132
 #define MLP_LDS_BYTES (2 * NF * MW_LD * 4)
 
+#ifndef MLP_NT_X
+#define MLP_NT_X 0   // streaming loads of stage-1 inputs on their last read: measured 5 % SLOWER (0.935 -> 0.984 ms), off
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int ldx, int row, int h) {
   const float4* xp = reinterpret_cast<const float4*>(X + (size_t)row * ldx + 4 * h);
 #pragma unroll
-  for (int t = 0; t < 16; ++t) x[t] = xp[2 * t];  // features 8t + 4h + {0..3}
+  for (int t = 0; t < 16; ++t)   // features 8t + 4h + {0..3}
+    x[t] = NT ? ld4_nt(reinterpret_cast<const float*>(xp + 2 * t)) : xp[2 * t];
 }
 
 // Stage both weight matrices of one MLP: all 16 requests of a thread are in flight before the first LDS write.
@@ -85,7 +90,10 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
     // weights first (L2 hits, returned first by the in-order vmcnt queue), then this wave's first X fragment: the LDS fill
     // and the barrier only wait for the weights, and stage 1 starts consuming X as its 16 pieces arrive
     MLP_W_REQUEST(P.a[0].W1, P.a[0].W2)
-    mlp_load_x(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
+    if (MLP_NT_X && (MODE == MODE_BWD || P.n == 1))
+      mlp_load_x<true>(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
+    else
+      mlp_load_x<false>(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
     __builtin_amdgcn_sched_barrier(0);
     MLP_W_COMMIT()
   }
@@ -188,7 +196,12 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
       const float* xn = (last && more) ? P.a[1].X : p.X;
       const int ldn = (last && more) ? P.a[1].ldx : p.ldx;
       const int nt = last ? tile0 : tile + tile_step;
-      mlp_load_x(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
+      // last read of this input?  adjoint: always (g_phi is consumed here); forward: msg is read by both phases
+      const bool last_use = MODE == MODE_BWD || P.n == 1 || ph == 1 || (last && more);
+      if (MLP_NT_X && last_use)
+        mlp_load_x<true>(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
+      else
+        mlp_load_x<false>(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
       __builtin_amdgcn_sched_barrier(0);
     }
 

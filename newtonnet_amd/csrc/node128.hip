@@ -78,10 +78,20 @@ __device__ __forceinline__ void blk_load(float (&v)[16], const float* __restrict
     v[4 * q + 3] = x.w;
   }
 }
+#ifndef NODE_NT
+#define NODE_NT 0   // streaming stores of the tensors kept only for the reverse sweep (q, hn): no measurable effect, off
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void blk_store(const float (&v)[16], float* __restrict__ base, size_t row_off, const Tile& t) {
   float4* p = reinterpret_cast<float4*>(base + row_off + t.nb * 32 + 4 * t.h);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  for (int q = 0; q < 4; ++q) {
+    const float4 w = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (NT)
+      st4_nt(reinterpret_cast<float*>(p + 2 * q), w);
+    else
+      p[2 * q] = w;
+  }
 }
 __device__ __forceinline__ void blk_to_tile(const float (&v)[16], const Tile& t) {
   float* p = t.xs + t.r * NT_LD + t.nb * 32 + 4 * t.h;
@@ -129,7 +139,7 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
       blk_load(a, p.a_mid, (size_t)rc * NF, t);
     acc_to(qv, tile_gemm(t, wf));
     if (c == 2 && p.W0) load_w(wf, t, p.W0);
-    if (live) blk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
+    if (live) blk_store<NODE_NT != 0>(qv, p.q, ((size_t)row * 3 + c) * NF, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
@@ -148,7 +158,7 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   load_w(wf, t, p.W2);
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
-  if (live) blk_store(hn, p.hn, (size_t)row * NF, t);
+  if (live) blk_store<NODE_NT != 0>(hn, p.hn, (size_t)row * NF, t);
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] = silu_f(hn[k]);
   __syncthreads();
