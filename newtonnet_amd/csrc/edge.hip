@@ -30,6 +30,9 @@
 // the non-owning endpoint's read of a pair row COSTS 10-20 % in force_fwd / force_bwd / msg_bwd (those reads do hit in L2
 // often enough), and streaming the msg store only moves time from msg_fwd to the MLP kernel -- so all four are off.  (The
 // one hint that pays is in mlp128.hip: the hidden pre-activations, written once and read once much later.)
+#ifndef EDGE_NT_GH
+#define EDGE_NT_GH 1    // g_phi rows written by force_bwd (read once by the MLP adjoint)
+#endif
 #ifndef EDGE_NT_MSG
 #define EDGE_NT_MSG 0
 #endif
@@ -308,7 +311,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
       float4 gp1 = mul4(sub4(gfi[0], gfj[0]), g.x);
       gp1 = fma4(sub4(gfi[1], gfj[1]), g.y, gp1);
       gp1 = fma4(sub4(gfi[2], gfj[2]), g.z, gp1);
-      if (ABL_ST(true)) st4_nt(g_h12 + p * 2 * NF + c4, gp1);
+      if (ABL_ST(true)) { if (EDGE_NT_GH) st4_nt(g_h12 + p * 2 * NF + c4, gp1); else st4(g_h12 + p * 2 * NF + c4, gp1); }
       if (HAS_F) {
         const float4 v2 = ld4(phi2 + (size_t)ABL_P(p, i) * NF + c4);
         float4 gp2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -318,7 +321,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
           gp2 = fma4(gfi[k], ld4(f_in + ((size_t)j * 3 + k) * NF + c4), gp2);
           gp2 = fma4(gfj[k], fi[k], gp2);
         }
-        if (ABL_ST(true)) st4_nt(g_h12 + p * 2 * NF + NF + c4, gp2);
+        if (ABL_ST(true)) { if (EDGE_NT_GH) st4_nt(g_h12 + p * 2 * NF + NF + c4, gp2); else st4(g_h12 + p * 2 * NF + NF + c4, gp2); }
       }
       const float s0 = half_sum_top(dot4(gfi[0], v1));
       const float s1 = half_sum_top(dot4(gfi[1], v1));

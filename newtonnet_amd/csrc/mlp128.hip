@@ -29,6 +29,9 @@
 #ifndef MLP_NT_H
 #define MLP_NT_H 1   // hidden pre-activations bypass the caches (streaming): they would only evict phi / msg
 #endif
+#ifndef MLP_NT_HL
+#define MLP_NT_HL 1   // ... and read back by the adjoint with the same hint
+#endif
 #define MW_LD 132
 #define MLP_LDS_BYTES (2 * NF * MW_LD * 4)
 
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
       if (MODE == MODE_BWD) {  // forward pre-activation of this block, same fragment layout as the stores below
         const float4* hp = reinterpret_cast<const float4*>(p.H + (size_t)ec * p.ldh + nb * 32 + 4 * h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_H ? ld4_nt(reinterpret_cast<const float*>(hp + 2 * q)) : hp[2 * q];
+        for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_HL ? ld4_nt(reinterpret_cast<const float*>(hp + 2 * q)) : hp[2 * q];
       }
       f32x16 acc;
 #pragma unroll
