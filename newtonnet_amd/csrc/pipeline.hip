@@ -342,6 +342,15 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
         na.b2 = nx.node2_b;
         na.hn = P(w.pub.hn[l + 1]);
         na.m = P(w.pub.m[l + 1]);
+      } else if (l + 1 == L && !lp.ln_w) {
+        // after the last layer the same slot runs the first two linears of the energy head (output.py:90-95):
+        // e1 = a W0^T + b0 ; e2 = silu(e1) W2^T + b2
+        na.W0 = model->head0_w;
+        na.b0 = model->head0_b;
+        na.W2 = model->head2_w;
+        na.b2 = model->head2_b;
+        na.hn = P(w.pub.e1);
+        na.m = P(w.pub.e2);
       }
       na.N = N;
       TRY(launch_node_fwd(na, s));
@@ -357,9 +366,10 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     a_in = A_OUT(l);
     f_in = F_OUT(l);
   }
-  // energy head
-  TRY(launch_mlp(MODE_FWD, false, {a_in, model->head0_w, model->head2_w, P(w.pub.e1), P(w.pub.e2), N, NF, NF, NF,
-                                   model->head0_b, model->head2_b}, s));
+  // energy head (fused into the last node launch unless that layer ends in a LayerNorm)
+  if (model->layer[L - 1].ln_w)
+    TRY(launch_mlp(MODE_FWD, false, {a_in, model->head0_w, model->head2_w, P(w.pub.e1), P(w.pub.e2), N, NF, NF, NF,
+                                     model->head0_b, model->head2_b}, s));
   float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
   TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
                       atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
