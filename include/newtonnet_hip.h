@@ -208,7 +208,16 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
                         const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
                         const int32_t* xg, const float* disp, int32_t n_atoms, int32_t n_edges,
                         int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
-                        float* virial, float* atom_energy, float* atom_node, float* force_node, void* stream);
+                        float* virial, float* atom_energy, float* atom_node, float* force_node,
+                        const void* prepared, void* stream);
+
+/* Parameter-only preparation (transposed weights for the reverse sweep, radial-filter tables, layer 0's
+ * message_nodepart per element): what the reference gets for free from nn.Module state.  `prepared` is a caller-owned
+ * 256-byte-aligned block of nnhip_prepared_bytes(n_layers); fill it with nnhip_prepare whenever the parameters may have
+ * changed (the Python mirror does it on every forward, on the stream, while the host waits for the edge count) and pass it
+ * to nnhip_energy_forces.  prepared == NULL: nnhip_energy_forces rebuilds the block inside its workspace on every call. */
+size_t nnhip_prepared_bytes(int32_t n_layers);
+int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream);
 
 /* --------------------------------------------------------------------------
  * One dense 128 -> 128 linear on the matrix cores (fp32 MFMA, exact fp32):

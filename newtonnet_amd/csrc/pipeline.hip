@@ -113,9 +113,7 @@ extern "C" int nnhip_timers_read(double* ms, int64_t* cnt, int32_t reset) {
 // ---- workspace ---------------------------------------------------------------------------------------
 struct WsInternal {
   nnhip_ws_layout pub;
-  size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
-  size_t headT[2];                 // head0^T, head2^T
-  size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
+  size_t prep;                     // PrepLayout block inside the workspace (fallback when none is passed)
   size_t xhat[NNHIP_MAX_LAYERS];   // [N][F] normalised atom_node of each layer (layer_norm=True only)
   size_t rstd[NNHIP_MAX_LAYERS];   // [N]    1/sigma of each row
   size_t g_h12;                    // [E][2F] adjoint scratch (g_phi -> g_h)
@@ -126,13 +124,42 @@ struct WsInternal {
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
   size_t atom_energy;              // [N]
-  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values, then [FT_ROWS][F] d/dx
 };
+struct PrepLayout {
+  size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
+  size_t headT[2];                 // head0^T, head2^T
+  size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
+  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values, then [FT_ROWS][F] d/dx
+  size_t total;
+};
+static size_t prep_bytes(int L);
 
 static size_t carve(size_t& off, size_t bytes) {
   const size_t o = off;
   off += (bytes + 255) & ~(size_t)255;
   return o;
+}
+
+// Everything that depends on the parameters only -- transposed weights for the reverse sweep, the radial-filter tables,
+// layer 0's message_nodepart per element -- lives in one "prepared" block (offsets relative to its base) that
+// nnhip_prepare fills.  Callers that do not pass one get it rebuilt inside the workspace on every call.
+static void make_prep_layout(int L, PrepLayout& q) {
+  memset(&q, 0, sizeof(q));
+  size_t off = 0;
+  for (int l = 0; l < L; ++l) {
+    for (int k = 0; k < 7; ++k) q.wT[l][k] = carve(off, NF * NF * 4);
+    q.ftab[l] = carve(off, (size_t)2 * FT_ROWS * NF * 4);
+  }
+  q.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
+  q.m_tab = carve(off, (size_t)128 * NF * 4);
+  q.headT[0] = carve(off, NF * NF * 4);
+  q.headT[1] = carve(off, NF * NF * 4);
+  q.total = off;
+}
+static size_t prep_bytes(int L) {
+  PrepLayout q;
+  make_prep_layout(L, q);
+  return q.total;
 }
 
 static void make_layout(int N, int E, int B, int L, WsInternal& w) {
@@ -153,17 +180,11 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
     w.pub.a_out[l] = carve(off, nf);
     w.pub.f_out[l] = carve(off, 3 * nf);
     w.pub.q[l] = carve(off, 3 * nf);
-    for (int k = 0; k < 7; ++k) w.wT[l][k] = carve(off, NF * NF * 4);
-    w.ftab[l] = carve(off, (size_t)2 * FT_ROWS * NF * 4);
   }
   for (int l = 0; l < L; ++l) {
     w.xhat[l] = carve(off, nf);
     w.rstd[l] = carve(off, (size_t)N * 4);
   }
-  w.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
-  w.m_tab = carve(off, (size_t)128 * NF * 4);
-  w.headT[0] = carve(off, NF * NF * 4);
-  w.headT[1] = carve(off, NF * NF * 4);
   w.pub.e1 = carve(off, nf);
   w.pub.e2 = carve(off, nf);
   w.pub.g_x = carve(off, (size_t)L * E * 4);
@@ -178,6 +199,7 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   w.g_e = carve(off, nf);
   w.g_d = carve(off, (size_t)E * 16);
   w.atom_energy = carve(off, (size_t)N * 4);
+  w.prep = carve(off, prep_bytes(L));   // used when the caller passes no prepared block
   w.pub.total = off;
 }
 
@@ -205,6 +227,86 @@ extern "C" int nnhip_workspace_layout(int32_t N, int32_t E, int32_t B, int32_t L
     if (_r) return _r;    \
   } while (0)
 
+// ---- parameter-only preparation ---------------------------------------------------------------------------
+static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pbase, hipStream_t s) {
+  const int L = model->n_layers;
+  auto Q = [&](size_t off) { return (float*)(pbase + off); };
+  // transposed weights for the reverse sweep
+  {
+    const float* src[40];
+    float* dst[40];
+    int c = 0;
+    for (int l = 0; l < L; ++l) {
+      const nnhip_layer_params& lp = model->layer[l];
+      const float* ws_[7] = {lp.node0_w, lp.node2_w, lp.eq1_0_w, lp.eq1_2_w, lp.eq2_0_w, lp.eq2_2_w, lp.update_w};
+      for (int k = 0; k < 7; ++k) {
+        if (c == 40) {
+          TRY(launch_transposes(src, dst, c, s));
+          c = 0;
+        }
+        src[c] = ws_[k];
+        dst[c] = Q(pq.wT[l][k]);
+        ++c;
+      }
+    }
+    if (c + 2 > 40) {
+      TRY(launch_transposes(src, dst, c, s));
+      c = 0;
+    }
+    src[c] = model->head0_w;
+    dst[c++] = Q(pq.headT[0]);
+    src[c] = model->head2_w;
+    dst[c++] = Q(pq.headT[1]);
+    TRY(launch_transposes(src, dst, c, s));
+  }
+  // radial-filter tables, one per layer
+  {
+    const float* ew[NNHIP_MAX_LAYERS];
+    float* tb[NNHIP_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) {
+      ew[l] = model->layer[l].edge_w;
+      tb[l] = Q(pq.ftab[l]);
+    }
+    TRY(launch_filter_tables(ew, tb, L, model->frequencies, s));
+  }
+  // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows); the atoms'
+  // rows are looked up (embed_kernel) instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is
+  // not kept per atom: its adjoint is never needed, the embedding does not depend on the positions.)
+  const nnhip_layer_params& l0 = model->layer[0];
+  TRY(launch_mlp(MODE_FWD, false, {model->node_embedding, l0.node0_w, l0.node2_w, Q(pq.hn_tab), Q(pq.m_tab), NNHIP_N_ELEMENTS,
+                                   NF, NF, NF, l0.node0_b, l0.node2_b}, s));
+  return NNHIP_OK;
+}
+
+static int check_model(const nnhip_model* model, const char* who) {
+  if (!model) {
+    nnhip_set_error("%s: bad arguments", who);
+    return NNHIP_E_INVALID;
+  }
+  if (model->n_features != NF || model->n_basis != NB || model->n_layers < 1 || model->n_layers > NNHIP_MAX_LAYERS) {
+    nnhip_set_error("%s: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d/%d/1..%d)", who,
+                    model->n_features, model->n_basis, model->n_layers, NF, NB, NNHIP_MAX_LAYERS);
+    return NNHIP_E_UNSUPPORTED;
+  }
+  return NNHIP_OK;
+}
+
+extern "C" size_t nnhip_prepared_bytes(int32_t L) {
+  if (L < 1 || L > NNHIP_MAX_LAYERS) return 0;
+  return prep_bytes(L);
+}
+
+extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream_) {
+  TRY(check_model(model, "nnhip_prepare"));
+  PrepLayout pq;
+  make_prep_layout(model->n_layers, pq);
+  if (!prepared || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
+    nnhip_set_error("nnhip_prepare: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  return run_prepare(model, pq, (char*)prepared, (hipStream_t)stream_);
+}
+
 // ---- the hot path --------------------------------------------------------------------------------------
 extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                                    const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
@@ -212,7 +314,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
                                    const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                                    size_t workspace_bytes, float* energy, float* forces, float* virial,
                                    float* atom_energy_out, float* atom_node_out, float* force_node_out,
-                                   void* stream_) {
+                                   const void* prepared, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -252,56 +354,18 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   auto P = [&](size_t off) { return (float*)(ws + off); };
   const bool want_forces = forces != nullptr;
 
-  // transposed weights for the reverse sweep (tiny; redone every call so they always match the parameters)
-  if (want_forces) {
-    const float* src[40];
-    float* dst[40];
-    int c = 0;
-    for (int l = 0; l < L; ++l) {
-      const nnhip_layer_params& lp = model->layer[l];
-      const float* ws_[7] = {lp.node0_w, lp.node2_w, lp.eq1_0_w, lp.eq1_2_w, lp.eq2_0_w, lp.eq2_2_w, lp.update_w};
-      for (int k = 0; k < 7; ++k) {
-        if (c == 40) {
-          TRY(launch_transposes(src, dst, c, s));
-          c = 0;
-        }
-        src[c] = ws_[k];
-        dst[c] = P(w.wT[l][k]);
-        ++c;
-      }
-    }
-    if (c + 2 > 40) {
-      TRY(launch_transposes(src, dst, c, s));
-      c = 0;
-    }
-    src[c] = model->head0_w;
-    dst[c++] = P(w.headT[0]);
-    src[c] = model->head2_w;
-    dst[c++] = P(w.headT[1]);
-    TRY(launch_transposes(src, dst, c, s));
-  }
-
-  // radial-filter tables (one per layer; rebuilt every call so they always match message_edgepart.weight)
-  {
-    const float* ew[NNHIP_MAX_LAYERS];
-    float* tb[NNHIP_MAX_LAYERS];
-    for (int l = 0; l < L; ++l) {
-      ew[l] = model->layer[l].edge_w;
-      tb[l] = P(w.ftab[l]);
-    }
-    TRY(launch_filter_tables(ew, tb, L, model->frequencies, s));
-  }
+  // parameter-only data: use the caller's prepared block, or rebuild it in the workspace
+  PrepLayout pq;
+  make_prep_layout(L, pq);
+  char* pbase = prepared ? (char*)prepared : ws + w.prep;
+  auto Q = [&](size_t off) { return (float*)(pbase + off); };
+  if (!prepared) TRY(run_prepare(model, pq, pbase, s));
 
   // ------------------------------------------------------------------ forward sweep
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
   // atoms' rows up, instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is not kept: its
   // adjoint is never needed, the embedding does not depend on the positions.)
-  {
-    const nnhip_layer_params& l0 = model->layer[0];
-    TRY(launch_mlp(MODE_FWD, false, {model->node_embedding, l0.node0_w, l0.node2_w, P(w.hn_tab), P(w.m_tab), NNHIP_N_ELEMENTS,
-                                     NF, NF, NF, l0.node0_b, l0.node2_b}, s));
-    TRY(launch_embed(z, model->node_embedding, P(w.m_tab), N, P(w.pub.a0), P(w.pub.m[0]), s));
-  }
+  TRY(launch_embed(z, model->node_embedding, Q(pq.m_tab), N, P(w.pub.a0), P(w.pub.m[0]), s));
   const float* a_in = P(w.pub.a0);
   const float* f_in = nullptr;  // force_node == 0 entering the first layer (newtonnet.py:143)
   // the last layer writes atom_node / force_node straight into the caller's output arrays when they are given
@@ -313,7 +377,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // message_nodepart (hn = a W0^T + b0 ; m = silu(hn) W2^T + b2) was produced by the fused node kernel that closed the
     // previous layer (by the per-element table for l = 0)
     // messages + invariant update
-    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
+    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
     if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
       float* h12 = P(w.pub.h12[l]);
@@ -383,14 +447,14 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     memset(&nb, 0, sizeof(nb));
     nb.g_top = P(w.g_e);
     nb.h_top = P(w.pub.e1);
-    nb.W2T = P(w.headT[1]);
-    nb.W0T = P(w.headT[0]);
+    nb.W2T = Q(pq.headT[1]);
+    nb.W0T = Q(pq.headT[0]);
     nb.g_a = P(w.pub.g_a);
     nb.acc_ga = 0;
     nb.f = F_OUT(L - 1);
     nb.q = P(w.pub.q[L - 1]);
     nb.G_f = nullptr;
-    nb.WuT = P(w.wT[L - 1][6]);
+    nb.WuT = Q(pq.wT[L - 1][6]);
     nb.gf = P(w.gf_mid);
     nb.N = N;
     const nnhip_layer_params& top = model->layer[L - 1];
@@ -418,15 +482,15 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
       float* h12 = P(w.pub.h12[l]);
-      const MlpArgs m1 = {gp, P(w.wT[l][3]), P(w.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
-      const MlpArgs m2 = {gp + NF, P(w.wT[l][5]), P(w.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
+      const MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
+      const MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
       if (has_f)
         TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
       else
         TRY(launch_mlp(MODE_BWD, false, m1, s));
     }
     // message adjoint -> g_m, g_x
-    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, P(w.ftab[l]), row_ptr, col, pid, P(w.g_m),
+    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, P(w.g_m),
                        P(w.pub.g_x) + (size_t)l * E, N, l > 0, s));
     // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
     // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
@@ -436,14 +500,14 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       memset(&nb, 0, sizeof(nb));
       nb.g_top = P(w.g_m);
       nb.h_top = P(w.pub.hn[l]);
-      nb.W2T = P(w.wT[l][1]);
-      nb.W0T = P(w.wT[l][0]);
+      nb.W2T = Q(pq.wT[l][1]);
+      nb.W0T = Q(pq.wT[l][0]);
       nb.g_a = P(w.pub.g_a);
       nb.acc_ga = 1;
       nb.f = F_OUT(l - 1);
       nb.q = P(w.pub.q[l - 1]);
       nb.G_f = g_fin;   // dE/d f_out of layer l-1, produced by force_bwd of layer l just above
-      nb.WuT = P(w.wT[l - 1][6]);
+      nb.WuT = Q(pq.wT[l - 1][6]);
       nb.gf = P(w.gf_mid);
       nb.N = N;
       const nnhip_layer_params& below = model->layer[l - 1];

@@ -89,7 +89,10 @@ def lib():
     L.nnhip_workspace_layout.argtypes = [i32, i32, i32, i32, C.POINTER(WsLayout)]
     L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
-                                      vp, vp, vp, vp, vp, vp, vp]
+                                      vp, vp, vp, vp, vp, vp, vp, vp]
+    L.nnhip_prepared_bytes.argtypes = [i32]
+    L.nnhip_prepared_bytes.restype = sz
+    L.nnhip_prepare.argtypes = [C.POINTER(Model), vp, sz, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.nnhip_direct_force.argtypes = [vp] * 10 + [i32, vp, vp, vp]
@@ -99,7 +102,8 @@ def lib():
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
-               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp'):
+               'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
+               'nnhip_prepare'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -109,7 +113,8 @@ EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'n
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
-                    'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp')
+                    'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
+                    'nnhip_prepare')
 
 
 def _check(rc: int, what: str):
@@ -140,9 +145,22 @@ class Graph:
                  'rbf', 'drbf', 'xg', 'pid', 'pair_ptr')
 
 
+def prepare(model: Model, device) -> torch.Tensor:
+    """Fill a prepared block (nnhip_prepare) for `model` on the current stream and return it."""
+    L = lib()
+    n = L.nnhip_prepared_bytes(model.n_layers)
+    buf = torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+    _check(L.nnhip_prepare(C.byref(model), _ptr(buf), buf.numel(), _stream(buf.device)), 'nnhip_prepare')
+    return buf
+
+
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
-                frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False) -> Graph:
-    """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU."""
+                frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False,
+                while_waiting=None) -> Graph:
+    """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU.
+    `while_waiting`: callable run after the counting kernels are queued and before the host waits for the edge count --
+    work it launches on the stream fills the GPU's idle time during that round trip (NewtonNet.forward passes
+    nnhip_prepare here)."""
     L = lib()
     dev = pos.device
     pos = _f32c(pos, 'pos')
@@ -172,7 +190,17 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     else:
         _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
                                    _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
-    tail = meta[B + N + 1:B + N + 3].tolist()  # (E, status): the one device->host sync of the path
+    tail_dev = meta[B + N + 1:B + N + 3]
+    if while_waiting is not None:
+        tail_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        tail_host.copy_(tail_dev, non_blocking=True)          # queue the read-back first ...
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        while_waiting()                                        # ... then the independent work, then wait for the copy only
+        ev.synchronize()
+        tail = tail_host.tolist()
+    else:
+        tail = tail_dev.tolist()  # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
     if bad:
         raise ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
@@ -229,7 +257,7 @@ def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
 
 def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
                   want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None,
-                  out: Optional[dict] = None):
+                  out: Optional[dict] = None, prepared: Optional[torch.Tensor] = None):
     """Run the whole hot path.  Returns dict(energy, forces, virial, atom_energy, atom_node, force_node, workspace).
     `out` = the dict of a previous call with the same sizes: its tensors are reused (static addresses for graph capture)."""
     L = lib()
@@ -252,7 +280,7 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
                                  _ptr(g.rev), _ptr(g.pid), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
-                                 _ptr(out['force_node']), _stream(dev)), 'nnhip_energy_forces')
+                                 _ptr(out['force_node']), _ptr(prepared), _stream(dev)), 'nnhip_energy_forces')
     return out
 
 

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 from torch import nn
 
@@ -170,10 +172,13 @@ class NewtonNet(nn.Module):
         with torch.no_grad():
             model = self._hip_model(energy_idx)
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
+            prep = []   # parameter-only preparation runs on the GPU while the host waits for the edge count
+            overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'      # (switch for A/B timing only)
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
-                                emb.edge_embedding.embedding.frequencies)
+                                emb.edge_embedding.embedding.frequencies,
+                                while_waiting=(lambda: prep.append(hip.prepare(model, pos.device))) if overlap else None)
             res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
-                                    want_virial=want_virial)
+                                    want_virial=want_virial, prepared=prep[0] if overlap else None)
 
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
                                   edge_index=g.edge_index, cell=cell, batch=batch)

@@ -148,6 +148,7 @@ class MLAseCalculator(_Base):
         st['cutoff'] = float(emb.cutoff)
         st['model'] = model._hip_model(list(model.output_properties).index('energy'))
         st['g'] = hip.build_graph(st['pos'], st['cell_dev'], st['batch'], st['cutoff'] + self.skin, st['freq'])
+        st['prep'] = hip.prepare(st['model'], dev)     # parameters are fixed while the calculator owns the model (eval)
         g = st['g']
         st['buf'] = torch.zeros(1 + 3 * n + 9, dtype=torch.float32, device=dev)
         st['out_host'] = torch.empty(1 + 3 * n + 9, dtype=torch.float32).pin_memory()
@@ -181,7 +182,8 @@ class MLAseCalculator(_Base):
         from newtonnet_amd import hip
         hip.refresh_graph(st['g'], st['pos'], st['cell_dev'], st['batch'], st['cutoff'], st['freq'])
         hip.energy_forces(st['model'], st['z_dev'], st['pos'], st['cell_dev'], st['g'], want_forces=st['want_forces'],
-                          want_virial=st['want_virial'], want_nodes=False, workspace=st['ws'], out=st['out'])
+                          want_virial=st['want_virial'], want_nodes=False, workspace=st['ws'], out=st['out'],
+                          prepared=st['prep'])
 
     # ------------------------------------------------------------------ ase_interface.py:83-129
     def load_model(self, model):
