@@ -184,7 +184,8 @@ typedef struct {
   size_t m[NNHIP_MAX_LAYERS];      /* [N][F]   message_nodepart output */
   size_t hn[NNHIP_MAX_LAYERS];     /* [N][F]   message_nodepart hidden pre-activation */
   size_t msg[NNHIP_MAX_LAYERS];    /* [P][F]   message, one row per undirected pair (P = E/2, row pid[e]) */
-  size_t h12[NNHIP_MAX_LAYERS];    /* [P][2F]  equiv_message{1,2} hidden pre-activations */
+  size_t h12[NNHIP_MAX_LAYERS];    /* 2 x [pad32(P)][F] equiv_message{1,2} hidden pre-activations, private to the MLP kernels
+                                      (MFMA-fragment order when P > 49152, row-major below) */
   size_t phi1[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t phi2[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */

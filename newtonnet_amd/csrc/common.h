@@ -174,6 +174,9 @@ struct MlpArgs {
   int M, ldx, ldh, ldy;
   const float* b1;  // optional biases (node MLP / energy head; forward mode, row-local small-M kernel only)
   const float* b2;
+  int h_frag;       // H is private scratch between a forward call and its adjoint (same M): the persistent kernel then keeps
+                    // it in MFMA-fragment order ([tile][block][q][lane] float4: every access a contiguous 1 KiB, so the
+                    // streaming stores write whole lines) in a region of pad32(M) x 128 floats; ldh is ignored
 };
 struct MlpPair {      // up to two MLPs over the same M rows, run back to back by one persistent launch (mlp128.hip)
   MlpArgs a[2];

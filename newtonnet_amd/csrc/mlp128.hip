@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
   for (int ph = 0; ph < P.n; ++ph) {
     // per-phase arguments picked with selects (indexing the kernel-argument array with `ph` would spill it to scratch)
     struct { const float* X; float* H; float* Y; int ldx, ldh, ldy; } p;
+    const bool h_frag = P.a[0].h_frag != 0;   // (both phases of a launch use the same H layout)
     p.X = ph ? P.a[1].X : P.a[0].X;
     p.H = ph ? P.a[1].H : P.a[0].H;
     p.Y = ph ? P.a[1].Y : P.a[0].Y;
@@ -136,9 +137,11 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
     for (int nb = 0; nb < 4; ++nb) {
       float4 hin[4];
       if (MODE == MODE_BWD) {  // forward pre-activation of this block, same fragment layout as the stores below
-        const float4* hp = reinterpret_cast<const float4*>(p.H + (size_t)ec * p.ldh + nb * 32 + 4 * h);
+        const float4* hp = h_frag ? reinterpret_cast<const float4*>(p.H) + ((size_t)tile * 4 + nb) * 256 + lane
+                                  : reinterpret_cast<const float4*>(p.H + (size_t)ec * p.ldh + nb * 32 + 4 * h);
+        const int hs4 = h_frag ? 64 : 2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_HL ? ld4_nt(reinterpret_cast<const float*>(hp + 2 * q)) : hp[2 * q];
+        for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_HL ? ld4_nt(reinterpret_cast<const float*>(hp + hs4 * q)) : hp[hs4 * q];
       }
       f32x16 acc;
 #pragma unroll
@@ -166,16 +169,18 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
 #ifdef ABL_NO_STORE   // tooling only
         if (live && M < 0) {
 #else
-        if (live) {
+        if (live || h_frag) {   // (fragment order: rows past M land in the pad32 tail of the region)
 #endif
-          float4* hp = reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
+          float4* hp = h_frag ? reinterpret_cast<float4*>(p.H) + ((size_t)tile * 4 + nb) * 256 + lane
+                              : reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
+          const int hs4 = h_frag ? 64 : 2;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4 hv = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             if (MLP_NT_H)
-              st4_nt(reinterpret_cast<float*>(hp + 2 * q), hv);   // written once, read once by the adjoint much later
+              st4_nt(reinterpret_cast<float*>(hp + hs4 * q), hv);   // written once, read once by the adjoint much later
             else
-              hp[2 * q] = hv;
+              hp[hs4 * q] = hv;
           }
         }
 #pragma unroll
@@ -305,7 +310,11 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1((a.b1 || a.b2) ? TC_LIN1 : TC_MLP, s);   // biased form = node MLP / energy head (node-level class)
-  if (mlp_use_wide(a)) return launch_mlp_wide(mode, accum, a, s);
+  if (mlp_use_wide(a)) {
+    MlpArgs w = a;
+    if (w.h_frag) w.ldh = NF;   // the row-local kernel keeps H row-major inside the same pad32(M) x 128 region
+    return launch_mlp_wide(mode, accum, w, s);
+  }
   if (mode != MODE_FWD && mode != MODE_BWD) {
     nnhip_set_error("launch_mlp: unsupported mode %d", mode);
     return NNHIP_E_INVALID;
@@ -319,7 +328,7 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
 
 // Two MLPs over the same rows in one persistent launch (phi1 | phi2 forward; the two terms of g_msg in the adjoint).
 int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s) {
-  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0) {   // only the last phase may accumulate
+  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0 || a0.h_frag != a1.h_frag) {   // (only the last phase may accumulate)
     nnhip_set_error("launch_mlp_pair: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -357,5 +366,6 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
   a.ldh = ldh;
   a.ldy = ldy;
   a.b1 = a.b2 = nullptr;
+  a.h_frag = 0;   // the C ABI exposes H row-major
   return launch_mlp(mode, accumulate != 0, a, (hipStream_t)stream);
 }

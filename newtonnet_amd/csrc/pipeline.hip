@@ -168,12 +168,13 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   size_t off = 0;
   const size_t nf = (size_t)N * NF * 4;
   const size_t ef = (size_t)((E + 1) / 2) * NF * 4;   // msg / h / phi / g_phi / g_msg live once per undirected pair
+  const size_t hf = (size_t)(((E + 1) / 2 + 31) / 32 * 32) * NF * 4;   // hidden tiles: whole 32-row tiles (fragment order)
   w.pub.a0 = carve(off, nf);
   for (int l = 0; l < L; ++l) {
     w.pub.m[l] = carve(off, nf);
     w.pub.hn[l] = carve(off, nf);
     w.pub.msg[l] = carve(off, ef);
-    w.pub.h12[l] = carve(off, 2 * ef);
+    w.pub.h12[l] = carve(off, 2 * hf);
     w.pub.phi1[l] = carve(off, ef);
     w.pub.phi2[l] = carve(off, ef);
     w.pub.a_mid[l] = carve(off, nf);
@@ -336,6 +337,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     return NNHIP_E_INVALID;
   }
   const int P_ = E / 2;   // undirected pairs
+  const size_t h2_off = (size_t)((P_ + 31) / 32 * 32) * NF;   // floats between the h1 and h2 regions of a layer
   WsInternal w;
   make_layout(N, E, B, L, w);
   if (workspace_bytes < w.pub.total || (!workspace && w.pub.total)) {
@@ -380,9 +382,10 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
     // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
     if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
-      float* h12 = P(w.pub.h12[l]);
-      const MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, 2 * NF, NF};
-      const MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + NF, P(w.pub.phi2[l]), P_, NF, 2 * NF, NF};
+      float* h12 = P(w.pub.h12[l]);   // h1 | h2: two pad32(P) x F regions, private to the MLP kernels (fragment order)
+      MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, NF, NF};
+      MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
+      m1.h_frag = m2.h_frag = 1;
       if (has_f)
         TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
       else
@@ -482,8 +485,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
       float* h12 = P(w.pub.h12[l]);
-      const MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
-      const MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + NF, P(w.g_msg), P_, 2 * NF, 2 * NF, NF};
+      MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, NF, NF};
+      MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
+      m1.h_frag = m2.h_frag = 1;
       if (has_f)
         TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
       else
