@@ -77,6 +77,39 @@ def algorithmic_counts(N, E, L=3, F=128):
     return edge_fwd, edge_bwd, fl, mlp_fl
 
 
+def pmc_traffic(kernel_prefixes):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of this same command
+    (profiles/<latest>_pmc_{fetch,write}_size.txt; FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide
+    reads by 2x on gfx950 -- MI355X_MICROARCH.md).  Counters cannot be collected from inside the timed process, so this is
+    the stored measurement, named in `traffic_source`; None when the files are missing."""
+    import glob
+    fetch = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')))
+    write = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')))
+    if not fetch or not write:
+        return None, None
+
+    def table(path):
+        rows = {}
+        with open(path) as f:
+            next(f)
+            for line in f:
+                parts = line.split()
+                if len(parts) < 4:
+                    continue
+                name = ' '.join(parts[:-3])
+                rows[name] = (int(parts[-3]), float(parts[-1]))      # launches, KiB per launch
+        return rows
+    tf, tw = table(fetch[-1]), table(write[-1])
+    n = by = 0.0
+    for name, (cnt, kib) in tf.items():
+        if any(name.startswith(p) or (' ' + p) in name for p in kernel_prefixes) and name in tw:
+            n += cnt
+            by += cnt * (2.0 * kib + tw[name][1]) * 1024.0
+    if n == 0:
+        return None, None
+    return by / n, f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -184,6 +217,18 @@ def main():
                'achieved': round(edge_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(edge_gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'ms_per_step': round(edge_ms, 4),
                'algorithmic_bytes_per_step': edge_fwd_b + edge_bwd_b}
+        if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
+            # algorithmic HBM bytes of one MLP phase over P pair rows, in units of 512 P: forward X in + hidden, output out
+            # = 3; adjoint g_phi, hidden in + g_msg out = 3, + g_msg in when accumulating = 4.  Per step (3 layers, phi2
+            # skipped in layer 0): 5 forward phases, 3 plain + 2 accumulating adjoint phases
+            mfma['algorithmic_bytes_per_launch'] = round((E // 2) * 512.0 * (5 * 3 + 3 * 3 + 2 * 4) / mlp_n)
+            t, src = pmc_traffic(['void mlp128_kernel', 'mlp128_kernel'])
+            if t is not None:
+                mfma['traffic'], mfma['traffic_source'] = round(t), src
+            t, src = pmc_traffic(['msg_fwd_kernel', 'void force_fwd_kernel', 'void force_bwd_kernel', 'void msg_bwd_kernel'])
+            if t is not None:
+                hbm['traffic'], hbm['traffic_source'] = round(t), src
+                hbm['traffic_note'] = 'average HBM bytes per edge-kernel launch (12 launches per step)'
         roofline, edge_roofline = (mfma, hbm) if lin_ms >= edge_ms else (hbm, mfma)
 
     # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
