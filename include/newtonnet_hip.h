@@ -17,8 +17,8 @@
  *     (PyTorch does, in the shipped host code);
  *   - return value 0 = success, anything else = error; nnhip_last_error()
  *     returns a static description for the calling thread.
- *   - F = n_features must be 128 and nb = n_basis must be 20 (the reference's
- *     defaults, scripts/config.yml:30-36); other sizes return NNHIP_E_UNSUPPORTED.
+ *   - F = n_features must be 128 (the reference's default, scripts/config.yml:30-36); nb = n_basis may be
+ *     1..NNHIP_MAX_NB (default 20); other sizes return NNHIP_E_UNSUPPORTED.
  */
 #ifndef NEWTONNET_HIP_H
 #define NEWTONNET_HIP_H
@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 #define NNHIP_F 128
-#define NNHIP_NB 20
+#define NNHIP_NB 20        /* the reference's default n_basis */
+#define NNHIP_MAX_NB 32    /* any 1 <= n_basis <= 32 runs: only the radial-filter table builder sees the basis */
 #define NNHIP_MAX_LAYERS 8
 #define NNHIP_N_ELEMENTS 119 /* rows of node_embedding / scale / shift (z = 0..118) */
 
@@ -70,7 +71,7 @@ typedef struct {
 
 typedef struct {
   int32_t n_features; /* 128 */
-  int32_t n_basis;    /* 20 */
+  int32_t n_basis;    /* 1..NNHIP_MAX_NB (20 in the reference's configs) */
   int32_t n_layers;   /* 1..NNHIP_MAX_LAYERS */
   float cutoff;       /* Angstrom */
   const float* node_embedding; /* embedding_layers.node_embedding.weight [119][F] */

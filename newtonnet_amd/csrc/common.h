@@ -6,7 +6,7 @@
 #include "../../include/newtonnet_hip.h"
 
 #define NF NNHIP_F    // 128 features: one wave = 64 lanes x float2
-#define NB NNHIP_NB   // 20 radial basis functions
+#define NB NNHIP_NB   // 20 radial basis functions (default; 1..NNHIP_MAX_NB supported)
 #define WAVE 64
 #ifndef FT_G
 #define FT_G 2048            // radial-filter table: intervals on x = r/cutoff in [0, 1)

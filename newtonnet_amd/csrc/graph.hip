@@ -338,9 +338,11 @@ struct FilterTableArgs {
   const float* edge_w[NNHIP_MAX_LAYERS];
   float* table[NNHIP_MAX_LAYERS];
   const float* freq;
+  int nb;
 };
 __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
-  __shared__ double rb[NB], drb[NB];
+  __shared__ double rb[NNHIP_MAX_NB], drb[NNHIP_MAX_NB];
+  const int nb = a.nb;
   const int g = blockIdx.x, l = blockIdx.y;
   if (g >= FT_ZERO_ROW) {   // the all-zero rows behind the table proper
     a.table[l][(size_t)g * NF + threadIdx.x] = 0.f;
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
     return;
   }
   const double x = (double)(g - 1) / (double)FT_G;
-  if (threadIdx.x < NB) {
+  if (threadIdx.x < nb) {
     const double w = (double)a.freq[threadIdx.x];
     const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
     const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);
@@ -367,10 +369,9 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
     drb[threadIdx.x] = denv * bes + env * dbes;
   }
   __syncthreads();
-  const float* __restrict__ we = a.edge_w[l] + (size_t)threadIdx.x * NB;
+  const float* __restrict__ we = a.edge_w[l] + (size_t)threadIdx.x * nb;
   double acc = 0.0, dacc = 0.0;
-#pragma unroll
-  for (int n = 0; n < NB; ++n) {
+  for (int n = 0; n < nb; ++n) {
     acc += (double)we[n] * rb[n];
     dacc += (double)we[n] * drb[n];
   }
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
   a.table[l][(size_t)(FT_ROWS + g) * NF + threadIdx.x] = (float)dacc;
 }
 
-int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq,
+int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,
                          hipStream_t s) {
   ScopedTimer tm(TC_OTHER, s);
   FilterTableArgs a;
@@ -387,6 +388,7 @@ int launch_filter_tables(const float* const* edge_w, float* const* tables, int n
     a.table[l] = tables[l];
   }
   a.freq = freq;
+  a.nb = nb;
   filter_table_kernel<<<dim3(FT_ROWS, n_layers), NF, 0, s>>>(a);
   LAUNCH_CHECK();
   return 0;
@@ -426,8 +428,8 @@ extern "C" int nnhip_edge_disp(const float* pos, const float* cell, const int64_
 extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,
                                 int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_basis != NB) {
-    nnhip_set_error("nnhip_edge_embed: n_basis=%d unsupported (built for %d)", n_basis, NB);
+  if (n_basis < 1 || n_basis > NNHIP_MAX_NB) {
+    nnhip_set_error("nnhip_edge_embed: n_basis=%d unsupported (1..%d)", n_basis, NNHIP_MAX_NB);
     return NNHIP_E_UNSUPPORTED;
   }
   if (n_edges == 0) return NNHIP_OK;

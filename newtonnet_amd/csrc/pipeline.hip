@@ -13,7 +13,8 @@
 #include "common.h"
 
 // ---- pieces defined in the other translation units ---------------------------------------------------
-int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, hipStream_t s);
+int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,
+                         hipStream_t s);
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
@@ -268,7 +269,7 @@ static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pba
       ew[l] = model->layer[l].edge_w;
       tb[l] = Q(pq.ftab[l]);
     }
-    TRY(launch_filter_tables(ew, tb, L, model->frequencies, s));
+    TRY(launch_filter_tables(ew, tb, L, model->frequencies, model->n_basis, s));
   }
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows); the atoms'
   // rows are looked up (embed_kernel) instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is
@@ -284,9 +285,10 @@ static int check_model(const nnhip_model* model, const char* who) {
     nnhip_set_error("%s: bad arguments", who);
     return NNHIP_E_INVALID;
   }
-  if (model->n_features != NF || model->n_basis != NB || model->n_layers < 1 || model->n_layers > NNHIP_MAX_LAYERS) {
-    nnhip_set_error("%s: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d/%d/1..%d)", who,
-                    model->n_features, model->n_basis, model->n_layers, NF, NB, NNHIP_MAX_LAYERS);
+  if (model->n_features != NF || model->n_basis < 1 || model->n_basis > NNHIP_MAX_NB || model->n_layers < 1 ||
+      model->n_layers > NNHIP_MAX_LAYERS) {
+    nnhip_set_error("%s: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d / 1..%d / 1..%d)", who,
+                    model->n_features, model->n_basis, model->n_layers, NF, NNHIP_MAX_NB, NNHIP_MAX_LAYERS);
     return NNHIP_E_UNSUPPORTED;
   }
   return NNHIP_OK;
@@ -321,9 +323,10 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nnhip_set_error("nnhip_energy_forces: bad arguments");
     return NNHIP_E_INVALID;
   }
-  if (model->n_features != NF || model->n_basis != NB || model->n_layers < 1 || model->n_layers > NNHIP_MAX_LAYERS) {
-    nnhip_set_error("nnhip_energy_forces: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d/%d/1..%d)",
-                    model->n_features, model->n_basis, model->n_layers, NF, NB, NNHIP_MAX_LAYERS);
+  if (model->n_features != NF || model->n_basis < 1 || model->n_basis > NNHIP_MAX_NB || model->n_layers < 1 ||
+      model->n_layers > NNHIP_MAX_LAYERS) {
+    nnhip_set_error("nnhip_energy_forces: n_features=%d n_basis=%d n_layers=%d unsupported (built for %d / 1..%d / 1..%d)",
+                    model->n_features, model->n_basis, model->n_layers, NF, NNHIP_MAX_NB, NNHIP_MAX_LAYERS);
     return NNHIP_E_UNSUPPORTED;
   }
   const int L = model->n_layers;

@@ -19,6 +19,7 @@ BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
 
 NNHIP_F = 128
 NNHIP_NB = 20
+NNHIP_MAX_NB = 32
 NNHIP_MAX_LAYERS = 8
 N_TIMER_CLASSES = 10
 TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',

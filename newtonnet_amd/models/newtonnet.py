@@ -91,8 +91,8 @@ class NewtonNet(nn.Module):
     def _hip_model(self, energy_idx: int) -> hip.Model:
         emb = self.embedding_layers
         F, nb, L = emb.n_features, emb.edge_embedding.n_basis, len(self.interaction_layers)
-        if F != hip.NNHIP_F or nb != hip.NNHIP_NB or not (1 <= L <= hip.NNHIP_MAX_LAYERS):
-            raise NotImplementedError(f'HIP kernels are built for n_features={hip.NNHIP_F}, n_basis={hip.NNHIP_NB}, '
+        if F != hip.NNHIP_F or not (1 <= nb <= hip.NNHIP_MAX_NB) or not (1 <= L <= hip.NNHIP_MAX_LAYERS):
+            raise NotImplementedError(f'HIP kernels are built for n_features={hip.NNHIP_F}, n_basis<={hip.NNHIP_MAX_NB}, '
                                       f'1..{hip.NNHIP_MAX_LAYERS} interactions (got {F}, {nb}, {L})')
         if self.activation_name not in HIP_FUSED:
             raise NotImplementedError(f"HIP kernels fuse SiLU only (activation='{self.activation_name}')")

@@ -414,3 +414,23 @@ def test_random_batches_against_oracle(seed):
     check_forces(out.gradient_force.cpu().numpy(), f_ref, scale=scale)
     v_ref = want['virial'].numpy()
     assert np.abs(out.virial.cpu().numpy() - v_ref).max() <= 2e-5 * max(1.0, float(np.abs(v_ref).max()))
+
+
+@pytest.mark.parametrize('n_basis,n_interactions', [(8, 2), (32, 1), (20, 5)])
+def test_other_basis_and_depth(n_basis, n_interactions):
+    """n_basis other than the default 20 (only the radial-filter table builder sees the basis) and other depths, against the
+    fp64 oracle with the model's own randomly initialised weights."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    torch.manual_seed(7)
+    model = NewtonNet(n_basis=n_basis, n_interactions=n_interactions, output_properties=['energy', 'gradient_force'])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to('cuda')
+    model.eval()
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert np.array_equal(out.edge_index.cpu().numpy(), want['edge_index'].numpy())
+    e = want['energy'].numpy()
+    assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e))
+    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy())
