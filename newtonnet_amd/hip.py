@@ -143,7 +143,7 @@ CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fa
 class Graph:
     """Neighbor list + edge embedding of one batch (device tensors)."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg')
 
 
 def prepare(model: Model, device) -> torch.Tensor:

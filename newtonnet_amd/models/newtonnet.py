@@ -216,7 +216,8 @@ class NewtonNet(nn.Module):
         self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
         if not pos.requires_grad:
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
-        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx)
+        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx,
+                                                                   graph=getattr(self, '_static_train_graph', None))
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=atom_node, force_node=force_node, edge_index=g.edge_index,
                                   cell=cell, displacement=displacement, batch=batch)
         outputs.energy = energy

@@ -84,13 +84,25 @@ def _lin(x, weight, bias=None):
     return y.float() if y.dtype != torch.float32 else y
 
 
-def forward_train(model, z, pos, cell, batch, energy_idx: int):
-    """Returns (energy [B], atom_node, force_node, edge_index, graph); everything attached to autograd."""
+def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
+    """Returns (energy [B], atom_node, force_node, edge_index, graph); everything attached to autograd.
+
+    graph: a STATIC candidate list (hip.build_graph with a cutoff of at least the model's, typically all pairs of each
+    molecule) reused across steps -- no neighbor-list build and no host sync in the step, which makes the whole training
+    step capturable in a HIP graph (distributed.GraphedTrainStep).  Its geometry is re-evaluated at `pos` and candidates at or
+    beyond the cutoff are masked to exactly zero (the envelope and its first two derivatives vanish there)."""
     emb = model.embedding_layers
     ee = emb.edge_embedding
+    static = graph is not None
     with torch.no_grad():
-        g = hip.build_graph(pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies)
-    eg = _EdgeGraph(g)
+        if static:
+            g = hip.refresh_graph(graph, pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies)
+            eg = getattr(g, '_train_eg', None)
+            if eg is None:
+                eg = g._train_eg = _EdgeGraph(g)
+        else:
+            g = hip.build_graph(pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies)
+            eg = _EdgeGraph(g)
     i, j = g.edge_index[0], g.edge_index[1]
     # disp = pos_i - pos_j - (constant periodic image shift found by the neighbor kernel)
     shift = (pos.detach()[i] - pos.detach()[j]) - g.disp
@@ -99,6 +111,8 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int):
     u = disp / r
     x = r / ee.cutoff
     rbf = _envelope(x) * (torch.sin(ee.embedding.frequencies * x) / x)
+    if static:
+        rbf = rbf * (x < 1.0).to(rbf.dtype)
 
     a = emb.node_embedding(z)
     f = torch.zeros(z.shape[0], 3, emb.n_features, dtype=pos.dtype, device=pos.device)

@@ -140,3 +140,39 @@ def test_bf16_autocast_training_gradients():
             ref_n += want[name].norm().item() ** 2
     assert abs(loss.item() - want_loss.item()) <= 2e-2 * abs(want_loss.item())
     assert np.sqrt(err) <= 2e-2 * np.sqrt(ref_n), (np.sqrt(err), np.sqrt(ref_n))
+
+
+def test_graphed_train_step_matches_eager():
+    """GraphedTrainStep (static candidate list + HIP-graph replay) against the eager TrainStep from the same initial
+    weights over the same three batches: same losses and parameters up to fp32 summation order; a batch of a different
+    structure re-captures."""
+    from newtonnet_amd.distributed import GraphedTrainStep, TrainStep
+    from newtonnet_amd.models import NewtonNet
+
+    def batch_of(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        eth0 = torch.tensor([[0.00, 0.00, 0.00], [1.52, 0.00, 0.00], [2.05, 1.32, 0.00], [-0.39, 1.02, 0.00],
+                             [-0.39, -0.51, 0.89], [-0.39, -0.51, -0.89], [1.90, -0.53, 0.88], [1.90, -0.53, -0.88],
+                             [3.01, 1.30, 0.00]])
+        pos = eth0.repeat(B, 1) + 0.1 * torch.randn(9 * B, 3, generator=g)
+        z = torch.tensor([6, 6, 8, 1, 1, 1, 1, 1, 1]).repeat(B)
+        batch = torch.repeat_interleave(torch.arange(B), 9)
+        return [t.cuda() for t in (z, pos, torch.zeros(B, 3, 3), batch, torch.randn(B, generator=g),
+                                   torch.randn(9 * B, 3, generator=g))]
+
+    def run(cls, **opt_kw):
+        torch.manual_seed(0)
+        model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+        model.train()
+        step = cls(model, torch.optim.Adam(model.parameters(), lr=1e-3, **opt_kw), 1.0, 50.0, 1.0)
+        losses = [float(step(*batch_of(8, s))) for s in (1, 2, 3)]
+        losses.append(float(step(*batch_of(5, 4))))            # different structure
+        losses.append(float(step(*batch_of(8, 5))))            # and back
+        return model, losses, step
+
+    m_e, l_e, _ = run(TrainStep)
+    m_g, l_g, st = run(GraphedTrainStep, capturable=True)
+    assert st.captures == 3
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-4)
+    for (k, a), b in zip(m_e.state_dict().items(), m_g.state_dict().values()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4, err_msg=k)

@@ -4,7 +4,7 @@ clip 1.0 -- GPU train-mode path (fp32 and bf16 autocast) vs the CPU oracle's dou
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from newtonnet_amd.distributed import TrainStep
+from newtonnet_amd.distributed import GraphedTrainStep, TrainStep
 from newtonnet_amd.models import NewtonNet
 from oracle import newtonnet_ref as ref
 
@@ -31,11 +31,19 @@ for B in (10, 32, 256):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(20): step(*args)
             torch.cuda.synchronize(); res[name] = (time.perf_counter() - t0) / 20
+    torch.manual_seed(0)
+    model_g = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda'); model_g.train()
+    gstep = GraphedTrainStep(model_g, torch.optim.Adam(model_g.parameters(), lr=1e-3, capturable=True), 1.0, 50.0, 1.0)
+    for _ in range(3): gstep(*args)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50): gstep(*args)
+    torch.cuda.synchronize(); res['graphed'] = (time.perf_counter() - t0) / 50
     torch.set_num_threads(min(16, os.cpu_count()))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref.training_loss_grads(sd, z, pos, cell, batch, e_lab, f_lab)
     t0 = time.perf_counter(); n = 3
     for _ in range(n): ref.training_loss_grads(sd, z, pos, cell, batch, e_lab, f_lab)
     cpu = (time.perf_counter() - t0) / n
-    print(f'B={B:4d} ({9*B} atoms): GPU train step fp32 {res["fp32"]*1e3:7.2f} ms | bf16 {res["bf16"]*1e3:7.2f} ms | '
-          f'CPU oracle loss+grads {cpu*1e3:8.1f} ms ({torch.get_num_threads()} threads) | speedup {cpu/res["fp32"]:.1f}x', flush=True)
+    print(f'B={B:4d} ({9*B} atoms): GPU train step eager fp32 {res["fp32"]*1e3:7.2f} ms | bf16 {res["bf16"]*1e3:7.2f} ms | '
+          f'HIP-graph replay fp32 {res["graphed"]*1e3:6.2f} ms | CPU oracle loss+grads {cpu*1e3:8.1f} ms '
+          f'({torch.get_num_threads()} threads) | speedup eager {cpu/res["fp32"]:.1f}x graphed {cpu/res["graphed"]:.1f}x', flush=True)
