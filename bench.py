@@ -139,7 +139,22 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
+            # RCCL carries only the launch contract's barrier and the max-over-ranks of the step time: the data path has no
+            # collective.  If RCCL cannot come up on this node, the same two calls run over gloo rather than losing the run.
+            try:
+                dist.init_process_group('nccl', device_id=device)
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001
+                print(f'[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); timing barrier over gloo',
+                      file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = 'gloo'
+                dist.init_process_group('gloo')
         else:
             dist.init_process_group(backend)
 
@@ -164,8 +179,9 @@ def main():
         return model(z, pos, cell, batch)
 
     def sync_all():
+        torch.cuda.synchronize()          # this rank's queued work is done ...
         if dist is not None:
-            dist.barrier()
+            dist.barrier()                # ... on every rank
         torch.cuda.synchronize()
 
     out = None
