@@ -104,11 +104,23 @@ class MLAseCalculator(_Base):
         cell = np.array(getattr(atoms.get_cell(), 'array', atoms.get_cell()), dtype=np.float64).reshape(3, 3).copy()
         cell[~np.asarray(atoms.get_pbc(), dtype=bool)] = 0.0
         st = self._md
-        moved = st is not None and st['z'].shape == z.shape and free.shape == st['ref'].shape and \
-            float(np.max(np.sum((free - st['ref']) ** 2, axis=1))) > (0.5 * self.skin) ** 2
-        if (st is None or moved or st['z'].shape != z.shape or not np.array_equal(st['z'], z)
-                or not np.array_equal(st['cell'], cell)):
+        stale = st is None or st['z'].shape != z.shape or not np.array_equal(st['z'], z) \
+            or not np.array_equal(st['cell'] != 0, cell != 0)
+        if not stale:
+            # Verlet criterion with a moving cell (NPT): a pair inside the cutoff now was inside cutoff + skin at build time
+            # as long as  2 max|dr| + strain * (cutoff + skin) <= skin   (dr: unwrapped displacement since the build)
+            moved = float(np.sqrt(np.max(np.sum((free - st['ref']) ** 2, axis=1))))
+            strain = 0.0
+            if np.any(cell != 0) and not np.array_equal(st['cell'], cell):
+                ref = np.where(st['cell'].any(axis=1, keepdims=True), st['cell'], np.eye(3))
+                cur = np.where(cell.any(axis=1, keepdims=True), cell, np.eye(3))
+                strain = float(np.linalg.norm(np.linalg.solve(ref, cur) - np.eye(3), 2))
+            stale = 2.0 * moved + strain * (st['cutoff'] + self.skin) > self.skin
+        if stale:
             st = self._md_build(z, pos, free, cell)
+        elif not np.array_equal(st['cell_now'], cell):
+            st['cell_now'] = cell.copy()
+            st['cell_dev'].copy_(torch.tensor(cell[None], dtype=torch.float32), non_blocking=False)
         st['pos_host'].copy_(torch.from_numpy(pos.astype(np.float32)))
         st['pos'].copy_(st['pos_host'], non_blocking=True)
         if st['graph'] is not None:
@@ -138,7 +150,8 @@ class MLAseCalculator(_Base):
         n = len(z)
         want_forces = any(isinstance(l, DerivativeProperty) for l in model.output_layers)
         want_virial = any(isinstance(l, (VirialOutput, StressOutput)) for l in model.output_layers)
-        st = dict(z=z.copy(), cell=cell.copy(), ref=free.copy(), graph=None, want_forces=want_forces, want_virial=want_virial)
+        st = dict(z=z.copy(), cell=cell.copy(), cell_now=cell.copy(), ref=free.copy(), graph=None, want_forces=want_forces,
+                  want_virial=want_virial)
         st['z_dev'] = torch.tensor(z, dtype=torch.long, device=dev)
         st['pos'] = torch.tensor(pos, dtype=torch.float32, device=dev)
         st['cell_dev'] = torch.tensor(cell[None], dtype=torch.float32, device=dev)
