@@ -273,6 +273,16 @@ def main():
                                   f'torch CPU with {cores} threads (host has {os.cpu_count()} cores), min of {reps} reps '
                                   f'after 1 warm-up ({best:.2f} s/rep)',
                         'force_mae_gpu_vs_cpu_fp32': float(f_err.mean()), 'force_max_gpu_vs_cpu_fp32': float(f_err.max())}
+        # the same port on ONE thread (SURVEY 8d asks for it beside the multi-thread figure): 32 conformers, ~1-2 s per rep
+        torch.set_num_threads(1)
+        n1 = min(32, n_s)
+        a1 = n1 * 21
+        ref.energy_forces(sd, zc[:a1], pc[:a1], cc[:n1], bc[:a1])
+        t1 = time.perf_counter()
+        ref.energy_forces(sd, zc[:a1], pc[:a1], cc[:n1], bc[:a1])
+        cpu_baseline['single_thread'] = {'value': round(a1 / (time.perf_counter() - t1), 1), 'unit': 'atom-steps/s',
+                                         'sample': f'first {n1} conformers, 1 thread, 1 rep after 1 warm-up'}
+        torch.set_num_threads(cores)
 
     if rank == 0:
         line = {
