@@ -176,3 +176,47 @@ def test_graphed_train_step_matches_eager():
     np.testing.assert_allclose(l_g, l_e, rtol=2e-4)
     for (k, a), b in zip(m_e.state_dict().items(), m_g.state_dict().values()):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4, err_msg=k)
+
+
+def test_molecule_shards_reproduce_the_global_gradient():
+    """BASELINE configs[3] (mixed MD17-shaped molecules, data-parallel training): the per-rank share of the loss, normalised by
+    the GLOBAL element counts (distributed.TrainStep), summed over contiguous molecule shards equals the single-process
+    gradient -- on the real train-mode model, ranks evaluated one after the other on this GPU."""
+    from newtonnet_amd.distributed import shard_molecules
+    from newtonnet_amd.models import NewtonNet
+    rng = np.random.default_rng(11)
+    sizes = [12, 12, 18, 21, 16, 9, 9, 15, 20, 21, 9, 12]       # benzene, uracil, naphthalene, aspirin, ... atom counts
+    zs, ps = [], []
+    for n in sizes:
+        m = int(np.ceil(n ** (1 / 3)))
+        grid = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing='ij'), -1).reshape(-1, 3)[:n] * 1.4
+        ps.append(grid + rng.normal(0, 0.1, grid.shape))
+        zs.append(rng.choice([1, 6, 7, 8], n))
+    z = torch.tensor(np.concatenate(zs), dtype=torch.long).cuda()
+    pos = torch.tensor(np.concatenate(ps), dtype=torch.float32).cuda()
+    batch = torch.tensor(np.concatenate([[b] * n for b, n in enumerate(sizes)]), dtype=torch.long).cuda()
+    e_lab = torch.tensor(rng.normal(size=len(sizes)), dtype=torch.float32).cuda()
+    f_lab = torch.tensor(rng.normal(size=(sum(sizes), 3)), dtype=torch.float32).cuda()
+    torch.manual_seed(3)
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).cuda()
+    model.train()
+    n_e, n_f = float(e_lab.numel()), float(f_lab.numel())
+
+    def grads(m0, m1):
+        a0, a1 = sum(sizes[:m0]), sum(sizes[:m1])
+        model.zero_grad(set_to_none=True)
+        p = pos[a0:a1].clone().requires_grad_(True)
+        out = model(z[a0:a1], p, torch.zeros(m1 - m0, 3, 3, device='cuda'), batch[a0:a1] - m0)
+        loss = (out.energy - e_lab[m0:m1]).pow(2).sum() / n_e + 50.0 * (out.gradient_force - f_lab[a0:a1]).pow(2).sum() / n_f
+        loss.backward()
+        return [q.grad.detach().clone() if q.grad is not None else torch.zeros_like(q) for q in model.parameters()]
+
+    full = grads(0, len(sizes))
+    for world in (2, 3):
+        acc = [torch.zeros_like(g) for g in full]
+        for m0, m1 in shard_molecules(sizes, world):
+            for a, g in zip(acc, grads(m0, m1)):
+                a += g
+        for (name, _), a, g in zip(model.named_parameters(), acc, full):
+            scale = max(float(g.abs().max()), 1e-6)
+            assert float((a - g).abs().max()) <= 2e-4 * scale + 1e-7, name
