@@ -290,6 +290,7 @@ static int launch_mlp_t(const MlpPair& a, hipStream_t s) {
 }
 
 int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s);   // node128.hip
+int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s);
 
 #define MLP_WIDE_MAX_TILES 1536   // up to ~49k rows one workgroup per tile beats the persistent form (tools/bench_mlp.py)
 
@@ -334,8 +335,20 @@ int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1,
   }
   if (a0.M <= 0) return 0;
   if (mlp_use_wide(a0) || mlp_use_wide(a1)) {
-    const int rc = launch_mlp(mode, accum0, a0, s);
-    return rc ? rc : launch_mlp(mode, accum1, a1, s);
+    if (a0.b1 || a0.b2 || a1.b1 || a1.b2 || (mode == MODE_FWD && accum1)) {   // (not a case the path produces)
+      const int rc = launch_mlp(mode, accum0, a0, s);
+      return rc ? rc : launch_mlp(mode, accum1, a1, s);
+    }
+    ScopedTimer t0(TC_LIN, s);
+    ScopedTimer t1(TC_MLP, s);
+    MlpPair W;
+    W.a[0] = a0;
+    W.a[1] = a1;
+    if (W.a[0].h_frag) W.a[0].ldh = W.a[1].ldh = NF;   // row-major inside the same pad32(M) x 128 region
+    W.n = 2;
+    W.accum[0] = 0;
+    W.accum[1] = accum1 ? 1 : 0;
+    return launch_mlp_wide_pair(mode, W, s);
   }
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1(TC_MLP, s);

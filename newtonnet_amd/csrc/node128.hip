@@ -267,14 +267,8 @@ int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
 // kernel costs one 512-MFMA chain plus a 132 KiB LDS fill even for a single tile (~35 us); this one runs two 64-MFMA
 // chains (~10 us).  Used for the single-molecule / MD-loop regime (MLAseCalculator, ase_interface.py:52-81).
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool ACCUM>
-__global__ void __launch_bounds__(256) mlp128_wide_kernel(const MlpArgs p) {
-  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
-  Tile t;
-  t.xs = xs;
-  t.r = threadIdx.x & 31;
-  t.h = (threadIdx.x >> 5) & 1;
-  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+template <int MODE>
+__device__ __forceinline__ void mlp_wide_body(const MlpArgs& p, const bool accum, Tile& t) {
   const int row = blockIdx.x * 32 + t.r;
   const int rc = min(row, p.M - 1);
   const bool live = row < p.M;
@@ -313,13 +307,47 @@ __global__ void __launch_bounds__(256) mlp128_wide_kernel(const MlpArgs p) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += b[k];
   }
-  if (ACCUM) {
+  if (accum) {   // uniform
     float yold[16];
     blk_load(yold, p.Y, (size_t)rc * p.ldy, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] += yold[k];
   }
   if (live) blk_store(y, p.Y, (size_t)row * p.ldy, t);
+}
+
+template <int MODE, bool ACCUM>
+__global__ void __launch_bounds__(256) mlp128_wide_kernel(const MlpArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  mlp_wide_body<MODE>(p, ACCUM, t);
+}
+
+// Two MLPs over the same rows in ONE launch of the small-M form (the single-molecule / MD-loop regime is bound by the number
+// of dependent dispatches, ~8 us each).  Forward: phi1 and phi2 are independent -- blockIdx.y picks the MLP.  Adjoint: the
+// second term accumulates onto the first one's g_msg rows, which the same lanes of the same workgroup wrote -- run in order.
+template <int MODE>
+__global__ void __launch_bounds__(256) mlp128_wide_pair_kernel(const MlpPair P) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (MODE == MODE_FWD) {
+    if (blockIdx.y == 0)
+      mlp_wide_body<MODE>(P.a[0], false, t);
+    else
+      mlp_wide_body<MODE>(P.a[1], false, t);
+  } else {
+    mlp_wide_body<MODE>(P.a[0], false, t);
+    __syncthreads();                     // the LDS tile is reused
+    mlp_wide_body<MODE>(P.a[1], P.accum[1] != 0, t);
+  }
 }
 
 int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
@@ -330,6 +358,18 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
     mlp128_wide_kernel<MODE_BWD, false><<<n_tiles, 256, 0, s>>>(a);
   else if (mode == MODE_BWD && accum)
     mlp128_wide_kernel<MODE_BWD, true><<<n_tiles, 256, 0, s>>>(a);
+  else
+    return NNHIP_E_INVALID;
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s) {
+  const int n_tiles = cdiv(P.a[0].M, 32);
+  if (mode == MODE_FWD)
+    mlp128_wide_pair_kernel<MODE_FWD><<<dim3(n_tiles, 2), 256, 0, s>>>(P);
+  else if (mode == MODE_BWD)
+    mlp128_wide_pair_kernel<MODE_BWD><<<n_tiles, 256, 0, s>>>(P);
   else
     return NNHIP_E_INVALID;
   LAUNCH_CHECK();
