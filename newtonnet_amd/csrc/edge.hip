@@ -77,7 +77,11 @@ __device__ __forceinline__ float4 ld4p(const float* p) {
 #endif
 
 __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
+#ifdef EDGE_NO_XCD_MAP   // tooling: A/B the XCD-aware block -> row-range map
+  const int tile = blockIdx.x;
+#else
   const int tile = xcd_tile(blockIdx.x, n_rows_padded_blocks);
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   return tile * ROWS_PER_BLOCK + wave;
 }
