@@ -25,6 +25,9 @@
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves = 256 threads
+#ifndef EDGE_ROWS
+#define EDGE_ROWS 4       // receiver rows (waves) per workgroup of the four edge kernels (2 and 8 measured: no difference)
+#endif
 
 // Cache-policy switches (streaming = non-temporal), kept for A/B timing (-DEDGE_NT_x=1).  Measured on config 2: streaming
 // the non-owning endpoint's read of a pair row COSTS 10-20 % in force_fwd / force_bwd / msg_bwd (those reads do hit in L2
@@ -83,7 +86,7 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
   const int tile = xcd_tile(blockIdx.x, n_rows_padded_blocks);
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  return tile * ROWS_PER_BLOCK + wave;
+  return tile * EDGE_ROWS + wave;
 }
 
 // Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx by cubic interpolation of
@@ -149,7 +152,7 @@ __device__ __forceinline__ int row_mid(const int* __restrict__ col, int beg, int
 // forward: message + invariant aggregation
 //   msg[pid e] = eps_e * m[i] * m[j] (written by the row with i < j);  a_mid[i] = a_in[i] + sum_{e in row i} msg_e
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * EDGE_ROWS)
 msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                const float* __restrict__ a_in, float* __restrict__ msg /*[P][F]*/, float* __restrict__ a_mid,
@@ -193,7 +196,7 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
 // HAS_F = false for the first layer, where force_node == 0 (newtonnet.py:143): the phi2 term vanishes.
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restrict__ phi2, const float* __restrict__ geo,
                  const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                  const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms) {
@@ -252,7 +255,7 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
 //   g_phi2[p]   = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]     -> g_h12[p][F:2F]
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
@@ -354,7 +357,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 // NEED_GM = false for the first layer: its m = message_nodepart(Embedding[z]) does not depend on the positions, so g_m is
 // never used and the rows only visit the pairs they own (for g_x).
 template <bool NEED_GM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * EDGE_ROWS)
 msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
                const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (used by pipeline.hip)
 // ---------------------------------------------------------------------------------------------
-static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, ROWS_PER_BLOCK); }
+static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, EDGE_ROWS); }
 // tooling: NNHIP_EDGE_LDS=<bytes> attaches unused dynamic LDS to the edge kernels to cap their occupancy
 static inline size_t edge_lds() {
   static const size_t v = getenv("NNHIP_EDGE_LDS") ? (size_t)atol(getenv("NNHIP_EDGE_LDS")) : 0;
@@ -652,7 +655,7 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<<<row_blocks(n_atoms), 256, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
+  msg_fwd_kernel<<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
                                                      msg, a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
@@ -663,9 +666,9 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   else
-    force_fwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -676,10 +679,10 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    force_bwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                g_fin, n_atoms);
   else
-    force_bwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                 g_fin, n_atoms);
   LAUNCH_CHECK();
   return 0;
@@ -691,10 +694,10 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   if (need_gm)
-    msg_bwd_kernel<true><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                             row_ptr, col, pid, g_m, g_x, n_atoms);
   else
-    msg_bwd_kernel<false><<<row_blocks(n_atoms), 256, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                              row_ptr, col, pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;
