@@ -36,6 +36,19 @@ extern "C" {
 #define NNHIP_MAX_LAYERS 8
 #define NNHIP_N_ELEMENTS 119 /* rows of node_embedding / scale / shift (z = 0..118) */
 
+/* activation ids (newtonnet/layers/activations.py:5-30); 'swish' and 'silu' are both NNHIP_ACT_SILU */
+enum {
+  NNHIP_ACT_SILU = 0,
+  NNHIP_ACT_RELU = 1,
+  NNHIP_ACT_ELU = 2,
+  NNHIP_ACT_LEAKY_RELU = 3,
+  NNHIP_ACT_TANH = 4,
+  NNHIP_ACT_SIGMOID = 5,
+  NNHIP_ACT_SOFTPLUS = 6,
+  NNHIP_ACT_GELU = 7,
+  NNHIP_ACT_SSP = 8
+};
+
 enum {
   NNHIP_OK = 0,
   NNHIP_E_INVALID = 1,      /* bad argument */
@@ -85,6 +98,7 @@ typedef struct {
   const float* head4_b; /* [1] */
   const float* scale;   /* scalers.k.scale.weight [119] (NULL = 1) */
   const float* shift;   /* scalers.k.shift.weight [119] (NULL = 0) */
+  int32_t activation;   /* NNHIP_ACT_* of every MLP of the model (constructor argument `activation`, newtonnet.py:30) */
 } nnhip_model;
 
 /* --------------------------------------------------------------------------
@@ -254,7 +268,7 @@ int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const float* W2, 
  * ------------------------------------------------------------------------ */
 int nnhip_direct_force(const float* atom_node, const float* force_node, const int64_t* z, const float* w0, const float* b0,
                        const float* w2, const float* b2, const float* w4, const float* b4, const float* scale,
-                       int32_t n_atoms, float* scratch, float* out, void* stream);
+                       int32_t activation, int32_t n_atoms, float* scratch, float* out, void* stream);
 
 /* --------------------------------------------------------------------------
  * Differentiable building blocks of the train-mode forward (both are linear maps and each other's adjoints, so

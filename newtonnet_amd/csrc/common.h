@@ -54,6 +54,61 @@ __device__ __forceinline__ float dsilu_f(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// The other activations of the reference's factory (newtonnet/layers/activations.py:5-30; torch defaults: ELU alpha 1,
+// LeakyReLU slope 0.01, Softplus beta 1 / threshold 20, exact-erf GELU, ShiftedSoftplus = softplus - ln 2).  SiLU is the
+// default of every published config and keeps its own fast path (NNHIP_ACT_SILU = 0: the kernels branch on it once,
+// wave-uniformly); the rest use the accurate libm forms -- nobody tunes for them.
+__device__ __forceinline__ float act_f(float x, int a) {
+  switch (a) {
+    case NNHIP_ACT_RELU: return fmaxf(x, 0.f);
+    case NNHIP_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case NNHIP_ACT_LEAKY_RELU: return x > 0.f ? x : 0.01f * x;
+    case NNHIP_ACT_TANH: return tanhf(x);
+    case NNHIP_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case NNHIP_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+    case NNHIP_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case NNHIP_ACT_SSP: return (x > 20.f ? x : log1pf(expf(x))) - 0.69314718055994531f;
+    default: return silu_f(x);
+  }
+}
+__device__ __forceinline__ float dact_f(float x, int a) {
+  switch (a) {
+    case NNHIP_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case NNHIP_ACT_ELU: return x > 0.f ? 1.f : expf(x);
+    case NNHIP_ACT_LEAKY_RELU: return x > 0.f ? 1.f : 0.01f;
+    case NNHIP_ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.f - t * t;
+    }
+    case NNHIP_ACT_SIGMOID: {
+      const float g = 1.0f / (1.0f + expf(-x));
+      return g * (1.f - g);
+    }
+    case NNHIP_ACT_SOFTPLUS:
+    case NNHIP_ACT_SSP: return x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+    case NNHIP_ACT_GELU:
+      return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    default: return dsilu_f(x);
+  }
+}
+// apply to a register block: one wave-uniform test keeps the SiLU loop exactly as it was
+#define NN_ACT_BLOCK(v, n, a)                                            \
+  do {                                                                   \
+    if ((a) == NNHIP_ACT_SILU) {                                         \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_)(v)[k_] = silu_f((v)[k_]);  \
+    } else {                                                             \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_)(v)[k_] = act_f((v)[k_], (a)); \
+    }                                                                    \
+  } while (0)
+#define NN_DACT_MUL_BLOCK(v, pre, n, a)                                  \
+  do {                                                                   \
+    if ((a) == NNHIP_ACT_SILU) {                                         \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_)(v)[k_] *= dsilu_f((pre)[k_]);  \
+    } else {                                                             \
+      _Pragma("unroll") for (int k_ = 0; k_ < (n); ++k_)(v)[k_] *= dact_f((pre)[k_], (a)); \
+    }                                                                    \
+  } while (0)
+
 // Wave-wide sum on the DPP path (register-to-register cross-lane moves, a few cycles each; __shfl_xor compiles to
 // ds_bpermute_b32, an LDS-pipe round trip of ~100 cycles per step, and six of those in a row were a third of the per-edge
 // latency chain of the message / force adjoints).  quad_perm swaps -> row_half_mirror -> row_mirror leave the 16-lane row
@@ -160,6 +215,7 @@ struct LinArgs {
   LinGroup g[2];      // blockIdx.y selects (two independent linears of the same shape in one launch)
   int M;
   int lda, ldc, ldh;  // row strides in floats
+  int act;            // NNHIP_ACT_* applied where PRO_SILU / EPI_DSILU say "SiLU" (0 = SiLU)
 };
 int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s);
 
@@ -174,6 +230,7 @@ struct MlpArgs {
   int M, ldx, ldh, ldy;
   const float* b1;  // optional biases (node MLP / energy head; forward mode, row-local small-M kernel only)
   const float* b2;
+  int act;          // NNHIP_ACT_* (0 = SiLU)
   int h_frag;       // H is private scratch between a forward call and its adjoint (same M): the persistent kernel then keeps
                     // it in MFMA-fragment order ([tile][block][q][lane] float4: every access a contiguous 1 KiB, so the
                     // streaming stores write whole lines) in a region of pad32(M) x 128 floats; ldh is ignored
@@ -196,6 +253,7 @@ struct NodeFwdArgs {
   const float *W0, *b0, *W2, *b2;  // next layer's message_nodepart (W0 == NULL: no next layer)
   float *hn, *m;       // [N][F] out (next layer)
   int N;
+  int act;             // NNHIP_ACT_* of the fused message_nodepart / head MLP
 };
 struct NodeBwdArgs {
   const float* g_top;  // [N][F]  g_m of the upper layer (or g_e2 at the head)
@@ -209,6 +267,7 @@ struct NodeBwdArgs {
   float* gf;           // [N][3][F] out
   int N;
   int acc_ga;
+  int act;
 };
 int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s);
 int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);

@@ -596,18 +596,23 @@ layer_norm_bwd_kernel(float* __restrict__ g_a /*in: dE/dy, out: dE/dx*/, const f
 __global__ void __launch_bounds__(256)
 head_out_kernel(const float* __restrict__ e2, const float* __restrict__ w4, const float* __restrict__ b4,
                 const float* __restrict__ scale, const float* __restrict__ shift, const int64_t* __restrict__ z,
-                int n_atoms, float* __restrict__ atom_energy, float* __restrict__ g_e2) {
+                int n_atoms, int act, float* __restrict__ atom_energy, float* __restrict__ g_e2) {
   const int i = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   const float2 h = ld2(e2 + (size_t)i * NF + 2 * lane);
   const float2 w = ld2(w4 + 2 * lane);
-  const float s = wave_sum(fmaf(silu_f(h.x), w.x, silu_f(h.y) * w.y));
+  const bool silu = act == NNHIP_ACT_SILU;   // uniform
+  const float ax = silu ? silu_f(h.x) : act_f(h.x, act), ay = silu ? silu_f(h.y) : act_f(h.y, act);
+  const float s = wave_sum(fmaf(ax, w.x, ay * w.y));
   const long zi = z[i];
   const float sc = scale ? scale[zi] : 1.0f;
   const float sh = shift ? shift[zi] : 0.0f;
   if (lane == 0) atom_energy[i] = fmaf(s + b4[0], sc, sh);
-  if (g_e2) st2(g_e2 + (size_t)i * NF + 2 * lane, make_float2(sc * w.x * dsilu_f(h.x), sc * w.y * dsilu_f(h.y)));
+  if (g_e2) {
+    const float dx = silu ? dsilu_f(h.x) : dact_f(h.x, act), dy = silu ? dsilu_f(h.y) : dact_f(h.y, act);
+    st2(g_e2 + (size_t)i * NF + 2 * lane, make_float2(sc * w.x * dx, sc * w.y * dy));
+  }
 }
 
 // E_b = sum of atom energies of molecule b  (output.py:246).  One wave per molecule, fp64 partial sums in a fixed
@@ -745,10 +750,10 @@ int launch_embed(const int64_t* z, const float* table, const float* m_table, int
 }
 
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
-                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
+                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
-  head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, atom_energy, g_e2);
+  head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, act, atom_energy, g_e2);
   LAUNCH_CHECK();
   mol_energy_kernel<<<cdiv(n_mol, ROWS_PER_BLOCK), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
   LAUNCH_CHECK();

@@ -57,7 +57,7 @@ __device__ __forceinline__ void lin_epilogue_nt(const f32x16& acc, const float (
     if (!CHECK || row0 + 4 * h + dr < p.M) {
       float v = acc[k];
       if (EPI == EPI_BIAS) v += bias;
-      if (EPI == EPI_DSILU) v *= dsilu_f(pre[k]);
+      if (EPI == EPI_DSILU) v *= (p.act == NNHIP_ACT_SILU) ? dsilu_f(pre[k]) : dact_f(pre[k], p.act);
       if (EPI == EPI_ACC) v += pre[k];
       cbase[(size_t)dr * p.ldc] = v;
     }
@@ -83,13 +83,20 @@ __device__ __forceinline__ void lin_load_a(float4 (&a)[16], const float* A, int 
 #pragma unroll
   for (int t = 0; t < 16; ++t) a[t] = ap[2 * t];
 }
-__device__ __forceinline__ void lin_silu_a(float4 (&a)[16]) {
+__device__ __forceinline__ void lin_silu_a(float4 (&a)[16], const int act) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
-    a[t].x = silu_f(a[t].x);
-    a[t].y = silu_f(a[t].y);
-    a[t].z = silu_f(a[t].z);
-    a[t].w = silu_f(a[t].w);
+    if (act == NNHIP_ACT_SILU) {
+      a[t].x = silu_f(a[t].x);
+      a[t].y = silu_f(a[t].y);
+      a[t].z = silu_f(a[t].z);
+      a[t].w = silu_f(a[t].w);
+    } else {
+      a[t].x = act_f(a[t].x, act);
+      a[t].y = act_f(a[t].y, act);
+      a[t].z = act_f(a[t].z, act);
+      a[t].w = act_f(a[t].w, act);
+    }
   }
 }
 
@@ -138,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) lin128_kernel(const LinArgs p) {
     const int row0 = tile << 5;
     // unconditional (clamped) prefetch: a branch here would make the pass assume the shorter queue
     if (!LIN_ABLATE_NO_LOAD) lin_load_a(a_next, G.A, p.lda, min((min(tile + tile_step, n_tiles - 1) << 5) + r, p.M - 1), h);
-    if (PRO == PRO_SILU) lin_silu_a(a);
+    if (PRO == PRO_SILU) lin_silu_a(a, p.act);
     const bool full = row0 + 32 <= p.M;  // wave-uniform: only the last tile pays for per-row predicates
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {

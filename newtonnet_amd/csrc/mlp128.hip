@@ -64,7 +64,9 @@ __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int 
 // terms of g_msg).  A launch costs ~15 us before the matrix pipes are busy (every wave's first X tile -- 33 MB -- and
 // 256 copies of the weights are requested at once) and the same again in stragglers at the end; the second phase only
 // restages the weights (L2 hits, the next X tile is already in flight) and reuses the running pipeline.
-template <int MODE, bool ACCUM_LAST>   // ACCUM_LAST: the last phase adds its result to Y (P.accum is checked by the host)
+// ACCUM_LAST: the last phase adds its result to Y (P.accum is checked by the host).  GEN_ACT: an activation other than SiLU
+// (P.a[0].act); the SiLU instantiation is untouched by it.
+template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
 __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* w1s = wl;
@@ -184,14 +186,14 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
           }
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) hs[nb][k] = silu_f(acc[k]);
+        for (int k = 0; k < 16; ++k) hs[nb][k] = GEN_ACT ? act_f(acc[k], P.a[0].act) : silu_f(acc[k]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          hs[nb][4 * q] = acc[4 * q] * dsilu_f(hin[q].x);
-          hs[nb][4 * q + 1] = acc[4 * q + 1] * dsilu_f(hin[q].y);
-          hs[nb][4 * q + 2] = acc[4 * q + 2] * dsilu_f(hin[q].z);
-          hs[nb][4 * q + 3] = acc[4 * q + 3] * dsilu_f(hin[q].w);
+          hs[nb][4 * q] = acc[4 * q] * (GEN_ACT ? dact_f(hin[q].x, P.a[0].act) : dsilu_f(hin[q].x));
+          hs[nb][4 * q + 1] = acc[4 * q + 1] * (GEN_ACT ? dact_f(hin[q].y, P.a[0].act) : dsilu_f(hin[q].y));
+          hs[nb][4 * q + 2] = acc[4 * q + 2] * (GEN_ACT ? dact_f(hin[q].z, P.a[0].act) : dsilu_f(hin[q].z));
+          hs[nb][4 * q + 3] = acc[4 * q + 3] * (GEN_ACT ? dact_f(hin[q].w, P.a[0].act) : dsilu_f(hin[q].w));
         }
       }
     }
@@ -273,18 +275,18 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
 #endif
 }
 
-template <int MODE, bool ACCUM_LAST>
+template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
 static int launch_mlp_t(const MlpPair& a, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM_LAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                MLP_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES));
     attr_set = true;
   }
   const int n_tiles = (a.a[0].M + 31) / 32;
   int blocks = cdiv(n_tiles, 8);
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU (135 KiB of LDS each)
-  mlp128_kernel<MODE, ACCUM_LAST><<<blocks, 512, MLP_LDS_BYTES, s>>>(a);
+  mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT><<<blocks, 512, MLP_LDS_BYTES, s>>>(a);
   LAUNCH_CHECK();
   return 0;
 }
@@ -295,9 +297,14 @@ int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s);
 #define MLP_WIDE_MAX_TILES 1536   // up to ~49k rows one workgroup per tile beats the persistent form (tools/bench_mlp.py)
 
 static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipStream_t s) {
-  if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false>(P, s);
-  if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false>(P, s);
-  if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true>(P, s);
+  if (P.a[0].act != NNHIP_ACT_SILU) {
+    if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false, true>(P, s);
+    if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false, true>(P, s);
+    if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true, true>(P, s);
+  }
+  if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false, false>(P, s);
+  if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false, false>(P, s);
+  if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true, false>(P, s);
   nnhip_set_error("launch_mlp: unsupported mode %d/%d", mode, (int)accum_last);
   return NNHIP_E_INVALID;
 }
@@ -329,7 +336,7 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
 
 // Two MLPs over the same rows in one persistent launch (phi1 | phi2 forward; the two terms of g_msg in the adjoint).
 int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s) {
-  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0 || a0.h_frag != a1.h_frag) {   // (only the last phase may accumulate)
+  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0 || a0.h_frag != a1.h_frag || a0.act != a1.act) {   // (only the last phase may accumulate)
     nnhip_set_error("launch_mlp_pair: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -379,6 +386,7 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
   a.ldh = ldh;
   a.ldy = ldy;
   a.b1 = a.b2 = nullptr;
+  a.act = NNHIP_ACT_SILU;
   a.h_frag = 0;   // the C ABI exposes H row-major
   return launch_mlp(mode, accumulate != 0, a, (hipStream_t)stream);
 }

@@ -159,8 +159,7 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
   if (live) blk_store<NODE_NT != 0>(hn, p.hn, (size_t)row * NF, t);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) hn[k] = silu_f(hn[k]);
+  NN_ACT_BLOCK(hn, 16, p.act);
   __syncthreads();
   blk_to_tile(hn, t);
   __syncthreads();
@@ -195,8 +194,7 @@ __global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
     __syncthreads();
     acc_to(g, tile_gemm(t, wf));
     load_w(wf, t, p.W0T);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
+    NN_DACT_MUL_BLOCK(g, hpre, 16, p.act);
     __syncthreads();
     blk_to_tile(g, t);
     __syncthreads();
@@ -290,11 +288,9 @@ __device__ __forceinline__ void mlp_wide_body(const MlpArgs& p, const bool accum
       for (int k = 0; k < 16; ++k) hv[k] += b[k];
     }
     if (live) blk_store(hv, p.H, (size_t)row * p.ldh, t);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hv[k] = silu_f(hv[k]);
+    NN_ACT_BLOCK(hv, 16, p.act);
   } else {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
+    NN_DACT_MUL_BLOCK(hv, hin, 16, p.act);
   }
   __syncthreads();
   blk_to_tile(hv, t);
@@ -403,9 +399,11 @@ direct_force_tail_kernel(const float* __restrict__ d, const float* __restrict__ 
 
 extern "C" int nnhip_direct_force(const float* atom_node, const float* force_node, const int64_t* z, const float* w0,
                                   const float* b0, const float* w2, const float* b2, const float* w4, const float* b4,
-                                  const float* scale, int32_t n_atoms, float* scratch, float* out, void* stream_) {
+                                  const float* scale, int32_t activation, int32_t n_atoms, float* scratch, float* out,
+                                  void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
-  if (!atom_node || !force_node || !z || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !scratch || !out || n_atoms < 0) {
+  if (!atom_node || !force_node || !z || !w0 || !b0 || !w2 || !b2 || !w4 || !b4 || !scratch || !out || n_atoms < 0 ||
+      activation < NNHIP_ACT_SILU || activation > NNHIP_ACT_SSP) {
     nnhip_set_error("nnhip_direct_force: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -424,6 +422,7 @@ extern "C" int nnhip_direct_force(const float* atom_node, const float* force_nod
   a.ldx = a.ldh = a.ldy = NF;
   a.b1 = b0;
   a.b2 = b2;
+  a.act = activation;
   int rc = launch_mlp(MODE_FWD, false, a, s);
   if (rc) return rc;
   LinArgs l;
@@ -431,6 +430,7 @@ extern "C" int nnhip_direct_force(const float* atom_node, const float* force_nod
   l.g[0] = {e2, w4, d, b4, nullptr};
   l.M = n_atoms;
   l.lda = l.ldc = NF;
+  l.act = activation;
   rc = launch_lin(PRO_SILU, EPI_BIAS, l, 1, s);
   if (rc) return rc;
   direct_force_tail_kernel<<<cdiv(n_atoms, 4), 256, 0, s>>>(d, force_node, scale, z, n_atoms, out);

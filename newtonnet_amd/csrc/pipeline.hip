@@ -36,7 +36,7 @@ int launch_layer_norm_bwd(float* g_a, const float* gamma, const float* xhat, con
 int launch_embed(const int64_t* z, const float* table, const float* m_table, int n_atoms, float* a0, float* m0,
                  hipStream_t s);
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
-                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, float* atom_energy, float* g_e2,
+                    const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s);
 int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
 
@@ -276,7 +276,7 @@ static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pba
   // not kept per atom: its adjoint is never needed, the embedding does not depend on the positions.)
   const nnhip_layer_params& l0 = model->layer[0];
   TRY(launch_mlp(MODE_FWD, false, {model->node_embedding, l0.node0_w, l0.node2_w, Q(pq.hn_tab), Q(pq.m_tab), NNHIP_N_ELEMENTS,
-                                   NF, NF, NF, l0.node0_b, l0.node2_b}, s));
+                                   NF, NF, NF, l0.node0_b, l0.node2_b, model->activation}, s));
   return NNHIP_OK;
 }
 
@@ -330,6 +330,11 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     return NNHIP_E_UNSUPPORTED;
   }
   const int L = model->n_layers;
+  const int act = model->activation;
+  if (act < NNHIP_ACT_SILU || act > NNHIP_ACT_SSP) {
+    nnhip_set_error("nnhip_energy_forces: unknown activation id %d", act);
+    return NNHIP_E_UNSUPPORTED;
+  }
   for (int l = 0; l < L; ++l)
     if ((model->layer[l].ln_w == nullptr) != (model->layer[l].ln_b == nullptr)) {
       nnhip_set_error("nnhip_energy_forces: layer %d has only one of layer_norm.weight / .bias", l);
@@ -389,6 +394,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, NF, NF};
       MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
+      m1.act = m2.act = act;
       if (has_f)
         TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
       else
@@ -423,6 +429,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
         na.m = P(w.pub.e2);
       }
       na.N = N;
+      na.act = act;
       TRY(launch_node_fwd(na, s));
     }
     if (lp.ln_w) {   // layer_norm=True (newtonnet.py:228-231): normalise in place, then the next message_nodepart unfused
@@ -430,7 +437,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       if (l + 1 < L) {
         const nnhip_layer_params& nx = model->layer[l + 1];
         TRY(launch_mlp(MODE_FWD, false, {A_OUT(l), nx.node0_w, nx.node2_w, P(w.pub.hn[l + 1]), P(w.pub.m[l + 1]), N, NF, NF,
-                                         NF, nx.node0_b, nx.node2_b}, s));
+                                         NF, nx.node0_b, nx.node2_b, act}, s));
       }
     }
     a_in = A_OUT(l);
@@ -439,10 +446,10 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   // energy head (fused into the last node launch unless that layer ends in a LayerNorm)
   if (model->layer[L - 1].ln_w)
     TRY(launch_mlp(MODE_FWD, false, {a_in, model->head0_w, model->head2_w, P(w.pub.e1), P(w.pub.e2), N, NF, NF, NF,
-                                     model->head0_b, model->head2_b}, s));
+                                     model->head0_b, model->head2_b, act}, s));
   float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
   TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
-                      atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
+                      act, atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
   if (!want_forces) return NNHIP_OK;
 
   // ------------------------------------------------------------------ reverse sweep
@@ -463,6 +470,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nb.WuT = Q(pq.wT[L - 1][6]);
     nb.gf = P(w.gf_mid);
     nb.N = N;
+    nb.act = act;
     const nnhip_layer_params& top = model->layer[L - 1];
     if (top.ln_w) {   // the LayerNorm adjoint sits between the head adjoint and the update adjoint: three launches
       NodeBwdArgs head = nb;
@@ -491,6 +499,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, NF, NF};
       MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
+      m1.act = m2.act = act;
       if (has_f)
         TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
       else
@@ -517,6 +526,8 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       nb.WuT = Q(pq.wT[l - 1][6]);
       nb.gf = P(w.gf_mid);
       nb.N = N;
+      nb.act = act;
+    nb.act = act;
       const nnhip_layer_params& below = model->layer[l - 1];
       if (below.ln_w) {
         NodeBwdArgs mlp = nb;

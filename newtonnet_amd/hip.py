@@ -20,6 +20,9 @@ BUILD_SCRIPT = os.path.join(_HERE, 'csrc', 'build.sh')
 NNHIP_F = 128
 NNHIP_NB = 20
 NNHIP_MAX_NB = 32
+# activation ids of include/newtonnet_hip.h, keyed by the reference's factory names (activations.py:5-30)
+ACTIVATION_IDS = {'swish': 0, 'silu': 0, 'relu': 1, 'elu': 2, 'leaky_relu': 3, 'tanh': 4, 'sigmoid': 5, 'softplus': 6,
+                  'gelu': 7, 'ssp': 8}
 NNHIP_MAX_LAYERS = 8
 N_TIMER_CLASSES = 10
 TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',
@@ -38,7 +41,8 @@ class Model(C.Structure):
                 ('node_embedding', C.c_void_p), ('frequencies', C.c_void_p),
                 ('layer', LayerParams * NNHIP_MAX_LAYERS),
                 ('head0_w', C.c_void_p), ('head0_b', C.c_void_p), ('head2_w', C.c_void_p), ('head2_b', C.c_void_p),
-                ('head4_w', C.c_void_p), ('head4_b', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+                ('head4_w', C.c_void_p), ('head4_b', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('activation', C.c_int32)]
 
 
 class WsLayout(C.Structure):
@@ -96,7 +100,7 @@ def lib():
     L.nnhip_prepare.argtypes = [C.POINTER(Model), vp, sz, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
-    L.nnhip_direct_force.argtypes = [vp] * 10 + [i32, vp, vp, vp]
+    L.nnhip_direct_force.argtypes = [vp] * 10 + [i32, i32, vp, vp, vp]
     L.nnhip_segment_sum.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_timers_enable.argtypes = [i32]
@@ -315,14 +319,16 @@ def mlp128(X: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, H: torch.Tensor,
     return Y
 
 
-def direct_force(atom_node: torch.Tensor, force_node: torch.Tensor, z: torch.Tensor, head, scale) -> torch.Tensor:
-    """direct_force head (output.py:115-132): head = nn.Sequential(Linear, act, Linear, act, Linear); scale [119,1] or None."""
+def direct_force(atom_node: torch.Tensor, force_node: torch.Tensor, z: torch.Tensor, head, scale,
+                 activation: int = 0) -> torch.Tensor:
+    """direct_force head (output.py:115-132): head = nn.Sequential(Linear, act, Linear, act, Linear); scale [119,1] or None;
+    activation = ACTIVATION_IDS[name]."""
     N = atom_node.shape[0]
     out = torch.empty(N, 3, dtype=torch.float32, device=atom_node.device)
     scratch = torch.empty(3 * max(N, 1) * NNHIP_F, dtype=torch.float32, device=atom_node.device)
     _check(lib().nnhip_direct_force(_ptr(atom_node), _ptr(force_node), _ptr(z), _ptr(head[0].weight), _ptr(head[0].bias),
                                     _ptr(head[2].weight), _ptr(head[2].bias), _ptr(head[4].weight), _ptr(head[4].bias),
-                                    _ptr(scale), N, _ptr(scratch), _ptr(out), _stream(atom_node.device)),
+                                    _ptr(scale), int(activation), N, _ptr(scratch), _ptr(out), _stream(atom_node.device)),
            'nnhip_direct_force')
     return out
 

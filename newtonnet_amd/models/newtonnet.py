@@ -95,7 +95,7 @@ class NewtonNet(nn.Module):
             raise NotImplementedError(f'HIP kernels are built for n_features={hip.NNHIP_F}, n_basis<={hip.NNHIP_MAX_NB}, '
                                       f'1..{hip.NNHIP_MAX_LAYERS} interactions (got {F}, {nb}, {L})')
         if self.activation_name not in HIP_FUSED:
-            raise NotImplementedError(f"HIP kernels fuse SiLU only (activation='{self.activation_name}')")
+            raise NotImplementedError(f"activation '{self.activation_name}' is not fused into the HIP kernels")
 
         def p(t):
             if t.dtype != torch.float32 or not t.is_cuda:
@@ -129,6 +129,7 @@ class NewtonNet(nn.Module):
         sc = self.scalers[energy_idx]
         m.scale = p(sc.scale.weight) if sc.scale is not None else None
         m.shift = p(sc.shift.weight) if sc.shift is not None else None
+        m.activation = hip.ACTIVATION_IDS[self.activation_name]
         return m
 
     # ------------------------------------------------------------------------------------------
@@ -202,7 +203,8 @@ class NewtonNet(nn.Module):
                 with torch.no_grad():
                     outputs.direct_force = hip.direct_force(res['atom_node'], res['force_node'], zc,
                                                             self.output_layers[k].layers,
-                                                            sc.weight if sc is not None else None)
+                                                            sc.weight if sc is not None else None,
+                                                            hip.ACTIVATION_IDS[self.activation_name])
         return outputs
 
     # ------------------------------------------------------------------------------------------
@@ -229,7 +231,7 @@ class NewtonNet(nn.Module):
         if 'direct_force' in keys:      # output.py:130-132 + scalers.py:55-56, plain differentiable torch
             k = keys.index('direct_force')
             head = self.output_layers[k].layers
-            d = head[4](torch.nn.functional.silu(head[2](torch.nn.functional.silu(head[0](atom_node)))))
+            d = head(atom_node)      # Linear, act, Linear, act, Linear
             df = (d.unsqueeze(1) * force_node).sum(dim=-1)
             if self.scalers[k].scale is not None:
                 df = df * self.scalers[k].scale(z)

@@ -62,7 +62,8 @@ def _envelope(x, p=9):
 
 
 def _mlp(seq, x):
-    return _lin(Fn.silu(_lin(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
+    """Linear -> activation -> Linear; seq[1] is the model's activation module (SiLU by default)."""
+    return _lin(seq[1](_lin(x, seq[0].weight, seq[0].bias)), seq[2].weight, seq[2].bias)
 
 
 class _Fp32(torch.autograd.Function):
@@ -132,7 +133,7 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
             a = il.layer_norm(a)
 
     head = model.output_layers[energy_idx].layers
-    e = _lin(Fn.silu(_lin(Fn.silu(_lin(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),
+    e = _lin(head[3](_lin(head[1](_lin(a, head[0].weight, head[0].bias)), head[2].weight, head[2].bias)),
              head[4].weight, head[4].bias)
     sc = model.scalers[energy_idx]
     if sc.scale is not None:

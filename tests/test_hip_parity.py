@@ -434,3 +434,39 @@ def test_other_basis_and_depth(n_basis, n_interactions):
     e = want['energy'].numpy()
     assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e))
     check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy())
+
+
+@pytest.mark.parametrize('activation', ['relu', 'elu', 'leaky_relu', 'tanh', 'sigmoid', 'softplus', 'gelu', 'ssp'])
+def test_other_activations(activation):
+    """The other activations of the reference's factory (activations.py:5-30), fused into the same kernels: eval and train
+    mode against the fp64 oracle, energy + gradient_force + direct_force heads."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    torch.manual_seed(11)
+    model = NewtonNet(activation=activation, output_properties=['energy', 'gradient_force', 'direct_force'])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to('cuda')
+    model.eval()
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    ref.set_activation(activation)
+    try:
+        sd64 = {k: v.double() for k, v in sd.items()}
+        want = ref.energy_forces(sd64, z, pos.double(), cell.double(), batch)
+        df = ref.direct_force_head(sd64, 2, want['atom_node'], want['force_node'], z)
+    finally:
+        ref.set_activation('swish')
+    # (softplus-like activations never vanish: with random weights the node features, energies and forces of this case grow
+    # to 1e7 / 1e3 -- the fp32 tolerances are taken relative to those magnitudes)
+    e = want['energy'].numpy()
+    f_ref = want['forces'].numpy()
+    scale = max(1.0, float(np.abs(f_ref).max()))
+    assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e) + 3e-6 * np.abs(e).max()), \
+        (out.energy.cpu().numpy() - e, e)
+    check_forces(out.gradient_force.cpu().numpy(), f_ref, scale=scale)
+    d_ref = df.numpy()
+    np.testing.assert_allclose(out.direct_force.cpu().numpy(), d_ref, rtol=0, atol=2e-5 * max(1.0, float(np.abs(d_ref).max())))
+    model.train()
+    p = pos.cuda().requires_grad_(True)
+    o2 = model(z.cuda(), p, cell.cuda(), batch.cuda())
+    check_forces(o2.gradient_force.detach().cpu().numpy(), f_ref, scale=scale)
