@@ -38,6 +38,14 @@ for B in (10, 32, 256):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): gstep(*args)
     torch.cuda.synchronize(); res['graphed'] = (time.perf_counter() - t0) / 50
+    torch.manual_seed(0)
+    model_b = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda'); model_b.train()
+    bstep = GraphedTrainStep(model_b, torch.optim.Adam(model_b.parameters(), lr=1e-3, capturable=True), 1.0, 50.0, 1.0)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        for _ in range(3): bstep(*args)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(50): bstep(*args)
+        torch.cuda.synchronize(); res['graphed_bf16'] = (time.perf_counter() - t0) / 50
     torch.set_num_threads(min(16, os.cpu_count()))
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref.training_loss_grads(sd, z, pos, cell, batch, e_lab, f_lab)
@@ -45,5 +53,5 @@ for B in (10, 32, 256):
     for _ in range(n): ref.training_loss_grads(sd, z, pos, cell, batch, e_lab, f_lab)
     cpu = (time.perf_counter() - t0) / n
     print(f'B={B:4d} ({9*B} atoms): GPU train step eager fp32 {res["fp32"]*1e3:7.2f} ms | bf16 {res["bf16"]*1e3:7.2f} ms | '
-          f'HIP-graph replay fp32 {res["graphed"]*1e3:6.2f} ms | CPU oracle loss+grads {cpu*1e3:8.1f} ms '
+          f'HIP-graph replay fp32 {res["graphed"]*1e3:6.2f} ms bf16 {res["graphed_bf16"]*1e3:6.2f} ms | CPU oracle loss+grads {cpu*1e3:8.1f} ms '
           f'({torch.get_num_threads()} threads) | speedup eager {cpu/res["fp32"]:.1f}x graphed {cpu/res["graphed"]:.1f}x', flush=True)
