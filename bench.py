@@ -77,6 +77,20 @@ def algorithmic_counts(N, E, L=3, F=128):
     return edge_fwd, edge_bwd, fl, mlp_fl
 
 
+def pair_layout_bytes(N, E, L=3, F=128):
+    """Algorithmic HBM bytes per step of the four edge kernels in the pair-once layout (P = E/2 pair rows of 4F bytes):
+    forward  : msg write + phi1 (+ phi2) read once per pair, 32-B edge record, node rows m, a_in, a_mid, f_in, f_out;
+    adjoint  : g_msg read + phi1 (+ phi2) read + g_phi1 (+ g_phi2) write per pair, 64 B of edge records / g_x / g_u,
+               node rows gf, f, g_fin, m, g_a, g_m.  Layer 0 has no phi2 branch (force_node == 0)."""
+    P, row = E // 2, 4 * F
+    total = 0
+    for l in range(L):
+        k = 1 if l == 0 else 2
+        total += P * row * (1 + k) + 32 * E + 9 * row * N            # forward
+        total += P * row * (1 + k + k) + 64 * E + 12 * row * N       # adjoint
+    return total
+
+
 def pmc_traffic(kernel_prefixes):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of this same command
     (profiles/<latest>_pmc_{fetch,write}_size.txt; FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide
@@ -134,29 +148,24 @@ def main():
     dev_index = local_rank % n_dev if os.environ.get('BENCH_SHARE_GPU') == '1' else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
-    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')     # "nccl" is RCCL on ROCm
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')     # "nccl" is RCCL on ROCm; gloo only for the 1-GPU launch test
     dist = None
+    ranks_joined = 1
     if world > 1:
         import torch.distributed as dist
+        # No silent fallback: if RCCL cannot come up the run fails (non-zero exit) -- a number produced over another
+        # transport would not be the multi-GPU measurement the line claims to be.
         if backend == 'nccl':
-            # RCCL carries only the launch contract's barrier and the max-over-ranks of the step time: the data path has no
-            # collective.  If RCCL cannot come up on this node, the same two calls run over gloo rather than losing the run.
-            try:
-                dist.init_process_group('nccl', device_id=device)
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as exc:  # noqa: BLE001
-                print(f'[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); timing barrier over gloo',
-                      file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = 'gloo'
-                dist.init_process_group('gloo')
+            dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
+        probe = torch.ones(1, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(probe)                 # every rank contributes 1: the sum is the number of ranks that joined
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+        ranks_joined = int(probe.item())
+        if ranks_joined != world:
+            raise SystemExit(f'[bench rank {rank}] {backend}: {ranks_joined} of {world} ranks joined the all-reduce')
 
     from newtonnet_amd import hip
     from newtonnet_amd.models import NewtonNet
@@ -219,7 +228,9 @@ def main():
         edge_ms = classes['edge_all']['ms_per_step']
         mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         lin_tf = lin_flops / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
-        edge_gbs = (edge_fwd_b + edge_bwd_b) / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
+        formula_gbs = (edge_fwd_b + edge_bwd_b) / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
+        pair_b = pair_layout_bytes(N, E)
+        edge_gbs = pair_b / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
         # dominant kernel: the fused two-layer edge MLP (mlp128_kernel, forward + adjoint launches)
         mfma = {'bound': 'mfma', 'kernel': 'mlp128_kernel (fused Linear-SiLU-Linear over edges, fwd + adjoint)',
                 'achieved': round(mlp_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -232,7 +243,12 @@ def main():
         hbm = {'bound': 'hbm', 'kernel': 'msg_fwd/force_fwd/force_bwd/msg_bwd (edge kernels of one step)',
                'achieved': round(edge_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(edge_gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'ms_per_step': round(edge_ms, 4),
-               'algorithmic_bytes_per_step': edge_fwd_b + edge_bwd_b}
+               'algorithmic_bytes_per_step': pair_b,
+               'algorithmic_note': 'bytes the pair-once layout must move (msg / phi / g_phi / g_msg rows once per undirected '
+                                   'pair, DESIGN.md section 4); frac_vs_formula prices the same time against SURVEY 8(d) '
+                                   "Decomposition A's per-directed-edge formula, which this layout undercuts (an upper-bound "
+                                   'model, not achieved bandwidth)',
+               'formula_bytes_per_step': edge_fwd_b + edge_bwd_b, 'frac_vs_formula': round(formula_gbs / HBM_PEAK_GBS, 4)}
         if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
             # algorithmic HBM bytes of one MLP phase over P pair rows, in units of 512 P: forward X in + hidden, output out
             # = 3; adjoint g_phi, hidden in + g_msg out = 3, + g_msg in when accumulating = 4.  Per step (3 layers, phi2
@@ -243,46 +259,62 @@ def main():
                 mfma['traffic'], mfma['traffic_source'] = round(t), src
             t, src = pmc_traffic(['msg_fwd_kernel', 'void force_fwd_kernel', 'void force_bwd_kernel', 'void msg_bwd_kernel'])
             if t is not None:
+                n_edge = max(classes['edge_all']['launches_per_step'], 1)
                 hbm['traffic'], hbm['traffic_source'] = round(t), src
-                hbm['traffic_note'] = 'average HBM bytes per edge-kernel launch (12 launches per step)'
+                hbm['traffic_note'] = f'average HBM bytes per edge-kernel launch from the PMC passes ({n_edge:.0f} launches per step)'
+                cnt_gbs = t * n_edge / (edge_ms * 1e-3) / 1e9
+                hbm['achieved_counter_bytes'] = round(cnt_gbs, 1)
+                hbm['frac_vs_counter_bytes'] = round(cnt_gbs / HBM_PEAK_GBS, 4)
         roofline, edge_roofline = (mfma, hbm) if lin_ms >= edge_ms else (hbm, mfma)
 
     # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'aspirin':
         from oracle import newtonnet_ref as ref          # timed CPU baseline leg (allowed use of the oracle)
-        # Bounded sample: the first 256 conformers of the same batch (about 1.5 s per evaluation), on 16 host threads
-        # -- the measured sweet spot of torch CPU on the GPU box (tools/cpu_sweep.py: 8/16/32/64 threads give
-        # 3.4k/3.8k/3.7k/2.5k atom-steps/s; all 256 cores: 0.36k).
-        cores = min(16, os.cpu_count() or 1)
-        torch.set_num_threads(cores)
-        n_s = min(256, args.conformers)
-        na = n_s * 21
+        # BASELINE.md section 3 / SURVEY 8(d): the SAME 1024-conformer batch, fp32, eval mode, energy + autograd force, on
+        # the host cores of this box.  Three thread counts: 16 (the measured sweet spot of torch CPU on the GPU box,
+        # profiles/r02_cpu_sweep.txt), every core, and one thread (on a 64-conformer slice: a full batch on one thread
+        # takes minutes).  `value` is the best of the three per-batch rates; all are reported.
+        host_cores = os.cpu_count() or 1
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        n_s = args.conformers
+        na = n_s * 21
         zc, pc, cc, bc = z[:na].cpu(), pos[:na].cpu(), cell[:n_s].cpu(), batch[:na].cpu()
-        ref.energy_forces(sd, zc, pc, cc, bc)            # warm-up
-        best, reps, t_start = float('inf'), 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - t_start < 10.0 and reps < 8):
-            t1 = time.perf_counter()
-            ref_out = ref.energy_forces(sd, zc, pc, cc, bc)
-            best = min(best, time.perf_counter() - t1)
-            reps += 1
+
+        def time_cpu(threads, n_conf, min_reps, budget_s, warm):
+            torch.set_num_threads(threads)
+            a = n_conf * 21
+            args_ = (sd, zc[:a], pc[:a], cc[:n_conf], bc[:a])
+            if warm:
+                ref.energy_forces(*args_)
+            best, reps, t_start, last = float('inf'), 0, time.perf_counter(), None
+            while reps < min_reps or (time.perf_counter() - t_start < budget_s and reps < 5):
+                t1 = time.perf_counter()
+                last = ref.energy_forces(*args_)
+                best = min(best, time.perf_counter() - t1)
+                reps += 1
+            return a / best, best, reps, last
+
+        t16 = min(16, host_cores)
+        v16, s16, r16, ref_out = time_cpu(t16, n_s, 2, 12.0, True)
         f_err = (out.gradient_force[:na].cpu() - ref_out['forces']).abs()
-        cpu_baseline = {'value': round(na / best, 1), 'unit': 'atom-steps/s', 'cores': cores, 'kind': 'port',
-                        'sample': f'first {n_s} conformers of the same batch, fp32, eval mode, energy+autograd force, '
-                                  f'torch CPU with {cores} threads (host has {os.cpu_count()} cores), min of {reps} reps '
-                                  f'after 1 warm-up ({best:.2f} s/rep)',
+        ei_equal = bool(torch.equal(out.edge_index.cpu(), ref_out['edge_index']))
+        legs = {f'{t16}_threads': {'value': round(v16, 1), 's_per_rep': round(s16, 2), 'reps': r16, 'conformers': n_s}}
+        if host_cores > t16:
+            va, sa, ra, _ = time_cpu(host_cores, n_s, 1, 0.0, False)
+            legs[f'all_{host_cores}_cores'] = {'value': round(va, 1), 's_per_rep': round(sa, 2), 'reps': ra, 'conformers': n_s}
+        n1 = min(64, n_s)
+        v1, s1, r1, _ = time_cpu(1, n1, 1, 0.0, True)
+        legs['1_thread'] = {'value': round(v1, 1), 's_per_rep': round(s1, 2), 'reps': r1, 'conformers': n1}
+        torch.set_num_threads(t16)
+        best_key = max((k for k in legs if k != '1_thread'), key=lambda k: legs[k]['value'])
+        cpu_baseline = {'value': legs[best_key]['value'], 'unit': 'atom-steps/s',
+                        'cores': host_cores if best_key.startswith('all_') else t16, 'kind': 'port',
+                        'sample': f'all {n_s} conformers of the same batch (N = {na} atoms), fp32, eval mode, energy + autograd '
+                                  f'force, CPU oracle (oracle/newtonnet_ref.py) on torch CPU; best of {list(legs)} '
+                                  f'(host has {host_cores} cores); min over reps after one warm-up',
+                        'threads': legs, 'edge_index_equal_gpu_vs_cpu': ei_equal,
                         'force_mae_gpu_vs_cpu_fp32': float(f_err.mean()), 'force_max_gpu_vs_cpu_fp32': float(f_err.max())}
-        # the same port on ONE thread (SURVEY 8d asks for it beside the multi-thread figure): 32 conformers, ~1-2 s per rep
-        torch.set_num_threads(1)
-        n1 = min(32, n_s)
-        a1 = n1 * 21
-        ref.energy_forces(sd, zc[:a1], pc[:a1], cc[:n1], bc[:a1])
-        t1 = time.perf_counter()
-        ref.energy_forces(sd, zc[:a1], pc[:a1], cc[:n1], bc[:a1])
-        cpu_baseline['single_thread'] = {'value': round(a1 / (time.perf_counter() - t1), 1), 'unit': 'atom-steps/s',
-                                         'sample': f'first {n1} conformers, 1 thread, 1 rep after 1 warm-up'}
-        torch.set_num_threads(cores)
 
     if rank == 0:
         line = {
@@ -296,6 +328,7 @@ def main():
                        'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
+            'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,
             'cpu_baseline': cpu_baseline,
         }

@@ -160,6 +160,14 @@ int nnhip_edge_disp(const float* pos, const float* cell, const int64_t* batch, c
                     float* disp, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Species check.  The reference indexes nn.Embedding(119, F) / the scale and shift tables with z and raises
+ * IndexError for z outside 0..118 (newtonnet.py:142, scalers.py:55-58); the kernels would read out of bounds.
+ * ORs 2 into status[0] (the word nnhip_graph_count ORs 1 into for a bad batch vector; the host reads it back
+ * together with the edge count) when any z[i] is outside [0, NNHIP_N_ELEMENTS).
+ * ------------------------------------------------------------------------ */
+int nnhip_check_species(const int64_t* z, int32_t n_atoms, int32_t* status, void* stream);
+
+/* --------------------------------------------------------------------------
  * Edge embedding.
  * Replaces: ScaledNorm.forward (representations.py:118-133), PolynomialCutoff
  *   p=9 (:155-171), RadialBesselLayer.forward (:223-235) and their product (:41).
@@ -168,7 +176,8 @@ int nnhip_edge_disp(const float* pos, const float* cell, const int64_t* batch, c
  * drbf[E][nb]= d rbf / d x                                  (may be NULL)
  * xg[E][2]   = (g0, bits of u): x = (g0 + u) / FT_G, the position of the edge on the radial-filter table that
  *              nnhip_energy_forces interpolates instead of contracting rbf with message_edgepart.weight per edge
- *              (may be NULL)
+ *              (may be NULL).  A candidate that fails the neighbor predicate `|disp| < cutoff` (fp32, as
+ *              representations.py:96) gets the all-zero filter row and is masked out of the force kernels.
  * ------------------------------------------------------------------------ */
 int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies, int32_t n_basis,
                      float* geo, float* rbf, float* drbf, int32_t* xg, void* stream);

@@ -199,7 +199,7 @@ template <bool HAS_F>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restrict__ phi2, const float* __restrict__ geo,
                  const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
-                 const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms) {
+                 const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms, const int2* __restrict__ xg) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -219,7 +219,11 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
       const int p0 = pid[e], p1 = pid[e1];
       const float4 g = hi ? g1 : g0;
       const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
-      if (!hi || e + 1 < re) {
+      // A candidate of a reused (Verlet-skin / static) list that is outside the cutoff right now (edge_embed_kernel points
+      // its filter row at FT_ZERO_ROW, by the same fp32 predicate as the neighbor list) has msg == 0 but phi = W2 act(0),
+      // which vanishes only when act(0) == 0 (not for sigmoid / softplus) -- mask it explicitly
+      const int gz0 = xg[e].x, gz1 = xg[e1].x;
+      if ((!hi || e + 1 < re) && (hi ? gz1 : gz0) != FT_ZERO_ROW) {
         const float4 v1 = ld4p<decltype(nt)::value>(phi1 + p * NF + c4);
         acc[0] = fma4(v1, g.x, acc[0]);
         acc[1] = fma4(v1, g.y, acc[1]);
@@ -259,7 +263,8 @@ __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
-                 float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms) {
+                 float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms,
+                 const int2* __restrict__ xg) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -280,7 +285,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const int p0 = pid[e], p1 = pid[e1];
     const int eh = hi ? e1 : e;
     const size_t p = (size_t)(hi ? p1 : p0);
-    if (!hi || e + 1 < mid) {
+    const int gz0 = xg[e].x, gz1 = xg[e1].x;
+    const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;   // (see force_fwd_kernel: candidates outside the cutoff contribute nothing)
+    if ((!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
+      reinterpret_cast<float4*>(g_u)[eh] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((!hi || e + 1 < mid) && inside) {
       const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
       float4 gfj[3];
       if (HAS_F) {
@@ -310,7 +319,15 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const size_t p = (size_t)(hi ? p1 : p0);
     const int j = ABL_J(hi ? j1 : j0, i);
     const float4 g = hi ? g1 : g0;
-    if (!hi || e + 1 < end) {
+    const int gz0 = xg[e].x, gz1 = xg[e1].x;
+    const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;
+    if ((!hi || e + 1 < end) && !inside) {   // outside the cutoff: zero adjoints for the pair rows this row owns
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      st4(g_h12 + p * 2 * NF + c4, zero);
+      if (HAS_F) st4(g_h12 + p * 2 * NF + NF + c4, zero);
+      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = zero;
+    }
+    if ((!hi || e + 1 < end) && inside) {
       const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
       float4 gfj[3];
 #pragma unroll
@@ -667,28 +684,29 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
 }
 
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
-                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, hipStream_t s) {
+                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg,
+                     hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_fwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms);
+    force_fwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, hipStream_t s) {
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
     force_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
-                                                               g_fin, n_atoms);
+                                                               g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   else
     force_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
-                                                                g_fin, n_atoms);
+                                                                g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }

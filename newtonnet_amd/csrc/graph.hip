@@ -37,11 +37,30 @@ __global__ void graph_init_kernel(int* __restrict__ status, int* __restrict__ mo
   if (i < n_atoms1) row_ptr[i] = 0;
 }
 
+// z outside the embedding / scale / shift tables (the reference raises IndexError, newtonnet.py:142): flag, never index
+__global__ void check_species_kernel(const int64_t* __restrict__ z, int n_atoms, int* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms) return;
+  const long zi = z[i];
+  if (zi < 0 || zi >= NNHIP_N_ELEMENTS) atomicOr(status, 2);
+}
+extern "C" int nnhip_check_species(const int64_t* z, int32_t n_atoms, int32_t* status, void* stream_) {
+  if (n_atoms < 0 || !status || (n_atoms && !z)) {
+    nnhip_set_error("nnhip_check_species: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0) return NNHIP_OK;
+  check_species_kernel<<<cdiv(n_atoms, 256), 256, 0, (hipStream_t)stream_>>>(z, n_atoms, status);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pair predicate shared by the count and fill passes (must be bit-identical in both)
 // ---------------------------------------------------------------------------------------------
 struct CellInfo {
   bool pbc;
+  bool diag;     // orthorhombic box along the axes: the fractional coordinate is an exact division (see pair_disp)
   float c[9];    // cell, rows = lattice vectors (ASE convention, ase_interface.py:136)
   float inv[9];  // inverse of cell^T (fp32 of an fp64 inverse)
 };
@@ -55,6 +74,8 @@ __device__ __forceinline__ CellInfo load_cell(const float* __restrict__ cell, lo
     any |= (ci.c[k] != 0.0f);
   }
   ci.pbc = any;
+  ci.diag = ci.c[1] == 0.f && ci.c[2] == 0.f && ci.c[3] == 0.f && ci.c[5] == 0.f && ci.c[6] == 0.f && ci.c[7] == 0.f &&
+            ci.c[0] != 0.f && ci.c[4] != 0.f && ci.c[8] != 0.f;
   if (any) {
     // A = cell^T ; frac = A^{-1} d   (representations.py:92)
     double a[9];
@@ -78,9 +99,18 @@ __device__ __forceinline__ CellInfo load_cell(const float* __restrict__ cell, lo
   return ci;
 }
 
-// disp = pos_i - pos_j with the reference's single-image shift; returns ||disp||.  fp32 with FMA contraction
-// switched off, so that the count and fill passes (and a plain CPU evaluation of the same expressions)
-// agree on the strict `< r` predicate.
+// disp = pos_i - pos_j with the reference's single-image shift; returns ||disp||.  fp32 with compiler FMA contraction
+// switched off and every rounding written out, so that the count and fill passes agree with each other AND with the
+// reference's fp32 CPU evaluation on the strict `< r` predicate (representations.py:96, pinned by
+// tests/golden/case_boundary.npz: pairs within a few ulp of the cutoff):
+//   * dist.norm(dim=1) on torch CPU is sqrt(fma(z, z, fma(y, y, x * x))) -- measured: 0 of 200,000 tie-range vectors differ
+//     (the plain (x*x + y*y) + z*z differs from it in 9.5 % of them, 1 % of the predicates);
+//   * torch.linalg.solve(cell^T, d) for an axis-aligned box is the exact division d_k / L_k (0 of 300,000 differ; the product
+//     with a rounded 1/L differs in 28 %).  For a general (triclinic) cell the reference goes through MKL's LU solve, whose
+//     roundings are not reproducible from outside (they also depend on the CPU dispatch): the product with the fp32 image of
+//     the fp64 inverse used here differs from it by <= 2 ulp, which can pick the other image only for a pair whose
+//     fractional separation is within 2 ulp of +-0.5 -- and then changes the edge SET only if that pair also sits within
+//     a few ulp of the cutoff (tests count those double ties).
 __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float xj, float yj, float zj,
                                            const CellInfo& ci, float& dx, float& dy, float& dz) {
 #pragma clang fp contract(off)
@@ -88,17 +118,24 @@ __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float x
   dy = yi - yj;
   dz = zi - zj;
   if (ci.pbc) {
-    const float f0 = (ci.inv[0] * dx + ci.inv[1] * dy) + ci.inv[2] * dz;
-    const float f1 = (ci.inv[3] * dx + ci.inv[4] * dy) + ci.inv[5] * dz;
-    const float f2 = (ci.inv[6] * dx + ci.inv[7] * dy) + ci.inv[8] * dz;
+    float f0, f1, f2;
+    if (ci.diag) {
+      f0 = __fdiv_rn(dx, ci.c[0]);
+      f1 = __fdiv_rn(dy, ci.c[4]);
+      f2 = __fdiv_rn(dz, ci.c[8]);
+    } else {
+      f0 = (ci.inv[0] * dx + ci.inv[1] * dy) + ci.inv[2] * dz;
+      f1 = (ci.inv[3] * dx + ci.inv[4] * dy) + ci.inv[5] * dz;
+      f2 = (ci.inv[6] * dx + ci.inv[7] * dy) + ci.inv[8] * dz;
+    }
     const float n0 = rintf(f0), n1 = rintf(f1), n2 = rintf(f2);  // round-half-even == torch.round
     // d -= cell @ n   (as the reference writes it, representations.py:93)
     dx = dx - ((ci.c[0] * n0 + ci.c[1] * n1) + ci.c[2] * n2);
     dy = dy - ((ci.c[3] * n0 + ci.c[4] * n1) + ci.c[5] * n2);
     dz = dz - ((ci.c[6] * n0 + ci.c[7] * n1) + ci.c[8] * n2);
   }
-  const float r2 = (dx * dx + dy * dy) + dz * dz;
-  return sqrtf(r2);
+  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+  return __fsqrt_rn(r2);
 }
 
 // One wavefront per receiver atom i; the lanes test 64 candidate senders j at a time and a ballot + prefix popcount
@@ -257,9 +294,12 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, con
     const double t = x * (double)FT_G;
     int g0 = (int)floor(t);
     g0 = g0 < 0 ? 0 : (g0 > FT_G - 1 ? FT_G - 1 : g0);
-    // x >= 1 only occurs for the candidates of a skin list that are outside the cutoff right now (the exact list holds
-    // r < cutoff): their filter and its derivative are exactly zero, so they drop out of every sum
-    xg[e] = (x >= 1.0) ? make_int2(FT_ZERO_ROW, 0) : make_int2(g0, __float_as_int((float)(t - (double)g0)));
+    // Candidates of a reused list (Verlet skin, static training list) that are outside the cutoff right now point at the
+    // all-zero filter rows and are masked out of the force kernels.  "Outside" is the neighbor list's own fp32 predicate
+    // (pair_disp: the reference's `norm < r`), so an edge of the exact list is never masked, whatever the fp64 value of x.
+    const float fx = disp[3 * (long)e], fy = disp[3 * (long)e + 1], fz = disp[3 * (long)e + 2];
+    const bool inside = __fsqrt_rn(__fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx))) < cutoff;
+    xg[e] = inside ? make_int2(g0, __float_as_int((float)(t - (double)g0))) : make_int2(FT_ZERO_ROW, 0);
   }
   if (!rbf) return;
   const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;

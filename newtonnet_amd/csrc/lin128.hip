@@ -199,12 +199,10 @@ static int env_int(const char* name, int dflt) {
 template <int PRO, int EPI>
 static int launch_lin_t(const LinArgs& a, int groups, hipStream_t s) {
   static const int block_cap = env_int("NNHIP_LIN_BLOCKS", 512);  // tuning knob (tools/bench_lin.py)
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)lin128_kernel<PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LIN_LDS_BYTES));
-    attr_set = true;
-  }
+  // one-time kernel attribute; a function-local static is initialised exactly once even with concurrent host threads
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)lin128_kernel<PRO, EPI>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LIN_LDS_BYTES);
+  HIP_TRY(attr_rc);
   const int n_tiles = (a.M + 31) / 32;
   int blocks = cdiv(n_tiles, 4);
   const int cap = block_cap / groups;  // default 512: 2 resident workgroups per CU x 256 CUs

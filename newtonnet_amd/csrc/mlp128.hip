@@ -277,12 +277,10 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
 
 template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
 static int launch_mlp_t(const MlpPair& a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES));
-    attr_set = true;
-  }
+  // one-time kernel attribute; a function-local static is initialised exactly once even with concurrent host threads
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+  HIP_TRY(attr_rc);
   const int n_tiles = (a.a[0].M + 31) / 32;
   int blocks = cdiv(n_tiles, 8);
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU (135 KiB of LDS each)

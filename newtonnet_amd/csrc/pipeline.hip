@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -18,10 +20,10 @@ int launch_filter_tables(const float* const* edge_w, float* const* tables, int n
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
-                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, hipStream_t s);
+                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg, hipStream_t s);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, hipStream_t s);
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm,
                    hipStream_t s);
@@ -56,23 +58,28 @@ struct TimerRec {
   int cls;
   hipEvent_t e0, e1;
 };
-static bool g_timers_on = false;
+// (host threads driving different streams may time concurrently: the switch is atomic, the lists are under one mutex)
+static std::atomic<bool> g_timers_on{false};
+static std::mutex g_timer_mu;
 static std::vector<TimerRec> g_pending;
 static std::vector<hipEvent_t> g_event_pool;
 static double g_ms[NNHIP_N_TIMER_CLASSES];
 static int64_t g_cnt[NNHIP_N_TIMER_CLASSES];
 
 static hipEvent_t get_event() {
-  if (!g_event_pool.empty()) {
-    hipEvent_t e = g_event_pool.back();
-    g_event_pool.pop_back();
-    return e;
+  {
+    std::lock_guard<std::mutex> lk(g_timer_mu);
+    if (!g_event_pool.empty()) {
+      hipEvent_t e = g_event_pool.back();
+      g_event_pool.pop_back();
+      return e;
+    }
   }
   hipEvent_t e;
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
-ScopedTimer::ScopedTimer(int c, hipStream_t st) : cls(c), s(st), e0(nullptr), on(g_timers_on) {
+ScopedTimer::ScopedTimer(int c, hipStream_t st) : cls(c), s(st), e0(nullptr), on(g_timers_on.load()) {
   if (on) {
     e0 = get_event();
     if (e0) (void)hipEventRecord(e0, s); else on = false;
@@ -83,6 +90,7 @@ ScopedTimer::~ScopedTimer() {
   hipEvent_t e1 = get_event();
   if (!e1) return;
   (void)hipEventRecord(e1, s);
+  std::lock_guard<std::mutex> lk(g_timer_mu);
   g_pending.push_back({cls, e0, e1});
 }
 extern "C" int nnhip_timers_enable(int32_t on) {
@@ -90,6 +98,7 @@ extern "C" int nnhip_timers_enable(int32_t on) {
   return NNHIP_OK;
 }
 extern "C" int nnhip_timers_read(double* ms, int64_t* cnt, int32_t reset) {
+  std::lock_guard<std::mutex> lk(g_timer_mu);
   for (auto& r : g_pending) {
     float t = 0.f;
     HIP_TRY(hipEventSynchronize(r.e1));
@@ -400,7 +409,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       else
         TRY(launch_mlp(MODE_FWD, false, m1, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, s));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, xg, s));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
@@ -491,7 +500,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
-                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, s));
+                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, xg, s));
     if (E > 0) {
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)

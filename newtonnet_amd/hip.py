@@ -85,6 +85,7 @@ def lib():
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.nnhip_check_species.argtypes = [vp, i32, vp, vp]
     L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
     L.nnhip_graph_cells_scratch_bytes.restype = sz
     L.nnhip_graph_count_cells.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp]
@@ -108,7 +109,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare'):
+               'nnhip_prepare', 'nnhip_check_species'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -119,7 +120,7 @@ EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'n
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
-                    'nnhip_prepare')
+                    'nnhip_prepare', 'nnhip_check_species')
 
 
 def _check(rc: int, what: str):
@@ -159,13 +160,37 @@ def prepare(model: Model, device) -> torch.Tensor:
     return buf
 
 
+_box_cache = [None, None]   # (key, box lengths or None) of the last single-box cell inspected by build_graph
+
+
+def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
+    """Box lengths (3 floats) when `cell` ([1,3,3]) is an axis-aligned periodic box of at least 3 cutoffs per side -- the
+    precondition of the O(N) cell-list kernels -- else None.  Inspecting a device tensor costs one device->host sync, so
+    the answer is cached on the tensor's identity (storage pointer + in-place version counter: the same cell tensor passed
+    step after step is looked at once), and callers that hold the cell on the host (the ASE calculator) pass it in."""
+    if cell_host is not None:
+        c = torch.as_tensor(cell_host, dtype=torch.float32).reshape(3, 3)
+    else:
+        key = (cell.data_ptr(), cell._version, str(cell.device), float(cutoff))
+        if _box_cache[0] == key:
+            return _box_cache[1]
+        c = cell.reshape(3, 3).cpu()
+    diag = torch.diagonal(c)
+    ok = bool((c - torch.diag(diag) == 0).all()) and bool((diag >= 3.0003 * cutoff).all())
+    box = tuple(float(v) for v in diag) if ok else None
+    if cell_host is None:
+        _box_cache[0], _box_cache[1] = key, box
+    return box
+
+
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
                 frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False,
-                while_waiting=None) -> Graph:
+                while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None) -> Graph:
     """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU.
     `while_waiting`: callable run after the counting kernels are queued and before the host waits for the edge count --
     work it launches on the stream fills the GPU's idle time during that round trip (NewtonNet.forward passes
-    nnhip_prepare here)."""
+    nnhip_prepare here).  `z` (int64, optional): species, range-checked on the device in the same round trip (the
+    reference raises IndexError for z outside 0..118).  `cell_host`: the cell as a host array, when the caller has it."""
     L = lib()
     dev = pos.device
     pos = _f32c(pos, 'pos')
@@ -183,10 +208,9 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     # One big orthorhombic periodic box -> O(N) cell-list kernels (bit-identical output to the all-pairs kernels).
     box = None
     if B == 1 and N >= CELL_LIST_MIN_ATOMS:
-        c = cell.reshape(3, 3).cpu()
-        diag = torch.diagonal(c)
-        if bool((c - torch.diag(diag) == 0).all()) and bool((diag >= 3.0003 * cutoff).all()):
-            box = (C.c_float * 3)(*[float(v) for v in diag])
+        lengths = _orthorhombic_box(cell, cutoff, cell_host)
+        if lengths is not None:
+            box = (C.c_float * 3)(*lengths)
     if box is not None:
         scratch = torch.empty(L.nnhip_graph_cells_scratch_bytes(N, box, float(cutoff)), dtype=torch.uint8, device=dev)
         status[:1].zero_()
@@ -195,6 +219,10 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     else:
         _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
                                    _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
+    if z is not None:
+        if z.dtype != torch.int64 or not z.is_contiguous():
+            z = z.long().contiguous()
+        _check(L.nnhip_check_species(_ptr(z), N, _ptr(status), st), 'nnhip_check_species')
     tail_dev = meta[B + N + 1:B + N + 3]
     if while_waiting is not None:
         tail_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
@@ -207,8 +235,10 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     else:
         tail = tail_dev.tolist()  # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
-    if bad:
+    if bad & 1:
         raise ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
+    if bad & 2:
+        raise IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
     g.n_edges = E
     ints = torch.empty(2 * E, dtype=torch.int32, device=dev)
     g.col, g.rev = ints[:E], ints[E:]
@@ -247,6 +277,8 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
         raise ValueError('refresh_graph needs a graph built with want_edge_index=True')
     st = _stream(pos.device)
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    if batch.dtype != torch.int64 or not batch.is_contiguous():
+        batch = batch.long().contiguous()
     E = g.n_edges
     _check(L.nnhip_edge_disp(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.edge_index), E, _ptr(g.disp), st), 'nnhip_edge_disp')
     _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(),

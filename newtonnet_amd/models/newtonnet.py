@@ -150,7 +150,9 @@ class NewtonNet(nn.Module):
             if key not in ('energy', 'gradient_force', 'direct_force', 'virial', 'stress'):
                 raise NotImplementedError(f"output property '{key}' is outside the MI355X hot path")
         deriv_layers = [ol for ol in self.output_layers if isinstance(ol, DerivativeProperty)]
-        train_graph = any(ol.create_graph for ol in deriv_layers) and torch.is_grad_enabled()
+        # differentiable path: whenever the module is in train mode with autograd on -- with or without a derivative head
+        # (the reference trains ['energy'] or ['energy', 'direct_force'] models just the same, trainer.py:299-313)
+        train_graph = torch.is_grad_enabled() and (self.training or any(ol.create_graph for ol in deriv_layers))
         energy_idx = keys.index('energy')
         want_forces = len(deriv_layers) > 0
         want_virial = any(isinstance(ol, (VirialOutput, StressOutput)) for ol in deriv_layers)
@@ -177,7 +179,8 @@ class NewtonNet(nn.Module):
             overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'      # (switch for A/B timing only)
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies,
-                                while_waiting=(lambda: prep.append(hip.prepare(model, pos.device))) if overlap else None)
+                                while_waiting=(lambda: prep.append(hip.prepare(model, pos.device))) if overlap else None,
+                                z=zc)
             res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
                                     want_virial=want_virial, prepared=prep[0] if overlap else None)
 
@@ -216,7 +219,7 @@ class NewtonNet(nn.Module):
             if key not in ('energy', 'gradient_force', 'direct_force'):
                 raise NotImplementedError(f"train-mode forward supports energy / gradient_force / direct_force (got '{key}')")
         self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
-        if not pos.requires_grad:
+        if 'gradient_force' in keys and not pos.requires_grad:
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
         energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx,
                                                                    graph=getattr(self, '_static_train_graph', None))

@@ -112,8 +112,10 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
     u = disp / r
     x = r / ee.cutoff
     rbf = _envelope(x) * (torch.sin(ee.embedding.frequencies * x) / x)
-    if static:
-        rbf = rbf * (x < 1.0).to(rbf.dtype)
+    inside = None
+    if static:   # candidates outside the cutoff: rbf -> 0 AND phi -> 0 (phi = W2 act(0) vanishes by itself only if act(0) = 0)
+        inside = (r.detach().float() < ee.cutoff).to(rbf.dtype)
+        rbf = rbf * inside
 
     a = emb.node_embedding(z)
     f = torch.zeros(z.shape[0], 3, emb.n_features, dtype=pos.dtype, device=pos.device)
@@ -124,9 +126,14 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
         msg = eps * Gather.apply(m, eg, 'row') * Gather.apply(m, eg, 'col')
         a = a + SegmentSum.apply(msg, eg)
         phi1 = _mlp(il.equiv_message1, msg)
+        if inside is not None:
+            phi1 = phi1 * inside
         eq = phi1.unsqueeze(1) * u.unsqueeze(2)
         if l > 0:   # force_node == 0 entering the first layer (newtonnet.py:143)
-            eq = eq + _mlp(il.equiv_message2, msg).unsqueeze(1) * Gather.apply(f, eg, 'col')
+            phi2 = _mlp(il.equiv_message2, msg)
+            if inside is not None:
+                phi2 = phi2 * inside
+            eq = eq + phi2.unsqueeze(1) * Gather.apply(f, eg, 'col')
         f = f + SegmentSum.apply(eq.contiguous(), eg)
         a = a + (f * _lin(f, il.equiv_update.weight)).sum(dim=1)
         if il.layer_norm is not None:          # newtonnet.py:228-231

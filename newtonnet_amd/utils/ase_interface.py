@@ -32,6 +32,36 @@ except Exception:  # noqa: BLE001
             self.atoms = atoms
 
 
+def _current_key(k: str) -> str:
+    """Parameter names of the pre-2.0 checkpoint layout (scripts/md17_model/training_1/models/best_model.pt) -> current."""
+    k = k.replace('embedding_layer.edge_embedding.frequencies', 'embedding_layers.edge_embedding.embedding.frequencies')
+    return k.replace('embedding_layer.', 'embedding_layers.')
+
+
+class _ReferenceUnpickler(__import__('pickle').Unpickler):
+    """Whole-module pickles written by the reference name classes of the `newtonnet` package (and of `les`).  When those
+    import, they are used as they are (and converted through state_dict()); when they do not -- this package does not depend
+    on the reference -- each missing class becomes an attribute-only nn.Module stand-in: nn.Module's own __setstate__
+    restores `_parameters` / `_modules`, which is all state_dict() needs."""
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except (ImportError, AttributeError):
+            if module.split('.')[0] in ('newtonnet', 'les'):
+                return type(name, (torch.nn.Module,), {'__module__': module})
+            raise
+
+
+class _ReferencePickle:
+    """pickle_module for torch.load (needs Unpickler and load)."""
+    __name__ = 'newtonnet_amd_reference_pickle'
+    Unpickler = _ReferenceUnpickler
+
+    @staticmethod
+    def load(f, **kw):
+        return _ReferenceUnpickler(f, **kw).load()
+
+
 def _is_single(atoms) -> bool:
     return hasattr(atoms, 'get_positions')
 
@@ -200,18 +230,26 @@ class MLAseCalculator(_Base):
 
     # ------------------------------------------------------------------ ase_interface.py:83-129
     def load_model(self, model):
+        """model: a NewtonNet of this package, ANY nn.Module with the reference's parameter names (e.g. the reference's own
+        NewtonNet), a state_dict, or the path of a whole-module pickle (torch.save(model), trainer.py:219 -- written by
+        this package OR by the reference, ase_interface.py:87), a state_dict file or an .npz of arrays.  Anything that is
+        not already a newtonnet_amd NewtonNet is rebuilt from its state_dict (the key names are identical by construction)."""
         from newtonnet_amd.models import NewtonNet
         if isinstance(model, torch.nn.Module):
             pass
+        elif isinstance(model, dict):
+            model = self._from_state_dict(model)
         elif str(model).endswith('.npz'):
             with np.load(model) as f:
                 sd = {k: torch.from_numpy(f[k]) for k in f.files}
             model = self._from_state_dict(sd)
         else:
-            obj = torch.load(model, map_location='cpu', weights_only=False)
+            obj = torch.load(model, map_location='cpu', weights_only=False, pickle_module=_ReferencePickle)
             model = self._from_state_dict(obj) if isinstance(obj, dict) else obj
         if not isinstance(model, NewtonNet):
-            raise TypeError(f'expected a newtonnet_amd NewtonNet, got {type(model)}')
+            if not isinstance(model, torch.nn.Module):
+                raise TypeError(f'expected a NewtonNet module, a state_dict or a path, got {type(model)}')
+            model = self._from_module(model)
         if self.properties is None:
             self.properties = [{'energy': 'energy', 'gradient_force': 'forces', 'stress': 'stress'}[k]
                                for k in model.output_properties if k in ('energy', 'gradient_force', 'stress')]
@@ -241,18 +279,50 @@ class MLAseCalculator(_Base):
         return model
 
     @staticmethod
-    def _from_state_dict(sd):
+    def _from_state_dict(sd, cutoff: float = 5.0, activation: str = 'swish', output_properties=None):
+        """Rebuild a NewtonNet from the reference's parameter names; the sizes are read off the tensors.  Keys of the
+        pre-2.0 layout of the shipped MD17 checkpoint (`embedding_layer.*`) are renamed."""
         from newtonnet_amd.models import NewtonNet
+        sd = {_current_key(k): v for k, v in sd.items()}
         n_layers = 0
         while f'interaction_layers.{n_layers}.equiv_update.weight' in sd:
             n_layers += 1
         F = sd['embedding_layers.node_embedding.weight'].shape[1]
         nb = sd['embedding_layers.edge_embedding.embedding.frequencies'].numel()
-        model = NewtonNet(n_features=F, n_basis=nb, n_interactions=n_layers,
-                          output_properties=['energy', 'gradient_force'])
+        props = list(output_properties) if output_properties else ['energy', 'gradient_force']
+        model = NewtonNet(cutoff=cutoff, n_features=F, n_basis=nb, n_interactions=n_layers, activation=activation,
+                          layer_norm='interaction_layers.0.layer_norm.weight' in sd, output_properties=props)
         model.to(torch.float64)
         model.load_state_dict({k: v.to(torch.float64) for k, v in sd.items()})
         return model
+
+    @classmethod
+    def _from_module(cls, obj):
+        """A module that is not this package's NewtonNet -- the reference's own class, or the attribute-only stand-in the
+        unpickler builds when the reference package is not importable: read the hyper-parameters the state_dict does not
+        carry (cutoff, activation, output heads) off the module tree, then rebuild from state_dict()."""
+        sd = {k: v.detach().cpu() for k, v in obj.state_dict().items()}
+        emb = getattr(obj, 'embedding_layers', None) or getattr(obj, 'embedding_layer', None)
+        cutoff = 5.0
+        ee = getattr(emb, 'edge_embedding', None)
+        for holder, attr in ((getattr(ee, 'norm', None), 'r'), (getattr(ee, 'radius_graph', None), 'r'), (ee, 'cutoff')):
+            if holder is not None and hasattr(holder, attr):
+                cutoff = float(getattr(holder, attr))
+                break
+        activation = 'swish'
+        layers = getattr(obj, 'interaction_layers', None)
+        if layers is not None and len(layers):
+            act = layers[0].message_nodepart[1]
+            names = {'SiLU': 'swish', 'ReLU': 'relu', 'ELU': 'elu', 'LeakyReLU': 'leaky_relu', 'Tanh': 'tanh',
+                     'Sigmoid': 'sigmoid', 'Softplus': 'softplus', 'GELU': 'gelu', 'ShiftedSoftplus': 'ssp'}
+            if type(act).__name__ not in names:
+                raise NotImplementedError(f'activation module {type(act).__name__} is outside the MI355X hot path')
+            activation = names[type(act).__name__]
+        props = [k for k in getattr(obj, 'output_properties', ['energy', 'gradient_force'])]
+        for k in props:
+            if k not in ('energy', 'gradient_force', 'direct_force', 'virial', 'stress'):
+                raise NotImplementedError(f"output property '{k}' of the loaded model is outside the MI355X hot path")
+        return cls._from_state_dict(sd, cutoff=cutoff, activation=activation, output_properties=props)
 
     # ------------------------------------------------------------------ ase_interface.py:131-142
     def format_data(self, atoms_list):

@@ -405,3 +405,156 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'extra':
     main_extra()
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'layernorm':
     main_layernorm()
+
+
+# ----------------------------------------------------------------------------
+# virial / stress heads (output.py:154-180; strain construction newtonnet.py:146-155)
+# ----------------------------------------------------------------------------
+def triclinic_box(seed=5):
+    """64 atoms in a triclinic cell (rows = lattice vectors), every lattice vector and height > 2 r."""
+    g = torch.Generator().manual_seed(seed)
+    cell = torch.tensor([[11.5, 0.0, 0.0], [2.3, 11.0, 0.0], [-1.7, 2.9, 10.8]], dtype=torch.float64)
+    idx = torch.arange(64)
+    frac = (torch.stack([idx // 16, (idx // 4) % 4, idx % 4], 1).double() + 0.5) / 4.0
+    frac = (frac + (torch.rand(64, 3, generator=g, dtype=torch.float64) - 0.5) * 0.12) % 1.0
+    pos = frac @ cell
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (64,), generator=g)]
+    return z, pos, cell.unsqueeze(0)
+
+
+def main_virial():
+    """Reference run with output_properties ['energy','gradient_force','virial','stress'] on aspirin8, pbc216, pbc_batch2 and a
+    triclinic box -> case_virial_<name>.npz (fp64 and fp32 runs).  stress is stored for the periodic cases only (the
+    reference divides by det(cell) = 0 otherwise)."""
+    NewtonNet = import_reference()
+    rnd = {k: torch.from_numpy(v).double() for k, v in np.load(f'{OUT}/rand_state_seed0.npz').items()}
+    train = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_train/raw/aspirin_ccsd-train.xyz', 8)
+    z_asp = torch.tensor(train[0][0], dtype=torch.long)
+    cases = {}
+    cases['aspirin8'] = (z_asp.repeat(8), torch.tensor(np.concatenate([f[1] for f in train])),
+                         torch.zeros(8, 3, 3, dtype=torch.float64), torch.repeat_interleave(torch.arange(8), 21))
+    zb, pb, cb = periodic_box(6, 100.0 / 47.0, 0.5, 0)
+    cases['pbc216'] = (zb, pb, cb, torch.zeros(216, dtype=torch.long))
+    zb2, pb2, _ = periodic_box(5, 2.4, 0.4, 1)
+    cb2 = torch.diag(torch.tensor([12.0, 12.0, 12.0], dtype=torch.float64)).unsqueeze(0)
+    cases['pbc_batch2'] = (torch.cat([zb, zb2]), torch.cat([pb, pb2]), torch.cat([cb, cb2]),
+                           torch.cat([torch.zeros(216, dtype=torch.long), torch.ones(125, dtype=torch.long)]))
+    zt, pt, ct = triclinic_box()
+    cases['triclinic64'] = (zt, pt, ct, torch.zeros(64, dtype=torch.long))
+    props = ['energy', 'gradient_force', 'virial', 'stress']
+    for name, (z, pos, cell, batch) in cases.items():
+        rec = dict(z=z.numpy(), pos=pos.numpy(), cell=cell.numpy(), batch=batch.numpy())
+        for dt, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+            model = NewtonNet(output_properties=props)
+            model.to(torch.float64)
+            sd = {k: v for k, v in rnd.items()}
+            missing = model.load_state_dict(sd, strict=False)   # virial / stress heads have no parameters
+            assert not missing.unexpected_keys and all('scalers' in k or 'output_layers' in k for k in missing.missing_keys), missing
+            model.to(dt)
+            model.eval()
+            out = model(z, pos.to(dt).clone(), cell.to(dt).clone(), batch)
+            rec[f'{tag}_energy'] = out.energy.detach().numpy()
+            rec[f'{tag}_forces'] = out.gradient_force.detach().numpy()
+            rec[f'{tag}_virial'] = out.virial.detach().numpy()
+            if bool((cell != 0).any()):
+                rec[f'{tag}_stress'] = out.stress.detach().numpy()
+            rec[f'{tag}_edge_index'] = out.edge_index.numpy()
+        np.savez_compressed(f'{OUT}/case_virial_{name}.npz', **rec)
+        print('virial', name, 'E', rec['f64_energy'][:2], '|virial|max', np.abs(rec['f64_virial']).max(),
+              'edges', rec['f64_edge_index'].shape[1],
+              'f32 == f64 edges:', np.array_equal(rec['f64_edge_index'], rec['f32_edge_index']))
+
+
+# ----------------------------------------------------------------------------
+# neighbor-predicate boundary cases (representations.py:85-98: strict `norm < r` in the model dtype; PBC round() at +-0.5)
+# ----------------------------------------------------------------------------
+def _ulp_steps(x, k):
+    """x moved by k fp32 ulps (k may be negative)."""
+    v = np.float32(x)
+    for _ in range(abs(int(k))):
+        v = np.nextafter(v, np.float32(np.inf if k > 0 else -np.inf))
+    return v
+
+
+def main_boundary():
+    """Adversarial fp32 inputs for RadiusGraph: the reference's own fp32 edge_index for
+      (a) 2-atom molecules whose separation is r (1 + k ulp), k in {-4..4}, along the axes, along (3,4,0)/5 and along
+          random directions, with and without a random common offset (so the subtraction rounds);
+      (b) periodic pairs whose fractional coordinate sits at +-0.5 +- k ulp (round-half-even), in orthorhombic and
+          triclinic cells whose lattice vector has length exactly 2 r, so that the image choice and the `< r` test tie
+          at the same time.
+    The fixture stores the fp32 inputs and the reference's edge_index (fp32 run); the HIP neighbor list must reproduce it
+    bit for bit (tests/test_hip_parity.py::test_neighbor_boundary_cases)."""
+    NewtonNet = import_reference()
+    from newtonnet.layers.representations import RadiusGraph
+    r = 5.0
+    rg = RadiusGraph(r)
+    g = torch.Generator().manual_seed(11)
+    # ---- (a) open boundary
+    pos, batch = [], []
+    b = 0
+
+    def add_pair(p0, p1):
+        nonlocal b
+        pos.extend([p0, p1])
+        batch.extend([b, b])
+        b += 1
+
+    dirs = [np.array(d, dtype=np.float64) for d in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [0.6, 0.8, 0], [0, 0.6, 0.8],
+                                                      [0.8, 0, 0.6])]
+    for _ in range(120):
+        v = torch.randn(3, generator=g, dtype=torch.float64).numpy()
+        dirs.append(v / np.linalg.norm(v))
+    for d in dirs:
+        for k in (-4, -2, -1, 0, 1, 2, 4):
+            for off in (False, True):
+                o = (torch.randn(3, generator=g, dtype=torch.float64).numpy() * 3.0) if off else np.zeros(3)
+                p0 = o.astype(np.float32)
+                target = np.float64(_ulp_steps(r, k))
+                p1 = (p0.astype(np.float64) + d * target).astype(np.float32)
+                add_pair(p0, p1)
+    pos_a = torch.tensor(np.stack(pos), dtype=torch.float32)
+    batch_a = torch.tensor(batch, dtype=torch.long)
+    ei_a, disp_a = rg(pos_a, torch.zeros(b, 3, 3), batch_a)
+    dn = (pos_a[0::2] - pos_a[1::2]).norm(dim=1)
+    ties_a = int(((dn - r).abs() <= 4 * np.spacing(np.float32(r))).sum())
+    # ---- (b) periodic: one cell per molecule (every pair has its own cell entry in the batch)
+    pos, batch, cells = [], [], []
+    b = 0
+    cell_list = [np.diag([10.0, 10.0, 10.0]), np.diag([10.0, 13.0, 11.0]),
+                 np.array([[10.0, 0, 0], [3.0, np.sqrt(100.0 - 9.0), 0], [0, 0, 12.0]]),
+                 np.array([[10.0, 0, 0], [2.0, 11.0, 0], [-6.0, 0.0, 8.0]])]
+    for c in cell_list:
+        c32 = c.astype(np.float32)
+        for axis in range(3):
+            a = c32[axis].astype(np.float64)
+            for sgn in (1.0, -1.0):
+                for k in (-4, -2, -1, 0, 1, 2, 4):
+                    for perp in (0.0, 1e-4, 0.3):
+                        for off in (False, True):
+                            o = (torch.rand(3, generator=g, dtype=torch.float64).numpy() * 2.0) if off else np.zeros(3)
+                            half = np.float64(_ulp_steps(0.5, k))
+                            e = np.zeros(3)
+                            e[(axis + 1) % 3] = perp
+                            p0 = o.astype(np.float32)
+                            p1 = (p0.astype(np.float64) + sgn * half * a + e).astype(np.float32)
+                            pos.extend([p0, p1])
+                            batch.extend([b, b])
+                            cells.append(c32)
+                            b += 1
+    pos_b = torch.tensor(np.stack(pos), dtype=torch.float32)
+    batch_b = torch.tensor(batch, dtype=torch.long)
+    cell_b = torch.tensor(np.stack(cells), dtype=torch.float32)
+    ei_b, disp_b = rg(pos_b, cell_b, batch_b)
+    np.savez_compressed(f'{OUT}/case_boundary.npz', cutoff=r,
+                        a_pos=pos_a.numpy(), a_batch=batch_a.numpy(), a_edge_index=ei_a.numpy(), a_disp=disp_a.numpy(),
+                        b_pos=pos_b.numpy(), b_batch=batch_b.numpy(), b_cell=cell_b.numpy(), b_edge_index=ei_b.numpy(),
+                        b_disp=disp_b.numpy())
+    print('boundary (a):', pos_a.shape[0] // 2, 'pairs,', ei_a.shape[1] // 2, 'inside;', ties_a, 'within 4 ulp of r')
+    print('boundary (b):', pos_b.shape[0] // 2, 'pairs,', ei_b.shape[1] // 2, 'inside')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'virial':
+    main_virial()
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'boundary':
+    main_boundary()

@@ -129,6 +129,9 @@ def test_K2_test_set_mae_through_hip():
     batch = torch.repeat_interleave(torch.arange(n_frames), n_atoms).cuda()
     out = model(z, pos, torch.zeros(n_frames, 3, 3, device='cuda'), batch)
     assert out.edge_index.shape[1] == 151366
+    from oracle import newtonnet_ref as ref
+    ei_ref, _ = ref.radius_graph(pos.cpu(), None, batch.cpu(), 5.0)          # fp32, as the model dtype
+    assert np.array_equal(out.edge_index.cpu().numpy(), ei_ref.numpy())      # every index, not only the count
     e_mae = np.abs(out.energy.cpu().numpy().astype(np.float64) - k['energy']).mean()
     f_mae = np.abs(out.gradient_force.cpu().numpy().reshape(n_frames, n_atoms, 3).astype(np.float64) - k['forces']).mean()
     assert abs(e_mae - float(k['log_test_energy_mae'])) < 1e-3      # fp32 ulp of |E| ~ 2e-3
@@ -150,6 +153,16 @@ def test_properties_config2_size():
     o1 = model(z, pos, cell, batch)
     o2 = model(z, pos, cell, batch)
     assert torch.equal(o1.energy, o2.energy) and torch.equal(o1.gradient_force, o2.gradient_force)  # deterministic
+    # the full neighbor list (313,006 edges) against the oracle's fp32 RadiusGraph, and how many of the 430,080 candidate
+    # pairs sit within 4 ulp of the cutoff (the pairs whose classification depends on the exact fp32 roundings)
+    from oracle import newtonnet_ref as ref
+    cand = ref.candidate_pairs(batch.cpu())
+    pc = pos.cpu()
+    dn = (pc[cand[0]] - pc[cand[1]]).norm(dim=1)
+    tie_risk = int(((dn - 5.0).abs() <= 4 * np.spacing(np.float32(5.0))).sum())
+    ei_ref = cand[:, dn < 5.0]
+    print(f'config-2 size: {cand.shape[1]} candidate pairs, {ei_ref.shape[1]} edges, {tie_risk} within 4 ulp of the cutoff')
+    assert np.array_equal(o1.edge_index.cpu().numpy(), ei_ref.numpy())
     net = o1.gradient_force.reshape(B, n, 3).sum(1).abs().max().item()
     assert net < 2e-4, net
     # reverse the molecule order: per-molecule results must be identical (bitwise: same per-row arithmetic)
@@ -187,28 +200,64 @@ def test_empty_and_degenerate_inputs():
     with pytest.raises(ValueError):
         model(torch.tensor([1, 1, 1], device='cuda'), torch.rand(3, 3, device='cuda'),
               torch.zeros(2, 3, 3, device='cuda'), torch.tensor([1, 0, 1], device='cuda'))
+    # atomic numbers outside the embedding / scale / shift tables raise like the reference's nn.Embedding (IndexError)
+    for bad in (119, -1):
+        with pytest.raises(IndexError):
+            model(torch.tensor([1, bad, 8], device='cuda'), torch.rand(3, 3, device='cuda'),
+                  torch.zeros(1, 3, 3, device='cuda'), torch.zeros(3, dtype=torch.long, device='cuda'))
     # CPU tensors are rejected loudly (no CPU path)
     with pytest.raises(RuntimeError):
         model(torch.tensor([1]), torch.zeros(1, 3), torch.zeros(1, 3, 3), torch.zeros(1, dtype=torch.long))
 
 
-@pytest.mark.parametrize('case', ['aspirin8_rand', 'pbc216_rand', 'pbc_batch2_rand'])
+@pytest.mark.parametrize('case', ['aspirin8', 'pbc216', 'pbc_batch2', 'triclinic64'])
 def test_virial_and_stress(case):
-    """virial = -dE/d(strain), stress = (dE/d strain)/det(cell) (output.py:154-180) vs the oracle's autograd through the
-    reference's own strain construction (including the `cell @ n` image shift)."""
+    """virial = -dE/d(strain), stress = (dE/d strain)/det(cell) (output.py:154-180) against the REFERENCE's own output for
+    ['energy','gradient_force','virial','stress'] (tests/golden/case_virial_*.npz, gen_golden.py virial), and against the
+    oracle's autograd through the reference's strain construction (including the `cell @ n` image shift)."""
     from oracle import newtonnet_ref as ref
-    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    c = util.load_npz(f'case_virial_{case}.npz')
+    z, batch = torch.from_numpy(c['z']).long(), torch.from_numpy(c['batch']).long()
+    pos, cell = torch.from_numpy(c['pos']).float(), torch.from_numpy(c['cell']).float()
     periodic = bool((cell != 0).any())
     props = ['energy', 'gradient_force', 'virial'] + (['stress'] if periodic else [])
     model, sd = make_model('rand', props)
     out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
-    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
-    scale = max(1.0, want['virial'].abs().max().item())
-    assert (out.virial.cpu().double() - want['virial']).abs().max().item() < 2e-5 * scale
+    assert np.array_equal(out.edge_index.cpu().numpy(), c['f32_edge_index'])
+    scale = max(1.0, float(np.abs(c['f64_virial']).max()))
+    assert np.abs(out.virial.cpu().double().numpy() - c['f64_virial']).max() < 2e-5 * scale
     if periodic:
-        stress = -want['virial'] / cell.double().det().view(-1, 1, 1)
-        assert (out.stress.cpu().double() - stress).abs().max().item() < 2e-5 * scale / cell.det().abs().min().item() + 1e-9
-    check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), max(1.0, want['forces'].abs().max().item() / 5))
+        vol = float(np.abs(np.linalg.det(c['cell'])).min())
+        assert np.abs(out.stress.cpu().double().numpy() - c['f64_stress']).max() < 2e-5 * scale / vol + 1e-9
+    check_forces(out.gradient_force.cpu().numpy(), c['f64_forces'], max(1.0, np.abs(c['f64_forces']).max() / 5))
+    e = out.energy.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(e - c['f64_energy']) <= util.energy_tol(c['f64_energy']))
+    want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert (out.virial.cpu().double() - want['virial']).abs().max().item() < 2e-5 * scale
+
+
+def test_neighbor_boundary_cases():
+    """Neighbor predicate at the boundary (representations.py:85-98): the HIP neighbor list against the reference's own fp32
+    edge_index for pairs at r (1 +- k ulp) and periodic pairs at fractional separations +-0.5 +- k ulp
+    (tests/golden/case_boundary.npz, gen_golden.py boundary).  Bit-exact, including the displacement vectors."""
+    from newtonnet_amd import hip
+    c = util.load_npz('case_boundary.npz')
+    r = float(c['cutoff'])
+    freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
+    for tag in ('a', 'b'):
+        pos, batch = torch.from_numpy(c[tag + '_pos']).cuda(), torch.from_numpy(c[tag + '_batch']).cuda()
+        n_mol = int(c[tag + '_batch'].max()) + 1
+        cell = torch.from_numpy(c['b_cell']).cuda() if tag == 'b' else torch.zeros(n_mol, 3, 3, device='cuda')
+        g = hip.build_graph(pos, cell, batch, r, freq)
+        want = c[tag + '_edge_index']
+        got = g.edge_index.cpu().numpy()
+        sw, sg = set(map(tuple, want.T)), set(map(tuple, got.T))
+        print(f'boundary ({tag}): {len(sw)} reference edges, {len(sw - sg)} missing, {len(sg - sw)} extra')
+        assert np.array_equal(got, want)
+        if tag == 'a':
+            assert np.array_equal(g.disp.cpu().numpy(), c['a_disp'])
+        else:   # the image shift `cell @ round(frac)` goes through MKL's bmm in the reference: same value up to its summation order
+            np.testing.assert_allclose(g.disp.cpu().numpy(), c['b_disp'], rtol=0, atol=2e-6)
 
 
 def periodic_lattice(n_side, n_atoms, seed=0):
@@ -240,6 +289,51 @@ def test_periodic_box_config5_recipe(n_side, n_atoms):
     assert np.all(np.abs(e - want['energy'].numpy()) <= np.maximum(util.energy_tol(want['energy'].numpy()), 1e-4 * np.abs(e)))
     fs = max(1.0, want['forces'].abs().max().item() / 5.0)
     check_forces(out.gradient_force.cpu().numpy(), want['forces'].numpy(), fs)
+
+
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at FULL size (100,000 atoms, ~5.4 M edges; the reference cannot run it: O(N^2) memory).
+    Size-independent properties: bitwise determinism, a symmetric edge set, the in-degree window of the recipe, zero net
+    force, and the neighbor rows of sampled atoms against a brute-force evaluation of the reference's fp32 predicate."""
+    import sys
+    sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+    from bench import synthetic_box
+    z, pos, cell, batch = synthetic_box(100000, 47, seed=0, device='cuda')
+    model, _ = make_model('rand')
+    o1 = model(z, pos, cell, batch)
+    o2 = model(z, pos, cell, batch)
+    assert torch.equal(o1.edge_index, o2.edge_index) and torch.equal(o1.energy, o2.energy)
+    assert torch.equal(o1.gradient_force, o2.gradient_force)
+    ei = o1.edge_index
+    N, E = 100000, ei.shape[1]
+    assert 5.0e6 < E < 5.8e6, E
+    deg = torch.bincount(ei[0], minlength=N)
+    assert 25 <= int(deg.min()) and int(deg.max()) <= 90, (int(deg.min()), int(deg.max()))
+    # CSR order (i ascending, j ascending within a row) and symmetry: the reversed list, re-sorted, is the list itself
+    key = ei[0] * N + ei[1]
+    assert bool((key[1:] > key[:-1]).all())
+    key_rev = torch.sort(ei[1] * N + ei[0]).values
+    assert torch.equal(key, key_rev)
+    f = o1.gradient_force.double()
+    assert torch.isfinite(f).all() and torch.isfinite(o1.energy).all()
+    net = f.sum(0).abs().max().item()
+    assert net <= 1e-6 * f.abs().sum().item(), (net, f.abs().sum().item())
+    # sampled rows vs the reference's own fp32 arithmetic (representations.py:85-98) over ALL 100k candidates
+    pc, cc = pos.cpu(), cell.cpu()
+    row_ptr = torch.zeros(N + 1, dtype=torch.long)
+    row_ptr[1:] = torch.cumsum(deg.cpu(), 0)
+    col = ei[1].cpu()
+    gen = torch.Generator().manual_seed(3)
+    for i in torch.randint(0, N, (64,), generator=gen).tolist():
+        d = pc[i].unsqueeze(0) - pc
+        c = cc.expand(N, 3, 3)
+        frac = torch.linalg.solve(c.transpose(1, 2), d)
+        d = d - torch.bmm(c, torch.round(frac).unsqueeze(-1)).squeeze(-1)
+        keep = d.norm(dim=1) < 5.0
+        keep[i] = False
+        want = torch.nonzero(keep).flatten()
+        got = col[row_ptr[i]:row_ptr[i + 1]]
+        assert torch.equal(got, want), i
 
 
 def test_cell_list_equals_all_pairs():

@@ -220,3 +220,44 @@ def test_molecule_shards_reproduce_the_global_gradient():
         for (name, _), a, g in zip(model.named_parameters(), acc, full):
             scale = max(float(g.abs().max()), 1e-6)
             assert float((a - g).abs().max()) <= 2e-4 * scale + 1e-7, name
+
+
+@pytest.mark.parametrize('props', [['energy'], ['energy', 'direct_force']])
+def test_training_without_gradient_force_head(props):
+    """The reference trains ['energy'] and ['energy', 'direct_force'] models like any other (trainer.py:299-313): in train
+    mode the outputs must stay attached to the parameters even though no derivative head asks for create_graph.
+    Parameter gradients against the fp64 oracle."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, c = util.case_inputs('ethanol4_rand', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    e_lab, d_lab = torch.randn(4, generator=g), torch.randn(36, 3, generator=g)
+    torch.manual_seed(21)
+    model = NewtonNet(output_properties=list(props))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to('cuda')
+    model.train()
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    assert out.energy.requires_grad
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda())
+    if 'direct_force' in props:
+        assert out.direct_force.requires_grad
+        loss = loss + torch.nn.functional.mse_loss(out.direct_force, d_lab.cuda())
+    loss.backward()
+    kw = dict(direct_head=1, direct_label=d_lab.double()) if 'direct_force' in props else {}
+    want_loss, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch,
+                                              e_lab.double(), None, **kw)
+    assert abs(loss.item() - want_loss.item()) <= 1e-4 * abs(want_loss.item())
+    err = nrm = 0.0
+    for name, prm in model.named_parameters():
+        if prm.requires_grad:
+            got = prm.grad.detach().cpu().double() if prm.grad is not None else torch.zeros_like(want[name])
+            err += (got - want[name]).norm().item() ** 2
+            nrm += want[name].norm().item() ** 2
+    assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm), (np.sqrt(err), np.sqrt(nrm))
+    # eval mode under no_grad still takes the inference kernels
+    model.eval()
+    with torch.no_grad():
+        o2 = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    assert not o2.energy.requires_grad
+    assert (o2.energy - out.energy.detach()).abs().max().item() < 2e-5 * max(1.0, out.energy.abs().max().item())

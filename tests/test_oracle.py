@@ -110,3 +110,47 @@ def test_layer_norm_pinned():
     np.testing.assert_allclose(out['energy'].numpy(), c['energy'], rtol=0, atol=1e-12)
     np.testing.assert_allclose(out['forces'].numpy(), c['forces'], rtol=0, atol=1e-12)
     np.testing.assert_allclose(out['atom_node'].numpy(), c['atom_node'], rtol=0, atol=1e-12)
+
+
+VIRIAL_CASES = ['aspirin8', 'pbc216', 'pbc_batch2', 'triclinic64']
+
+
+@pytest.mark.parametrize('case', VIRIAL_CASES)
+def test_oracle_virial_stress_pinned(case):
+    """virial / stress heads (output.py:154-180, strain construction newtonnet.py:146-155): the oracle's autograd virial
+    against the reference's own output for ['energy','gradient_force','virial','stress'] (gen_golden.py virial)."""
+    c = util.load_npz(f'case_virial_{case}.npz')
+    sd = util.load_state('rand')
+    z, batch = torch.from_numpy(c['z']).long(), torch.from_numpy(c['batch']).long()
+    pos, cell = torch.from_numpy(c['pos']), torch.from_numpy(c['cell'])
+    out = ref.energy_forces(sd, z, pos, cell, batch)
+    assert np.array_equal(out['edge_index'].numpy(), c['f64_edge_index'])
+    np.testing.assert_allclose(out['energy'].numpy(), c['f64_energy'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out['forces'].numpy(), c['f64_forces'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(out['virial'].numpy(), c['f64_virial'], rtol=1e-10, atol=1e-11)
+    if 'f64_stress' in c:      # stress = dE/d(strain) / det(cell) = -virial / volume (output.py:175-179)
+        stress = -out['virial'] / cell.det().view(-1, 1, 1)
+        np.testing.assert_allclose(stress.numpy(), c['f64_stress'], rtol=1e-10, atol=1e-13)
+    # fp32 run of the reference vs the fp32 oracle
+    out32 = ref.energy_forces(ref.cast_state(sd, torch.float32), z, pos.float(), cell.float(), batch)
+    assert np.array_equal(out32['edge_index'].numpy(), c['f32_edge_index'])
+    scale = max(1.0, float(np.abs(c['f64_virial']).max()))
+    assert np.abs(out32['virial'].numpy() - c['f32_virial']).max() < 5e-5 * scale
+
+
+def test_oracle_boundary_cases_fp32():
+    """Neighbor predicate at the boundary (representations.py:85-98, fp32): pairs at r (1 +- k ulp) and periodic pairs at a
+    fractional separation of +-0.5 +- k ulp -- the oracle's fp32 radius_graph against the reference's own edge_index."""
+    c = util.load_npz('case_boundary.npz')
+    r = float(c['cutoff'])
+    n_a = int(c['a_batch'].max()) + 1
+    ei, d = ref.radius_graph(torch.from_numpy(c['a_pos']), torch.zeros(n_a, 3, 3), torch.from_numpy(c['a_batch']), r)
+    assert np.array_equal(ei.numpy(), c['a_edge_index']) and np.array_equal(d.numpy(), c['a_disp'])
+    ei, d = ref.radius_graph(torch.from_numpy(c['b_pos']), torch.from_numpy(c['b_cell']), torch.from_numpy(c['b_batch']), r)
+    assert np.array_equal(ei.numpy(), c['b_edge_index']) and np.array_equal(d.numpy(), c['b_disp'])
+    # the fixture is adversarial: almost every open-boundary pair is within 4 ulp of the cutoff, on both sides of it
+    pa = torch.from_numpy(c['a_pos'])
+    dn = (pa[0::2] - pa[1::2]).norm(dim=1)
+    ties = int(((dn - r).abs() <= 4 * np.spacing(np.float32(r))).sum())
+    inside = c['a_edge_index'].shape[1] // 2
+    assert ties > 1500 and 0.2 < inside / (len(pa) // 2) < 0.8
