@@ -99,7 +99,7 @@ __device__ __forceinline__ CellInfo load_cell(const float* __restrict__ cell, lo
   return ci;
 }
 
-// disp = pos_i - pos_j with the reference's single-image shift; returns ||disp||.  fp32 with compiler FMA contraction
+// disp = pos_i - pos_j with the reference's single-image shift; returns ||disp||^2 (see cut2_of for the predicate).  fp32 with compiler FMA contraction
 // switched off and every rounding written out, so that the count and fill passes agree with each other AND with the
 // reference's fp32 CPU evaluation on the strict `< r` predicate (representations.py:96, pinned by
 // tests/golden/case_boundary.npz: pairs within a few ulp of the cutoff):
@@ -111,6 +111,18 @@ __device__ __forceinline__ CellInfo load_cell(const float* __restrict__ cell, lo
 //     the fp64 inverse used here differs from it by <= 2 ulp, which can pick the other image only for a pair whose
 //     fractional separation is within 2 ulp of +-0.5 -- and then changes the edge SET only if that pair also sits within
 //     a few ulp of the cutoff (tests count those double ties).
+// The reference's predicate is sqrt_rn(r2) < cutoff.  gfx950 has no correctly rounded fp32 square root (v_sqrt_f32 is
+// 1 ulp; hipcc emits it bare for sqrtf and __fsqrt_rn alike -- on the boundary fixture it admitted 162 pairs the reference
+// rejects), so the host turns the cutoff into the equivalent threshold on r2 once: the smallest float T with
+// sqrt_rn(T) >= cutoff (the host's sqrtf IS correctly rounded, and sqrt is monotone), and the kernels test r2 < T.
+static float cut2_of(float cutoff) {
+  float t = cutoff * cutoff;
+  if (!(t < INFINITY)) return INFINITY;
+  while (t > 0.f && sqrtf(t) >= cutoff) t = nextafterf(t, 0.f);
+  while (sqrtf(t) < cutoff) t = nextafterf(t, INFINITY);
+  return t;
+}
+
 __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float xj, float yj, float zj,
                                            const CellInfo& ci, float& dx, float& dy, float& dz) {
 #pragma clang fp contract(off)
@@ -134,8 +146,7 @@ __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float x
     dy = dy - ((ci.c[3] * n0 + ci.c[4] * n1) + ci.c[5] * n2);
     dz = dz - ((ci.c[6] * n0 + ci.c[7] * n1) + ci.c[8] * n2);
   }
-  const float r2 = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-  return __fsqrt_rn(r2);
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));   // |disp|^2; callers compare with cut2_of(cutoff)
 }
 
 // One wavefront per receiver atom i; the lanes test 64 candidate senders j at a time and a ballot + prefix popcount
@@ -143,7 +154,7 @@ __device__ __forceinline__ float pair_disp(float xi, float yi, float zi, float x
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
-                  const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cutoff, int* __restrict__ deg,
+                  const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cut2, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
                   float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -164,8 +175,8 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
     bool hit = false;
     float dx = 0.f, dy = 0.f, dz = 0.f;
     if (j < e && j != i) {
-      const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
-      hit = r < cutoff;
+      const float r2 = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
+      hit = r2 < cut2;
     }
     const unsigned long long mask = __ballot(hit);
     if (FILL) {
@@ -276,7 +287,7 @@ __global__ void edge_rev_kernel(const int* __restrict__ row_ptr, const int* __re
 // cancellation of the p=9 polynomial envelope near x -> 1 from the fp32 error budget).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, const float* __restrict__ freq, int nb,
+edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, float cut2, const float* __restrict__ freq, int nb,
                   float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
@@ -298,7 +309,7 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, con
     // all-zero filter rows and are masked out of the force kernels.  "Outside" is the neighbor list's own fp32 predicate
     // (pair_disp: the reference's `norm < r`), so an edge of the exact list is never masked, whatever the fp64 value of x.
     const float fx = disp[3 * (long)e], fy = disp[3 * (long)e + 1], fz = disp[3 * (long)e + 2];
-    const bool inside = __fsqrt_rn(__fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx))) < cutoff;
+    const bool inside = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx)) < cut2;
     xg[e] = inside ? make_int2(g0, __float_as_int((float)(t - (double)g0))) : make_int2(FT_ZERO_ROW, 0);
   }
   if (!rbf) return;
@@ -338,7 +349,7 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
   mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status);
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
-  graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, row_ptr,
+  graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), row_ptr,
                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
   {
@@ -359,7 +370,7 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
   // `rev` doubles as the receiver-of-edge scratch during the fill; edge_rev_kernel then replaces it in place
-  graph_rows_kernel<true><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cutoff, nullptr,
+  graph_rows_kernel<true><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), nullptr,
                                                                   row_ptr, col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
@@ -474,7 +485,7 @@ extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff
   }
   if (n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
-  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, frequencies, n_basis, geo, rbf, drbf,
+  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, cut2_of(cutoff), frequencies, n_basis, geo, rbf, drbf,
                                                             reinterpret_cast<int2*>(xg));
   LAUNCH_CHECK();
   return NNHIP_OK;
@@ -528,7 +539,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
 cells_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int* __restrict__ bin_of,
                   const int* __restrict__ bin_ptr, const int* __restrict__ bin_atoms, CellGrid g, int n_atoms,
-                  float cutoff, int* __restrict__ deg, const int* __restrict__ row_ptr, int* col,
+                  float cut2, int* __restrict__ deg, const int* __restrict__ row_ptr, int* col,
                   int* __restrict__ erow, float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
@@ -549,8 +560,8 @@ cells_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
           const int j = bin_atoms[k];
           if (j == i) continue;
           float ddx, ddy, ddz;
-          const float r = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, ddx, ddy, ddz);
-          if (r < cutoff) {
+          const float r2 = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, ddx, ddy, ddz);
+          if (r2 < cut2) {
             if (FILL) {  // insertion sort by j inside this row's slice of col[]
               int p = base + cnt;
               while (p > base && col[p - 1] > j) {
@@ -656,7 +667,7 @@ extern "C" int nnhip_graph_count_cells(const float* pos, const float* cell, int3
   if (rc) return rc;
   const int32_t mp[2] = {0, n_atoms};
   HIP_TRY(hipMemcpyAsync(mol_ptr, mp, sizeof(mp), hipMemcpyHostToDevice, stream));
-  cells_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cutoff,
+  cells_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cut2_of(cutoff),
                                                                    row_ptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
   LAUNCH_CHECK();
   {
@@ -680,7 +691,7 @@ extern "C" int nnhip_graph_fill_cells(const float* pos, const float* cell, int32
   int *bin_of, *bin_ptr, *cursor, *bin_atoms;
   const int rc = cells_common(pos, n_atoms, box_len_host, cutoff, scratch, g, bin_of, bin_ptr, cursor, bin_atoms, false, stream);
   if (rc) return rc;
-  cells_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cutoff,
+  cells_rows_kernel<true><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cut2_of(cutoff),
                                                                   nullptr, row_ptr, col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
