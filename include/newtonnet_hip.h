@@ -291,6 +291,150 @@ int nnhip_direct_force(const float* atom_node, const float* force_node, const in
 int nnhip_segment_sum(const float* x, const int32_t* row_ptr, int32_t n_rows, int32_t width, float* out, void* stream);
 int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_out, int32_t width, float* out, void* stream);
 
+/* ==========================================================================
+ * Per-stage entry points (last row) and TRAINING.
+ *
+ * The stages nnhip_energy_forces runs internally, exported one by one, plus the kernels that differentiate them
+ * once more.  Training (newtonnet/train/trainer.py:299-313: loss.backward() through the autograd force of
+ * newtonnet/models/output.py:66-73, create_graph=True) is evaluated as "tangent over reverse": with c_b = dL/dE_b and
+ * d = dL/dF,   dL/dtheta = sum_b c_b dE_b/dtheta - D_d[grad_theta E_tot],   i.e. the reverse sweep is differentiated in
+ * forward (tangent) mode along v = -d with the reverse seed carried as the dual number 1 + eps c_b.  Every stage below has a
+ * value form (*_fwd / *_bwd = its adjoint) and a tangent form (*_tan_fwd / *_tan_bwd); all are deterministic (segmented
+ * sums over the receiver CSR, pair rows written by the lower endpoint, no float atomics).  The host side that strings
+ * them together is newtonnet_amd/train_fused.py; tests/tangent_ref.py states the same sweeps in fp64.
+ * Shapes: N atoms, E directed edges, P = E/2 pairs (row pid[e]); node rows [N][F], [N][3][F]; pair rows [P][F].
+ * ========================================================================== */
+
+/* atom_node = Embedding[z]  (newtonnet.py:142) */
+int nnhip_embed(const int64_t* z, const float* table, int32_t n_atoms, float* out, void* stream);
+
+/* Radial-filter tables of `n_layers` layers (message_edgepart applied to the Bessel basis, newtonnet.py:186,210): for each
+ * layer two planes [FT_ROWS][F] (values, d/dx) on 2048 intervals of x = r/cutoff; tables[l] needs
+ * nnhip_filter_table_bytes() bytes.  The message kernels interpolate them instead of contracting rbf per edge. */
+size_t nnhip_filter_table_bytes(void);
+int nnhip_filter_tables(const float* const* edge_w_host_array, float* const* tables_host_array, int32_t n_layers,
+                        const float* frequencies, int32_t n_basis, void* stream);
+
+/* out[k] = in[k]^T for `count` <= 40 [128][128] matrices (weights for the adjoint products) */
+int nnhip_transpose128(const float* const* src_host_array, float* const* dst_host_array, int32_t count, void* stream);
+
+/* K1: message + invariant aggregation (newtonnet.py:210-215) and its adjoint.
+ *   fwd: msg[p] = eps(x_e) m_i m_j;  a_mid[i] = a_in[i] + sum_{e in row i} msg
+ *   bwd: G = g_msg[p] + g_a[i] + g_a[j];  g_m[i] = sum_e G eps m_j;  g_x[e] = <G m_i m_j, d eps/dx> (pair owner's edge) */
+int nnhip_message_fwd(const float* m, const int32_t* xg, const float* table, const int32_t* row_ptr, const int32_t* col,
+                      const int32_t* pid, const float* a_in, float* msg, float* a_mid, int32_t n_atoms, void* stream);
+int nnhip_message_bwd(const float* g_msg, const float* g_a, const float* m, const int32_t* xg, const float* table,
+                      const int32_t* row_ptr, const int32_t* col, const int32_t* pid, float* g_m, float* g_x,
+                      int32_t n_atoms, int32_t need_gm, void* stream);
+
+/* K2: equivariant messages + aggregation (newtonnet.py:219-227) and its adjoint.  f_in NULL = first layer (force_node == 0).
+ *   fwd: f_out[i][k] = f_in[i][k] + sum_e phi1[p] u_e[k] + phi2[p] f_in[j][k]
+ *   bwd: g_h12[p] = (g_phi1 | g_phi2) (both directions summed), g_u[e][k] = <gf_i[k], phi1[p]>,
+ *        g_fin[i][k] = gf[i][k] + sum_e phi2[p] gf[j][k] */
+int nnhip_force_message_fwd(const float* phi1, const float* phi2, const float* geo, const int32_t* xg,
+                            const int32_t* row_ptr, const int32_t* col, const int32_t* pid, const float* f_in,
+                            float* f_out, int32_t n_atoms, void* stream);
+int nnhip_force_message_bwd(const float* gf, const float* phi1, const float* phi2, const float* geo, const int32_t* xg,
+                            const int32_t* row_ptr, const int32_t* col, const int32_t* pid, const float* f_in,
+                            float* g_h12, float* g_u, float* g_fin, int32_t n_atoms, void* stream);
+
+/* Adjoint of the edge embedding: g_x[L][E], g_u[L][E][4] of all layers -> g_d[E][4] -> forces[N][3] (= -dE/dpos) and,
+ * optionally, virial[B][3][3] (output.py:154-165; needs disp / pos / cell / mol_ptr). */
+int nnhip_edge_embed_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
+                         const float* cell, const int32_t* row_ptr, const int32_t* col, const int32_t* rev,
+                         const int32_t* mol_ptr, int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers,
+                         float cutoff, float* g_d, float* forces, float* virial, void* stream);
+
+/* Row-local node stages between two edge phases (newtonnet.py:229-231 and, for the next layer, :181-185,209).
+ *   node_fwd: q_k = f_k Wu^T; a_out = a_mid + sum_k f_k q_k; [hn = a_out W0^T + b0; m = act(hn) W2^T + b2 when W0 != NULL]
+ *   node_bwd: [g_hn = (g_top W2T^T) act'(h_top); g_a (+)= g_hn W0T^T when W2T != NULL];
+ *             [gf_k = G_f,k + g_a q_k + (g_a f_k) WuT^T when WuT != NULL]     (W*T = transposed weights) */
+int nnhip_node_fwd(const float* f, const float* a_mid, const float* Wu, float* q, float* a_out, const float* W0,
+                   const float* b0, const float* W2, const float* b2, float* hn, float* m, int32_t n_atoms,
+                   int32_t activation, void* stream);
+int nnhip_node_bwd(const float* g_top, const float* h_top, const float* W2T, const float* W0T, float* g_a,
+                   int32_t accumulate_ga, const float* f, const float* q, const float* G_f, const float* WuT, float* gf,
+                   int32_t n_atoms, int32_t activation, void* stream);
+
+/* Energy head tail (output.py:98-100 last linear, scalers.py:55-58, output.py:246) and the reverse seed:
+ *   atom_energy[i] = (<act(e2_i), w4> + b4) scale[z_i] + shift[z_i];  energy[b] = sum;  g_e2[i] = scale w4 act'(e2)  (may be NULL) */
+int nnhip_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
+                   const int64_t* z, const int32_t* mol_ptr, int32_t n_atoms, int32_t n_mol, int32_t activation,
+                   float* atom_energy, float* g_e2, float* energy, void* stream);
+
+/* Fused Linear -> act -> Linear with every option (nnhip_mlp128 is the plain subset):
+ *   mode 0 FWD : H = X W1^T + b1 (stored);  Y = act(H) W2^T + b2
+ *   mode 1 BWD : T = X W1^T;  Y (+)= (T act'(H)) W2^T
+ *   mode 2 TAN : as BWD, and T is stored            -- tangent of FWD (X = dX: T = dH, Y = dY), or BWD keeping its hidden product
+ *   mode 3 TAN2: dT = X W1^T;  G = dT act'(H) + T2 act''(H) Hd (stored);  Y (+)= G W2^T      -- tangent of BWD
+ * H / T / T2 / Hd / G share the row pitch ldh. */
+typedef struct {
+  const float* X; int32_t ldx;
+  const float* W1; const float* W2; const float* b1; const float* b2;
+  float* H; int32_t ldh;
+  float* Y; int32_t ldy;
+  int32_t M, mode, accumulate, activation;
+  float* T; const float* T2; const float* Hd; float* G;
+} nnhip_mlp_desc;
+int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
+
+/* ---- tangent kernels (sweeps 3 and 4) ---- */
+/* tgeo[e] = (du_e, dx_e): tangent of (dir, x = r/cutoff) along the position direction v[N][3] */
+int nnhip_edge_tangent_geom(const float* v, const int64_t* edge_index, const float* geo, int32_t n_edges, float cutoff,
+                            float* tgeo, void* stream);
+/* dmsg[p] = deps dx m_i m_j + eps (dm_i m_j + m_i dm_j);  da_mid = da_in + sum_e dmsg   (dm = da_in = NULL: first layer) */
+int nnhip_message_tan_fwd(const float* m, const float* dm, const int32_t* xg, const float* tgeo, const float* table,
+                          const int32_t* row_ptr, const int32_t* col, const int32_t* pid, const float* da_in, float* dmsg,
+                          float* da_mid, int32_t n_atoms, void* stream);
+/* df_out = df_in + sum_e dphi1 u + phi1 du + dphi2 f_j + phi2 df_j   (f_in = df_in = NULL: first layer) */
+int nnhip_force_message_tan_fwd(const float* phi1, const float* dphi1, const float* phi2, const float* dphi2,
+                                const float* geo, const float* tgeo, const int32_t* xg, const int32_t* row_ptr,
+                                const int32_t* col, const int32_t* pid, const float* f_in, const float* df_in,
+                                float* df_out, int32_t n_atoms, void* stream);
+/* dg_h12[p] = (dg_phi1 | dg_phi2),  dg_fin = dgf + sum_e dphi2 gf_j + phi2 dgf_j */
+int nnhip_force_message_tan_bwd(const float* gf, const float* dgf, const float* phi2, const float* dphi2, const float* geo,
+                                const float* tgeo, const int32_t* xg, const int32_t* row_ptr, const int32_t* col,
+                                const int32_t* pid, const float* f_in, const float* df_in, float* dg_h12, float* dg_fin,
+                                int32_t n_atoms, void* stream);
+/* dg_m[i] = sum_e dG eps m_j + G deps dx m_j + G eps dm_j;  g_eps[p] = G m_i m_j;  dg_eps[p] = dG m_i m_j + G (dm_i m_j + m_i dm_j) */
+int nnhip_message_tan_bwd(const float* g_msg, const float* dg_msg, const float* ga, const float* dga, const float* m,
+                          const float* dm, const int32_t* xg, const float* tgeo, const float* table,
+                          const int32_t* row_ptr, const int32_t* col, const int32_t* pid, float* dg_m, float* g_eps,
+                          float* dg_eps, int32_t n_atoms, void* stream);
+/* da_out = da_mid + sum_k df_k q_k + f_k dq_k */
+int nnhip_update_tan_fwd(const float* da_mid, const float* f, const float* df, const float* q, const float* dq,
+                         int32_t n_atoms, float* da_out, void* stream);
+/* gq_k = GA f_k;  dgq_k = dGA f_k + GA df_k;  dgf_k = dgf_in,k + dGA q_k + GA dq_k   (the W_u product follows as a linear) */
+int nnhip_update_tan_bwd(const float* ga, const float* dga, const float* f, const float* df, const float* q,
+                         const float* dq, const float* dgf_in, int32_t n_atoms, float* gq, float* dgq, float* dgf,
+                         void* stream);
+/* seed of the tangent reverse sweep at the energy head, see csrc/train.hip:head_seed_tan_kernel */
+int nnhip_head_seed_tan(const float* e2, const float* de2, const float* w4, const float* b4, const float* scale,
+                        const int64_t* z, const int64_t* batch, const float* g_energy, int32_t n_atoms, int32_t activation,
+                        float* dg_e2, float* w4row, float* scal, void* stream);
+/* rb[p][0:nb] = rbf_e, rb[p][32:32+nb] = drbf_e dx_e for the owner edge of pair p ([P][64], zero padded) */
+int nnhip_pair_rbf(const float* rbf, const float* drbf, const float* tgeo, const int64_t* edge_index, const int32_t* pid,
+                   int32_t n_edges, int32_t n_basis, float* rb, void* stream);
+/* out[zz][c] = sum_{i: z_i = zz} x[i][c], c < width <= 128 (z NULL: one bin, out[0][c] = column sums) */
+int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, const int64_t* z, int32_t n_atoms, float* out,
+                      int32_t ldo, void* stream);
+
+/* Weight gradients dW[o][i] = sum_r A1[r][o] B1[r][i] + A2[r][o] B2[r][i] over M rows, batched; split-K on the fp32 matrix
+ * cores with per-workgroup slabs and an ordered final sum.  type 0: operands as stored; 1: B1 = act(hB), B2 = act'(hB) dhB;
+ * 2: A2 = A2 * act'(hA).  A2/B2 NULL: one product.  b_cols32: B rows are 32 wide (radial basis).  ld* = 0 means 128.
+ * The problem table is DEVICE memory. */
+typedef struct {
+  const float* A1; const float* B1; const float* A2; const float* B2;
+  const float* hA; const float* hB; const float* dhB;
+  float* out;
+  int32_t M, lda1, lda2, ldb1, ldb2, ldh, type, b_cols32, activation, ldo, ncols, pad_;
+} nnhip_wgrad_problem;
+size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks);
+int nnhip_wgrad_batch(const nnhip_wgrad_problem* problems_dev, int32_t n_problems, int32_t chunks, float* slabs, void* stream);
+/* out[c] = sum_r src[r][c] for [rows][128] arrays (bias gradients); device table */
+typedef struct { const float* src; float* out; int32_t rows; int32_t pad_; } nnhip_colsum_problem;
+int nnhip_colsum_batch(const nnhip_colsum_problem* problems_dev, int32_t n, void* stream);
+
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.

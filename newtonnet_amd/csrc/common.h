@@ -91,6 +91,37 @@ __device__ __forceinline__ float dact_f(float x, int a) {
     default: return dsilu_f(x);
   }
 }
+// second derivatives: the tangent (forward-mode) sweeps of training differentiate act'(h) once more (train.hip)
+__device__ __forceinline__ float d2silu_f(float x) {
+  const float s = sigmoid_f(x);
+  return s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s));
+}
+__device__ __forceinline__ float d2act_f(float x, int a) {
+  switch (a) {
+    case NNHIP_ACT_RELU:
+    case NNHIP_ACT_LEAKY_RELU: return 0.f;
+    case NNHIP_ACT_ELU: return x > 0.f ? 0.f : expf(x);
+    case NNHIP_ACT_TANH: {
+      const float t = tanhf(x);
+      return -2.f * t * (1.f - t * t);
+    }
+    case NNHIP_ACT_SIGMOID: {
+      const float g = 1.0f / (1.0f + expf(-x));
+      return g * (1.f - g) * (1.f - 2.f * g);
+    }
+    case NNHIP_ACT_SOFTPLUS:
+    case NNHIP_ACT_SSP: {
+      if (x > 20.f) return 0.f;
+      const float g = 1.0f / (1.0f + expf(-x));
+      return g * (1.f - g);
+    }
+    case NNHIP_ACT_GELU: return (2.f - x * x) * 0.3989422804014327f * expf(-0.5f * x * x);
+    default: return d2silu_f(x);
+  }
+}
+__device__ __forceinline__ float act_any(float x, int a) { return a == NNHIP_ACT_SILU ? silu_f(x) : act_f(x, a); }
+__device__ __forceinline__ float dact_any(float x, int a) { return a == NNHIP_ACT_SILU ? dsilu_f(x) : dact_f(x, a); }
+__device__ __forceinline__ float d2act_any(float x, int a) { return a == NNHIP_ACT_SILU ? d2silu_f(x) : d2act_f(x, a); }
 // apply to a register block: one wave-uniform test keeps the SiLU loop exactly as it was
 #define NN_ACT_BLOCK(v, n, a)                                            \
   do {                                                                   \
@@ -220,7 +251,10 @@ struct LinArgs {
 int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s);
 
 // ---- fused two-layer edge MLP launcher (mlp128.hip) -------------------------------
-enum { MODE_FWD = 0, MODE_BWD = 1 };
+// MODE_TAN  = MODE_BWD that also stores T (the stage-1 product before the act' factor) -- the tangent of the forward MLP
+//             (T = d h) and, in train mode, the adjoint of the forward MLP with its intermediate kept (T = g_phi V2)
+// MODE_TAN2 = tangent of the adjoint: stage 1  dT = X W1^T;  G = dT * act'(H) + T2 * act''(H) * Hd  (stored);  Y (+)= G W2^T
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_TAN = 2, MODE_TAN2 = 3 };
 struct MlpArgs {
   const float* X;   // [M][ldx]  stage-1 input (msg, or g_phi)
   const float* W1;  // [128][128] row-major, stage 1:  H^T = W1 . X^T
@@ -234,6 +268,11 @@ struct MlpArgs {
   int h_frag;       // H is private scratch between a forward call and its adjoint (same M): the persistent kernel then keeps
                     // it in MFMA-fragment order ([tile][block][q][lane] float4: every access a contiguous 1 KiB, so the
                     // streaming stores write whole lines) in a region of pad32(M) x 128 floats; ldh is ignored
+  // training modes (row pitch ldh, row-local kernel only):
+  float* T;         // MODE_TAN: [M][ldh] out, stage-1 product before the act' factor
+  const float* T2;  // MODE_TAN2: [M][ldh] in, the T of the value sweep
+  const float* Hd;  // MODE_TAN2: [M][ldh] in, tangent of H
+  float* G;         // MODE_TAN2: [M][ldh] out, the hidden adjoint's tangent
 };
 struct MlpPair {      // up to two MLPs over the same M rows, run back to back by one persistent launch (mlp128.hip)
   MlpArgs a[2];

@@ -301,18 +301,26 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, flo
   g.w = (float)r;
   reinterpret_cast<float4*>(geo)[e] = g;
   const double x = r / (double)cutoff;
+  // Candidates of a reused list (Verlet skin, static training list) that are outside the cutoff right now point at the
+  // all-zero filter rows, are masked out of the force kernels and get an all-zero radial basis.  "Outside" is the neighbor
+  // list's own fp32 predicate (pair_disp: the reference's `norm < r`), so an edge of the exact list is never masked,
+  // whatever the fp64 value of x.
+  const float fx = disp[3 * (long)e], fy = disp[3 * (long)e + 1], fz = disp[3 * (long)e + 2];
+  const bool inside = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx)) < cut2;
   if (xg) {  // position on the radial-filter table grid (edge.hip): interval index and fraction, fraction in fp64 accuracy
     const double t = x * (double)FT_G;
     int g0 = (int)floor(t);
     g0 = g0 < 0 ? 0 : (g0 > FT_G - 1 ? FT_G - 1 : g0);
-    // Candidates of a reused list (Verlet skin, static training list) that are outside the cutoff right now point at the
-    // all-zero filter rows and are masked out of the force kernels.  "Outside" is the neighbor list's own fp32 predicate
-    // (pair_disp: the reference's `norm < r`), so an edge of the exact list is never masked, whatever the fp64 value of x.
-    const float fx = disp[3 * (long)e], fy = disp[3 * (long)e + 1], fz = disp[3 * (long)e + 2];
-    const bool inside = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx)) < cut2;
     xg[e] = inside ? make_int2(g0, __float_as_int((float)(t - (double)g0))) : make_int2(FT_ZERO_ROW, 0);
   }
   if (!rbf) return;
+  if (!inside) {
+    for (int n = 0; n < nb; ++n) {
+      rbf[(long)e * nb + n] = 0.f;
+      if (drbf) drbf[(long)e * nb + n] = 0.f;
+    }
+    return;
+  }
   const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
   const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);   // 1 - 55x^9 + 99x^10 - 45x^11
   const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);        // -495x^8 + 990x^9 - 495x^10

@@ -316,7 +316,7 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1((a.b1 || a.b2) ? TC_LIN1 : TC_MLP, s);   // biased form = node MLP / energy head (node-level class)
-  if (mlp_use_wide(a)) {
+  if (mlp_use_wide(a) || mode == MODE_TAN || mode == MODE_TAN2) {   // (the training modes exist in the row-local form only)
     MlpArgs w = a;
     if (w.h_frag) w.ldh = NF;   // the row-local kernel keeps H row-major inside the same pad32(M) x 128 region
     return launch_mlp_wide(mode, accum, w, s);
@@ -374,6 +374,7 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
     return NNHIP_E_INVALID;
   }
   MlpArgs a;
+  memset(&a, 0, sizeof(a));
   a.X = X;
   a.W1 = W1;
   a.W2 = W2;
@@ -387,4 +388,34 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
   a.act = NNHIP_ACT_SILU;
   a.h_frag = 0;   // the C ABI exposes H row-major
   return launch_mlp(mode, accumulate != 0, a, (hipStream_t)stream);
+}
+
+// Extended form: biases, any activation of the factory, and the training modes (include/newtonnet_hip.h: nnhip_mlp_desc)
+extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {
+  if (!d || !d->X || !d->W1 || !d->W2 || !d->H || !d->Y || d->M < 0 || d->ldx < NF || d->ldh < NF || d->ldy < NF ||
+      (d->ldx & 3) || (d->ldh & 3) || (d->ldy & 3) || d->mode < MODE_FWD || d->mode > MODE_TAN2 ||
+      d->activation < NNHIP_ACT_SILU || d->activation > NNHIP_ACT_SSP || (d->mode == MODE_TAN && !d->T) ||
+      (d->mode == MODE_TAN2 && (!d->T2 || !d->Hd || !d->G)) || (d->mode != MODE_FWD && (d->b1 || d->b2))) {
+    nnhip_set_error("nnhip_mlp128_ex: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.X = d->X;
+  a.W1 = d->W1;
+  a.W2 = d->W2;
+  a.H = d->H;
+  a.Y = d->Y;
+  a.M = d->M;
+  a.ldx = d->ldx;
+  a.ldh = d->ldh;
+  a.ldy = d->ldy;
+  a.b1 = d->b1;
+  a.b2 = d->b2;
+  a.act = d->activation;
+  a.T = d->T;
+  a.T2 = d->T2;
+  a.Hd = d->Hd;
+  a.G = d->G;
+  return launch_mlp(d->mode, d->accumulate != 0, a, (hipStream_t)stream);
 }

@@ -275,7 +275,7 @@ __device__ __forceinline__ void mlp_wide_body(const MlpArgs& p, const bool accum
   load_w(wf, t, p.W1);
   float x[16], hv[16], hin[16];
   blk_load(x, p.X, (size_t)rc * p.ldx, t);
-  if (MODE == MODE_BWD) blk_load(hin, p.H, (size_t)rc * p.ldh, t);
+  if (MODE != MODE_FWD) blk_load(hin, p.H, (size_t)rc * p.ldh, t);
   blk_to_tile(x, t);
   __syncthreads();
   acc_to(hv, tile_gemm(t, wf));
@@ -289,7 +289,16 @@ __device__ __forceinline__ void mlp_wide_body(const MlpArgs& p, const bool accum
     }
     if (live) blk_store(hv, p.H, (size_t)row * p.ldh, t);
     NN_ACT_BLOCK(hv, 16, p.act);
+  } else if (MODE == MODE_TAN2) {
+    float t2[16], hd[16];
+    blk_load(t2, p.T2, (size_t)rc * p.ldh, t);
+    blk_load(hd, p.Hd, (size_t)rc * p.ldh, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      hv[k] = fmaf(hv[k], dact_any(hin[k], p.act), t2[k] * d2act_any(hin[k], p.act) * hd[k]);
+    if (live) blk_store(hv, p.G, (size_t)row * p.ldh, t);
   } else {
+    if (MODE == MODE_TAN && live) blk_store(hv, p.T, (size_t)row * p.ldh, t);
     NN_DACT_MUL_BLOCK(hv, hin, 16, p.act);
   }
   __syncthreads();
@@ -354,6 +363,14 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
     mlp128_wide_kernel<MODE_BWD, false><<<n_tiles, 256, 0, s>>>(a);
   else if (mode == MODE_BWD && accum)
     mlp128_wide_kernel<MODE_BWD, true><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_TAN && !accum)
+    mlp128_wide_kernel<MODE_TAN, false><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_TAN && accum)
+    mlp128_wide_kernel<MODE_TAN, true><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_TAN2 && !accum)
+    mlp128_wide_kernel<MODE_TAN2, false><<<n_tiles, 256, 0, s>>>(a);
+  else if (mode == MODE_TAN2 && accum)
+    mlp128_wide_kernel<MODE_TAN2, true><<<n_tiles, 256, 0, s>>>(a);
   else
     return NNHIP_E_INVALID;
   LAUNCH_CHECK();

@@ -553,3 +553,84 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
                           model->cutoff, P(w.g_d), forces, virial, s));
   return NNHIP_OK;
 }
+
+// ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----
+extern "C" size_t nnhip_filter_table_bytes(void) { return (size_t)2 * FT_ROWS * NF * sizeof(float); }
+extern "C" int nnhip_filter_tables(const float* const* edge_w, float* const* tables, int32_t n_layers, const float* freq,
+                                   int32_t nb, void* stream) {
+  if (!edge_w || !tables || !freq || n_layers < 1 || n_layers > NNHIP_MAX_LAYERS || nb < 1 || nb > NNHIP_MAX_NB) {
+    nnhip_set_error("nnhip_filter_tables: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  return launch_filter_tables(edge_w, tables, n_layers, freq, nb, (hipStream_t)stream);
+}
+extern "C" int nnhip_transpose128(const float* const* src, float* const* dst, int32_t count, void* stream) {
+  if (!src || !dst || count < 0 || count > 40) {
+    nnhip_set_error("nnhip_transpose128: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  return count ? launch_transposes(src, dst, count, (hipStream_t)stream) : NNHIP_OK;
+}
+extern "C" int nnhip_message_fwd(const float* m, const int32_t* xg, const float* table, const int32_t* row_ptr,
+                                 const int32_t* col, const int32_t* pid, const float* a_in, float* msg, float* a_mid,
+                                 int32_t n_atoms, void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_msg_fwd(m, xg, table, row_ptr, col, pid, a_in, msg, a_mid, n_atoms, (hipStream_t)stream);
+}
+extern "C" int nnhip_message_bwd(const float* g_msg, const float* g_a, const float* m, const int32_t* xg, const float* table,
+                                 const int32_t* row_ptr, const int32_t* col, const int32_t* pid, float* g_m, float* g_x,
+                                 int32_t n_atoms, int32_t need_gm, void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_msg_bwd(g_msg, g_a, m, xg, table, row_ptr, col, pid, g_m, g_x, n_atoms, need_gm != 0, (hipStream_t)stream);
+}
+extern "C" int nnhip_force_message_fwd(const float* phi1, const float* phi2, const float* geo, const int32_t* xg,
+                                       const int32_t* row_ptr, const int32_t* col, const int32_t* pid, const float* f_in,
+                                       float* f_out, int32_t n_atoms, void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_force_fwd(f_in != nullptr, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, xg, (hipStream_t)stream);
+}
+extern "C" int nnhip_force_message_bwd(const float* gf, const float* phi1, const float* phi2, const float* geo,
+                                       const int32_t* xg, const int32_t* row_ptr, const int32_t* col, const int32_t* pid,
+                                       const float* f_in, float* g_h12, float* g_u, float* g_fin, int32_t n_atoms,
+                                       void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_force_bwd(f_in != nullptr, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, xg,
+                          (hipStream_t)stream);
+}
+extern "C" int nnhip_edge_embed_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
+                                    const float* cell, const int32_t* row_ptr, const int32_t* col, const int32_t* rev,
+                                    const int32_t* mol_ptr, int32_t n_atoms, int32_t n_edges, int32_t n_mol, int32_t n_layers,
+                                    float cutoff, float* g_d, float* forces, float* virial, void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_geometry_bwd(g_x, g_u, geo, disp, pos, cell, row_ptr, col, rev, mol_ptr, n_atoms, n_edges, n_mol, n_layers,
+                             cutoff, g_d, forces, virial, (hipStream_t)stream);
+}
+extern "C" int nnhip_node_fwd(const float* f, const float* a_mid, const float* Wu, float* q, float* a_out, const float* W0,
+                              const float* b0, const float* W2, const float* b2, float* hn, float* m, int32_t n_atoms,
+                              int32_t activation, void* stream) {
+  NodeFwdArgs na;
+  memset(&na, 0, sizeof(na));
+  na.f = f; na.a_mid = a_mid; na.Wu = Wu; na.q = q; na.a_out = a_out;
+  na.W0 = W0; na.b0 = b0; na.W2 = W2; na.b2 = b2; na.hn = hn; na.m = m;
+  na.N = n_atoms;
+  na.act = activation;
+  return launch_node_fwd(na, (hipStream_t)stream);
+}
+extern "C" int nnhip_node_bwd(const float* g_top, const float* h_top, const float* W2T, const float* W0T, float* g_a,
+                              int32_t accumulate_ga, const float* f, const float* q, const float* G_f, const float* WuT,
+                              float* gf, int32_t n_atoms, int32_t activation, void* stream) {
+  NodeBwdArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.g_top = g_top; nb.h_top = h_top; nb.W2T = W2T; nb.W0T = W0T; nb.g_a = g_a; nb.acc_ga = accumulate_ga;
+  nb.f = f; nb.q = q; nb.G_f = G_f; nb.WuT = WuT; nb.gf = gf;
+  nb.N = n_atoms;
+  nb.act = activation;
+  return launch_node_bwd(nb, (hipStream_t)stream);
+}
+extern "C" int nnhip_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
+                              const int64_t* z, const int32_t* mol_ptr, int32_t n_atoms, int32_t n_mol, int32_t activation,
+                              float* atom_energy, float* g_e2, float* energy, void* stream) {
+  if (n_atoms <= 0) return NNHIP_OK;
+  return launch_head_out(e2, w4, b4, scale, shift, z, mol_ptr, n_atoms, n_mol, activation, atom_energy, g_e2, energy,
+                         (hipStream_t)stream);
+}

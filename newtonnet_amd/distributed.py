@@ -133,7 +133,8 @@ class GraphedTrainStep:
                   e=energy_label.detach().clone(), f=force_label.detach().clone())
         st['n_e'], st['n_f'] = allreduce_counts(energy_label.numel(), force_label.numel(), dev, self.group)
         # static candidate list: every ordered pair of every molecule (minimum image when periodic)
-        st['graph'] = hip.build_graph(st['pos'].detach(), st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies)
+        st['graph'] = hip.build_graph(st['pos'].detach(), st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies,
+                                      want_rbf=True)
         self._st = st
         self.model._static_train_graph = st['graph']
         try:

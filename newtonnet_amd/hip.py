@@ -51,6 +51,30 @@ class WsLayout(C.Structure):
                 + [(n, C.c_size_t) for n in ('a0', 'e1', 'e2', 'g_x', 'g_u', 'g_a', 'g_f', 'total')])
 
 
+class MlpDesc(C.Structure):
+    """nnhip_mlp_desc (include/newtonnet_hip.h)."""
+    _fields_ = [('X', C.c_void_p), ('ldx', C.c_int32), ('W1', C.c_void_p), ('W2', C.c_void_p), ('b1', C.c_void_p),
+                ('b2', C.c_void_p), ('H', C.c_void_p), ('ldh', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32),
+                ('M', C.c_int32), ('mode', C.c_int32), ('accumulate', C.c_int32), ('activation', C.c_int32),
+                ('T', C.c_void_p), ('T2', C.c_void_p), ('Hd', C.c_void_p), ('G', C.c_void_p)]
+
+
+class WgradProblem(C.Structure):
+    """nnhip_wgrad_problem."""
+    _fields_ = [(n, C.c_void_p) for n in ('A1', 'B1', 'A2', 'B2', 'hA', 'hB', 'dhB', 'out')] + \
+               [(n, C.c_int32) for n in ('M', 'lda1', 'lda2', 'ldb1', 'ldb2', 'ldh', 'type', 'b_cols32', 'activation', 'ldo',
+                                         'ncols', 'pad_')]
+
+
+class ColsumProblem(C.Structure):
+    """nnhip_colsum_problem."""
+    _fields_ = [('src', C.c_void_p), ('out', C.c_void_p), ('rows', C.c_int32), ('pad_', C.c_int32)]
+
+
+MODE_FWD, MODE_BWD, MODE_TAN, MODE_TAN2 = 0, 1, 2, 3
+WG_PLAIN, WG_ACT, WG_TDACT = 0, 1, 2
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -106,6 +130,38 @@ def lib():
     L.nnhip_gather_rows.argtypes = [vp, vp, i32, i32, vp, vp]
     L.nnhip_timers_enable.argtypes = [i32]
     L.nnhip_timers_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    # per-stage entry points and training kernels
+    pp = C.POINTER(vp)
+    L.nnhip_embed.argtypes = [vp, vp, i32, vp, vp]
+    L.nnhip_filter_table_bytes.restype = sz
+    L.nnhip_filter_tables.argtypes = [pp, pp, i32, vp, i32, vp]
+    L.nnhip_transpose128.argtypes = [pp, pp, i32, vp]
+    L.nnhip_message_fwd.argtypes = [vp] * 9 + [i32, vp]
+    L.nnhip_message_bwd.argtypes = [vp] * 10 + [i32, i32, vp]
+    L.nnhip_force_message_fwd.argtypes = [vp] * 9 + [i32, vp]
+    L.nnhip_force_message_bwd.argtypes = [vp] * 12 + [i32, vp]
+    L.nnhip_edge_embed_bwd.argtypes = [vp] * 10 + [i32, i32, i32, i32, f32, vp, vp, vp, vp]
+    L.nnhip_node_fwd.argtypes = [vp] * 11 + [i32, i32, vp]
+    L.nnhip_node_bwd.argtypes = [vp] * 5 + [i32] + [vp] * 5 + [i32, i32, vp]
+    L.nnhip_head_out.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp]
+    L.nnhip_mlp128_ex.argtypes = [C.POINTER(MlpDesc), vp]
+    L.nnhip_edge_tangent_geom.argtypes = [vp, vp, vp, i32, f32, vp, vp]
+    L.nnhip_message_tan_fwd.argtypes = [vp] * 11 + [i32, vp]
+    L.nnhip_force_message_tan_fwd.argtypes = [vp] * 13 + [i32, vp]
+    L.nnhip_force_message_tan_bwd.argtypes = [vp] * 14 + [i32, vp]
+    L.nnhip_message_tan_bwd.argtypes = [vp] * 15 + [i32, vp]
+    L.nnhip_update_tan_fwd.argtypes = [vp] * 5 + [i32, vp, vp]
+    L.nnhip_update_tan_bwd.argtypes = [vp] * 7 + [i32, vp, vp, vp, vp]
+    L.nnhip_head_seed_tan.argtypes = [vp] * 8 + [i32, i32, vp, vp, vp, vp]
+    L.nnhip_pair_rbf.argtypes = [vp] * 5 + [i32, i32, vp, vp]
+    L.nnhip_species_sum.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp]
+    L.nnhip_wgrad_slab_bytes.argtypes = [i32, i32]
+    L.nnhip_wgrad_slab_bytes.restype = sz
+    L.nnhip_wgrad_batch.argtypes = [vp, i32, i32, vp, vp]
+    L.nnhip_colsum_batch.argtypes = [vp, i32, vp]
+    for fn in STAGE_SYMBOLS:
+        if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes'):
+            getattr(L, fn).restype = C.c_int
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
@@ -115,7 +171,14 @@ def lib():
     return L
 
 
-EXPORTED_SYMBOLS = ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
+STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables', 'nnhip_transpose128', 'nnhip_message_fwd',
+                 'nnhip_message_bwd', 'nnhip_force_message_fwd', 'nnhip_force_message_bwd', 'nnhip_edge_embed_bwd',
+                 'nnhip_node_fwd', 'nnhip_node_bwd', 'nnhip_head_out', 'nnhip_mlp128_ex', 'nnhip_edge_tangent_geom',
+                 'nnhip_message_tan_fwd', 'nnhip_force_message_tan_fwd', 'nnhip_force_message_tan_bwd',
+                 'nnhip_message_tan_bwd', 'nnhip_update_tan_fwd', 'nnhip_update_tan_bwd', 'nnhip_head_seed_tan',
+                 'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_wgrad_slab_bytes', 'nnhip_wgrad_batch', 'nnhip_colsum_batch')
+
+EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',

@@ -214,15 +214,25 @@ class NewtonNet(nn.Module):
     def _forward_train(self, z, pos, cell, batch, keys, energy_idx, displacement):
         """Train mode (create_graph=True): outputs stay attached to autograd so a force loss can be back-propagated
         (trainer.py:301-313).  Built from twice-differentiable HIP primitives, see newtonnet_amd/train_ops.py."""
-        from newtonnet_amd import train_ops
+        from newtonnet_amd import train_fused, train_ops
         for key in keys:
             if key not in ('energy', 'gradient_force', 'direct_force'):
                 raise NotImplementedError(f"train-mode forward supports energy / gradient_force / direct_force (got '{key}')")
         self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
         if 'gradient_force' in keys and not pos.requires_grad:
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
-        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx,
-                                                                   graph=getattr(self, '_static_train_graph', None))
+        static = getattr(self, '_static_train_graph', None)
+        if train_fused.supported(self, keys) and os.environ.get('NNHIP_TRAIN_PATH', 'fused') == 'fused':
+            # energy + gradient_force: ONE autograd node on the hand-written kernels (tangent-over-reverse, csrc/train.hip)
+            energy, forces, g, ws = train_fused.forward_train(self, z, pos, cell, batch, graph=static)
+            outputs = CustomOutputSet(z=z, pos=pos, edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
+            outputs.lazy('atom_node', lambda: ws.a_out[-1].clone())
+            outputs.lazy('force_node', lambda: ws.f_out[-1].clone())
+            outputs.energy = energy
+            outputs.gradient_force = forces
+            outputs.lazy('pos_grad', lambda: -forces)
+            return outputs
+        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx, graph=static)
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=atom_node, force_node=force_node, edge_index=g.edge_index,
                                   cell=cell, displacement=displacement, batch=batch)
         outputs.energy = energy
