@@ -377,6 +377,8 @@ typedef struct {
   float* T; const float* T2; const float* Hd; float* G;
 } nnhip_mlp_desc;
 int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
+/* two MLPs over the same M rows in one launch (same mode / activation; only the second may accumulate) */
+int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* desc0, const nnhip_mlp_desc* desc1, void* stream);
 
 /* ---- tangent kernels (sweeps 3 and 4) ---- */
 /* tgeo[e] = (du_e, dx_e): tangent of (dir, x = r/cutoff) along the position direction v[N][3] */
@@ -415,9 +417,14 @@ int nnhip_head_seed_tan(const float* e2, const float* de2, const float* w4, cons
 /* rb[p][0:nb] = rbf_e, rb[p][32:32+nb] = drbf_e dx_e for the owner edge of pair p ([P][64], zero padded) */
 int nnhip_pair_rbf(const float* rbf, const float* drbf, const float* tgeo, const int64_t* edge_index, const int32_t* pid,
                    int32_t n_edges, int32_t n_basis, float* rb, void* stream);
-/* out[zz][c] = sum_{i: z_i = zz} x[i][c], c < width <= 128 (z NULL: one bin, out[0][c] = column sums) */
-int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, const int64_t* z, int32_t n_atoms, float* out,
-                      int32_t ldo, void* stream);
+/* Per-element sums of the first `width` (<= 128) columns of x[N][ldx], two deterministic passes through `scratch`
+ * (nnhip_species_scratch_bytes(width)).  Up to two outputs, each a column range of the element table, and a plain total:
+ *   out_k[zz][0:cols_k] (pitch ldo_k) = sum_{i: z_i = zz} x[i][c_k : c_k + cols_k];   total[0] = sum_i x[i][c_total]
+ * (node_embedding / scale / shift gradients and dL/d b4). */
+size_t nnhip_species_scratch_bytes(int32_t width);
+int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, const int64_t* z, int32_t n_atoms, float* scratch,
+                      float* out0, int32_t c0, int32_t cols0, int32_t ldo0, float* out1, int32_t c1, int32_t cols1,
+                      int32_t ldo1, float* total, int32_t c_total, void* stream);
 
 /* Weight gradients dW[o][i] = sum_r A1[r][o] B1[r][i] + A2[r][o] B2[r][i] over M rows, batched; split-K on the fp32 matrix
  * cores with per-workgroup slabs and an ordered final sum.  type 0: operands as stored; 1: B1 = act(hB), B2 = act'(hB) dhB;
@@ -431,9 +438,22 @@ typedef struct {
 } nnhip_wgrad_problem;
 size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks);
 int nnhip_wgrad_batch(const nnhip_wgrad_problem* problems_dev, int32_t n_problems, int32_t chunks, float* slabs, void* stream);
+/* Training objective of the reference (newtonnet/train/loss.py:48,72,96; scripts/config.yml:45-51) and its gradient:
+ *   loss = w[0] sum (E - E*)^2 + w[1] sum (F - F*)^2;  g_energy = 2 w[0] (E - E*);  g_forces = 2 w[1] (F - F*)
+ * weights_dev[2] = (w_E / n_E, w_F / n_F) lives in DEVICE memory (a data-parallel run refreshes the global counts there). */
+int nnhip_mse_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
+                        const float* force_label, int32_t n_force, const float* weights_dev, float* loss, float* g_energy,
+                        float* g_forces, void* stream);
+/* clip_grad_norm_(max_norm) + torch.optim.Adam step (trainer.py:311-313; no weight decay / amsgrad) on flat buffers of n
+ * floats.  state[2] (device) = (step count, last gradient norm); scratch: nnhip_clip_adam_scratch_bytes().  max_norm <= 0:
+ * no clipping. */
+size_t nnhip_clip_adam_scratch_bytes(void);
+int nnhip_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                    float* state, float lr, float beta1, float beta2, float eps, float max_norm, void* stream);
 /* out[c] = sum_r src[r][c] for [rows][128] arrays (bias gradients); device table */
 typedef struct { const float* src; float* out; int32_t rows; int32_t pad_; } nnhip_colsum_problem;
-int nnhip_colsum_batch(const nnhip_colsum_problem* problems_dev, int32_t n, void* stream);
+size_t nnhip_colsum_scratch_bytes(int32_t n);
+int nnhip_colsum_batch(const nnhip_colsum_problem* problems_dev, int32_t n, float* scratch, void* stream);
 
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call

@@ -231,6 +231,8 @@ int launch_lin(int pro, int epi, const LinArgs& a, int groups, hipStream_t s) {
   return NNHIP_E_INVALID;
 }
 
+int launch_lin_wide(const float* X, int ldx, const float* W, float* Y, int ldy, int M, bool acc, hipStream_t s);   // node128.hip
+
 // C ABI: one dense 128->128 linear (see include/newtonnet_hip.h)
 extern "C" int nnhip_linear128(const float* A, int32_t lda, const float* W, float* C, int32_t ldc, const float* bias,
                                const float* H, int32_t ldh, int32_t M, int32_t prologue, int32_t epilogue,
@@ -240,6 +242,9 @@ extern "C" int nnhip_linear128(const float* A, int32_t lda, const float* W, floa
     nnhip_set_error("nnhip_linear128: bad arguments");
     return NNHIP_E_INVALID;
   }
+  // small products without prologue / bias: the row-local form (node128.hip), no weight staging
+  if (prologue == PRO_NONE && (epilogue == EPI_STORE || epilogue == EPI_ACC) && M <= 32 * 1536)
+    return launch_lin_wide(A, lda, W, C, ldc, M, epilogue == EPI_ACC, (hipStream_t)stream);
   LinArgs a;
   memset(&a, 0, sizeof(a));
   a.g[0] = {A, W, C, bias, H};

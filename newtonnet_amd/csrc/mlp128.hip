@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
     // weights first (L2 hits, returned first by the in-order vmcnt queue), then this wave's first X fragment: the LDS fill
     // and the barrier only wait for the weights, and stage 1 starts consuming X as its 16 pieces arrive
     MLP_W_REQUEST(P.a[0].W1, P.a[0].W2)
-    if (MLP_NT_X && (MODE == MODE_BWD || P.n == 1))
+    if (MLP_NT_X && (MODE != MODE_FWD || P.n == 1))
       mlp_load_x<true>(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
     else
       mlp_load_x<false>(x, P.a[0].X, P.a[0].ldx, min((min(tile0, n_tiles - 1) << 5) + r, M - 1), h);
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       float4 hin[4];
-      if (MODE == MODE_BWD) {  // forward pre-activation of this block, same fragment layout as the stores below
+      if (MODE != MODE_FWD) {  // forward pre-activation of this block, same fragment layout as the stores below
         const float4* hp = h_frag ? reinterpret_cast<const float4*>(p.H) + ((size_t)tile * 4 + nb) * 256 + lane
                                   : reinterpret_cast<const float4*>(p.H + (size_t)ec * p.ldh + nb * 32 + 4 * h);
         const int hs4 = h_frag ? 64 : 2;
@@ -187,7 +187,36 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) hs[nb][k] = GEN_ACT ? act_f(acc[k], P.a[0].act) : silu_f(acc[k]);
+      } else if (MODE == MODE_TAN2) {
+        // tangent of the adjoint: G = dT act'(H) + T2 act''(H) Hd, kept (row-major) for the weight-gradient products
+        const float* t2p = (ph ? P.a[1].T2 : P.a[0].T2) + (size_t)ec * p.ldh + nb * 32 + 4 * h;
+        const float* hdp = (ph ? P.a[1].Hd : P.a[0].Hd) + (size_t)ec * p.ldh + nb * 32 + 4 * h;
+        float* gp = (ph ? P.a[1].G : P.a[0].G) + (size_t)e * p.ldh + nb * 32 + 4 * h;
+        const int act = P.a[0].act;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t2 = ld4(t2p + 8 * q), hd = ld4(hdp + 8 * q);
+          float4 gv;
+#define MLP_D1(v) (GEN_ACT ? dact_f(v, act) : dsilu_f(v))
+#define MLP_D2(v) (GEN_ACT ? d2act_f(v, act) : d2silu_f(v))
+          gv.x = fmaf(acc[4 * q], MLP_D1(hin[q].x), t2.x * MLP_D2(hin[q].x) * hd.x);
+          gv.y = fmaf(acc[4 * q + 1], MLP_D1(hin[q].y), t2.y * MLP_D2(hin[q].y) * hd.y);
+          gv.z = fmaf(acc[4 * q + 2], MLP_D1(hin[q].z), t2.z * MLP_D2(hin[q].z) * hd.z);
+          gv.w = fmaf(acc[4 * q + 3], MLP_D1(hin[q].w), t2.w * MLP_D2(hin[q].w) * hd.w);
+#undef MLP_D1
+#undef MLP_D2
+          hs[nb][4 * q] = gv.x;
+          hs[nb][4 * q + 1] = gv.y;
+          hs[nb][4 * q + 2] = gv.z;
+          hs[nb][4 * q + 3] = gv.w;
+          if (live) st4(gp + 8 * q, gv);
+        }
       } else {
+        if (MODE == MODE_TAN && live) {   // keep the stage-1 product (row-major): the tangent sweeps and weight gradients read it
+          float* tp = (ph ? P.a[1].T : P.a[0].T) + (size_t)e * p.ldh + nb * 32 + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) st4(tp + 8 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           hs[nb][4 * q] = acc[4 * q] * (GEN_ACT ? dact_f(hin[q].x, P.a[0].act) : dsilu_f(hin[q].x));
@@ -207,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
       const int ldn = (last && more) ? P.a[1].ldx : p.ldx;
       const int nt = last ? tile0 : tile + tile_step;
       // last read of this input?  adjoint: always (g_phi is consumed here); forward: msg is read by both phases
-      const bool last_use = MODE == MODE_BWD || P.n == 1 || ph == 1 || (last && more);
+      const bool last_use = MODE != MODE_FWD || P.n == 1 || ph == 1 || (last && more);
       if (MLP_NT_X && last_use)
         mlp_load_x<true>(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
       else
@@ -299,10 +328,18 @@ static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipS
     if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false, true>(P, s);
     if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false, true>(P, s);
     if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true, true>(P, s);
+    if (mode == MODE_TAN && !accum_last) return launch_mlp_t<MODE_TAN, false, true>(P, s);
+    if (mode == MODE_TAN && accum_last) return launch_mlp_t<MODE_TAN, true, true>(P, s);
+    if (mode == MODE_TAN2 && !accum_last) return launch_mlp_t<MODE_TAN2, false, true>(P, s);
+    if (mode == MODE_TAN2 && accum_last) return launch_mlp_t<MODE_TAN2, true, true>(P, s);
   }
   if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false, false>(P, s);
   if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false, false>(P, s);
   if (mode == MODE_BWD && accum_last) return launch_mlp_t<MODE_BWD, true, false>(P, s);
+  if (mode == MODE_TAN && !accum_last) return launch_mlp_t<MODE_TAN, false, false>(P, s);
+  if (mode == MODE_TAN && accum_last) return launch_mlp_t<MODE_TAN, true, false>(P, s);
+  if (mode == MODE_TAN2 && !accum_last) return launch_mlp_t<MODE_TAN2, false, false>(P, s);
+  if (mode == MODE_TAN2 && accum_last) return launch_mlp_t<MODE_TAN2, true, false>(P, s);
   nnhip_set_error("launch_mlp: unsupported mode %d/%d", mode, (int)accum_last);
   return NNHIP_E_INVALID;
 }
@@ -316,12 +353,12 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1((a.b1 || a.b2) ? TC_LIN1 : TC_MLP, s);   // biased form = node MLP / energy head (node-level class)
-  if (mlp_use_wide(a) || mode == MODE_TAN || mode == MODE_TAN2) {   // (the training modes exist in the row-local form only)
+  if (mlp_use_wide(a)) {
     MlpArgs w = a;
     if (w.h_frag) w.ldh = NF;   // the row-local kernel keeps H row-major inside the same pad32(M) x 128 region
     return launch_mlp_wide(mode, accum, w, s);
   }
-  if (mode != MODE_FWD && mode != MODE_BWD) {
+  if (mode < MODE_FWD || mode > MODE_TAN2 || ((mode == MODE_TAN || mode == MODE_TAN2) && a.h_frag)) {
     nnhip_set_error("launch_mlp: unsupported mode %d", mode);
     return NNHIP_E_INVALID;
   }
@@ -334,7 +371,8 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
 
 // Two MLPs over the same rows in one persistent launch (phi1 | phi2 forward; the two terms of g_msg in the adjoint).
 int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s) {
-  if (a0.M != a1.M || (mode != MODE_FWD && mode != MODE_BWD) || accum0 || a0.h_frag != a1.h_frag || a0.act != a1.act) {   // (only the last phase may accumulate)
+  if (a0.M != a1.M || mode < MODE_FWD || mode > MODE_TAN2 || accum0 || a0.h_frag != a1.h_frag || a0.act != a1.act ||
+      a0.ldh != a1.ldh) {   // (only the last phase may accumulate)
     nnhip_set_error("launch_mlp_pair: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -391,15 +429,14 @@ extern "C" int nnhip_mlp128(const float* X, int32_t ldx, const float* W1, const 
 }
 
 // Extended form: biases, any activation of the factory, and the training modes (include/newtonnet_hip.h: nnhip_mlp_desc)
-extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {
+static int desc_to_args(const nnhip_mlp_desc* d, MlpArgs& a, const char* who) {
   if (!d || !d->X || !d->W1 || !d->W2 || !d->H || !d->Y || d->M < 0 || d->ldx < NF || d->ldh < NF || d->ldy < NF ||
       (d->ldx & 3) || (d->ldh & 3) || (d->ldy & 3) || d->mode < MODE_FWD || d->mode > MODE_TAN2 ||
       d->activation < NNHIP_ACT_SILU || d->activation > NNHIP_ACT_SSP || (d->mode == MODE_TAN && !d->T) ||
       (d->mode == MODE_TAN2 && (!d->T2 || !d->Hd || !d->G)) || (d->mode != MODE_FWD && (d->b1 || d->b2))) {
-    nnhip_set_error("nnhip_mlp128_ex: bad arguments");
+    nnhip_set_error("%s: bad arguments", who);
     return NNHIP_E_INVALID;
   }
-  MlpArgs a;
   memset(&a, 0, sizeof(a));
   a.X = d->X;
   a.W1 = d->W1;
@@ -417,5 +454,25 @@ extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {
   a.T2 = d->T2;
   a.Hd = d->Hd;
   a.G = d->G;
+  return NNHIP_OK;
+}
+extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {
+  MlpArgs a;
+  const int rc = desc_to_args(d, a, "nnhip_mlp128_ex");
+  if (rc) return rc;
   return launch_mlp(d->mode, d->accumulate != 0, a, (hipStream_t)stream);
+}
+// Two MLPs over the same M rows in ONE launch (equiv_message1 | equiv_message2 and their adjoints / tangents): same mode and
+// activation; only the second may accumulate (then it runs after the first, on the same rows).
+extern "C" int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* d0, const nnhip_mlp_desc* d1, void* stream) {
+  MlpArgs a0, a1;
+  int rc = desc_to_args(d0, a0, "nnhip_mlp128_pair_ex");
+  if (rc) return rc;
+  rc = desc_to_args(d1, a1, "nnhip_mlp128_pair_ex");
+  if (rc) return rc;
+  if (d0->mode != d1->mode || d0->M != d1->M || d0->accumulate || d0->activation != d1->activation) {
+    nnhip_set_error("nnhip_mlp128_pair_ex: the two MLPs must share mode, M and activation; only the second may accumulate");
+    return NNHIP_E_INVALID;
+  }
+  return launch_mlp_pair(d0->mode, a0, false, a1, d1->accumulate != 0, (hipStream_t)stream);
 }

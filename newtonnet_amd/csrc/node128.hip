@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) mlp128_wide_kernel(const MlpArgs p) {
 // Two MLPs over the same rows in ONE launch of the small-M form (the single-molecule / MD-loop regime is bound by the number
 // of dependent dispatches, ~8 us each).  Forward: phi1 and phi2 are independent -- blockIdx.y picks the MLP.  Adjoint: the
 // second term accumulates onto the first one's g_msg rows, which the same lanes of the same workgroup wrote -- run in order.
-template <int MODE>
+template <int MODE, bool PAR>
 __global__ void __launch_bounds__(256) mlp128_wide_pair_kernel(const MlpPair P) {
   __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
   Tile t;
@@ -343,16 +343,54 @@ __global__ void __launch_bounds__(256) mlp128_wide_pair_kernel(const MlpPair P) 
   t.r = threadIdx.x & 31;
   t.h = (threadIdx.x >> 5) & 1;
   t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (MODE == MODE_FWD) {
+  if (PAR) {   // independent outputs: blockIdx.y picks the MLP
     if (blockIdx.y == 0)
       mlp_wide_body<MODE>(P.a[0], false, t);
     else
       mlp_wide_body<MODE>(P.a[1], false, t);
-  } else {
+  } else {     // the second one accumulates onto rows the same lanes of this workgroup just wrote: run in order
     mlp_wide_body<MODE>(P.a[0], false, t);
     __syncthreads();                     // the LDS tile is reused
     mlp_wide_body<MODE>(P.a[1], P.accum[1] != 0, t);
   }
+}
+
+// One dense linear Y (+)= X W^T in the same row-local form (no LDS staging of W: a 0.03 GFLOP product is all latency, the
+// persistent lin128 kernel spends 17 us on its 64 KiB weight fill alone)
+template <bool ACC>
+__global__ void __launch_bounds__(256)
+lin128_wide_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, float* __restrict__ Y, int ldy, int M) {
+  __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
+  Tile t;
+  t.xs = xs;
+  t.r = threadIdx.x & 31;
+  t.h = (threadIdx.x >> 5) & 1;
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, M - 1);
+  float4 wf[16];
+  load_w(wf, t, W);
+  float x[16], y[16];
+  blk_load(x, X, (size_t)rc * ldx, t);
+  blk_to_tile(x, t);
+  __syncthreads();
+  if (ACC) blk_load(x, Y, (size_t)rc * ldy, t);
+  acc_to(y, tile_gemm(t, wf));
+  if (ACC) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += x[k];
+  }
+  if (row < M) blk_store(y, Y, (size_t)row * ldy, t);
+}
+int launch_lin_wide(const float* X, int ldx, const float* W, float* Y, int ldy, int M, bool acc, hipStream_t s) {
+  if (M <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  if (acc)
+    lin128_wide_kernel<true><<<cdiv(M, 32), 256, 0, s>>>(X, ldx, W, Y, ldy, M);
+  else
+    lin128_wide_kernel<false><<<cdiv(M, 32), 256, 0, s>>>(X, ldx, W, Y, ldy, M);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
@@ -379,14 +417,22 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
 
 int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s) {
   const int n_tiles = cdiv(P.a[0].M, 32);
-  if (mode == MODE_FWD)
-    mlp128_wide_pair_kernel<MODE_FWD><<<dim3(n_tiles, 2), 256, 0, s>>>(P);
-  else if (mode == MODE_BWD)
-    mlp128_wide_pair_kernel<MODE_BWD><<<n_tiles, 256, 0, s>>>(P);
-  else
-    return NNHIP_E_INVALID;
-  LAUNCH_CHECK();
-  return 0;
+  const bool par = !P.accum[1];   // two independent MLPs: side by side (blockIdx.y)
+#define WIDE_PAIR(M_)                                                                  \
+  if (mode == M_) {                                                                    \
+    if (par)                                                                           \
+      mlp128_wide_pair_kernel<M_, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);           \
+    else                                                                               \
+      mlp128_wide_pair_kernel<M_, false><<<n_tiles, 256, 0, s>>>(P);                   \
+    LAUNCH_CHECK();                                                                    \
+    return 0;                                                                          \
+  }
+  WIDE_PAIR(MODE_FWD)
+  WIDE_PAIR(MODE_BWD)
+  WIDE_PAIR(MODE_TAN)
+  WIDE_PAIR(MODE_TAN2)
+#undef WIDE_PAIR
+  return NNHIP_E_INVALID;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

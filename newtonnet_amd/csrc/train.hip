@@ -414,44 +414,90 @@ typedef nnhip_wgrad_problem WgProb;   // the problem table lives in device memor
 
 __device__ __forceinline__ float comp(const float4& v, int w) { return w == 0 ? v.x : (w == 1 ? v.y : (w == 2 ? v.z : v.w)); }
 
-struct WgOps {   // operands of one pair of rows for this lane
-  float a1, a2;
-  float4 b1, b2;
+// Workgroup = 4 waves; a trip handles WG_R rows.  All 256 threads fetch the trip's operand rows once (float4 per lane),
+// apply the prologue (activation factors are evaluated once per element, not once per wave) and stage them in LDS:
+// B rows as stored ([row][128]), A rows split by output-feature class ([class][row][32]) so that wave w reads its class
+// with unit stride.  Two LDS buffers: the next trip's rows are requested before this trip's MFMAs and written behind them.
+#define WG_R 16
+struct WgStage {   // what one thread fetched for the next trip: rows (t >> 5) and (t >> 5) + 8, lane column c = t & 31
+  float4 a1[2], a2[2], b1[2], b2[2];
 };
-__device__ __forceinline__ WgOps wg_load(const WgProb& P, int rr, bool live, int c, int w, bool two) {
-  WgOps o;
-  o.a2 = 0.f;
-  o.b2 = make_float4(0.f, 0.f, 0.f, 0.f);
+struct WgLds {
+  float a1[4][WG_R][32], a2[4][WG_R][32];
+  float b1[WG_R][NF], b2[WG_R][NF];
+};
+
+__device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int r_safe, bool two, WgStage& g) {
+  const int c = threadIdx.x & 31;
   const int act = P.activation;
-  o.a1 = comp(ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c), w);
-  if (P.b_cols32) {
-    o.b1 = make_float4(P.B1[(size_t)rr * P.ldb1 + c], 0.f, 0.f, 0.f);
-    if (two) o.b2 = make_float4(P.B2[(size_t)rr * P.ldb2 + c], 0.f, 0.f, 0.f);
-  } else if (P.type == WG_ACT) {
-    const float4 hv = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
-    o.b1 = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
-    if (two) {
-      const float4 dh = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
-      o.b2 = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
-                         dact_any(hv.w, act) * dh.w);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = r0 + (threadIdx.x >> 5) + 8 * q;
+    const bool live = r < r_end;
+    const int rr = live ? r : r_safe;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
+    g.a2[q] = zero;
+    g.b2[q] = zero;
+    if (P.b_cols32) {   // B rows are 32 floats wide: lane column c carries one of them (in .x)
+      g.b1[q] = make_float4(P.B1[(size_t)rr * P.ldb1 + c], 0.f, 0.f, 0.f);
+      if (two) g.b2[q] = make_float4(P.B2[(size_t)rr * P.ldb2 + c], 0.f, 0.f, 0.f);
+    } else if (P.type == WG_ACT) {
+      const float4 hv = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
+      g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
+      if (two) {
+        const float4 dh = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
+        g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
+                              dact_any(hv.w, act) * dh.w);
+      }
+    } else {
+      g.b1[q] = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
+      if (two) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
     }
-  } else {
-    o.b1 = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
-    if (two) o.b2 = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
+    if (two) {
+      g.a2[q] = ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c);
+      if (P.type == WG_TDACT) {
+        const float4 hv = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
+        g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
+                              g.a2[q].w * dact_any(hv.w, act));
+      }
+    }
+    if (!live) {
+      g.a1[q] = zero;
+      g.a2[q] = zero;
+    }
   }
-  if (two) {
-    o.a2 = comp(ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c), w);
-    if (P.type == WG_TDACT) o.a2 *= dact_any(comp(ld4(P.hA + (size_t)rr * P.ldh + 4 * c), w), act);
+}
+__device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g, bool two, bool nb32) {
+  const int c = threadIdx.x & 31;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (threadIdx.x >> 5) + 8 * q;
+    L.a1[0][row][c] = g.a1[q].x;
+    L.a1[1][row][c] = g.a1[q].y;
+    L.a1[2][row][c] = g.a1[q].z;
+    L.a1[3][row][c] = g.a1[q].w;
+    if (nb32)
+      L.b1[row][c] = g.b1[q].x;
+    else
+      *reinterpret_cast<float4*>(&L.b1[row][4 * c]) = g.b1[q];
+    if (two) {
+      L.a2[0][row][c] = g.a2[q].x;
+      L.a2[1][row][c] = g.a2[q].y;
+      L.a2[2][row][c] = g.a2[q].z;
+      L.a2[3][row][c] = g.a2[q].w;
+      if (nb32)
+        L.b2[row][c] = g.b2[q].x;
+      else
+        *reinterpret_cast<float4*>(&L.b2[row][4 * c]) = g.b2[q];
+    }
   }
-  if (!live) {
-    o.a1 = 0.f;
-    o.a2 = 0.f;
-  }
-  return o;
 }
 
 __global__ void __launch_bounds__(256)
 wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
+  WgLds* lds = reinterpret_cast<WgLds*>(wg_lds_raw);   // [2]
   WgProb P = probs[blockIdx.y];
   if (!P.lda1) P.lda1 = NF;
   if (!P.lda2) P.lda2 = NF;
@@ -462,8 +508,8 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // output-feature class of this wave
   const int c = lane & 31, h = lane >> 5;
   const int M = P.M;
-  // rows of this workgroup: whole pairs of rows, contiguous
-  const int per = ((M + 2 * chunks - 1) / (2 * chunks)) * 2;
+  // rows of this workgroup: contiguous, a multiple of the trip size
+  const int per = ((M + WG_R * chunks - 1) / (WG_R * chunks)) * WG_R;
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
   f32x16 acc[4];
 #pragma unroll
@@ -472,31 +518,42 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
     for (int k = 0; k < 16; ++k) acc[q][k] = 0.f;
   const bool two = P.A2 != nullptr;
   const bool nb32 = P.b_cols32 != 0;
-  // four pairs of rows per trip: all operands are requested before the first MFMA
-  for (int r0 = r_beg; r0 < r_end; r0 += 8) {
-    WgOps o[4];
+  if (r_beg < r_end) {
+    WgStage g;
+    wg_fetch(P, r_beg, r_end, r_beg, two, g);
+    wg_commit(lds[0], g, two, nb32);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_beg; r0 < r_end; r0 += WG_R) {
+      const bool more = r0 + WG_R < r_end;
+      if (more) wg_fetch(P, r0 + WG_R, r_end, r_beg, two, g);   // requests in flight under the MFMAs below
+      const WgLds& L = lds[buf];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = r0 + 2 * u + h;
-      const bool live = r < r_end;
-      o[u] = wg_load(P, live ? r : r_beg, live, c, w, two);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a1, o[u].b1.x, acc[0], 0, 0, 0);
-      if (!nb32) {
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a1, o[u].b1.y, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a1, o[u].b1.z, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a1, o[u].b1.w, acc[3], 0, 0, 0);
-      }
-      if (two) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a2, o[u].b2.x, acc[0], 0, 0, 0);
-        if (!nb32) {
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a2, o[u].b2.y, acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a2, o[u].b2.z, acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(o[u].a2, o[u].b2.w, acc[3], 0, 0, 0);
+      for (int kk = 0; kk < WG_R / 2; ++kk) {
+        const int row = 2 * kk + h;
+        const float a1 = L.a1[w][row][c];
+        if (nb32) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.b1[row][c], acc[0], 0, 0, 0);
+          if (two) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.a2[w][row][c], L.b2[row][c], acc[0], 0, 0, 0);
+        } else {
+          const float4 b1 = *reinterpret_cast<const float4*>(&L.b1[row][4 * c]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.w, acc[3], 0, 0, 0);
+          if (two) {
+            const float a2 = L.a2[w][row][c];
+            const float4 b2 = *reinterpret_cast<const float4*>(&L.b2[row][4 * c]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.w, acc[3], 0, 0, 0);
+          }
         }
       }
+      if (more) wg_commit(lds[buf ^ 1], g, two, nb32);
+      __syncthreads();
+      buf ^= 1;
     }
   }
   // D[row][col]: row = (k & 3) + 8 (k >> 2) + 4 h -> output feature 4 row + w; col = c -> input feature 4 c + q
@@ -527,38 +584,70 @@ wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* _
 }
 
 // column sums of [M][128] arrays (bias gradients, dL/d w4): one workgroup per problem, fixed summation order
-__global__ void __launch_bounds__(1024) colsum_kernel(const nnhip_colsum_problem* __restrict__ probs) {
-  __shared__ float part[8][NF];
-  const nnhip_colsum_problem P = probs[blockIdx.x];
-  const int col = threadIdx.x & (NF - 1), g = threadIdx.x >> 7;   // 8 row groups
+// Column sums in two passes (fixed order, no atomics): pass 1, grid (chunks, problems), a workgroup sums its slice of rows
+// (4 row groups x 128 columns) into part[problem][chunk][128]; pass 2 adds the chunks.
+#define CS_CHUNKS 64
+__global__ void __launch_bounds__(512)
+colsum_partial_kernel(const nnhip_colsum_problem* __restrict__ probs, float* __restrict__ part) {
+  __shared__ float sh[4][NF];
+  const nnhip_colsum_problem P = probs[blockIdx.y];
+  const int col = threadIdx.x & (NF - 1), g = threadIdx.x >> 7;
+  const int per = (P.rows + CS_CHUNKS - 1) / CS_CHUNKS;
+  const int r0 = blockIdx.x * per, r1 = min(P.rows, r0 + per);
   float s = 0.f;
-  for (int r = g; r < P.rows; r += 8) s += P.src[(size_t)r * NF + col];
-  part[g][col] = s;
+  for (int r = r0 + g; r < r1; r += 4) s += P.src[(size_t)r * NF + col];
+  sh[g][col] = s;
   __syncthreads();
-  if (g == 0) {
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) tot += part[q][col];
-    P.out[col] = tot;
-  }
+  if (g == 0) part[((size_t)blockIdx.y * CS_CHUNKS + blockIdx.x) * NF + col] = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+}
+__global__ void __launch_bounds__(NF)
+colsum_final_kernel(const nnhip_colsum_problem* __restrict__ probs, const float* __restrict__ part) {
+  const float* p = part + (size_t)blockIdx.x * CS_CHUNKS * NF + threadIdx.x;
+  float s = 0.f;
+  for (int k = 0; k < CS_CHUNKS; ++k) s += p[(size_t)k * NF];
+  probs[blockIdx.x].out[threadIdx.x] = s;
 }
 
-// per-element sums:  out[zz][c] = sum_{i : z_i = zz} x[i][c]   (embedding / scale / shift gradients); width <= 128 floats per row.
-// One workgroup per element: every thread scans z (N is small next to the edge work) -- deterministic, no atomics.
-// z == NULL: a single bin (plain column sums of a narrow array).
-__global__ void __launch_bounds__(256)
-species_sum_kernel(const float* __restrict__ x, int ldx, int width, const int64_t* __restrict__ z, int n_atoms,
-                   float* __restrict__ out, int ldo) {
-  __shared__ float part[2][NF];
-  const int zz = blockIdx.x;
-  const int col = threadIdx.x & (NF - 1), g = threadIdx.x >> 7;   // 2 row groups
-  float s = 0.f;
-  if (col < width)
-    for (int i = g; i < n_atoms; i += 2)
-      if (!z || z[i] == zz) s += x[(size_t)i * ldx + col];
-  part[g][col] = s;
+// Per-element sums  out[zz][c] = sum_{i : z_i = zz} x[i][c]  (embedding / scale / shift gradients), two passes: a workgroup
+// walks its slice of atoms and accumulates rows into an LDS table [119][width] (thread = column: no conflicts, fixed order);
+// pass 2 adds the per-workgroup tables.  width <= 128.
+#define SP_CHUNKS 128
+__global__ void __launch_bounds__(NF)
+species_partial_kernel(const float* __restrict__ x, int ldx, int width, const int64_t* __restrict__ z, int n_atoms,
+                       float* __restrict__ part /*[SP_CHUNKS][119][width]*/) {
+  extern __shared__ float tab[];   // [119][width]
+  const int col = threadIdx.x;
+  for (int k = col; k < NNHIP_N_ELEMENTS * width; k += NF) tab[k] = 0.f;
   __syncthreads();
-  if (g == 0 && col < width) out[(size_t)zz * ldo + col] = part[0][col] + part[1][col];
+  const int per = (n_atoms + SP_CHUNKS - 1) / SP_CHUNKS;
+  const int i0 = blockIdx.x * per, i1 = min(n_atoms, i0 + per);
+  if (col < width)
+    for (int i = i0; i < i1; ++i) tab[(int)z[i] * width + col] += x[(size_t)i * ldx + col];
+  __syncthreads();
+  for (int k = col; k < NNHIP_N_ELEMENTS * width; k += NF) part[(size_t)blockIdx.x * NNHIP_N_ELEMENTS * width + k] = tab[k];
+}
+// out[zz][c] (pitch ldo) = sum over chunks; `cols` columns starting at part column c0
+__global__ void __launch_bounds__(NF)
+species_final_kernel(const float* __restrict__ part, int width, int c0, int cols, float* __restrict__ out, int ldo) {
+  const int zz = blockIdx.x, c = threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < SP_CHUNKS; ++k) s += part[((size_t)k * NNHIP_N_ELEMENTS + zz) * width + c0 + c];
+  out[(size_t)zz * ldo + c] = s;
+}
+// out[0] = sum over chunks and elements of column c0 (a plain sum over atoms, e.g. dL/d b4)
+__global__ void __launch_bounds__(NF)
+species_total_kernel(const float* __restrict__ part, int width, int c0, float* __restrict__ out) {
+  __shared__ float sh[NF];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < SP_CHUNKS * NNHIP_N_ELEMENTS; k += NF) s += part[(size_t)k * width + c0];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < NF; ++k) t += sh[k];
+    out[0] = t;
+  }
 }
 
 // out[i][:] = table[z[i]][:]   (node embedding lookup, newtonnet.py:142)
@@ -568,6 +657,95 @@ embed_rows_kernel(const int64_t* __restrict__ z, const float* __restrict__ table
   if (t >= (size_t)n_atoms * (NF / 4)) return;
   const size_t i = t / (NF / 4), c = t % (NF / 4);
   reinterpret_cast<float4*>(out)[t] = reinterpret_cast<const float4*>(table + (size_t)z[i] * NF)[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The reference's training objective and its gradient in one launch (newtonnet/train/loss.py:48,72,96; scripts/config.yml:45-51):
+//   loss = w[0] sum_b (E_b - E*_b)^2 + w[1] sum_{i,k} (F_ik - F*_ik)^2       w = (w_E / n_E, w_F / n_F) read from DEVICE memory
+//   gE = 2 w[0] (E - E*),  gF = 2 w[1] (F - F*)                               (data-parallel runs refresh the global counts there)
+// One workgroup, fixed summation order (the arrays are a few thousand elements; the step is launch-bound at that size).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+mse_loss_grad_kernel(const float* __restrict__ e, const float* __restrict__ e_lab, int n_e, const float* __restrict__ f,
+                     const float* __restrict__ f_lab, int n_f, const float* __restrict__ w, float* __restrict__ loss,
+                     float* __restrict__ g_e, float* __restrict__ g_f) {
+  __shared__ double sh[1024];
+  const float we = w[0], wf = w[1];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n_e; k += 1024) {
+    const float d = e[k] - e_lab[k];
+    g_e[k] = 2.f * we * d;
+    s += (double)we * d * d;
+  }
+  for (int k = threadIdx.x; k < n_f; k += 1024) {
+    const float d = f[k] - f_lab[k];
+    g_f[k] = 2.f * wf * d;
+    s += (double)wf * d * d;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// clip_grad_norm_ + Adam on FLAT parameter / gradient / moment buffers (trainer.py:311-313 with torch.optim.Adam defaults:
+// no weight decay, no amsgrad), two launches:
+//   pass 1: per-workgroup partial sums of g^2 (fixed order); workgroup 0 also advances the device-side step counter
+//   pass 2: every workgroup adds the partials in the same order -> total norm, clip = min(1, max_norm / (norm + 1e-6));
+//           g' = clip g;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
+//           p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// state[0] = step t (float), state[1] = last total norm (for logging).  max_norm <= 0: no clipping.
+// ---------------------------------------------------------------------------------------------
+#define OPT_BLOCKS 256
+__global__ void __launch_bounds__(256)
+gradnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part, float* __restrict__ state) {
+  __shared__ double sh[256];
+  const long per = (n + OPT_BLOCKS - 1) / OPT_BLOCKS;
+  const long k0 = blockIdx.x * per, k1 = min(n, k0 + per);
+  double s = 0.0;
+  for (long k = k0 + threadIdx.x; k < k1; k += 256) s += (double)g[k] * (double)g[k];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (float)sh[0];
+    if (blockIdx.x == 0) state[0] += 1.0f;
+  }
+}
+__global__ void __launch_bounds__(256)
+clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                 const float* __restrict__ part, float* __restrict__ state, float lr, float b1, float b2, float eps,
+                 float max_norm) {
+  __shared__ float s_clip, s_c1, s_c2;
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < OPT_BLOCKS; ++k) tot += (double)part[k];
+    const float norm = (float)sqrt(tot);
+    s_clip = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    const float t = state[0];
+    s_c1 = lr / (1.0f - powf(b1, t));
+    s_c2 = 1.0f / sqrtf(1.0f - powf(b2, t));
+    if (blockIdx.x == 0) state[1] = norm;
+  }
+  __syncthreads();
+  const float clip = s_clip, c1 = s_c1, c2 = s_c2;
+  const long per = (n + OPT_BLOCKS - 1) / OPT_BLOCKS;
+  const long k0 = blockIdx.x * per, k1 = min(n, k0 + per);
+  for (long k = k0 + threadIdx.x; k < k1; k += 256) {
+    const float gk = g[k] * clip;
+    const float mk = fmaf(b1, m[k], (1.0f - b1) * gk);
+    const float vk = fmaf(b2, v[k], (1.0f - b2) * gk * gk);
+    m[k] = mk;
+    v[k] = vk;
+    p[k] -= c1 * mk / (sqrtf(vk) * c2 + eps);
+  }
 }
 
 // =============================================================================================
@@ -722,11 +900,31 @@ extern "C" int nnhip_pair_rbf(const float* rbf, const float* drbf, const float* 
   return NNHIP_OK;
 }
 
-extern "C" int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, const int64_t* z, int32_t n_atoms, float* out,
-                                 int32_t ldo, void* stream) {
-  ARG_CHECK(n_atoms >= 0 && x && out && width >= 1 && width <= NF && ldx >= width && ldo >= width, "nnhip_species_sum");
-  species_sum_kernel<<<z ? NNHIP_N_ELEMENTS : 1, 256, 0, (hipStream_t)stream>>>(x, ldx, width, z, n_atoms, out, ldo);
+extern "C" size_t nnhip_species_scratch_bytes(int32_t width) {
+  return width >= 1 && width <= NF ? (size_t)SP_CHUNKS * NNHIP_N_ELEMENTS * width * sizeof(float) : 0;
+}
+// Per-element sums of x[N][ldx] (first `width` columns): up to three outputs, each a column range of the element table:
+//   out_k[zz][0:cols_k] (pitch ldo_k) = sum_{i: z_i = zz} x[i][c0_k : c0_k + cols_k];   total (may be NULL) = sum_i x[i][c_total]
+extern "C" int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, const int64_t* z, int32_t n_atoms, float* scratch,
+                                 float* out0, int32_t c0, int32_t cols0, int32_t ldo0, float* out1, int32_t c1, int32_t cols1,
+                                 int32_t ldo1, float* total, int32_t c_total, void* stream) {
+  ARG_CHECK(n_atoms >= 0 && x && z && scratch && width >= 1 && width <= NF && ldx >= width && (!out0 || (c0 >= 0 && c0 + cols0 <= width)) &&
+                (!out1 || (c1 >= 0 && c1 + cols1 <= width)) && (!total || (c_total >= 0 && c_total < width)), "nnhip_species_sum");
+  hipStream_t s = (hipStream_t)stream;
+  species_partial_kernel<<<SP_CHUNKS, NF, NNHIP_N_ELEMENTS * width * sizeof(float), s>>>(x, ldx, width, z, n_atoms, scratch);
   LAUNCH_CHECK();
+  if (out0) {
+    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, width, c0, cols0, out0, ldo0);
+    LAUNCH_CHECK();
+  }
+  if (out1) {
+    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, width, c1, cols1, out1, ldo1);
+    LAUNCH_CHECK();
+  }
+  if (total) {
+    species_total_kernel<<<1, NF, 0, s>>>(scratch, width, c_total, total);
+    LAUNCH_CHECK();
+  }
   return NNHIP_OK;
 }
 
@@ -742,17 +940,49 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
   if (n_problems == 0) return NNHIP_OK;
   hipStream_t s = (hipStream_t)stream;
   ScopedTimer t0(TC_LIN, s);
-  wgrad_kernel<<<dim3(chunks, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        2 * sizeof(WgLds));
+  HIP_TRY(attr_rc);
+  wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();
   wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
 
-extern "C" int nnhip_colsum_batch(const nnhip_colsum_problem* probs_dev, int32_t n, void* stream) {
-  ARG_CHECK(n >= 0 && (n == 0 || probs_dev), "nnhip_colsum_batch");
+extern "C" size_t nnhip_colsum_scratch_bytes(int32_t n) { return n > 0 ? (size_t)n * CS_CHUNKS * NF * sizeof(float) : 0; }
+extern "C" int nnhip_colsum_batch(const nnhip_colsum_problem* probs_dev, int32_t n, float* scratch, void* stream) {
+  ARG_CHECK(n >= 0 && (n == 0 || (probs_dev && scratch)), "nnhip_colsum_batch");
   if (n == 0) return NNHIP_OK;
-  colsum_kernel<<<n, 1024, 0, (hipStream_t)stream>>>(probs_dev);
+  colsum_partial_kernel<<<dim3(CS_CHUNKS, n), 512, 0, (hipStream_t)stream>>>(probs_dev, scratch);
+  LAUNCH_CHECK();
+  colsum_final_kernel<<<n, NF, 0, (hipStream_t)stream>>>(probs_dev, scratch);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_mse_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
+                                   const float* force_label, int32_t n_force, const float* weights_dev, float* loss,
+                                   float* g_energy, float* g_forces, void* stream) {
+  ARG_CHECK(n_energy >= 0 && n_force >= 0 && energy && energy_label && forces && force_label && weights_dev && loss && g_energy &&
+                g_forces, "nnhip_mse_loss_grad");
+  mse_loss_grad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(energy, energy_label, n_energy, forces, force_label, n_force,
+                                                            weights_dev, loss, g_energy, g_forces);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+extern "C" size_t nnhip_clip_adam_scratch_bytes(void) { return OPT_BLOCKS * sizeof(float); }
+extern "C" int nnhip_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                               float* state, float lr, float beta1, float beta2, float eps, float max_norm, void* stream) {
+  ARG_CHECK(n >= 0 && params && grads && exp_avg && exp_avg_sq && scratch && state && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f &&
+                beta2 >= 0.f && beta2 < 1.f, "nnhip_clip_adam");
+  if (n == 0) return NNHIP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  gradnorm_partial_kernel<<<OPT_BLOCKS, 256, 0, s>>>(grads, (long)n, scratch, state);
+  LAUNCH_CHECK();
+  clip_adam_kernel<<<OPT_BLOCKS, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, (long)n, scratch, state, lr, beta1, beta2, eps,
+                                              max_norm);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

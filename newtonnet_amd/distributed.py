@@ -42,17 +42,38 @@ def allreduce_counts(n_energy: int, n_force: int, device, group=None) -> Tuple[f
     return float(t[0]), float(t[1])
 
 
+def _flat_view_of(params) -> Optional[torch.Tensor]:
+    """The single contiguous fp32 tensor the gradients are views of, when they are laid out back to back in parameter order
+    (the fused training path, train_fused.py, produces them that way); else None."""
+    if any(p.grad is None or p.grad.dtype != torch.float32 or not p.grad.is_contiguous() for p in params):
+        return None
+    base = params[0].grad
+    st, ptr = base.untyped_storage(), base.data_ptr()
+    for p in params:
+        if p.grad.untyped_storage().data_ptr() != st.data_ptr() or p.grad.data_ptr() != ptr:
+            return None
+        ptr += 4 * p.grad.numel()
+    n = (ptr - base.data_ptr()) // 4
+    return torch.as_strided(base, (n,), (1,))
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None) -> Optional[torch.Tensor]:
-    """One flat all-reduce(sum) over all parameter gradients (in place).  Returns the flat buffer."""
+    """One flat all-reduce(sum) over all parameter gradients (in place).  Returns the flat buffer (None when there is no
+    process group: nothing to do).  Parameters without a gradient get zeros, with or without a process group."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return None
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
-    if dist.is_available() and dist.is_initialized():
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    flat = _flat_view_of(params)
+    if flat is not None:                      # gradients already live in one buffer: reduce it where it is
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return flat
+    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for p in params:
         n = p.numel()
@@ -85,6 +106,64 @@ class TrainStep:
         return loss.detach()
 
 
+def flatten_parameters(model) -> torch.Tensor:
+    """Re-home the trainable parameters as views of ONE flat fp32 tensor, in parameter order (the layout of the flat gradient the
+    fused training path produces): clip + Adam then run as two launches over the flat buffers and the data-parallel all-reduce
+    moves one tensor.  Idempotent; `model.to(...)` afterwards breaks the aliasing and the next call restores it."""
+    from newtonnet_amd.train_fused import trainable_parameters
+    params = trainable_parameters(model)
+    flat = getattr(model, '_flat_params', None)
+    if flat is not None and flat.device == params[0].device:
+        ptr, ok = flat.data_ptr(), True
+        for p in params:
+            ok = ok and p.data_ptr() == ptr and p.is_contiguous()
+            ptr += 4 * p.numel()
+        if ok:
+            return flat
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+    off = 0
+    for p in params:
+        p.data = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    model.__dict__['_flat_params'] = flat
+    return flat
+
+
+class FusedClipAdam:
+    """clip_grad_norm_(max_norm) + Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; trainer.py:311-313) as two HIP
+    launches over the model's flat parameter buffer (csrc/train.hip: gradnorm_partial_kernel, clip_adam_kernel).  The step
+    counter lives on the device, so the update captures into a HIP graph."""
+
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0):
+        from newtonnet_amd import hip
+        self.model, self.lr, self.betas, self.eps, self.max_norm = model, float(lr), betas, float(eps), float(max_norm or 0.0)
+        self.flat = flatten_parameters(model)
+        dev = self.flat.device
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.state = torch.zeros(2, dtype=torch.float32, device=dev)          # (step, last gradient norm)
+        self.scratch = torch.empty(hip.lib().nnhip_clip_adam_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+
+    def step(self, flat_grad: torch.Tensor):
+        from newtonnet_amd import hip
+        self.flat = flatten_parameters(self.model)
+        if flat_grad.numel() != self.flat.numel() or flat_grad.dtype != torch.float32 or not flat_grad.is_contiguous():
+            raise ValueError('FusedClipAdam.step needs the flat fp32 gradient of the model (train_fused.TrainWorkspace.flat_grad)')
+        hip._check(hip.lib().nnhip_clip_adam(hip._ptr(self.flat), hip._ptr(flat_grad), hip._ptr(self.exp_avg),
+                                             hip._ptr(self.exp_avg_sq), self.flat.numel(), hip._ptr(self.scratch),
+                                             hip._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps, self.max_norm,
+                                             hip._stream(self.flat.device)), 'nnhip_clip_adam')
+
+    def state_dict(self):
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), state=self.state.clone(), lr=self.lr,
+                    betas=self.betas, eps=self.eps, max_norm=self.max_norm)
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.state.copy_(sd['state'])
+        self.lr, self.betas, self.eps, self.max_norm = sd['lr'], sd['betas'], sd['eps'], sd['max_norm']
+
+
 class GraphedTrainStep:
     """TrainStep replayed from HIP graphs for batches of fixed STRUCTURE (same z / batch / cell from step to step -- the
     MD17-style case: one molecule type, fixed batch size, shuffled conformations; trainer.py:301-313).
@@ -98,13 +177,95 @@ class GraphedTrainStep:
     smaller batch of an epoch) re-captures; optimizers must be capture-safe (torch.optim.Adam(..., capturable=True)).
     """
     def __init__(self, model, optimizer, w_energy: float = 1.0, w_force: float = 50.0, clip_grad: float = 1.0,
-                 group=None):
+                 group=None, assume_static: bool = False):
+        """optimizer: a capturable torch optimizer (the step is then torch autograd + torch optimizer, captured), or a
+        FusedClipAdam (its max_norm is the clipping; `clip_grad` is ignored): the whole step then runs on hand-written kernels
+        with NO autograd -- value sweeps, the loss and its gradient, tangent sweeps, weight gradients, clip + Adam.
+        assume_static: skip the per-step check that z / batch / cell are unchanged (it costs a device->host sync)."""
         self.model, self.optimizer = model, optimizer
         self.w_energy, self.w_force, self.clip_grad, self.group = w_energy, w_force, clip_grad, group
+        self.assume_static = assume_static
+        self.fused = isinstance(optimizer, FusedClipAdam)
         self._st = None
         self.captures = 0
 
-    # -- the two captured pieces -------------------------------------------------------------------------
+    # -- fully fused mode ------------------------------------------------------------------------------------
+    def _capture_fused(self, z, pos, cell, batch, energy_label, force_label, norm):
+        from newtonnet_amd import hip, train_fused
+        model = self.model
+        if not train_fused.supported(model, list(model.output_properties)):
+            raise NotImplementedError("FusedClipAdam / the fused step needs output_properties ['energy', 'gradient_force'] and "
+                                      'layer_norm=False')
+        dev = pos.device
+        emb = model.embedding_layers.edge_embedding
+        flatten_parameters(model)
+        st = dict(z=z.long().contiguous().clone(), cell=cell.float().contiguous().clone(),
+                  batch=batch.long().contiguous().clone(), pos=pos.detach().float().contiguous().clone(),
+                  e=energy_label.detach().float().contiguous().clone(), f=force_label.detach().float().contiguous().clone())
+        N, B = st['pos'].shape[0], st['cell'].shape[0]
+        st['graph'] = hip.build_graph(st['pos'], st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies, want_rbf=True,
+                                      z=st['z'])                      # static candidate list: all pairs of every molecule
+        g = st['graph']
+        ws = train_fused.TrainWorkspace(model, N, g.n_edges, B, dev)
+        runner = train_fused.Runner(model, st['z'], st['pos'], st['cell'], st['batch'], g, ws)
+        st.update(ws=ws, runner=runner, norm=torch.zeros(2, dtype=torch.float32, device=dev),
+                  loss=torch.zeros(1, dtype=torch.float32, device=dev), gE=torch.empty(B, dtype=torch.float32, device=dev),
+                  gF=torch.empty(N, 3, dtype=torch.float32, device=dev))
+        L_ = hip.lib()
+
+        def body():
+            hip.refresh_graph(g, st['pos'], st['cell'], st['batch'], emb.cutoff, emb.embedding.frequencies)
+            runner.values()
+            hip._check(L_.nnhip_mse_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(ws.forces), hip._ptr(st['f']),
+                                              3 * N, hip._ptr(st['norm']), hip._ptr(st['loss']), hip._ptr(st['gE']),
+                                              hip._ptr(st['gF']), hip._stream(dev)), 'nnhip_mse_loss_grad')
+            runner.grads(st['gE'], st['gF'])
+        self._st = st
+        st['norm'].copy_(norm)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            body()                                   # warm-up: one-time kernel attributes, lazy module loads
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        st['g1'] = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(st['g1']):
+            body()
+        st['g2'] = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(st['g2'], pool=st['g1'].pool()):
+            self.optimizer.step(ws.flat_grad)
+        self.captures += 1
+
+    def _call_fused(self, z, pos, cell, batch, energy_label, force_label):
+        """Per step: (1) agree on the global loss normalisation -- and, unless assume_static, on whether ANY rank's batch
+        structure changed (then all ranks re-capture together: a rank-local decision would leave collectives unmatched) -- with
+        one tiny all-reduce; (2) replay forward + loss + gradients; (3) all-reduce the flat gradient; (4) replay clip + Adam."""
+        distributed = dist.is_available() and dist.is_initialized()
+        dev = pos.device
+        changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
+        counts = torch.tensor([float(energy_label.numel()), float(force_label.numel()), 1.0 if changed else 0.0],
+                              dtype=torch.float32, device=dev)
+        w = torch.tensor([self.w_energy, self.w_force], dtype=torch.float32, device=dev)
+        if distributed:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+            if not (self.assume_static and self._st is not None):
+                changed = bool(counts[2].item() > 0)             # (host sync; skipped when the structure is declared static)
+        norm = w / counts[:2]                                     # (w_E / n_E, w_F / n_F) with GLOBAL element counts, on the device
+        if changed:
+            self._capture_fused(z, pos, cell, batch, energy_label, force_label, norm)
+        st = self._st
+        st['norm'].copy_(norm)
+        st['pos'].copy_(pos.detach(), non_blocking=True)
+        st['e'].copy_(energy_label.detach(), non_blocking=True)
+        st['f'].copy_(force_label.detach(), non_blocking=True)
+        st['g1'].replay()
+        if distributed:
+            dist.all_reduce(st['ws'].flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        st['g2'].replay()
+        return st['loss'][0].clone()
+
+    # -- the two captured pieces (torch autograd + torch optimizer) -------------------------------------------------------------------------
     def _fwd_bwd(self, st):
         self.optimizer.zero_grad(set_to_none=True)
         out = self.model(st['z'], st['pos'], st['cell'], st['batch'])
@@ -163,6 +324,8 @@ class GraphedTrainStep:
     def __call__(self, z, pos, cell, batch, energy_label, force_label):
         if not self.model.training:
             raise RuntimeError('GraphedTrainStep needs model.train()')
+        if self.fused:
+            return self._call_fused(z, pos, cell, batch, energy_label, force_label)
         if not self._same_structure(z, cell, batch):
             # The warm-up / capture passes run optimizer steps of their own on this batch: snapshot and restore IN PLACE (the
             # graphs hold the addresses of the parameters and of the optimizer's state tensors).

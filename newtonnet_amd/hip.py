@@ -145,6 +145,7 @@ def lib():
     L.nnhip_node_bwd.argtypes = [vp] * 5 + [i32] + [vp] * 5 + [i32, i32, vp]
     L.nnhip_head_out.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp]
     L.nnhip_mlp128_ex.argtypes = [C.POINTER(MlpDesc), vp]
+    L.nnhip_mlp128_pair_ex.argtypes = [C.POINTER(MlpDesc), C.POINTER(MlpDesc), vp]
     L.nnhip_edge_tangent_geom.argtypes = [vp, vp, vp, i32, f32, vp, vp]
     L.nnhip_message_tan_fwd.argtypes = [vp] * 11 + [i32, vp]
     L.nnhip_force_message_tan_fwd.argtypes = [vp] * 13 + [i32, vp]
@@ -154,13 +155,21 @@ def lib():
     L.nnhip_update_tan_bwd.argtypes = [vp] * 7 + [i32, vp, vp, vp, vp]
     L.nnhip_head_seed_tan.argtypes = [vp] * 8 + [i32, i32, vp, vp, vp, vp]
     L.nnhip_pair_rbf.argtypes = [vp] * 5 + [i32, i32, vp, vp]
-    L.nnhip_species_sum.argtypes = [vp, i32, i32, vp, i32, vp, i32, vp]
+    L.nnhip_species_scratch_bytes.argtypes = [i32]
+    L.nnhip_species_scratch_bytes.restype = sz
+    L.nnhip_species_sum.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]
+    L.nnhip_colsum_scratch_bytes.argtypes = [i32]
+    L.nnhip_colsum_scratch_bytes.restype = sz
     L.nnhip_wgrad_slab_bytes.argtypes = [i32, i32]
     L.nnhip_wgrad_slab_bytes.restype = sz
     L.nnhip_wgrad_batch.argtypes = [vp, i32, i32, vp, vp]
-    L.nnhip_colsum_batch.argtypes = [vp, i32, vp]
+    L.nnhip_colsum_batch.argtypes = [vp, i32, vp, vp]
+    L.nnhip_mse_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.nnhip_clip_adam_scratch_bytes.restype = sz
+    L.nnhip_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, f32, f32, f32, f32, f32, vp]
     for fn in STAGE_SYMBOLS:
-        if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes'):
+        if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes', 'nnhip_species_scratch_bytes',
+                      'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes'):
             getattr(L, fn).restype = C.c_int
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
@@ -173,10 +182,12 @@ def lib():
 
 STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables', 'nnhip_transpose128', 'nnhip_message_fwd',
                  'nnhip_message_bwd', 'nnhip_force_message_fwd', 'nnhip_force_message_bwd', 'nnhip_edge_embed_bwd',
-                 'nnhip_node_fwd', 'nnhip_node_bwd', 'nnhip_head_out', 'nnhip_mlp128_ex', 'nnhip_edge_tangent_geom',
+                 'nnhip_node_fwd', 'nnhip_node_bwd', 'nnhip_head_out', 'nnhip_mlp128_ex', 'nnhip_mlp128_pair_ex', 'nnhip_edge_tangent_geom',
                  'nnhip_message_tan_fwd', 'nnhip_force_message_tan_fwd', 'nnhip_force_message_tan_bwd',
                  'nnhip_message_tan_bwd', 'nnhip_update_tan_fwd', 'nnhip_update_tan_bwd', 'nnhip_head_seed_tan',
-                 'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_wgrad_slab_bytes', 'nnhip_wgrad_batch', 'nnhip_colsum_batch')
+                 'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_species_scratch_bytes', 'nnhip_wgrad_slab_bytes',
+                 'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad',
+                 'nnhip_clip_adam', 'nnhip_clip_adam_scratch_bytes')
 
 EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',

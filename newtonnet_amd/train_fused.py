@@ -109,8 +109,15 @@ class TrainWorkspace:
         n_tab = hip.lib().nnhip_filter_table_bytes() // 4
         self.ftab = [buf(n_tab) for _ in range(L)]
         # ---- gradient outputs (zero-initialised once: the parameters the path never touches keep an exact zero gradient)
+        # ONE flat buffer, the per-parameter gradients are views into it: the backward hands autograd views of a single copy,
+        # and a data-parallel all-reduce moves the flat tensor as it is
         self.params = trainable_parameters(model)
-        self.grads = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=device)
+        self.grads, off = [], 0
+        for p in self.params:
+            self.grads.append(self.flat_grad[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        self.sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(F) // 4)
         self._tables(model, device)
 
     # device-resident tables of the batched launches (pointer lists of the transposes / filter tables stay on the host)
@@ -175,7 +182,9 @@ class TrainWorkspace:
         self.prob_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         arr = (hip.ColsumProblem * len(sums))(*sums)
         self.sum_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        self.chunks = max(1, min(256, (max(P, N) + 63) // 64))
+        self.cs_scratch = torch.empty(max(hip.lib().nnhip_colsum_scratch_bytes(self.n_sums) // 4, 1), dtype=torch.float32,
+                                      device=device)
+        self.chunks = max(1, min(256, (max(P, N) + 31) // 32))
         self.slabs = torch.empty(hip.lib().nnhip_wgrad_slab_bytes(self.n_probs, self.chunks) // 4, dtype=torch.float32,
                                  device=device)
 
@@ -187,13 +196,17 @@ class Runner:
         self.model, self.z, self.pos, self.cell, self.batch, self.g, self.ws = model, z, pos, cell, batch, g, ws
         self.act = hip.ACTIVATION_IDS[model.activation_name]
         self.energy_idx = list(model.output_properties).index('energy')
-        self.st = hip._stream(pos.device)
         if g.rbf is None or g.drbf is None:
             raise ValueError('the training path needs a graph built with want_rbf=True')
 
+    @property
+    def st(self):
+        """the CURRENT torch stream at the time of the call (a HIP-graph capture runs on its own stream)"""
+        return hip._stream(self.pos.device)
+
     # -- small helpers ------------------------------------------------------------------------------------------------
-    def _mlp(self, mode, X, W1, W2, H, Y, M, *, ldx=F, b1=None, b2=None, accumulate=False, T=None, T2=None, Hd=None, G=None,
-             x_off=0):
+    def _desc(self, mode, X, W1, W2, H, Y, M, *, ldx=F, b1=None, b2=None, accumulate=False, T=None, T2=None, Hd=None, G=None,
+              x_off=0):
         d = hip.MlpDesc()
         d.X, d.ldx = _p(X, x_off).value, ldx
         d.W1, d.W2 = _p(W1).value, _p(W2).value
@@ -204,8 +217,16 @@ class Runner:
         d.T2 = _p(T2).value if T2 is not None else None
         d.Hd = _p(Hd).value if Hd is not None else None
         d.G = _p(G).value if G is not None else None
+        return d
+
+    def _mlp(self, mode, X, W1, W2, H, Y, M, **kw):
         if M > 0:
-            _chk(hip.lib().nnhip_mlp128_ex(C.byref(d), self.st), 'nnhip_mlp128_ex')
+            _chk(hip.lib().nnhip_mlp128_ex(C.byref(self._desc(mode, X, W1, W2, H, Y, M, **kw)), self.st), 'nnhip_mlp128_ex')
+
+    def _mlp2(self, d0, d1):
+        """equiv_message1 | equiv_message2 (or their adjoints / tangents) over the same pair rows in one launch"""
+        if d0.M > 0:
+            _chk(hip.lib().nnhip_mlp128_pair_ex(C.byref(d0), C.byref(d1), self.st), 'nnhip_mlp128_pair_ex')
 
     def _lin(self, A, W, out, M, acc=False):
         if M > 0:
@@ -253,10 +274,12 @@ class Runner:
         for l, il in enumerate(layers):
             _chk(L_.nnhip_message_fwd(_p(ws.m[l]), _p(g.xg), _p(ws.ftab[l]), *idx, _p(a_in), _p(ws.msg[l]), _p(ws.a_mid[l]), N, st),
                  'nnhip_message_fwd')
-            self._mlp(hip.MODE_FWD, ws.msg[l], il.equiv_message1[0].weight, il.equiv_message1[2].weight, ws.h1[l], ws.phi1[l], P)
+            e1w, e2w = il.equiv_message1, il.equiv_message2
             if l > 0:
-                self._mlp(hip.MODE_FWD, ws.msg[l], il.equiv_message2[0].weight, il.equiv_message2[2].weight, ws.h2[l],
-                          ws.phi2[l], P)
+                self._mlp2(self._desc(hip.MODE_FWD, ws.msg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.phi1[l], P),
+                           self._desc(hip.MODE_FWD, ws.msg[l], e2w[0].weight, e2w[2].weight, ws.h2[l], ws.phi2[l], P))
+            else:
+                self._mlp(hip.MODE_FWD, ws.msg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.phi1[l], P)
             _chk(L_.nnhip_force_message_fwd(_p(ws.phi1[l]), _p(ws.phi2[l]), _p(g.geo), _p(g.xg), *idx, _p(f_in), _p(ws.f_out[l]),
                                             N, st), 'nnhip_force_message_fwd')
             if l + 1 < L:
@@ -281,10 +304,12 @@ class Runner:
             Gf = ws.Gf[pp]
             _chk(L_.nnhip_force_message_bwd(_p(ws.gf[l]), _p(ws.phi1[l]), _p(ws.phi2[l]), _p(g.geo), _p(g.xg), *idx, _p(f_prev),
                                             _p(ws.g_h12[l]), _p(ws.g_u[l]), _p(Gf), N, st), 'nnhip_force_message_bwd')
-            self._mlp(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.g_msg[l], P, ldx=2 * F, T=ws.t1[l])
+            d1 = self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.g_msg[l], P, ldx=2 * F, T=ws.t1[l])
             if l > 0:
-                self._mlp(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.g_msg[l], P, ldx=2 * F, T=ws.t2[l],
-                          accumulate=True, x_off=F)
+                self._mlp2(d1, self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.g_msg[l], P, ldx=2 * F,
+                                          T=ws.t2[l], accumulate=True, x_off=F))
+            elif P > 0:
+                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
             _chk(L_.nnhip_message_bwd(_p(ws.g_msg[l]), _p(ws.GA[l]), _p(ws.m[l]), _p(g.xg), _p(ws.ftab[l]), *idx,
                                       _p(ws.g_m[l]) if l > 0 else None, _p(ws.g_x[l]), N, 1 if l > 0 else 0, st),
                  'nnhip_message_bwd')
@@ -320,11 +345,13 @@ class Runner:
             da_in = None if first else ws.da_out[l - 1]
             _chk(L_.nnhip_message_tan_fwd(_p(ws.m[l]), None if first else _p(ws.dm[l]), _p(g.xg), _p(ws.tgeo), _p(ws.ftab[l]), *idx,
                                           _p(da_in), _p(ws.dmsg[l]), _p(ws.da_mid), N, st), 'nnhip_message_tan_fwd')
-            self._mlp(hip.MODE_TAN, ws.dmsg[l], il.equiv_message1[0].weight, il.equiv_message1[2].weight, ws.h1[l], ws.dphi1[l], P,
-                      T=ws.dh1[l])
+            e1w, e2w = il.equiv_message1, il.equiv_message2
+            d1 = self._desc(hip.MODE_TAN, ws.dmsg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.dphi1[l], P, T=ws.dh1[l])
             if not first:
-                self._mlp(hip.MODE_TAN, ws.dmsg[l], il.equiv_message2[0].weight, il.equiv_message2[2].weight, ws.h2[l],
-                          ws.dphi2[l], P, T=ws.dh2[l])
+                self._mlp2(d1, self._desc(hip.MODE_TAN, ws.dmsg[l], e2w[0].weight, e2w[2].weight, ws.h2[l], ws.dphi2[l], P,
+                                          T=ws.dh2[l]))
+            elif P > 0:
+                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
             _chk(L_.nnhip_force_message_tan_fwd(_p(ws.phi1[l]), _p(ws.dphi1[l]), _p(ws.phi2[l]), _p(ws.dphi2[l]), _p(g.geo),
                                                 _p(ws.tgeo), _p(g.xg), *idx, None if first else _p(ws.f_out[l - 1]),
                                                 None if first else _p(ws.df_out[l - 1]), _p(ws.df_out[l]), N, st),
@@ -353,11 +380,13 @@ class Runner:
                                                 _p(g.xg), *idx, None if first else _p(ws.f_out[l - 1]),
                                                 None if first else _p(ws.df_out[l - 1]), _p(ws.dg_h12[l]),
                                                 None if first else _p(nxt), N, st), 'nnhip_force_message_tan_bwd')
-            self._mlp(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.dg_msg, P, ldx=2 * F, T2=ws.t1[l],
-                      Hd=ws.dh1[l], G=ws.dg_h1[l])
+            d1 = self._desc(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.dg_msg, P, ldx=2 * F, T2=ws.t1[l],
+                            Hd=ws.dh1[l], G=ws.dg_h1[l])
             if not first:
-                self._mlp(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.dg_msg, P, ldx=2 * F, T2=ws.t2[l],
-                          Hd=ws.dh2[l], G=ws.dg_h2[l], accumulate=True, x_off=F)
+                self._mlp2(d1, self._desc(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.dg_msg, P, ldx=2 * F,
+                                          T2=ws.t2[l], Hd=ws.dh2[l], G=ws.dg_h2[l], accumulate=True, x_off=F))
+            elif P > 0:
+                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
             _chk(L_.nnhip_message_tan_bwd(_p(ws.g_msg[l]), _p(ws.dg_msg), _p(ws.GA[l]), _p(ws.dGA), _p(ws.m[l]),
                                           None if first else _p(ws.dm[l]), _p(g.xg), _p(ws.tgeo), _p(ws.ftab[l]), *idx,
                                           _p(ws.dg_m[l]), _p(ws.g_eps[l]), _p(ws.dg_eps[l]), N, st), 'nnhip_message_tan_bwd')
@@ -369,15 +398,15 @@ class Runner:
         _chk(L_.nnhip_pair_rbf(_p(g.rbf), _p(g.drbf), _p(ws.tgeo), _p(g.edge_index), _p(g.pid), E, emb.n_basis, _p(ws.rb), st),
              'nnhip_pair_rbf')
         _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), st), 'nnhip_wgrad_batch')
-        _chk(L_.nnhip_colsum_batch(_p(ws.sum_dev), ws.n_sums, st), 'nnhip_colsum_batch')
+        _chk(L_.nnhip_colsum_batch(_p(ws.sum_dev), ws.n_sums, _p(ws.cs_scratch), st), 'nnhip_colsum_batch')
         gmap = {id(p): gr for p, gr in zip(ws.params, ws.grads)}
-        _chk(L_.nnhip_species_sum(_p(ws.dGA), F, F, _p(self.z), N, _p(gmap[id(model.embedding_layers.node_embedding.weight)]), F,
-                                  st), 'nnhip_species_sum')
-        if sc.scale is not None:
-            _chk(L_.nnhip_species_sum(_p(ws.scal), 4, 1, _p(self.z), N, _p(gmap[id(sc.scale.weight)]), 1, st), 'nnhip_species_sum')
-        if sc.shift is not None:
-            _chk(L_.nnhip_species_sum(_p(ws.scal, 1), 4, 1, _p(self.z), N, _p(gmap[id(sc.shift.weight)]), 1, st), 'nnhip_species_sum')
-        _chk(L_.nnhip_species_sum(_p(ws.scal, 2), 4, 1, None, N, _p(ws.g_head4_b), 1, st), 'nnhip_species_sum')
+        _chk(L_.nnhip_species_sum(_p(ws.dGA), F, F, _p(self.z), N, _p(ws.sp_scratch),
+                                  _p(gmap[id(model.embedding_layers.node_embedding.weight)]), 0, F, F, None, 0, 0, 0, None, 0, st),
+             'nnhip_species_sum')
+        _chk(L_.nnhip_species_sum(_p(ws.scal), 4, 4, _p(self.z), N, _p(ws.sp_scratch),
+                                  _p(gmap[id(sc.scale.weight)]) if sc.scale is not None else None, 0, 1, 1,
+                                  _p(gmap[id(sc.shift.weight)]) if sc.shift is not None else None, 1, 1, 1,
+                                  _p(ws.g_head4_b), 2, st), 'nnhip_species_sum')
         return ws.grads
 
 
@@ -399,9 +428,16 @@ class FusedEnergyForces(torch.autograd.Function):
             g_energy = torch.zeros(ws.B, dtype=torch.float32, device=ws.energy.device)
         if g_forces is None:
             g_forces = torch.zeros(ws.N, 3, dtype=torch.float32, device=ws.energy.device)
-        grads = r.grads(g_energy, g_forces)
+        r.grads(g_energy, g_forces)
         ws.busy = False
-        return (None, None) + tuple(grads)
+        # one copy of the flat gradient; autograd receives views of it (AccumulateGrad keeps them as the .grad tensors), and
+        # distributed.allreduce_gradients recognises the flat layout and reduces it in place
+        flat = ws.flat_grad.clone()
+        out, off = [], 0
+        for p in ws.params:
+            out.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None) + tuple(out)
 
 
 def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None):

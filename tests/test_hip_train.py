@@ -261,3 +261,150 @@ def test_training_without_gradient_force_head(props):
         o2 = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
     assert not o2.energy.requires_grad
     assert (o2.energy - out.energy.detach()).abs().max().item() < 2e-5 * max(1.0, out.energy.abs().max().item())
+
+
+@pytest.mark.parametrize('case,activation', [('ethanol4_rand', 'swish'), ('mixed_rand', 'swish'), ('pbc216_rand', 'swish'),
+                                             ('mixed_rand', 'tanh'), ('ethanol4_rand', 'softplus')])
+def test_fused_training_stages_against_fp64_model(case, activation):
+    """The fused training path (newtonnet_amd/train_fused.py over csrc/train.hip: value sweeps, tangent sweeps, weight-gradient
+    products) stage by stage against the fp64 statement of the same algorithm (tests/tangent_ref.py), and the parameter
+    gradients against the oracle's autograd double backward (the reference's own way, trainer.py:299-313)."""
+    from newtonnet_amd import hip
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    from tests import tangent_ref as tr
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    torch.manual_seed(0)
+    model = NewtonNet(activation=activation, output_properties=['energy', 'gradient_force'])
+    if activation == 'swish':
+        model.load_state_dict(util.load_state('rand', torch.float32))
+    sd = {k: v.detach().clone().double() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    B, N = cell.shape[0], pos.shape[0]
+    e_lab, f_lab = torch.randn(B, generator=g), torch.randn(N, 3, generator=g)
+    out = model(z.cuda(), pos.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'       # the hand-written path, not a torch graph
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(
+        out.gradient_force, f_lab.cuda())
+    gE, gF = torch.autograd.grad(loss, (out.energy, out.gradient_force), retain_graph=True)
+    loss.backward()
+    ws = model._train_ws[-1]
+    E_, F_, grads, S = tr.train_grads(sd, z, pos.double(), cell.double(), batch, gE.cpu().double(), gF.cpu().double(),
+                                       activation=activation, keep=True)
+    ei = out.edge_index.cpu()
+    assert torch.equal(ei, S['edge_index'])
+    gr = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, model.embedding_layers.edge_embedding.embedding.frequencies)
+    pid, rev, i_ = gr.pid.cpu().long(), gr.rev.cpu().long(), ei[0]
+
+    def close(name, got, want, tol=3e-4):
+        got, want = got.detach().cpu().double(), want.double()
+        err, scale = (got - want).abs().max().item(), max(want.abs().max().item(), 1e-30)
+        assert err <= tol * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
+
+    pairsum = lambda x: x + x[rev]  # noqa: E731   directed-edge adjoints of the model -> both directions of the shared pair row
+    close('energy', out.energy, E_, 1e-5)
+    close('forces', out.gradient_force, F_, 1e-4)
+    for l, st in enumerate(S['layers']):
+        for name, got, want in (
+                ('GA', ws.GA[l], st['GA']), ('gf', ws.gf[l], st['gf']), ('t1', ws.t1[l][pid], pairsum(st['t1'])),
+                ('g_msg', ws.g_msg[l][pid], pairsum(st['G'] - st['GA'][i_])), ('dmsg', ws.dmsg[l][pid], st['dmsg']),
+                ('dh1', ws.dh1[l][pid], st['dh1']), ('dphi1', ws.dphi1[l][pid], st['dphi1']), ('df_out', ws.df_out[l], st['df_out']),
+                ('dq', ws.dq[l], st['dq']), ('da_out', ws.da_out[l], st['da_out']),
+                ('dg_phi1', ws.dg_h12[l][:, :128][pid], pairsum(st['dg_phi1'])), ('dg_h1', ws.dg_h1[l][pid], pairsum(st['dg_h1'])),
+                ('dg_m', ws.dg_m[l], st['dg_m']), ('dg_hn', ws.dg_hn[l], st['dg_hn']),
+                ('g_eps', ws.g_eps[l][pid], pairsum(st['g_eps'])), ('dg_eps', ws.dg_eps[l][pid], pairsum(st['dg_eps']))):
+            close(f'{name}[{l}]', got, want)
+        if l > 0:
+            for name, got, want in (('dphi2', ws.dphi2[l][pid], st['dphi2']), ('dm', ws.dm[l], st['dm']),
+                                    ('dg_phi2', ws.dg_h12[l][:, 128:][pid], pairsum(st['dg_phi2'])),
+                                    ('dg_h2', ws.dg_h2[l][pid], pairsum(st['dg_h2'])), ('g_m', ws.g_m[l], st['g_m'])):
+                close(f'{name}[{l}]', got, want)
+    close('dg_e1', ws.dg_e1, S['dg_e1'])
+    close('dGA', ws.dGA, S['dGA0'])
+    ref.set_activation(activation)
+    try:
+        want_loss, want = ref.training_loss_grads(sd, z, pos.double(), cell.double(), batch, e_lab.double(), f_lab.double())
+    finally:
+        ref.set_activation('swish')
+    assert abs(loss.item() - want_loss.item()) <= 1e-4 * abs(want_loss.item())
+    err = nrm = 0.0
+    for name, prm in model.named_parameters():
+        if prm.requires_grad:
+            err += (prm.grad.detach().cpu().double() - want[name]).norm().item() ** 2
+            nrm += want[name].norm().item() ** 2
+    print(f'{case} {activation}: relative gradient-norm error {np.sqrt(err / nrm):.2e}')
+    assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm)
+
+
+def test_fused_training_config2_size_properties():
+    """The config-2 batch (1024 aspirin conformers) through the fused training path: finite, bitwise deterministic gradients;
+    the loss gradient of a batch is the sum of the gradients of its two halves (molecules are independent)."""
+    from newtonnet_amd.models import NewtonNet
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 1024, 21
+    g = torch.Generator().manual_seed(0)
+    pos = (torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=g)).cuda()
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    e_lab, f_lab = torch.randn(B, generator=g).cuda(), torch.randn(B * n, 3, generator=g).cuda()
+    torch.manual_seed(0)
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).cuda()
+    model.train()
+
+    def grads(m0, m1):
+        model.zero_grad(set_to_none=True)
+        sl = slice(m0 * n, m1 * n)
+        out = model(z[sl], pos[sl].clone().requires_grad_(True), torch.zeros(m1 - m0, 3, 3, device='cuda'), batch[sl] - m0)
+        loss = (out.energy - e_lab[m0:m1]).pow(2).sum() / B + 50.0 * (out.gradient_force - f_lab[sl]).pow(2).sum() / (3 * B * n)
+        loss.backward()
+        return [p.grad.detach().clone() for p in model.parameters() if p.requires_grad]
+
+    full, again = grads(0, B), grads(0, B)
+    assert all(torch.isfinite(t).all() for t in full)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(full, again))          # no float atomics anywhere
+    halves = [x + y for x, y in zip(grads(0, B // 2), grads(B // 2, B))]
+    for a_, b_ in zip(full, halves):
+        scale = max(float(a_.abs().max()), 1e-6)
+        assert float((a_ - b_).abs().max()) <= 5e-4 * scale + 1e-6
+
+
+def test_fully_fused_graphed_step_matches_torch_optimizer():
+    """GraphedTrainStep with FusedClipAdam: value sweeps, loss, tangent sweeps, weight gradients, clip + Adam all on hand-written
+    kernels, no autograd, replayed from two HIP graphs -- against the eager TrainStep (fused autograd node + torch
+    clip_grad_norm_ + torch.optim.Adam) from the same initial weights over the same batches, including a change of structure."""
+    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep, TrainStep
+    from newtonnet_amd.models import NewtonNet
+
+    def batch_of(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        eth0 = torch.tensor([[0.00, 0.00, 0.00], [1.52, 0.00, 0.00], [2.05, 1.32, 0.00], [-0.39, 1.02, 0.00],
+                             [-0.39, -0.51, 0.89], [-0.39, -0.51, -0.89], [1.90, -0.53, 0.88], [1.90, -0.53, -0.88],
+                             [3.01, 1.30, 0.00]])
+        pos = eth0.repeat(B, 1) + 0.1 * torch.randn(9 * B, 3, generator=g)
+        z = torch.tensor([6, 6, 8, 1, 1, 1, 1, 1, 1]).repeat(B)
+        batch = torch.repeat_interleave(torch.arange(B), 9)
+        return [t.cuda() for t in (z, pos, torch.zeros(B, 3, 3), batch, torch.randn(B, generator=g),
+                                   torch.randn(9 * B, 3, generator=g))]
+
+    seq = [(8, 1), (8, 2), (8, 3), (5, 4), (8, 5), (8, 6)]
+    torch.manual_seed(0)
+    m_e = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+    m_e.train()
+    eager = TrainStep(m_e, torch.optim.Adam(m_e.parameters(), lr=1e-3), 1.0, 50.0, 1.0)
+    l_e = [float(eager(*batch_of(B, s))) for B, s in seq]
+    torch.manual_seed(0)
+    m_f = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+    m_f.train()
+    opt = FusedClipAdam(m_f, lr=1e-3, max_norm=1.0)
+    fused = GraphedTrainStep(m_f, opt, 1.0, 50.0)
+    l_f = [float(fused(*batch_of(B, s))) for B, s in seq]
+    assert fused.captures == 3 and fused.fused
+    np.testing.assert_allclose(l_f, l_e, rtol=2e-4)
+    for (k, a), b in zip(m_e.state_dict().items(), m_f.state_dict().values()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4, err_msg=k)
+    assert float(opt.state[0]) == len(seq)
+    # the flat layout survives: every trainable parameter is a view of the one buffer the optimizer updates
+    base = m_f._flat_params.data_ptr()
+    assert all(base <= p.data_ptr() < base + 4 * m_f._flat_params.numel() for n, p in m_f.named_parameters() if 'frequencies' not in n)
