@@ -56,6 +56,104 @@ def synthetic_box(n_atoms, n_side, seed, device):
     return z.to(device), pos.to(device), cell.to(device), torch.zeros(n_atoms, dtype=torch.long, device=device)
 
 
+# the nine MD17 molecules by atom count / species (only aspirin's geometry is in-tree; the others are
+# synthetic: random non-overlapping placement, min distance 0.9 A inside a 6 A sphere, seed = molecule index)
+MD17_SHAPES = [('benzene', [6] * 6 + [1] * 6), ('uracil', [6] * 4 + [1] * 4 + [7] * 2 + [8] * 2),
+               ('naphthalene', [6] * 10 + [1] * 8), ('aspirin', None), ('salicylic', [6] * 7 + [1] * 6 + [8] * 3),
+               ('malonaldehyde', [6] * 3 + [1] * 4 + [8] * 2), ('ethanol', [6] * 2 + [1] * 6 + [8]),
+               ('toluene', [6] * 7 + [1] * 8), ('paracetamol', [6] * 8 + [1] * 9 + [7] + [8] * 2)]
+
+
+def synthetic_md17_mixed(n_mol, seed, device):
+    """BASELINE configs[3] / SURVEY 8(d) config 4: `n_mol` molecules per rank, uniformly mixed over the nine MD17 shapes, each
+    conformer = the shape's base geometry + N(0, 0.05^2) noise; labels E ~ N(0,1), F ~ N(0,1) (seeded by `seed` = rank)."""
+    with np.load(os.path.join(ROOT, 'tests', 'golden', 'aspirin_frames.npz')) as f:
+        z_asp, p_asp = f['z'], f['test0_pos']
+    bases = []
+    for k, (name, zs) in enumerate(MD17_SHAPES):
+        if zs is None:
+            bases.append((np.asarray(z_asp), np.asarray(p_asp, dtype=np.float64)))
+            continue
+        rng = np.random.default_rng(k)
+        pts = []
+        while len(pts) < len(zs):
+            c = rng.uniform(-6, 6, 3)
+            if np.linalg.norm(c) <= 6.0 and all(np.linalg.norm(c - q) >= 0.9 for q in pts):
+                pts.append(c)
+        bases.append((np.asarray(zs), np.asarray(pts)))
+    g = torch.Generator().manual_seed(1000 + seed)
+    zs, ps, bs = [], [], []
+    for m in range(n_mol):
+        zk, pk = bases[m % len(bases)]
+        zs.append(torch.from_numpy(zk).long())
+        ps.append(torch.from_numpy(pk).float() + 0.05 * torch.randn(len(zk), 3, generator=g))
+        bs.append(torch.full((len(zk),), m, dtype=torch.long))
+    z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+    e_lab, f_lab = torch.randn(n_mol, generator=g), torch.randn(len(z), 3, generator=g)
+    return [t.to(device) for t in (z, pos, torch.zeros(n_mol, 3, 3), batch, e_lab, f_lab)]
+
+
+def train_leg(device, dist, backend, world, rank, steps, warmup, molecules=32):
+    """Data-parallel training step (BASELINE configs[2]-[3]): every rank holds `molecules` mixed MD17-shaped molecules; one step =
+    value sweeps + loss + tangent sweeps + weight gradients (hand-written kernels, replayed from a HIP graph), ONE all-reduce of
+    the flat fp32 gradient over RCCL/xGMI, clip + Adam (second graph).  Timed like the headline: barrier + max over ranks."""
+    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep
+    from newtonnet_amd.models import NewtonNet
+    data = synthetic_md17_mixed(molecules, rank, device)
+    torch.manual_seed(0)                          # identical replicas
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).to(device)
+    model.train()
+    opt = FusedClipAdam(model, lr=1e-3, max_norm=1.0)
+    step = GraphedTrainStep(model, opt, 1.0, 50.0, assume_static=True)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    loss0 = float(step(*data))
+    for _ in range(max(warmup, 1)):
+        loss = step(*data)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(*data)
+    sync_all()
+    dt = time.perf_counter() - t0
+    n_atoms = data[0].shape[0]
+    tot = torch.tensor([dt, float(n_atoms)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    flat = step._st['ws'].flat_grad
+    ar_us = None
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt, n_atoms = float(mx[0]), int(tot[1])
+        buf = flat.clone()
+        for _ in range(3):
+            dist.all_reduce(buf)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_us = (time.perf_counter() - t1) / 20 * 1e6
+        # replicas must still hold identical parameters (same global gradient, same update)
+        chk = model._flat_params.double().sum().reshape(1).to(tot.device)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((hi - lo).abs().item() <= 1e-9 * max(1.0, abs(hi.item())))
+    else:
+        in_sync = True
+    return {'workload': f'mixed MD17-shaped molecules (9 shapes), {molecules} molecules per rank, loss MSE(E) + 50 MSE(F), '
+                        'Adam 1e-3, clip 1.0 (BASELINE.json configs[3]); fp32; fully fused HIP-graph step',
+            'atoms_total': n_atoms, 'ms_per_step': round(1e3 * dt / steps, 4),
+            'atom_steps_per_s': round(n_atoms * steps / dt, 1), 'molecule_steps_per_s': round(world * molecules * steps / dt, 1),
+            'gradient_bytes': int(flat.numel() * 4), 'allreduce_us': None if ar_us is None else round(ar_us, 1),
+            'replicas_in_sync': in_sync, 'first_loss': round(loss0, 5), 'last_loss': round(float(loss), 5)}
+
+
 def algorithmic_counts(N, E, L=3, F=128):
     """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step.
     The edge MLPs are evaluated once per undirected pair (P = E/2 rows): the FLOP counts below are the FLOPs actually
@@ -134,6 +232,10 @@ def main():
     ap.add_argument('--weights', default='seed0', choices=['seed0', 'ckpt'])
     ap.add_argument('--workload', default='aspirin', choices=['aspirin', 'box100k'],
                     help="aspirin = BASELINE configs[1] (the headline); box100k = configs[4], 100k-atom periodic box")
+    ap.add_argument('--mode', default='inference', choices=['inference', 'train'],
+                    help='inference (default): the headline metric, with the data-parallel train step reported beside it in '
+                         '"train"; train: the train step (BASELINE configs[3]) is the reported value')
+    ap.add_argument('--no-train-leg', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -316,7 +418,21 @@ def main():
                         'threads': legs, 'edge_index_equal_gpu_vs_cpu': ei_equal,
                         'force_mae_gpu_vs_cpu_fp32': float(f_err.mean()), 'force_max_gpu_vs_cpu_fp32': float(f_err.max())}
 
-    if rank == 0:
+    # ---- data-parallel training step: the ONE collective of the design (flat fp32 gradient all-reduce over RCCL) ----------
+    train = None
+    if not args.no_train_leg and args.workload == 'aspirin':
+        train = train_leg(device, dist, backend, world, rank, max(args.steps, 10), args.warmup)
+
+    if rank == 0 and args.mode == 'train':
+        print(json.dumps({
+            'metric': 'training atom-steps/sec (force-loss step) on mixed MD17-shaped molecules, data-parallel',
+            'value': train['atom_steps_per_s'], 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': max(args.steps, 10),
+            'warmup': args.warmup, 'ms_per_step': train['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': train['workload'], 'parallelism': f'dp{world}: replicas + one flat-gradient all-reduce per step'},
+            'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
+            'allreduce_us': train['allreduce_us'], 'train': train}))
+    elif rank == 0:
         line = {
             'metric': 'atom-steps/sec (energy+force) on batched MD17 aspirin',
             'value': round(value, 1), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -329,6 +445,7 @@ def main():
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
+            'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,
             'cpu_baseline': cpu_baseline,
         }
