@@ -35,6 +35,9 @@ extern "C" {
 #define NNHIP_MAX_NB 32    /* any 1 <= n_basis <= 32 runs: only the radial-filter table builder sees the basis */
 #define NNHIP_MAX_LAYERS 8
 #define NNHIP_N_ELEMENTS 119 /* rows of node_embedding / scale / shift (z = 0..118) */
+/* cutoff envelope of the edge embedding: a positive value p = PolynomialCutoff(p) (representations.py:138-171; the model
+ * uses p = 9, :17; 0 means 9), NNHIP_ENVELOPE_COSINE = CosineCutoff (representations.py:177-203) */
+#define NNHIP_ENVELOPE_COSINE (-1)
 
 /* activation ids (newtonnet/layers/activations.py:5-30); 'swish' and 'silu' are both NNHIP_ACT_SILU */
 enum {
@@ -99,6 +102,7 @@ typedef struct {
   const float* scale;   /* scalers.k.scale.weight [119] (NULL = 1) */
   const float* shift;   /* scalers.k.shift.weight [119] (NULL = 0) */
   int32_t activation;   /* NNHIP_ACT_* of every MLP of the model (constructor argument `activation`, newtonnet.py:30) */
+  int32_t envelope;     /* cutoff envelope (see NNHIP_ENVELOPE_COSINE); 0 = the model's PolynomialCutoff(9) */
 } nnhip_model;
 
 /* --------------------------------------------------------------------------
@@ -180,7 +184,7 @@ int nnhip_check_species(const int64_t* z, int32_t n_atoms, int32_t* status, void
  *              representations.py:96) gets the all-zero filter row and is masked out of the force kernels.
  * ------------------------------------------------------------------------ */
 int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies, int32_t n_basis,
-                     float* geo, float* rbf, float* drbf, int32_t* xg, void* stream);
+                     float* geo, float* rbf, float* drbf, int32_t* xg, int32_t envelope, void* stream);
 
 /* --------------------------------------------------------------------------
  * Whole hot path: energy and forces (= -dE/dpos) for a batch.
@@ -313,7 +317,7 @@ int nnhip_embed(const int64_t* z, const float* table, int32_t n_atoms, float* ou
  * nnhip_filter_table_bytes() bytes.  The message kernels interpolate them instead of contracting rbf per edge. */
 size_t nnhip_filter_table_bytes(void);
 int nnhip_filter_tables(const float* const* edge_w_host_array, float* const* tables_host_array, int32_t n_layers,
-                        const float* frequencies, int32_t n_basis, void* stream);
+                        const float* frequencies, int32_t n_basis, int32_t envelope, void* stream);
 
 /* out[k] = in[k]^T for `count` <= 40 [128][128] matrices (weights for the adjoint products) */
 int nnhip_transpose128(const float* const* src_host_array, float* const* dst_host_array, int32_t count, void* stream);

@@ -281,13 +281,33 @@ __global__ void edge_rev_kernel(const int* __restrict__ row_ptr, const int* __re
   rev[e] = found;
 }
 
+// Cutoff envelope and its derivative (fp64).  env > 0: PolynomialCutoff(p = env), representations.py:138-171 (the model uses
+// p = 9, :17):  1 - (p+1)(p+2)/2 x^p + p(p+2) x^(p+1) - p(p+1)/2 x^(p+2),  derivative  -p(p+1)(p+2)/2 x^(p-1) (1-x)^2;
+// env == NNHIP_ENVELOPE_COSINE: CosineCutoff, representations.py:177-203:  (1 + cos(pi x)) / 2.
+__device__ __forceinline__ void envelope_eval(double x, int env, double& e, double& de) {
+  if (env == NNHIP_ENVELOPE_COSINE) {
+    double sn, cs;
+    sincos(3.14159265358979323846 * x, &sn, &cs);
+    e = 0.5 * (1.0 + cs);
+    de = -0.5 * 3.14159265358979323846 * sn;
+  } else if (env == 9) {
+    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
+    e = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);      // 1 - 55x^9 + 99x^10 - 45x^11
+    de = -495.0 * x8 * (1.0 - x) * (1.0 - x);           // -495x^8 + 990x^9 - 495x^10
+  } else {
+    const double p = (double)env, xp = pow(x, p - 1.0);   // x^(p-1)
+    e = 1.0 - 0.5 * (p + 1.0) * (p + 2.0) * xp * x + p * (p + 2.0) * xp * x * x - 0.5 * p * (p + 1.0) * xp * x * x * x;
+    de = -0.5 * p * (p + 1.0) * (p + 2.0) * xp * (1.0 - x) * (1.0 - x);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // edge embedding: geo = (dir, r), rbf = env(x) sin(w x)/x, drbf = d rbf/dx.  Evaluated in fp64 and
 // rounded once (E x nb values; the cost is negligible next to the [E,F] tensors and it removes the
 // cancellation of the p=9 polynomial envelope near x -> 1 from the fp32 error budget).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, float cut2, const float* __restrict__ freq, int nb,
+edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, float cut2, int env_id, const float* __restrict__ freq, int nb,
                   float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
@@ -321,9 +341,8 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, flo
     }
     return;
   }
-  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
-  const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);   // 1 - 55x^9 + 99x^10 - 45x^11
-  const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);        // -495x^8 + 990x^9 - 495x^10
+  double env, denv;
+  envelope_eval(x, env_id, env, denv);
   const double ix = 1.0 / x;
   for (int n = 0; n < nb; ++n) {
     const double w = (double)freq[n];
@@ -398,6 +417,7 @@ struct FilterTableArgs {
   float* table[NNHIP_MAX_LAYERS];
   const float* freq;
   int nb;
+  int env;
 };
 __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
   __shared__ double rb[NNHIP_MAX_NB], drb[NNHIP_MAX_NB];
@@ -411,9 +431,8 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
   const double x = (double)(g - 1) / (double)FT_G;
   if (threadIdx.x < nb) {
     const double w = (double)a.freq[threadIdx.x];
-    const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x9 = x8 * x;
-    const double env = 1.0 - x9 * (55.0 - 99.0 * x + 45.0 * x2);
-    const double denv = -495.0 * x8 * (1.0 - x) * (1.0 - x);
+    double env, denv;
+    envelope_eval(x, a.env, env, denv);
     double bes, dbes;
     if (x == 0.0) {
       bes = w;       // sin(wx)/x -> w
@@ -439,7 +458,7 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
 }
 
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,
-                         hipStream_t s) {
+                         int envelope, hipStream_t s) {
   ScopedTimer tm(TC_OTHER, s);
   FilterTableArgs a;
   for (int l = 0; l < n_layers; ++l) {
@@ -448,6 +467,7 @@ int launch_filter_tables(const float* const* edge_w, float* const* tables, int n
   }
   a.freq = freq;
   a.nb = nb;
+  a.env = envelope ? envelope : 9;
   filter_table_kernel<<<dim3(FT_ROWS, n_layers), NF, 0, s>>>(a);
   LAUNCH_CHECK();
   return 0;
@@ -485,15 +505,16 @@ extern "C" int nnhip_edge_disp(const float* pos, const float* cell, const int64_
 }
 
 extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,
-                                int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg, void* stream_) {
+                                int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg, int32_t envelope,
+                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_basis < 1 || n_basis > NNHIP_MAX_NB) {
-    nnhip_set_error("nnhip_edge_embed: n_basis=%d unsupported (1..%d)", n_basis, NNHIP_MAX_NB);
+  if (n_basis < 1 || n_basis > NNHIP_MAX_NB || (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_edge_embed: n_basis=%d (1..%d) / envelope=%d unsupported", n_basis, NNHIP_MAX_NB, envelope);
     return NNHIP_E_UNSUPPORTED;
   }
   if (n_edges == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
-  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, cut2_of(cutoff), frequencies, n_basis, geo, rbf, drbf,
+  edge_embed_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(disp, n_edges, cutoff, cut2_of(cutoff), envelope ? envelope : 9, frequencies, n_basis, geo, rbf, drbf,
                                                             reinterpret_cast<int2*>(xg));
   LAUNCH_CHECK();
   return NNHIP_OK;

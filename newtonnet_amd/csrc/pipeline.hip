@@ -16,7 +16,7 @@
 
 // ---- pieces defined in the other translation units ---------------------------------------------------
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,
-                         hipStream_t s);
+                         int envelope, hipStream_t s);
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
@@ -278,7 +278,7 @@ static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pba
       ew[l] = model->layer[l].edge_w;
       tb[l] = Q(pq.ftab[l]);
     }
-    TRY(launch_filter_tables(ew, tb, L, model->frequencies, model->n_basis, s));
+    TRY(launch_filter_tables(ew, tb, L, model->frequencies, model->n_basis, model->envelope, s));
   }
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows); the atoms'
   // rows are looked up (embed_kernel) instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is
@@ -557,12 +557,13 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----
 extern "C" size_t nnhip_filter_table_bytes(void) { return (size_t)2 * FT_ROWS * NF * sizeof(float); }
 extern "C" int nnhip_filter_tables(const float* const* edge_w, float* const* tables, int32_t n_layers, const float* freq,
-                                   int32_t nb, void* stream) {
-  if (!edge_w || !tables || !freq || n_layers < 1 || n_layers > NNHIP_MAX_LAYERS || nb < 1 || nb > NNHIP_MAX_NB) {
+                                   int32_t nb, int32_t envelope, void* stream) {
+  if (!edge_w || !tables || !freq || n_layers < 1 || n_layers > NNHIP_MAX_LAYERS || nb < 1 || nb > NNHIP_MAX_NB ||
+      (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
     nnhip_set_error("nnhip_filter_tables: bad arguments");
     return NNHIP_E_INVALID;
   }
-  return launch_filter_tables(edge_w, tables, n_layers, freq, nb, (hipStream_t)stream);
+  return launch_filter_tables(edge_w, tables, n_layers, freq, nb, envelope, (hipStream_t)stream);
 }
 extern "C" int nnhip_transpose128(const float* const* src, float* const* dst, int32_t count, void* stream) {
   if (!src || !dst || count < 0 || count > 40) {

@@ -420,49 +420,58 @@ __device__ __forceinline__ float comp(const float4& v, int w) { return w == 0 ? 
 // with unit stride.  Two LDS buffers: the next trip's rows are requested before this trip's MFMAs and written behind them.
 #define WG_R 16
 struct WgStage {   // what one thread fetched for the next trip: rows (t >> 5) and (t >> 5) + 8, lane column c = t & 31
-  float4 a1[2], a2[2], b1[2], b2[2];
+  float4 a1[2], a2[2], b1[2], b2[2], ha[2];   // raw as loaded (b1 / b2 hold hB / dhB for WG_ACT); wg_finish applies the prologue
+  bool live[2];
 };
 struct WgLds {
   float a1[4][WG_R][32], a2[4][WG_R][32];
   float b1[WG_R][NF], b2[WG_R][NF];
 };
 
+// Issue the loads only: nothing here consumes a loaded value, so the requests stay in flight under the MFMAs that follow.
 __device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int r_safe, bool two, WgStage& g) {
   const int c = threadIdx.x & 31;
-  const int act = P.activation;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = r0 + (threadIdx.x >> 5) + 8 * q;
-    const bool live = r < r_end;
-    const int rr = live ? r : r_safe;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    g.live[q] = r < r_end;
+    const int rr = g.live[q] ? r : r_safe;
     g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
-    g.a2[q] = zero;
-    g.b2[q] = zero;
     if (P.b_cols32) {   // B rows are 32 floats wide: lane column c carries one of them (in .x)
-      g.b1[q] = make_float4(P.B1[(size_t)rr * P.ldb1 + c], 0.f, 0.f, 0.f);
-      if (two) g.b2[q] = make_float4(P.B2[(size_t)rr * P.ldb2 + c], 0.f, 0.f, 0.f);
+      g.b1[q].x = P.B1[(size_t)rr * P.ldb1 + c];
+      if (two) g.b2[q].x = P.B2[(size_t)rr * P.ldb2 + c];
     } else if (P.type == WG_ACT) {
-      const float4 hv = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
-      g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
-      if (two) {
-        const float4 dh = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
-        g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
-                              dact_any(hv.w, act) * dh.w);
-      }
+      g.b1[q] = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
+      if (two) g.b2[q] = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
     } else {
       g.b1[q] = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
       if (two) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
     }
     if (two) {
       g.a2[q] = ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c);
-      if (P.type == WG_TDACT) {
-        const float4 hv = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
-        g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
-                              g.a2[q].w * dact_any(hv.w, act));
-      }
+      if (P.type == WG_TDACT) g.ha[q] = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
     }
-    if (!live) {
+  }
+}
+// the prologue of the operand forms, applied once per element (after the MFMAs of the current trip)
+__device__ __forceinline__ void wg_finish(const WgProb& P, bool two, WgStage& g) {
+  const int act = P.activation;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (!P.b_cols32 && P.type == WG_ACT) {
+      const float4 hv = g.b1[q], dh = g.b2[q];
+      g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
+      if (two)
+        g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
+                              dact_any(hv.w, act) * dh.w);
+    }
+    if (two && P.type == WG_TDACT) {
+      const float4 hv = g.ha[q];
+      g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
+                            g.a2[q].w * dact_any(hv.w, act));
+    }
+    if (!g.live[q]) {
       g.a1[q] = zero;
       g.a2[q] = zero;
     }
@@ -521,6 +530,7 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
   if (r_beg < r_end) {
     WgStage g;
     wg_fetch(P, r_beg, r_end, r_beg, two, g);
+    wg_finish(P, two, g);
     wg_commit(lds[0], g, two, nb32);
     __syncthreads();
     int buf = 0;
@@ -551,7 +561,10 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
           }
         }
       }
-      if (more) wg_commit(lds[buf ^ 1], g, two, nb32);
+      if (more) {
+        wg_finish(P, two, g);
+        wg_commit(lds[buf ^ 1], g, two, nb32);
+      }
       __syncthreads();
       buf ^= 1;
     }

@@ -204,7 +204,7 @@ class GraphedTrainStep:
                   e=energy_label.detach().float().contiguous().clone(), f=force_label.detach().float().contiguous().clone())
         N, B = st['pos'].shape[0], st['cell'].shape[0]
         st['graph'] = hip.build_graph(st['pos'], st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies, want_rbf=True,
-                                      z=st['z'])                      # static candidate list: all pairs of every molecule
+                                      z=st['z'], envelope=emb.envelope_id)                      # static candidate list: all pairs of every molecule
         g = st['graph']
         ws = train_fused.TrainWorkspace(model, N, g.n_edges, B, dev)
         runner = train_fused.Runner(model, st['z'], st['pos'], st['cell'], st['batch'], g, ws)
@@ -295,7 +295,7 @@ class GraphedTrainStep:
         st['n_e'], st['n_f'] = allreduce_counts(energy_label.numel(), force_label.numel(), dev, self.group)
         # static candidate list: every ordered pair of every molecule (minimum image when periodic)
         st['graph'] = hip.build_graph(st['pos'].detach(), st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies,
-                                      want_rbf=True)
+                                      want_rbf=True, envelope=emb.envelope_id)
         self._st = st
         self.model._static_train_graph = st['graph']
         try:

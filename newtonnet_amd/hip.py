@@ -42,7 +42,7 @@ class Model(C.Structure):
                 ('layer', LayerParams * NNHIP_MAX_LAYERS),
                 ('head0_w', C.c_void_p), ('head0_b', C.c_void_p), ('head2_w', C.c_void_p), ('head2_b', C.c_void_p),
                 ('head4_w', C.c_void_p), ('head4_b', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
-                ('activation', C.c_int32)]
+                ('activation', C.c_int32), ('envelope', C.c_int32)]
 
 
 class WsLayout(C.Structure):
@@ -107,7 +107,7 @@ def lib():
     L.nnhip_last_error.restype = C.c_char_p
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
-    L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, vp]
+    L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_check_species.argtypes = [vp, i32, vp, vp]
     L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
@@ -134,7 +134,7 @@ def lib():
     pp = C.POINTER(vp)
     L.nnhip_embed.argtypes = [vp, vp, i32, vp, vp]
     L.nnhip_filter_table_bytes.restype = sz
-    L.nnhip_filter_tables.argtypes = [pp, pp, i32, vp, i32, vp]
+    L.nnhip_filter_tables.argtypes = [pp, pp, i32, vp, i32, i32, vp]
     L.nnhip_transpose128.argtypes = [pp, pp, i32, vp]
     L.nnhip_message_fwd.argtypes = [vp] * 9 + [i32, vp]
     L.nnhip_message_bwd.argtypes = [vp] * 10 + [i32, i32, vp]
@@ -222,7 +222,7 @@ CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fa
 class Graph:
     """Neighbor list + edge embedding of one batch (device tensors)."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope')
 
 
 def prepare(model: Model, device) -> torch.Tensor:
@@ -259,7 +259,7 @@ def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
 
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
                 frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False,
-                while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None) -> Graph:
+                while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None, envelope: int = 9) -> Graph:
     """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU.
     `while_waiting`: callable run after the counting kernels are queued and before the host waits for the edge count --
     work it launches on the stream fills the GPU's idle time during that round trip (NewtonNet.forward passes
@@ -274,7 +274,7 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         batch = batch.long()
     N, B = pos.shape[0], cell.shape[0]
     g = Graph()
-    g.n_atoms, g.n_mol = N, B
+    g.n_atoms, g.n_mol, g.envelope = N, B, int(envelope)
     n_scan = (N + 1023) // 1024 + 1
     meta = torch.empty(B + 1 + N + 1 + 1 + n_scan, dtype=torch.int32, device=dev)
     g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]   # status[0] + scan scratch
@@ -337,7 +337,7 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     g.drbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None
     g.xg = torch.empty(E, 2, dtype=torch.int32, device=dev)
     _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), nb,
-                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), st), 'nnhip_edge_embed')
+                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
     return g
 
 
@@ -356,7 +356,7 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
     E = g.n_edges
     _check(L.nnhip_edge_disp(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.edge_index), E, _ptr(g.disp), st), 'nnhip_edge_disp')
     _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(),
-                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), st), 'nnhip_edge_embed')
+                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
     return g
 
 

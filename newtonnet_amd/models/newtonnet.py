@@ -130,6 +130,7 @@ class NewtonNet(nn.Module):
         m.scale = p(sc.scale.weight) if sc.scale is not None else None
         m.shift = p(sc.shift.weight) if sc.shift is not None else None
         m.activation = hip.ACTIVATION_IDS[self.activation_name]
+        m.envelope = emb.edge_embedding.envelope_id
         return m
 
     # ------------------------------------------------------------------------------------------
@@ -180,7 +181,7 @@ class NewtonNet(nn.Module):
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies,
                                 while_waiting=(lambda: prep.append(hip.prepare(model, pos.device))) if overlap else None,
-                                z=zc)
+                                z=zc, envelope=emb.edge_embedding.envelope_id)
             res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
                                     want_virial=want_virial, prepared=prep[0] if overlap else None)
 

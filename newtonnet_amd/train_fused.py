@@ -255,7 +255,8 @@ class Runner:
         ew = (_vp * n)(*[il.message_edgepart.weight.data_ptr() for il in model.interaction_layers])
         tb = (_vp * n)(*[t.data_ptr() for t in ws.ftab])
         emb = model.embedding_layers.edge_embedding
-        _chk(L_.nnhip_filter_tables(ew, tb, n, _p(emb.embedding.frequencies), emb.n_basis, self.st), 'nnhip_filter_tables')
+        _chk(L_.nnhip_filter_tables(ew, tb, n, _p(emb.embedding.frequencies), emb.n_basis, emb.envelope_id, self.st),
+             'nnhip_filter_tables')
 
     # -- sweeps 1 and 2: values ------------------------------------------------------------------------------------------
     def values(self):
@@ -453,7 +454,7 @@ def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None)
         if graph is not None:
             g = hip.refresh_graph(graph, pd, cd, bc, emb.cutoff, emb.embedding.frequencies)
         else:
-            g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc)
+            g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
     cache = model.__dict__.setdefault('_train_ws', [])
     key = (g.n_atoms, g.n_edges, g.n_mol, pos.device)
     ws = next((w for w in cache if not w.busy and (w.N, w.E, w.B, w.energy.device) == key

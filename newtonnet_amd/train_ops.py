@@ -102,7 +102,7 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
             if eg is None:
                 eg = g._train_eg = _EdgeGraph(g)
         else:
-            g = hip.build_graph(pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies)
+            g = hip.build_graph(pos.detach(), cell.detach(), batch, ee.cutoff, ee.embedding.frequencies, envelope=ee.envelope_id)
             eg = _EdgeGraph(g)
     i, j = g.edge_index[0], g.edge_index[1]
     # disp = pos_i - pos_j - (constant periodic image shift found by the neighbor kernel)

@@ -190,7 +190,8 @@ class MLAseCalculator(_Base):
         st['freq'] = emb.embedding.frequencies
         st['cutoff'] = float(emb.cutoff)
         st['model'] = model._hip_model(list(model.output_properties).index('energy'))
-        st['g'] = hip.build_graph(st['pos'], st['cell_dev'], st['batch'], st['cutoff'] + self.skin, st['freq'])
+        st['g'] = hip.build_graph(st['pos'], st['cell_dev'], st['batch'], st['cutoff'] + self.skin, st['freq'], cell_host=cell[None],
+                                  envelope=emb.envelope_id)
         st['prep'] = hip.prepare(st['model'], dev)     # parameters are fixed while the calculator owns the model (eval)
         g = st['g']
         st['buf'] = torch.zeros(1 + 3 * n + 9, dtype=torch.float32, device=dev)

@@ -558,3 +558,37 @@ if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'virial':
     main_virial()
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'boundary':
     main_boundary()
+
+
+def main_cosine():
+    """Reference run with the edge embedding's envelope swapped for CosineCutoff (representations.py:177-203) and, second,
+    PolynomialCutoff(p=6): aspirin8 geometry, seeded weights, ['energy', 'gradient_force'] -> case_envelope.npz."""
+    NewtonNet = import_reference()
+    from newtonnet.layers.representations import CosineCutoff, PolynomialCutoff
+    rnd = {k: torch.from_numpy(v).double() for k, v in np.load(f'{OUT}/rand_state_seed0.npz').items()}
+    train = read_extxyz(f'{REF}/scripts/md17_data/aspirin/ccsd_train/raw/aspirin_ccsd-train.xyz', 8)
+    z = torch.tensor(train[0][0], dtype=torch.long).repeat(8)
+    pos = torch.tensor(np.concatenate([f[1] for f in train]))
+    batch = torch.repeat_interleave(torch.arange(8), 21)
+    cell = torch.zeros(8, 3, 3, dtype=torch.float64)
+    rec = dict(z=z.numpy(), pos=pos.numpy(), cell=cell.numpy(), batch=batch.numpy())
+    for tag, env in (('cosine', CosineCutoff()), ('poly6', PolynomialCutoff(6))):
+        model = NewtonNet(output_properties=['energy', 'gradient_force'])
+        model.to(torch.float64)
+        model.load_state_dict(rnd, strict=True)
+        model.embedding_layers.edge_embedding.envelope = env
+        model.eval()
+        edge = {}
+        h = model.embedding_layers.edge_embedding.register_forward_hook(lambda m, i, o: edge.update(dist_edge=o[0].detach().clone()))
+        out = model(z, pos.clone(), cell, batch)
+        h.remove()
+        rec[f'{tag}_energy'] = out.energy.detach().numpy()
+        rec[f'{tag}_forces'] = out.gradient_force.detach().numpy()
+        rec[f'{tag}_dist_edge'] = edge['dist_edge'].numpy()
+        rec['edge_index'] = out.edge_index.numpy()
+        print('envelope', tag, rec[f'{tag}_energy'][:2], float(np.abs(rec[f'{tag}_forces']).max()))
+    np.savez_compressed(f'{OUT}/case_envelope.npz', **rec)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'cosine':
+    main_cosine()

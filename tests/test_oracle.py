@@ -154,3 +154,21 @@ def test_oracle_boundary_cases_fp32():
     ties = int(((dn - r).abs() <= 4 * np.spacing(np.float32(r))).sum())
     inside = c['a_edge_index'].shape[1] // 2
     assert ties > 1500 and 0.2 < inside / (len(pa) // 2) < 0.8
+
+
+@pytest.mark.parametrize('tag,name,p', [('cosine', 'cosine', 9), ('poly6', 'polynomial', 6)])
+def test_oracle_other_envelopes_pinned(tag, name, p):
+    """CosineCutoff (representations.py:177-203) and PolynomialCutoff(p != 9) swapped into the edge embedding: the oracle against
+    the reference's own output (gen_golden.py cosine)."""
+    c = util.load_npz('case_envelope.npz')
+    sd = util.load_state('rand')
+    z, batch = torch.from_numpy(c['z']).long(), torch.from_numpy(c['batch']).long()
+    ref.set_envelope(name, p)
+    try:
+        out = ref.energy_forces(sd, z, torch.from_numpy(c['pos']), torch.from_numpy(c['cell']), batch)
+    finally:
+        ref.set_envelope()
+    assert np.array_equal(out['edge_index'].numpy(), c['edge_index'])
+    np.testing.assert_allclose(out['dist_edge'].numpy(), c[f'{tag}_dist_edge'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(out['energy'].numpy(), c[f'{tag}_energy'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out['forces'].numpy(), c[f'{tag}_forces'], rtol=1e-10, atol=1e-12)
