@@ -34,6 +34,10 @@
 #endif
 #define MW_LD 132
 #define MLP_LDS_BYTES (2 * NF * MW_LD * 4)
+#ifndef MLP_WAVES
+#define MLP_WAVES 8   // waves per persistent workgroup (tooling: -DMLP_WAVES=4 = one wave per SIMD, half the register file free)
+#endif
+#define MLP_THREADS (64 * MLP_WAVES)
 
 #ifndef MLP_NT_X
 #define MLP_NT_X 0   // streaming loads of stage-1 inputs on their last read: measured 5 % SLOWER (0.935 -> 0.984 ms), off
@@ -48,6 +52,7 @@ __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int 
 
 // Stage both weight matrices of one MLP: all 16 requests of a thread are in flight before the first LDS write.
 // (Macros, not functions: the fragments must stay in registers.)
+#if MLP_WAVES == 8
 #define MLP_W_LD(q, W1p, W2p)                                                                   \
   const float4 w1v##q = reinterpret_cast<const float4*>(W1p)[threadIdx.x + 512 * q];             \
   const float4 w2v##q = reinterpret_cast<const float4*>(W2p)[threadIdx.x + 512 * q];
@@ -59,6 +64,14 @@ __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int 
   MLP_W_LD(4, W1p, W2p) MLP_W_LD(5, W1p, W2p) MLP_W_LD(6, W1p, W2p) MLP_W_LD(7, W1p, W2p)        \
   __builtin_amdgcn_sched_barrier(0);
 #define MLP_W_COMMIT() MLP_W_ST(0) MLP_W_ST(1) MLP_W_ST(2) MLP_W_ST(3) MLP_W_ST(4) MLP_W_ST(5) MLP_W_ST(6) MLP_W_ST(7)
+#else   // tooling variant: plain staging loop
+#define MLP_W_REQUEST(W1p, W2p)                                                                  \
+  for (int q_ = threadIdx.x; q_ < NF * NF / 4; q_ += MLP_THREADS) {                              \
+    *reinterpret_cast<float4*>(&w1s[(q_ >> 5) * MW_LD + (q_ & 31) * 4]) = reinterpret_cast<const float4*>(W1p)[q_]; \
+    *reinterpret_cast<float4*>(&w2s[(q_ >> 5) * MW_LD + (q_ & 31) * 4]) = reinterpret_cast<const float4*>(W2p)[q_]; \
+  }
+#define MLP_W_COMMIT()
+#endif
 
 // One launch runs P.n (1 or 2) MLPs of the same row count back to back ("phases": phi1 then phi2, or the two adjoint
 // terms of g_msg).  A launch costs ~15 us before the matrix pipes are busy (every wave's first X tile -- 33 MB -- and
@@ -67,7 +80,7 @@ __device__ __forceinline__ void mlp_load_x(float4 (&x)[16], const float* X, int 
 // ACCUM_LAST: the last phase adds its result to Y (P.accum is checked by the host).  GEN_ACT: an activation other than SiLU
 // (P.a[0].act); the SiLU instantiation is untouched by it.
 template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
-__global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
+__global__ void __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) mlp128_kernel(const MlpPair P) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   float* w1s = wl;
   float* w2s = wl + NF * MW_LD;
@@ -89,7 +102,7 @@ __global__ void __launch_bounds__(512, 2) mlp128_kernel(const MlpPair P) {
   // (e.g. 4891 tiles, 1024 SIMDs: 3 + 2 on 795 of them, 2 + 2 on the rest -- not 3 + 3 on 400 and 2 + 2 elsewhere).
   const int n_simd = gridDim.x * 4;
   const int tile0 = (wave >> 2) * n_simd + blockIdx.x * 4 + (wave & 3);
-  const int tile_step = gridDim.x * 8;
+  const int tile_step = gridDim.x * MLP_WAVES;
   float4 x[16];
   {
     // weights first (L2 hits, returned first by the in-order vmcnt queue), then this wave's first X fragment: the LDS fill
@@ -311,9 +324,9 @@ static int launch_mlp_t(const MlpPair& a, hipStream_t s) {
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
   HIP_TRY(attr_rc);
   const int n_tiles = (a.a[0].M + 31) / 32;
-  int blocks = cdiv(n_tiles, 8);
+  int blocks = cdiv(n_tiles, MLP_WAVES);
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU (135 KiB of LDS each)
-  mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT><<<blocks, 512, MLP_LDS_BYTES, s>>>(a);
+  mlp128_kernel<MODE, ACCUM_LAST, GEN_ACT><<<blocks, MLP_THREADS, MLP_LDS_BYTES, s>>>(a);
   LAUNCH_CHECK();
   return 0;
 }

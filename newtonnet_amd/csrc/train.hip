@@ -624,7 +624,7 @@ colsum_final_kernel(const nnhip_colsum_problem* __restrict__ probs, const float*
 // Per-element sums  out[zz][c] = sum_{i : z_i = zz} x[i][c]  (embedding / scale / shift gradients), two passes: a workgroup
 // walks its slice of atoms and accumulates rows into an LDS table [119][width] (thread = column: no conflicts, fixed order);
 // pass 2 adds the per-workgroup tables.  width <= 128.
-#define SP_CHUNKS 128
+#define SP_CHUNKS 256
 __global__ void __launch_bounds__(NF)
 species_partial_kernel(const float* __restrict__ x, int ldx, int width, const int64_t* __restrict__ z, int n_atoms,
                        float* __restrict__ part /*[SP_CHUNKS][119][width]*/) {
