@@ -203,7 +203,10 @@ def pmc_traffic(kernel_prefixes):
     def table(path):
         rows = {}
         with open(path) as f:
-            next(f)
+            head = next(f)
+            if head.startswith('#'):          # "# tree <sha>": the commit the counters were collected on
+                sha.append(head[1:].strip())
+                next(f)
             for line in f:
                 parts = line.split()
                 if len(parts) < 4:
@@ -211,6 +214,7 @@ def pmc_traffic(kernel_prefixes):
                 name = ' '.join(parts[:-3])
                 rows[name] = (int(parts[-3]), float(parts[-1]))      # launches, KiB per launch
         return rows
+    sha = []
     tf, tw = table(fetch[-1]), table(write[-1])
     n = by = 0.0
     for name, (cnt, kib) in tf.items():
@@ -219,7 +223,8 @@ def pmc_traffic(kernel_prefixes):
             by += cnt * (2.0 * kib + tw[name][1]) * 1024.0
     if n == 0:
         return None, None
-    return by / n, f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
+    return by / n, (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
+                    + (f' [{sha[0]}]' if sha else ' [round-1 tree]'))
 
 
 def main():
