@@ -385,9 +385,10 @@ int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
 int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* desc0, const nnhip_mlp_desc* desc1, void* stream);
 
 /* ---- tangent kernels (sweeps 3 and 4) ---- */
-/* tgeo[e] = (du_e, dx_e): tangent of (dir, x = r/cutoff) along the position direction v[N][3] */
-int nnhip_edge_tangent_geom(const float* v, const int64_t* edge_index, const float* geo, int32_t n_edges, float cutoff,
-                            float* tgeo, void* stream);
+/* tgeo[e] = (du_e, dx_e): tangent of (dir, x = r/cutoff) along the position direction sign * v[N][3]
+ * (training passes v = dL/dF with sign = -1) */
+int nnhip_edge_tangent_geom(const float* v, float sign, const int64_t* edge_index, const float* geo, int32_t n_edges,
+                            float cutoff, float* tgeo, void* stream);
 /* dmsg[p] = deps dx m_i m_j + eps (dm_i m_j + m_i dm_j);  da_mid = da_in + sum_e dmsg   (dm = da_in = NULL: first layer) */
 int nnhip_message_tan_fwd(const float* m, const float* dm, const int32_t* xg, const float* tgeo, const float* table,
                           const int32_t* row_ptr, const int32_t* col, const int32_t* pid, const float* da_in, float* dmsg,

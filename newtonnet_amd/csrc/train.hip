@@ -25,13 +25,13 @@
 //   dd = v_i - v_j;  dr = u . dd;  du = (dd - u dr) / r;  dx = dr / r_c          -> tgeo[e] = (du, dx)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-edge_tan_geom_kernel(const float* __restrict__ v, const int64_t* __restrict__ edge_index, const float* __restrict__ geo,
-                     int n_edges, float inv_rc, float* __restrict__ tgeo) {
+edge_tan_geom_kernel(const float* __restrict__ v, float sign, const int64_t* __restrict__ edge_index,
+                     const float* __restrict__ geo, int n_edges, float inv_rc, float* __restrict__ tgeo) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   const long i = edge_index[e], j = edge_index[(long)n_edges + e];
   const float4 g = reinterpret_cast<const float4*>(geo)[e];
-  const float dx = v[3 * i] - v[3 * j], dy = v[3 * i + 1] - v[3 * j + 1], dz = v[3 * i + 2] - v[3 * j + 2];
+  const float dx = sign * (v[3 * i] - v[3 * j]), dy = sign * (v[3 * i + 1] - v[3 * j + 1]), dz = sign * (v[3 * i + 2] - v[3 * j + 2]);
   const float dr = g.x * dx + g.y * dy + g.z * dz;
   const float ir = 1.0f / g.w;
   reinterpret_cast<float4*>(tgeo)[e] = make_float4((dx - g.x * dr) * ir, (dy - g.y * dr) * ir, (dz - g.z * dr) * ir, dr * inv_rc);
@@ -625,14 +625,18 @@ colsum_final_kernel(const nnhip_colsum_problem* __restrict__ probs, const float*
 // walks its slice of atoms and accumulates rows into an LDS table [119][width] (thread = column: no conflicts, fixed order);
 // pass 2 adds the per-workgroup tables.  width <= 128.
 #define SP_CHUNKS 256
+static inline int species_chunks(int n_atoms) {   // ~64 atoms per workgroup, at most SP_CHUNKS
+  const int c = (n_atoms + 63) / 64;
+  return c < 1 ? 1 : (c > SP_CHUNKS ? SP_CHUNKS : c);
+}
 __global__ void __launch_bounds__(NF)
 species_partial_kernel(const float* __restrict__ x, int ldx, int width, const int64_t* __restrict__ z, int n_atoms,
-                       float* __restrict__ part /*[SP_CHUNKS][119][width]*/) {
+                       float* __restrict__ part /*[chunks][119][width]*/) {
   extern __shared__ float tab[];   // [119][width]
   const int col = threadIdx.x;
   for (int k = col; k < NNHIP_N_ELEMENTS * width; k += NF) tab[k] = 0.f;
   __syncthreads();
-  const int per = (n_atoms + SP_CHUNKS - 1) / SP_CHUNKS;
+  const int per = (n_atoms + gridDim.x - 1) / gridDim.x;
   const int i0 = blockIdx.x * per, i1 = min(n_atoms, i0 + per);
   if (col < width)
     for (int i = i0; i < i1; ++i) tab[(int)z[i] * width + col] += x[(size_t)i * ldx + col];
@@ -641,26 +645,26 @@ species_partial_kernel(const float* __restrict__ x, int ldx, int width, const in
 }
 // out[zz][c] (pitch ldo) = sum over chunks; `cols` columns starting at part column c0
 __global__ void __launch_bounds__(NF)
-species_final_kernel(const float* __restrict__ part, int width, int c0, int cols, float* __restrict__ out, int ldo) {
+species_final_kernel(const float* __restrict__ part, int chunks, int width, int c0, int cols, float* __restrict__ out, int ldo) {
   const int zz = blockIdx.x, c = threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
-  for (int k = 0; k < SP_CHUNKS; ++k) s += part[((size_t)k * NNHIP_N_ELEMENTS + zz) * width + c0 + c];
+  for (int k = 0; k < chunks; ++k) s += part[((size_t)k * NNHIP_N_ELEMENTS + zz) * width + c0 + c];
   out[(size_t)zz * ldo + c] = s;
 }
-// out[0] = sum over chunks and elements of column c0 (a plain sum over atoms, e.g. dL/d b4)
-__global__ void __launch_bounds__(NF)
-species_total_kernel(const float* __restrict__ part, int width, int c0, float* __restrict__ out) {
-  __shared__ float sh[NF];
+// out[0] = sum over chunks and elements of column c0 (a plain sum over atoms, e.g. dL/d b4); fixed order
+__global__ void __launch_bounds__(1024)
+species_total_kernel(const float* __restrict__ part, int chunks, int width, int c0, float* __restrict__ out) {
+  __shared__ float sh[1024];
   float s = 0.f;
-  for (int k = threadIdx.x; k < SP_CHUNKS * NNHIP_N_ELEMENTS; k += NF) s += part[(size_t)k * width + c0];
+  for (int k = threadIdx.x; k < chunks * NNHIP_N_ELEMENTS; k += 1024) s += part[(size_t)k * width + c0];
   sh[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < NF; ++k) t += sh[k];
-    out[0] = t;
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // out[i][:] = table[z[i]][:]   (node embedding lookup, newtonnet.py:142)
@@ -781,11 +785,11 @@ extern "C" int nnhip_embed(const int64_t* z, const float* table, int32_t n_atoms
   return NNHIP_OK;
 }
 
-extern "C" int nnhip_edge_tangent_geom(const float* v, const int64_t* edge_index, const float* geo, int32_t n_edges,
+extern "C" int nnhip_edge_tangent_geom(const float* v, float sign, const int64_t* edge_index, const float* geo, int32_t n_edges,
                                        float cutoff, float* tgeo, void* stream) {
   ARG_CHECK(n_edges >= 0 && cutoff > 0.f && (n_edges == 0 || (v && edge_index && geo && tgeo)), "nnhip_edge_tangent_geom");
   if (n_edges == 0) return NNHIP_OK;
-  edge_tan_geom_kernel<<<cdiv(n_edges, 256), 256, 0, (hipStream_t)stream>>>(v, edge_index, geo, n_edges, 1.0f / cutoff, tgeo);
+  edge_tan_geom_kernel<<<cdiv(n_edges, 256), 256, 0, (hipStream_t)stream>>>(v, sign, edge_index, geo, n_edges, 1.0f / cutoff, tgeo);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
@@ -924,18 +928,19 @@ extern "C" int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, con
   ARG_CHECK(n_atoms >= 0 && x && z && scratch && width >= 1 && width <= NF && ldx >= width && (!out0 || (c0 >= 0 && c0 + cols0 <= width)) &&
                 (!out1 || (c1 >= 0 && c1 + cols1 <= width)) && (!total || (c_total >= 0 && c_total < width)), "nnhip_species_sum");
   hipStream_t s = (hipStream_t)stream;
-  species_partial_kernel<<<SP_CHUNKS, NF, NNHIP_N_ELEMENTS * width * sizeof(float), s>>>(x, ldx, width, z, n_atoms, scratch);
+  const int chunks = species_chunks(n_atoms);
+  species_partial_kernel<<<chunks, NF, NNHIP_N_ELEMENTS * width * sizeof(float), s>>>(x, ldx, width, z, n_atoms, scratch);
   LAUNCH_CHECK();
   if (out0) {
-    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, width, c0, cols0, out0, ldo0);
+    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, chunks, width, c0, cols0, out0, ldo0);
     LAUNCH_CHECK();
   }
   if (out1) {
-    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, width, c1, cols1, out1, ldo1);
+    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, chunks, width, c1, cols1, out1, ldo1);
     LAUNCH_CHECK();
   }
   if (total) {
-    species_total_kernel<<<1, NF, 0, s>>>(scratch, width, c_total, total);
+    species_total_kernel<<<1, 1024, 0, s>>>(scratch, chunks, width, c_total, total);
     LAUNCH_CHECK();
   }
   return NNHIP_OK;

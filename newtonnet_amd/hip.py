@@ -146,7 +146,7 @@ def lib():
     L.nnhip_head_out.argtypes = [vp] * 7 + [i32, i32, i32, vp, vp, vp, vp]
     L.nnhip_mlp128_ex.argtypes = [C.POINTER(MlpDesc), vp]
     L.nnhip_mlp128_pair_ex.argtypes = [C.POINTER(MlpDesc), C.POINTER(MlpDesc), vp]
-    L.nnhip_edge_tangent_geom.argtypes = [vp, vp, vp, i32, f32, vp, vp]
+    L.nnhip_edge_tangent_geom.argtypes = [vp, f32, vp, vp, i32, f32, vp, vp]
     L.nnhip_message_tan_fwd.argtypes = [vp] * 11 + [i32, vp]
     L.nnhip_force_message_tan_fwd.argtypes = [vp] * 13 + [i32, vp]
     L.nnhip_force_message_tan_bwd.argtypes = [vp] * 14 + [i32, vp]

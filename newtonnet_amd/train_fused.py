@@ -336,10 +336,10 @@ class Runner:
         sc = model.scalers[self.energy_idx]
         emb = model.embedding_layers.edge_embedding
         idx = (_p(g.row_ptr), _p(g.col), _p(g.pid))
-        torch.neg(g_forces.reshape(N, 3).to(torch.float32), out=ws.v)
+        g_forces = g_forces.reshape(N, 3).to(torch.float32).contiguous()
         g_energy = g_energy.to(torch.float32).contiguous()
-        # ---- sweep 3: tangent forward along v
-        _chk(L_.nnhip_edge_tangent_geom(_p(ws.v), _p(g.edge_index), _p(g.geo), E, float(emb.cutoff), _p(ws.tgeo), st),
+        # ---- sweep 3: tangent forward along v = -dL/dF
+        _chk(L_.nnhip_edge_tangent_geom(_p(g_forces), -1.0, _p(g.edge_index), _p(g.geo), E, float(emb.cutoff), _p(ws.tgeo), st),
              'nnhip_edge_tangent_geom')
         for l, il in enumerate(layers):
             first = l == 0

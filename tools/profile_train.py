@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run a few training steps (fused path, HIP-graph replay unless --eager) for rocprofv3.
-usage: tools/profile_train.py [ethanol|aspirin] [B] [--eager] [--steps K]"""
+usage: tools/profile_train.py [ethanol|aspirin] [B] [--eager | --fused] [--steps K]"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from bench_train import aspirin_batch, ethanol_batch  # noqa: E402
-from newtonnet_amd.distributed import GraphedTrainStep, TrainStep  # noqa: E402
+from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep, TrainStep  # noqa: E402
 from newtonnet_amd.models import NewtonNet  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else 'ethanol'
@@ -21,7 +21,9 @@ args = [t.cuda() for t in (aspirin_batch if kind == 'aspirin' else ethanol_batch
 torch.manual_seed(0)
 model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
 model.train()
-if eager:
+if '--fused' in sys.argv:
+    step = GraphedTrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0, assume_static=True)
+elif eager:
     step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), 1.0, 50.0, 1.0)
 else:
     step = GraphedTrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True), 1.0, 50.0, 1.0)
