@@ -21,6 +21,9 @@
 
 #include "common.h"
 
+#ifndef NODE_WG_PER_CU
+#define NODE_WG_PER_CU 2   // launch-bounds hint (min waves per SIMD = workgroups per CU for 256-thread workgroups); tooling: 3
+#endif
 #define NT_LD 132                       // LDS tile row pitch (floats): conflict-free ds_read_b128 / ds_write_b128
 #define NODE_LDS_FLOATS (32 * NT_LD)
 
@@ -104,7 +107,7 @@ __device__ __forceinline__ void acc_to(float (&v)[16], const f32x16& a) {
   for (int k = 0; k < 16; ++k) v[k] = a[k];
 }
 
-__global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
+__global__ void __launch_bounds__(256, NODE_WG_PER_CU) node_fwd_kernel(const NodeFwdArgs p) {
   __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
   Tile t;
   t.xs = xs;
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(256) node_fwd_kernel(const NodeFwdArgs p) {
   if (live) blk_store(m, p.m, (size_t)row * NF, t);
 }
 
-__global__ void __launch_bounds__(256) node_bwd_kernel(const NodeBwdArgs p) {
+__global__ void __launch_bounds__(256, NODE_WG_PER_CU) node_bwd_kernel(const NodeBwdArgs p) {
   __shared__ __attribute__((aligned(16))) float xs[NODE_LDS_FLOATS];
   Tile t;
   t.xs = xs;

@@ -429,7 +429,9 @@ struct WgLds {
 };
 
 // Issue the loads only: nothing here consumes a loaded value, so the requests stay in flight under the MFMAs that follow.
-__device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int r_safe, bool two, WgStage& g) {
+// (TYPE / TWO / NB32 are compile-time: the trip loop of each operand form is straight-line code.)
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int r_safe, WgStage& g) {
   const int c = threadIdx.x & 31;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -437,47 +439,49 @@ __device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int
     g.live[q] = r < r_end;
     const int rr = g.live[q] ? r : r_safe;
     g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
-    if (P.b_cols32) {   // B rows are 32 floats wide: lane column c carries one of them (in .x)
+    if (NB32) {   // B rows are 32 floats wide: lane column c carries one of them (in .x)
       g.b1[q].x = P.B1[(size_t)rr * P.ldb1 + c];
-      if (two) g.b2[q].x = P.B2[(size_t)rr * P.ldb2 + c];
-    } else if (P.type == WG_ACT) {
+      if (TWO) g.b2[q].x = P.B2[(size_t)rr * P.ldb2 + c];
+    } else if (TYPE == WG_ACT) {
       g.b1[q] = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
-      if (two) g.b2[q] = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
     } else {
       g.b1[q] = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
-      if (two) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
     }
-    if (two) {
+    if (TWO) {
       g.a2[q] = ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c);
-      if (P.type == WG_TDACT) g.ha[q] = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
+      if (TYPE == WG_TDACT) g.ha[q] = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
     }
   }
 }
 // the prologue of the operand forms, applied once per element (after the MFMAs of the current trip)
-__device__ __forceinline__ void wg_finish(const WgProb& P, bool two, WgStage& g) {
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wg_finish(const WgProb& P, WgStage& g) {
   const int act = P.activation;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    if (!P.b_cols32 && P.type == WG_ACT) {
+    if (!NB32 && TYPE == WG_ACT) {
       const float4 hv = g.b1[q], dh = g.b2[q];
       g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
-      if (two)
+      if (TWO)
         g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
                               dact_any(hv.w, act) * dh.w);
     }
-    if (two && P.type == WG_TDACT) {
+    if (TWO && TYPE == WG_TDACT) {
       const float4 hv = g.ha[q];
       g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
                             g.a2[q].w * dact_any(hv.w, act));
     }
     if (!g.live[q]) {
       g.a1[q] = zero;
-      g.a2[q] = zero;
+      if (TWO) g.a2[q] = zero;
     }
   }
 }
-__device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g, bool two, bool nb32) {
+template <bool TWO, bool NB32>
+__device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g) {
   const int c = threadIdx.x & 31;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -486,20 +490,66 @@ __device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g, bool two, 
     L.a1[1][row][c] = g.a1[q].y;
     L.a1[2][row][c] = g.a1[q].z;
     L.a1[3][row][c] = g.a1[q].w;
-    if (nb32)
+    if (NB32)
       L.b1[row][c] = g.b1[q].x;
     else
       *reinterpret_cast<float4*>(&L.b1[row][4 * c]) = g.b1[q];
-    if (two) {
+    if (TWO) {
       L.a2[0][row][c] = g.a2[q].x;
       L.a2[1][row][c] = g.a2[q].y;
       L.a2[2][row][c] = g.a2[q].z;
       L.a2[3][row][c] = g.a2[q].w;
-      if (nb32)
+      if (NB32)
         L.b2[row][c] = g.b2[q].x;
       else
         *reinterpret_cast<float4*>(&L.b2[row][4 * c]) = g.b2[q];
     }
+  }
+}
+
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[4]) {
+  WgStage g;
+  wg_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
+  wg_finish<TYPE, TWO, NB32>(P, g);
+  wg_commit<TWO, NB32>(lds[0], g);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = r_beg; r0 < r_end; r0 += WG_R) {
+    const bool more = r0 + WG_R < r_end;
+    if (more) wg_fetch<TYPE, TWO, NB32>(P, r0 + WG_R, r_end, r_beg, g);   // requests in flight under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);          // (pin them here: the scheduler would sink the loads to their uses)
+    const WgLds& L = lds[buf];
+#pragma unroll
+    for (int kk = 0; kk < WG_R / 2; ++kk) {
+      const int row = 2 * kk + h;
+      const float a1 = L.a1[w][row][c];
+      if (NB32) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.b1[row][c], acc[0], 0, 0, 0);
+        if (TWO) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.a2[w][row][c], L.b2[row][c], acc[0], 0, 0, 0);
+      } else {
+        const float4 b1 = *reinterpret_cast<const float4*>(&L.b1[row][4 * c]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.w, acc[3], 0, 0, 0);
+        if (TWO) {
+          const float a2 = L.a2[w][row][c];
+          const float4 b2 = *reinterpret_cast<const float4*>(&L.b2[row][4 * c]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.w, acc[3], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      wg_finish<TYPE, TWO, NB32>(P, g);
+      wg_commit<TWO, NB32>(lds[buf ^ 1], g);
+    }
+    __syncthreads();
+    buf ^= 1;
   }
 }
 
@@ -527,46 +577,19 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
     for (int k = 0; k < 16; ++k) acc[q][k] = 0.f;
   const bool two = P.A2 != nullptr;
   const bool nb32 = P.b_cols32 != 0;
-  if (r_beg < r_end) {
-    WgStage g;
-    wg_fetch(P, r_beg, r_end, r_beg, two, g);
-    wg_finish(P, two, g);
-    wg_commit(lds[0], g, two, nb32);
-    __syncthreads();
-    int buf = 0;
-    for (int r0 = r_beg; r0 < r_end; r0 += WG_R) {
-      const bool more = r0 + WG_R < r_end;
-      if (more) wg_fetch(P, r0 + WG_R, r_end, r_beg, two, g);   // requests in flight under the MFMAs below
-      const WgLds& L = lds[buf];
-#pragma unroll
-      for (int kk = 0; kk < WG_R / 2; ++kk) {
-        const int row = 2 * kk + h;
-        const float a1 = L.a1[w][row][c];
-        if (nb32) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.b1[row][c], acc[0], 0, 0, 0);
-          if (two) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.a2[w][row][c], L.b2[row][c], acc[0], 0, 0, 0);
-        } else {
-          const float4 b1 = *reinterpret_cast<const float4*>(&L.b1[row][4 * c]);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.z, acc[2], 0, 0, 0);
-          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.w, acc[3], 0, 0, 0);
-          if (two) {
-            const float a2 = L.a2[w][row][c];
-            const float4 b2 = *reinterpret_cast<const float4*>(&L.b2[row][4 * c]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.y, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.z, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.w, acc[3], 0, 0, 0);
-          }
-        }
-      }
-      if (more) {
-        wg_finish(P, two, g);
-        wg_commit(lds[buf ^ 1], g, two, nb32);
-      }
-      __syncthreads();
-      buf ^= 1;
+  if (r_beg < r_end) {   // (uniform per workgroup: one straight-line trip loop per operand form)
+    if (nb32) {
+      if (two) wg_run<WG_PLAIN, true, true>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wg_run<WG_PLAIN, false, true>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_ACT) {
+      if (two) wg_run<WG_ACT, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wg_run<WG_ACT, false, false>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_TDACT) {
+      if (two) wg_run<WG_TDACT, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wg_run<WG_PLAIN, false, false>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else {
+      if (two) wg_run<WG_PLAIN, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wg_run<WG_PLAIN, false, false>(P, lds, r_beg, r_end, w, c, h, acc);
     }
   }
   // D[row][col]: row = (k & 3) + 8 (k >> 2) + 4 h -> output feature 4 row + w; col = c -> input feature 4 c + q
