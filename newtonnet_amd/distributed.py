@@ -230,10 +230,10 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
         st['g1'] = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(st['g1']):
+        with torch.no_grad(), torch.cuda.graph(st['g1'], capture_error_mode='thread_local'):
             body()
         st['g2'] = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(st['g2'], pool=st['g1'].pool()):
+        with torch.no_grad(), torch.cuda.graph(st['g2'], pool=st['g1'].pool(), capture_error_mode='thread_local'):
             self.optimizer.step(ws.flat_grad)
         self.captures += 1
 
@@ -311,11 +311,11 @@ class GraphedTrainStep:
             st['g1'] = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             st['pos'].grad = None
-            with torch.cuda.graph(st['g1']):
+            with torch.cuda.graph(st['g1'], capture_error_mode='thread_local'):
                 st['loss'] = self._fwd_bwd(st)
             # the update graph shares g1's memory pool: it reads the .grad tensors g1 produces
             st['g2'] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(st['g2'], pool=st['g1'].pool()):
+            with torch.cuda.graph(st['g2'], pool=st['g1'].pool(), capture_error_mode='thread_local'):
                 self._update()
         finally:
             self.model._static_train_graph = None

@@ -210,7 +210,7 @@ class MLAseCalculator(_Base):
                     self._md_step(st)
                 torch.cuda.current_stream().wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     self._md_step(st)
                 st['graph'] = graph
             except Exception as exc:  # noqa: BLE001 -- capture is an optimisation; fall back to plain launches
