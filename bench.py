@@ -426,7 +426,13 @@ def main():
     # ---- data-parallel training step: the ONE collective of the design (flat fp32 gradient all-reduce over RCCL) ----------
     train = None
     if not args.no_train_leg and args.workload == 'aspirin':
-        train = train_leg(device, dist, backend, world, rank, max(args.steps, 10), args.warmup)
+        try:
+            train = train_leg(device, dist, backend, world, rank, max(args.steps, 10), args.warmup)
+        except Exception as exc:  # noqa: BLE001 -- the headline line must survive a failure of the secondary leg; it is REPORTED
+            if args.mode == 'train':
+                raise
+            train = {'error': f'{type(exc).__name__}: {exc}'[:400], 'allreduce_us': None}
+            print(f'[bench rank {rank}] train leg failed: {train["error"]}', file=sys.stderr, flush=True)
 
     if rank == 0 and args.mode == 'train':
         print(json.dumps({
