@@ -349,7 +349,7 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
     L = lib()
     if g.edge_index is None:
         raise ValueError('refresh_graph needs a graph built with want_edge_index=True')
-    st = _stream(pos.device)
+    st = _stream(g.row_ptr.device)     # (pos may be a pinned HOST array read in place by the kernels: the MD loop's zero-copy input)
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
     if batch.dtype != torch.int64 or not batch.is_contiguous():
         batch = batch.long().contiguous()

@@ -8,6 +8,8 @@ get_pbc works (this image has no ase; the parity tests drive it with such an obj
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -152,12 +154,14 @@ class MLAseCalculator(_Base):
             st['cell_now'] = cell.copy()
             st['cell_dev'].copy_(torch.tensor(cell[None], dtype=torch.float32), non_blocking=False)
         st['pos_host'].copy_(torch.from_numpy(pos.astype(np.float32)))
-        st['pos'].copy_(st['pos_host'], non_blocking=True)
+        if not st['zero_copy_in']:
+            st['pos'].copy_(st['pos_host'], non_blocking=True)
         if st['graph'] is not None:
             st['graph'].replay()
         else:
             self._md_step(st)
-        st['out_host'].copy_(st['buf'], non_blocking=True)
+        if not st['zero_copy']:
+            st['out_host'].copy_(st['buf'], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         self.md_stats['steps'] += 1
         n = len(z)
@@ -186,16 +190,25 @@ class MLAseCalculator(_Base):
         st['pos'] = torch.tensor(pos, dtype=torch.float32, device=dev)
         st['cell_dev'] = torch.tensor(cell[None], dtype=torch.float32, device=dev)
         st['batch'] = torch.zeros(n, dtype=torch.long, device=dev)
-        st['pos_host'] = torch.empty(n, 3, dtype=torch.float32).pin_memory()
+        st['pos_host'] = torch.tensor(pos, dtype=torch.float32).pin_memory()
+        # (reading the positions in place from the pinned host array as well measured no gain: 393 vs 388 us; off by default)
+        st['zero_copy_in'] = os.environ.get('NNHIP_MD_ZERO_COPY_IN', '0') != '0'
+        pos_dev = st['pos']
+        if st['zero_copy_in']:
+            st['pos'] = st['pos_host']
         st['freq'] = emb.embedding.frequencies
         st['cutoff'] = float(emb.cutoff)
         st['model'] = model._hip_model(list(model.output_properties).index('energy'))
-        st['g'] = hip.build_graph(st['pos'], st['cell_dev'], st['batch'], st['cutoff'] + self.skin, st['freq'], cell_host=cell[None],
+        st['g'] = hip.build_graph(pos_dev, st['cell_dev'], st['batch'], st['cutoff'] + self.skin, st['freq'], cell_host=cell[None],
                                   envelope=emb.envelope_id)
         st['prep'] = hip.prepare(st['model'], dev)     # parameters are fixed while the calculator owns the model (eval)
         g = st['g']
-        st['buf'] = torch.zeros(1 + 3 * n + 9, dtype=torch.float32, device=dev)
-        st['out_host'] = torch.empty(1 + 3 * n + 9, dtype=torch.float32).pin_memory()
+        # Results (energy, forces, virial: a few hundred bytes) are written by the last kernels STRAIGHT into pinned host memory
+        # (hipHostMalloc memory is mapped into the device's address space on ROCm): no device->host copy per step, whose DMA
+        # start-up latency was ~80 us of the ~390 us step.  NNHIP_MD_ZERO_COPY=0 restores the device buffer + copy.
+        st['zero_copy'] = os.environ.get('NNHIP_MD_ZERO_COPY', '1') != '0'
+        st['out_host'] = torch.zeros(1 + 3 * n + 9, dtype=torch.float32).pin_memory()
+        st['buf'] = st['out_host'] if st['zero_copy'] else torch.zeros(1 + 3 * n + 9, dtype=torch.float32, device=dev)
         st['out'] = dict(energy=st['buf'][0:1], forces=st['buf'][1:1 + 3 * n].view(n, 3) if want_forces else None,
                          virial=st['buf'][1 + 3 * n:].view(1, 3, 3) if want_virial else None,
                          atom_energy=torch.empty(n, dtype=torch.float32, device=dev), atom_node=None, force_node=None)
