@@ -605,6 +605,194 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand form of the same products (BASELINE configs[2] names bf16): operands are rounded to bf16 AFTER their fp32
+// prologue, the products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (16 rows per instruction, 16x the fp32 rate), so the
+// kernel is bound by the operand traffic alone.  The MFMA wants 8 consecutive ROWS per lane for a fixed feature: the LDS
+// image is transposed, [class][lane column][row] bf16 with a 40-element pitch (conflict-free ds_read_b128), two rows packed
+// per 32-bit LDS write.  Trip = 32 rows; same slabs, same deterministic reduction.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define WB_R 32
+#define WB_P 40                                  // row pitch (bf16 elements) of one (class, column) line
+struct WbLds {
+  unsigned short a1[4][32][WB_P], a2[4][32][WB_P], b1[4][32][WB_P], b2[4][32][WB_P];
+};
+struct WbStage {   // rows 2g, 2g+1, 2g+16, 2g+17 of the trip (g = t >> 5), lane column c = t & 31
+  float4 a1[4], a2[4], b1[4], b2[4], ha[4];
+  bool live[4];
+};
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ int wb_row(int q) { return 2 * (threadIdx.x >> 5) + (q & 1) + 16 * (q >> 1); }
+
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wb_fetch(const WgProb& P, int r0, int r_end, int r_safe, WbStage& g) {
+  const int c = threadIdx.x & 31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + wb_row(q);
+    g.live[q] = r < r_end;
+    const int rr = g.live[q] ? r : r_safe;
+    g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
+    if (NB32) {
+      g.b1[q].x = P.B1[(size_t)rr * P.ldb1 + c];
+      if (TWO) g.b2[q].x = P.B2[(size_t)rr * P.ldb2 + c];
+    } else if (TYPE == WG_ACT) {
+      g.b1[q] = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
+    } else {
+      g.b1[q] = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
+    }
+    if (TWO) {
+      g.a2[q] = ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c);
+      if (TYPE == WG_TDACT) g.ha[q] = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
+    }
+  }
+}
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wb_finish_commit(const WgProb& P, WbLds& L, WbStage& g) {
+  const int act = P.activation;
+  const int c = threadIdx.x & 31;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!NB32 && TYPE == WG_ACT) {
+      const float4 hv = g.b1[q], dh = g.b2[q];
+      g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
+      if (TWO)
+        g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
+                              dact_any(hv.w, act) * dh.w);
+    }
+    if (TWO && TYPE == WG_TDACT) {
+      const float4 hv = g.ha[q];
+      g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
+                            g.a2[q].w * dact_any(hv.w, act));
+    }
+    if (!g.live[q]) {
+      g.a1[q] = zero;
+      if (TWO) g.a2[q] = zero;
+    }
+  }
+  // two adjacent rows per 32-bit write: (q = 0, 1) -> rows 2g, 2g+1;  (q = 2, 3) -> rows 2g+16, 2g+17
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const int row = 2 * (threadIdx.x >> 5) + 16 * pr;
+    const float4 x0 = g.a1[2 * pr], x1 = g.a1[2 * pr + 1];
+    *reinterpret_cast<unsigned*>(&L.a1[0][c][row]) = pack_bf16(x0.x, x1.x);
+    *reinterpret_cast<unsigned*>(&L.a1[1][c][row]) = pack_bf16(x0.y, x1.y);
+    *reinterpret_cast<unsigned*>(&L.a1[2][c][row]) = pack_bf16(x0.z, x1.z);
+    *reinterpret_cast<unsigned*>(&L.a1[3][c][row]) = pack_bf16(x0.w, x1.w);
+    const float4 y0 = g.b1[2 * pr], y1 = g.b1[2 * pr + 1];
+    *reinterpret_cast<unsigned*>(&L.b1[0][c][row]) = pack_bf16(y0.x, y1.x);
+    if (!NB32) {
+      *reinterpret_cast<unsigned*>(&L.b1[1][c][row]) = pack_bf16(y0.y, y1.y);
+      *reinterpret_cast<unsigned*>(&L.b1[2][c][row]) = pack_bf16(y0.z, y1.z);
+      *reinterpret_cast<unsigned*>(&L.b1[3][c][row]) = pack_bf16(y0.w, y1.w);
+    }
+    if (TWO) {
+      const float4 u0 = g.a2[2 * pr], u1 = g.a2[2 * pr + 1];
+      *reinterpret_cast<unsigned*>(&L.a2[0][c][row]) = pack_bf16(u0.x, u1.x);
+      *reinterpret_cast<unsigned*>(&L.a2[1][c][row]) = pack_bf16(u0.y, u1.y);
+      *reinterpret_cast<unsigned*>(&L.a2[2][c][row]) = pack_bf16(u0.z, u1.z);
+      *reinterpret_cast<unsigned*>(&L.a2[3][c][row]) = pack_bf16(u0.w, u1.w);
+      const float4 z0 = g.b2[2 * pr], z1 = g.b2[2 * pr + 1];
+      *reinterpret_cast<unsigned*>(&L.b2[0][c][row]) = pack_bf16(z0.x, z1.x);
+      if (!NB32) {
+        *reinterpret_cast<unsigned*>(&L.b2[1][c][row]) = pack_bf16(z0.y, z1.y);
+        *reinterpret_cast<unsigned*>(&L.b2[2][c][row]) = pack_bf16(z0.z, z1.z);
+        *reinterpret_cast<unsigned*>(&L.b2[3][c][row]) = pack_bf16(z0.w, z1.w);
+      }
+    }
+  }
+}
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void wb_run(const WgProb& P, WbLds* lds, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[4]) {
+  WbStage g;
+  wb_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
+  wb_finish_commit<TYPE, TWO, NB32>(P, lds[0], g);
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = r_beg; r0 < r_end; r0 += WB_R) {
+    const bool more = r0 + WB_R < r_end;
+    if (more) wb_fetch<TYPE, TWO, NB32>(P, r0 + WB_R, r_end, r_beg, g);
+    __builtin_amdgcn_sched_barrier(0);
+    const WbLds& L = lds[buf];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k0 = 16 * s + 8 * h;             // this lane's 8 rows of the 16-row step
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&L.a1[w][c][k0]);
+      bf16x8 a2;
+      if (TWO) a2 = *reinterpret_cast<const bf16x8*>(&L.a2[w][c][k0]);
+#pragma unroll
+      for (int q = 0; q < (NB32 ? 1 : 4); ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(&L.b1[q][c][k0]), acc[q], 0, 0, 0);
+        if (TWO)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, *reinterpret_cast<const bf16x8*>(&L.b2[q][c][k0]), acc[q], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) wb_finish_commit<TYPE, TWO, NB32>(P, lds[buf ^ 1], g);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
+  WbLds* lds = reinterpret_cast<WbLds*>(wg_lds_raw);   // [2]
+  WgProb P = probs[blockIdx.y];
+  if (!P.lda1) P.lda1 = NF;
+  if (!P.lda2) P.lda2 = NF;
+  if (!P.ldb1) P.ldb1 = NF;
+  if (!P.ldb2) P.ldb2 = NF;
+  if (!P.ldh) P.ldh = NF;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int M = P.M;
+  const int per = ((M + WB_R * chunks - 1) / (WB_R * chunks)) * WB_R;
+  const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[q][k] = 0.f;
+  const bool two = P.A2 != nullptr;
+  const bool nb32 = P.b_cols32 != 0;
+  if (r_beg < r_end) {
+    if (nb32) {
+      if (two) wb_run<WG_PLAIN, true, true>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wb_run<WG_PLAIN, false, true>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_ACT) {
+      if (two) wb_run<WG_ACT, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wb_run<WG_ACT, false, false>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_TDACT && two) {
+      wb_run<WG_TDACT, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+    } else {
+      if (two) wb_run<WG_PLAIN, true, false>(P, lds, r_beg, r_end, w, c, h, acc);
+      else wb_run<WG_PLAIN, false, false>(P, lds, r_beg, r_end, w, c, h, acc);
+    }
+  }
+  float* slab = slabs + ((size_t)blockIdx.y * chunks + blockIdx.x) * NF * NF;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+    const int o = 4 * row + w;
+    if (nb32)
+      slab[(size_t)o * NF + c] = acc[0][k];
+    else
+      st4(slab + (size_t)o * NF + 4 * c, make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]));
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* __restrict__ slabs) {
   const WgProb& P = probs[blockIdx.y];
@@ -976,7 +1164,7 @@ extern "C" size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks) {
   return (size_t)n_problems * chunks * NF * NF * sizeof(float);
 }
 extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n_problems, int32_t chunks, float* slabs,
-                                 void* stream) {
+                                 int32_t bf16_operands, void* stream) {
   ARG_CHECK(n_problems >= 0 && chunks >= 1 && (n_problems == 0 || (probs_dev && slabs)), "nnhip_wgrad_batch");
   if (n_problems == 0) return NNHIP_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -984,7 +1172,13 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
   static const hipError_t attr_rc = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         2 * sizeof(WgLds));
   HIP_TRY(attr_rc);
-  wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs);
+  static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(WbLds));
+  HIP_TRY(attr_rc2);
+  if (bf16_operands)
+    wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs);
+  else
+    wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();
   wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();

@@ -16,6 +16,7 @@ reference would return it, no trainer uses it.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -196,6 +197,10 @@ class Runner:
         self.model, self.z, self.pos, self.cell, self.batch, self.g, self.ws = model, z, pos, cell, batch, g, ws
         self.act = hip.ACTIVATION_IDS[model.activation_name]
         self.energy_idx = list(model.output_properties).index('energy')
+        # under torch.autocast(bfloat16) -- the way BASELINE configs[2] asks for bf16 -- the weight-gradient products take bf16
+        # operands (fp32 prologues, fp32 accumulation); every other kernel stays exact fp32
+        self.bf16 = bool(torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+            or os.environ.get('NNHIP_TRAIN_BF16') == '1'
         if g.rbf is None or g.drbf is None:
             raise ValueError('the training path needs a graph built with want_rbf=True')
 
@@ -398,7 +403,8 @@ class Runner:
         # ---- weight gradients: one batched split-K launch + its reduction, column sums, per-element sums
         _chk(L_.nnhip_pair_rbf(_p(g.rbf), _p(g.drbf), _p(ws.tgeo), _p(g.edge_index), _p(g.pid), E, emb.n_basis, _p(ws.rb), st),
              'nnhip_pair_rbf')
-        _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), st), 'nnhip_wgrad_batch')
+        _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), 1 if self.bf16 else 0, st),
+             'nnhip_wgrad_batch')
         _chk(L_.nnhip_colsum_batch(_p(ws.sum_dev), ws.n_sums, _p(ws.cs_scratch), st), 'nnhip_colsum_batch')
         gmap = {id(p): gr for p, gr in zip(ws.params, ws.grads)}
         _chk(L_.nnhip_species_sum(_p(ws.dGA), F, F, _p(self.z), N, _p(ws.sp_scratch),

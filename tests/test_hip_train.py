@@ -139,7 +139,10 @@ def test_bf16_autocast_training_gradients():
             err += (prm.grad.detach().cpu().double() - want[name]).norm().item() ** 2
             ref_n += want[name].norm().item() ** 2
     assert abs(loss.item() - want_loss.item()) <= 2e-2 * abs(want_loss.item())
-    assert np.sqrt(err) <= 2e-2 * np.sqrt(ref_n), (np.sqrt(err), np.sqrt(ref_n))
+    rel = np.sqrt(err / ref_n)
+    print(f'bf16-operand weight gradients: relative gradient-norm error {rel:.2e}')
+    assert rel <= 2e-2, (np.sqrt(err), np.sqrt(ref_n))
+    assert rel > 1e-5          # the bf16-operand weight-gradient kernel really ran (the fp32 one lands at ~5e-7)
 
 
 def test_graphed_train_step_matches_eager():

@@ -75,6 +75,13 @@ def main():
         mf.train()
         fstep = GraphedTrainStep(mf, FusedClipAdam(mf, lr=1e-3, max_norm=1.0), 1.0, 50.0, assume_static=True)
         res['all_hip_graph'] = timeit(lambda: fstep(*args), 3, 30)
+        os.environ['NNHIP_TRAIN_BF16'] = '1'           # bf16-operand weight-gradient products (fp32 everywhere else)
+        torch.manual_seed(0)
+        mb = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+        mb.train()
+        bstep = TrainStep(mb, torch.optim.Adam(mb.parameters(), lr=1e-3), 1.0, 50.0, 1.0)
+        res['fused_eager_bf16wgrad'] = timeit(lambda: bstep(*args), 3, 10)
+        os.environ.pop('NNHIP_TRAIN_BF16')
         model.eval()
         with torch.no_grad():
             res['inference'] = timeit(lambda: model(*args[:4]), 3, 20)
