@@ -242,16 +242,8 @@ class GraphedTrainStep:
         structure changed (then all ranks re-capture together: a rank-local decision would leave collectives unmatched) -- with
         one tiny all-reduce; (2) replay forward + loss + gradients; (3) all-reduce the flat gradient; (4) replay clip + Adam."""
         distributed = dist.is_available() and dist.is_initialized()
-        dev = pos.device
         changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
-        counts = torch.tensor([float(energy_label.numel()), float(force_label.numel()), 1.0 if changed else 0.0],
-                              dtype=torch.float32, device=dev)
-        w = torch.tensor([self.w_energy, self.w_force], dtype=torch.float32, device=dev)
-        if distributed:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
-            if not (self.assume_static and self._st is not None):
-                changed = bool(counts[2].item() > 0)             # (host sync; skipped when the structure is declared static)
-        norm = w / counts[:2]                                     # (w_E / n_E, w_F / n_F) with GLOBAL element counts, on the device
+        norm, changed = self._global_norm(energy_label, force_label, changed, pos.device)
         if changed:
             self._capture_fused(z, pos, cell, batch, energy_label, force_label, norm)
         st = self._st
@@ -271,7 +263,7 @@ class GraphedTrainStep:
         out = self.model(st['z'], st['pos'], st['cell'], st['batch'])
         sse_e = (out.energy - st['e']).pow(2).sum()
         sse_f = (out.gradient_force - st['f']).pow(2).sum()
-        loss = self.w_energy * sse_e / st['n_e'] + self.w_force * sse_f / st['n_f']
+        loss = st['norm'][0] * sse_e + st['norm'][1] * sse_f      # (w_E / n_E, w_F / n_F): a DEVICE tensor, refreshed every step
         loss.backward()
         return loss.detach()
 
@@ -286,13 +278,25 @@ class GraphedTrainStep:
             return False
         return bool(((st['z'] == z).all() & (st['batch'] == batch).all() & (st['cell'] == cell).all()).item())
 
-    def _capture(self, z, pos, cell, batch, energy_label, force_label):
+    def _global_norm(self, energy_label, force_label, changed: bool, dev):
+        """(w_E / n_E, w_F / n_F) with the GLOBAL element counts as a device tensor, and whether ANY rank's batch structure
+        changed -- one small all-reduce per step under torch.distributed (every rank must take the same re-capture decision,
+        or the collectives inside the capture's warm-up would be unmatched)."""
+        counts = torch.tensor([float(energy_label.numel()), float(force_label.numel()), 1.0 if changed else 0.0],
+                              dtype=torch.float32, device=dev)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+            if not (self.assume_static and self._st is not None):
+                changed = bool(counts[2].item() > 0)
+        w = torch.tensor([self.w_energy, self.w_force], dtype=torch.float32, device=dev)
+        return w / counts[:2], changed
+
+    def _capture(self, z, pos, cell, batch, energy_label, force_label, norm):
         from newtonnet_amd import hip
         dev = pos.device
         emb = self.model.embedding_layers.edge_embedding
         st = dict(z=z.clone(), cell=cell.clone(), batch=batch.clone(), pos=pos.detach().clone().requires_grad_(True),
-                  e=energy_label.detach().clone(), f=force_label.detach().clone())
-        st['n_e'], st['n_f'] = allreduce_counts(energy_label.numel(), force_label.numel(), dev, self.group)
+                  e=energy_label.detach().clone(), f=force_label.detach().clone(), norm=norm.clone())
         # static candidate list: every ordered pair of every molecule (minimum image when periodic)
         st['graph'] = hip.build_graph(st['pos'].detach(), st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies,
                                       want_rbf=True, envelope=emb.envelope_id)
@@ -326,13 +330,15 @@ class GraphedTrainStep:
             raise RuntimeError('GraphedTrainStep needs model.train()')
         if self.fused:
             return self._call_fused(z, pos, cell, batch, energy_label, force_label)
-        if not self._same_structure(z, cell, batch):
+        changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
+        norm, changed = self._global_norm(energy_label, force_label, changed, pos.device)
+        if changed:
             # The warm-up / capture passes run optimizer steps of their own on this batch: snapshot and restore IN PLACE (the
             # graphs hold the addresses of the parameters and of the optimizer's state tensors).
             params = [p.detach().clone() for p in self.model.parameters()]
             saved = {id(p): {k: v.detach().clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)}
                      for p in self.model.parameters()}
-            self._capture(z, pos, cell, batch, energy_label, force_label)
+            self._capture(z, pos, cell, batch, energy_label, force_label, norm)
             with torch.no_grad():
                 for p, q in zip(self.model.parameters(), params):
                     p.copy_(q)
@@ -341,6 +347,7 @@ class GraphedTrainStep:
                             old = saved[id(p)].get(k)
                             v.copy_(old) if old is not None else v.zero_()   # state created by the warm-up: back to its start
         st = self._st
+        st['norm'].copy_(norm)
         st['pos'].data.copy_(pos.detach())
         st['e'].copy_(energy_label.detach())
         st['f'].copy_(force_label.detach())

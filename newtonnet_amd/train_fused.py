@@ -199,7 +199,7 @@ class Runner:
         self.energy_idx = list(model.output_properties).index('energy')
         # under torch.autocast(bfloat16) -- the way BASELINE configs[2] asks for bf16 -- the weight-gradient products take bf16
         # operands (fp32 prologues, fp32 accumulation); every other kernel stays exact fp32
-        self.bf16 = bool(torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+        self.bf16 = bool(torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16) \
             or os.environ.get('NNHIP_TRAIN_BF16') == '1'
         if g.rbf is None or g.drbf is None:
             raise ValueError('the training path needs a graph built with want_rbf=True')
