@@ -99,8 +99,10 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
       const size_t p = (size_t)ABL_P(hi ? p1 : p0, i);
       // A candidate of a reused (Verlet-skin / static) list that is outside the cutoff right now (edge_embed_kernel points
       // its filter row at FT_ZERO_ROW, by the same fp32 predicate as the neighbor list) has msg == 0 but phi = W2 act(0),
-      // which vanishes only when act(0) == 0 (not for sigmoid / softplus) -- mask it explicitly
-      const int gz0 = xg[e].x, gz1 = xg[e1].x;
+      // which vanishes only when act(0) == 0 (not for sigmoid / softplus) -- mask it explicitly.  The caller passes
+      // xg == NULL when act(0) == 0 (every contribution of such a candidate then vanishes by itself, and the per-edge
+      // scalar loads of the mask cost 6 % of the edge time on a 54-neighbour periodic box)
+      const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
       if ((!hi || e + 1 < re) && (hi ? gz1 : gz0) != FT_ZERO_ROW) {
         const float4 v1 = ld4p<decltype(nt)::value>(phi1 + p * NF + c4);
         acc[0] = fma4(v1, g.x, acc[0]);
@@ -163,7 +165,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const int p0 = pid[e], p1 = pid[e1];
     const int eh = hi ? e1 : e;
     const size_t p = (size_t)(hi ? p1 : p0);
-    const int gz0 = xg[e].x, gz1 = xg[e1].x;
+    const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;   // (see force_fwd_kernel: candidates outside the cutoff contribute nothing)
     if ((!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
       reinterpret_cast<float4*>(g_u)[eh] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -197,7 +199,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const size_t p = (size_t)(hi ? p1 : p0);
     const int j = ABL_J(hi ? j1 : j0, i);
     const float4 g = hi ? g1 : g0;
-    const int gz0 = xg[e].x, gz1 = xg[e1].x;
+    const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;
     if ((!hi || e + 1 < end) && !inside) {   // outside the cutoff: zero adjoints for the pair rows this row owns
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);

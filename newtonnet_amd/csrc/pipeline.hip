@@ -340,6 +340,8 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   }
   const int L = model->n_layers;
   const int act = model->activation;
+  // explicit candidate mask in the force kernels: only when act(0) != 0 (edge.hip:force_fwd_kernel)
+  const int32_t* mask_xg = (act == NNHIP_ACT_SIGMOID || act == NNHIP_ACT_SOFTPLUS) ? xg : nullptr;
   if (act < NNHIP_ACT_SILU || act > NNHIP_ACT_SSP) {
     nnhip_set_error("nnhip_energy_forces: unknown activation id %d", act);
     return NNHIP_E_UNSUPPORTED;
@@ -409,7 +411,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       else
         TRY(launch_mlp(MODE_FWD, false, m1, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, xg, s));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
@@ -500,7 +502,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
-                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, xg, s));
+                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s));
     if (E > 0) {
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
