@@ -442,9 +442,11 @@ typedef struct {
   int32_t M, lda1, lda2, ldb1, ldb2, ldh, type, b_cols32, activation, ldo, ncols, pad_;
 } nnhip_wgrad_problem;
 size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks);
-/* bf16_operands != 0: operands rounded to bf16 after their fp32 prologue, fp32 accumulation (v_mfma_f32_32x32x16_bf16) */
+/* bf16_operands != 0: operands rounded to bf16 after their fp32 prologue, fp32 accumulation (v_mfma_f32_32x32x16_bf16).
+ * pair_rows: the row count of the problems whose M is negative (pair-level problems of a table built for a capacity: the
+ * number of pairs changes from batch to batch, the table does not) */
 int nnhip_wgrad_batch(const nnhip_wgrad_problem* problems_dev, int32_t n_problems, int32_t chunks, float* slabs,
-                      int32_t bf16_operands, void* stream);
+                      int32_t bf16_operands, int32_t pair_rows, void* stream);
 /* Training objective of the reference (newtonnet/train/loss.py:48,72,96; scripts/config.yml:45-51) and its gradient:
  *   loss = w[0] sum (E - E*)^2 + w[1] sum (F - F*)^2;  g_energy = 2 w[0] (E - E*);  g_forces = 2 w[1] (F - F*)
  * weights_dev[2] = (w_E / n_E, w_F / n_F) lives in DEVICE memory (a data-parallel run refreshes the global counts there). */

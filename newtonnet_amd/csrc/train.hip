@@ -554,10 +554,11 @@ __device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, i
 }
 
 __global__ void __launch_bounds__(256)
-wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs) {
+wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
   WgLds* lds = reinterpret_cast<WgLds*>(wg_lds_raw);   // [2]
   WgProb P = probs[blockIdx.y];
+  if (P.M < 0) P.M = pair_rows;                         // pair-level problem: the row count of THIS step (capacity-sized tables)
   if (!P.lda1) P.lda1 = NF;
   if (!P.lda2) P.lda2 = NF;
   if (!P.ldb1) P.ldb1 = NF;
@@ -745,10 +746,11 @@ __device__ __forceinline__ void wb_run(const WgProb& P, WbLds* lds, int r_beg, i
 }
 
 __global__ void __launch_bounds__(256)
-wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs) {
+wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
   WbLds* lds = reinterpret_cast<WbLds*>(wg_lds_raw);   // [2]
   WgProb P = probs[blockIdx.y];
+  if (P.M < 0) P.M = pair_rows;
   if (!P.lda1) P.lda1 = NF;
   if (!P.lda2) P.lda2 = NF;
   if (!P.ldb1) P.ldb1 = NF;
@@ -1164,8 +1166,8 @@ extern "C" size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks) {
   return (size_t)n_problems * chunks * NF * NF * sizeof(float);
 }
 extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n_problems, int32_t chunks, float* slabs,
-                                 int32_t bf16_operands, void* stream) {
-  ARG_CHECK(n_problems >= 0 && chunks >= 1 && (n_problems == 0 || (probs_dev && slabs)), "nnhip_wgrad_batch");
+                                 int32_t bf16_operands, int32_t pair_rows, void* stream) {
+  ARG_CHECK(n_problems >= 0 && chunks >= 1 && pair_rows >= 0 && (n_problems == 0 || (probs_dev && slabs)), "nnhip_wgrad_batch");
   if (n_problems == 0) return NNHIP_OK;
   hipStream_t s = (hipStream_t)stream;
   ScopedTimer t0(TC_LIN, s);
@@ -1176,9 +1178,9 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(WbLds));
   HIP_TRY(attr_rc2);
   if (bf16_operands)
-    wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs);
+    wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   else
-    wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs);
+    wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   LAUNCH_CHECK();
   wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();

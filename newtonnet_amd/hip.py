@@ -162,7 +162,7 @@ def lib():
     L.nnhip_colsum_scratch_bytes.restype = sz
     L.nnhip_wgrad_slab_bytes.argtypes = [i32, i32]
     L.nnhip_wgrad_slab_bytes.restype = sz
-    L.nnhip_wgrad_batch.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.nnhip_wgrad_batch.argtypes = [vp, i32, i32, vp, i32, i32, vp]
     L.nnhip_colsum_batch.argtypes = [vp, i32, vp, vp]
     L.nnhip_mse_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.nnhip_clip_adam_scratch_bytes.restype = sz

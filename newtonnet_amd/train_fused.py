@@ -47,13 +47,15 @@ def supported(model, keys) -> bool:
 
 
 class TrainWorkspace:
-    """Every buffer of one training step for fixed (N, E, B): value and tangent intermediates of all layers (the weight-gradient
-    launch at the end reads them all), gradient outputs, and the device-resident problem tables."""
+    """Every buffer of one training step for N atoms, B molecules and UP TO `E` edges: value and tangent intermediates of all
+    layers (the weight-gradient launch at the end reads them all), gradient outputs, and the device-resident problem tables.
+    The edge count of real batches changes every step: the workspace is sized for a capacity and the kernels get the step's
+    own counts (the pair-level problems of the weight-gradient table carry M = -1 = "this launch's pair count")."""
 
     def __init__(self, model, N: int, E: int, B: int, device):
         L = len(model.interaction_layers)
         P = E // 2
-        self.N, self.E, self.B, self.L, self.P = N, E, B, L, P
+        self.N, self.E, self.B, self.L, self.P = N, E, B, L, P      # E, P: capacities
         self.busy = False
 
         def buf(*shape):
@@ -81,7 +83,8 @@ class TrainWorkspace:
         self.t1, self.t2 = per_layer(Pn, F), per_layer(Pn, F, first=1)
         self.g_msg = per_layer(Pn, F)
         self.g_m, self.t_n = per_layer(N, F, first=1), per_layer(N, F, first=1)
-        self.g_x, self.g_u, self.g_d = buf(L, max(E, 1)), buf(L, max(E, 1), 4), buf(max(E, 1), 4)
+        # ([L][E] / [L][E][4] packed for the step's own E inside flat capacity-sized buffers)
+        self.g_x, self.g_u, self.g_d = buf(L * max(E, 1)), buf(L * max(E, 1) * 4), buf(max(E, 1), 4)
         # ---- tangents, forward
         self.v, self.tgeo = buf(N, 3), buf(max(E, 1), 4)
         self.da_mid = buf(N, F)
@@ -155,10 +158,10 @@ class TrainWorkspace:
                                                           (il.equiv_message2, self.h2, self.dh2, self.t2, self.dg_h2))):
                     if k == 1 and l == 0:
                         continue          # layer 0: phi2 multiplies force_node == 0 (newtonnet.py:143): exact zero gradient
-                    add(G(seq[2].weight), P, self.dg_h12[l], A2=self.g_h12[l], typ=hip.WG_ACT, hB=h[l], dhB=dh[l], lda1=2 * F,
+                    add(G(seq[2].weight), -1, self.dg_h12[l], A2=self.g_h12[l], typ=hip.WG_ACT, hB=h[l], dhB=dh[l], lda1=2 * F,
                         lda2=2 * F, a1_off=k * F, a2_off=k * F)
-                    add(G(seq[0].weight), P, dgh[l], B1=self.msg[l], A2=t[l], B2=self.dmsg[l], typ=hip.WG_TDACT, hA=h[l])
-                add(G(il.message_edgepart.weight), P, self.dg_eps[l], B1=self.rb, A2=self.g_eps[l], B2=self.rb, ldb1=64, ldb2=64,
+                    add(G(seq[0].weight), -1, dgh[l], B1=self.msg[l], A2=t[l], B2=self.dmsg[l], typ=hip.WG_TDACT, hA=h[l])
+                add(G(il.message_edgepart.weight), -1, self.dg_eps[l], B1=self.rb, A2=self.g_eps[l], B2=self.rb, ldb1=64, ldb2=64,
                     b2_off=32, cols32=True, ldo=nb, ncols=nb)
             n2, n0 = il.message_nodepart[2], il.message_nodepart[0]
             if l > 0:
@@ -195,6 +198,9 @@ class Runner:
 
     def __init__(self, model, z, pos, cell, batch, g: hip.Graph, ws: TrainWorkspace):
         self.model, self.z, self.pos, self.cell, self.batch, self.g, self.ws = model, z, pos, cell, batch, g, ws
+        if g.n_atoms != ws.N or g.n_mol != ws.B or g.n_edges > ws.E:
+            raise ValueError(f'workspace for N={ws.N}, B={ws.B}, E<={ws.E} cannot hold a batch with N={g.n_atoms}, '
+                             f'B={g.n_mol}, E={g.n_edges}')
         self.act = hip.ACTIVATION_IDS[model.activation_name]
         self.energy_idx = list(model.output_properties).index('energy')
         # under torch.autocast(bfloat16) -- the way BASELINE configs[2] asks for bf16 -- the weight-gradient products take bf16
@@ -266,7 +272,8 @@ class Runner:
     # -- sweeps 1 and 2: values ------------------------------------------------------------------------------------------
     def values(self):
         L_, ws, g, model, st, act = hip.lib(), self.ws, self.g, self.model, self.st, self.act
-        N, E, B, L, P = ws.N, ws.E, ws.B, ws.L, ws.P
+        N, B, L = ws.N, ws.B, ws.L
+        E, P = g.n_edges, g.n_edges // 2                     # this batch's own counts (the workspace holds capacities)
         self._prepare()
         layers = list(model.interaction_layers)
         head = model.output_layers[self.energy_idx].layers
@@ -309,7 +316,7 @@ class Runner:
             f_prev = ws.f_out[l - 1] if l > 0 else None
             Gf = ws.Gf[pp]
             _chk(L_.nnhip_force_message_bwd(_p(ws.gf[l]), _p(ws.phi1[l]), _p(ws.phi2[l]), _p(g.geo), _p(g.xg), *idx, _p(f_prev),
-                                            _p(ws.g_h12[l]), _p(ws.g_u[l]), _p(Gf), N, st), 'nnhip_force_message_bwd')
+                                            _p(ws.g_h12[l]), _p(ws.g_u, 4 * l * E), _p(Gf), N, st), 'nnhip_force_message_bwd')
             d1 = self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.g_msg[l], P, ldx=2 * F, T=ws.t1[l])
             if l > 0:
                 self._mlp2(d1, self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.g_msg[l], P, ldx=2 * F,
@@ -317,7 +324,7 @@ class Runner:
             elif P > 0:
                 _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
             _chk(L_.nnhip_message_bwd(_p(ws.g_msg[l]), _p(ws.GA[l]), _p(ws.m[l]), _p(g.xg), _p(ws.ftab[l]), *idx,
-                                      _p(ws.g_m[l]) if l > 0 else None, _p(ws.g_x[l]), N, 1 if l > 0 else 0, st),
+                                      _p(ws.g_m[l]) if l > 0 else None, _p(ws.g_x, l * E), N, 1 if l > 0 else 0, st),
                  'nnhip_message_bwd')
             if l > 0:
                 ws.GA[l - 1].copy_(ws.GA[l])
@@ -335,7 +342,8 @@ class Runner:
     # -- sweeps 3 and 4: tangents, then the weight gradients ---------------------------------------------------------------
     def grads(self, g_energy: torch.Tensor, g_forces: torch.Tensor):
         L_, ws, g, model, st, act = hip.lib(), self.ws, self.g, self.model, self.st, self.act
-        N, E, B, L, P = ws.N, ws.E, ws.B, ws.L, ws.P
+        N, B, L = ws.N, ws.B, ws.L
+        E, P = g.n_edges, g.n_edges // 2
         layers = list(model.interaction_layers)
         head = model.output_layers[self.energy_idx].layers
         sc = model.scalers[self.energy_idx]
@@ -403,7 +411,7 @@ class Runner:
         # ---- weight gradients: one batched split-K launch + its reduction, column sums, per-element sums
         _chk(L_.nnhip_pair_rbf(_p(g.rbf), _p(g.drbf), _p(ws.tgeo), _p(g.edge_index), _p(g.pid), E, emb.n_basis, _p(ws.rb), st),
              'nnhip_pair_rbf')
-        _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), 1 if self.bf16 else 0, st),
+        _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), 1 if self.bf16 else 0, P, st),
              'nnhip_wgrad_batch')
         _chk(L_.nnhip_colsum_batch(_p(ws.sum_dev), ws.n_sums, _p(ws.cs_scratch), st), 'nnhip_colsum_batch')
         gmap = {id(p): gr for p, gr in zip(ws.params, ws.grads)}
@@ -462,12 +470,15 @@ def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None)
         else:
             g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
     cache = model.__dict__.setdefault('_train_ws', [])
-    key = (g.n_atoms, g.n_edges, g.n_mol, pos.device)
-    ws = next((w for w in cache if not w.busy and (w.N, w.E, w.B, w.energy.device) == key
-               and all(a is b for a, b in zip(w.params, trainable_parameters(model)))), None)
+    params = trainable_parameters(model)
+    ws = next((w for w in cache if not w.busy and (w.N, w.B, w.energy.device) == (g.n_atoms, g.n_mol, pos.device)
+               and g.n_edges <= w.E and all(a is b for a, b in zip(w.params, params))), None)
     if ws is None:
-        ws = TrainWorkspace(model, g.n_atoms, g.n_edges, g.n_mol, pos.device)
-        del cache[:max(0, len(cache) - 3)]          # keep a few shapes around (train / validation batch sizes)
+        # capacity: real batches differ in their edge count from step to step -- leave 12.5 % head room (even, >= 64) so that
+        # the next batches of the same shape reuse the buffers and the uploaded problem tables
+        e_cap = g.n_edges if graph is not None else ((g.n_edges + g.n_edges // 8 + 64) & ~1)
+        ws = TrainWorkspace(model, g.n_atoms, e_cap, g.n_mol, pos.device)
+        cache[:] = [w for w in cache if w.busy or (w.N, w.B) != (ws.N, ws.B)][-3:]   # superseded capacities go, a few shapes stay
         cache.append(ws)
     ws.busy = torch.is_grad_enabled()
     runner = Runner(model, zc, pd, cd, bc, g, ws)

@@ -474,3 +474,38 @@ def test_rccl_single_rank_step():
     flat, losses, gnorm = ddp_worker.run(z, pos, cell, batch, e_lab, f_lab, 3, False)
     assert float((r0['flat'] - flat).abs().max()) <= 2e-6 * float(flat.abs().max())
     np.testing.assert_allclose(r0['losses'], losses, rtol=1e-5)
+
+
+def test_workspace_is_reused_across_batches_with_different_edge_counts():
+    """Real training batches differ in their edge count from step to step: the training workspace is sized for a capacity and
+    reused (buffers AND the uploaded weight-gradient tables) while the kernels get each step's own counts.  Second batch =
+    the first one stretched by 8 % (fewer pairs inside the cutoff): same workspace, gradients still match the oracle."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, c = util.case_inputs('aspirin8_rand', torch.float32)
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    sd = util.load_state('rand', torch.float32)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.train()
+    g = torch.Generator().manual_seed(3)
+    e_lab, f_lab = torch.randn(8, generator=g), torch.randn(168, 3, generator=g)
+    edges = []
+    for scale in (1.0, 1.08, 0.97):
+        p = (pos * scale).contiguous()
+        model.zero_grad(set_to_none=True)
+        out = model(z.cuda(), p.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+        edges.append(out.edge_index.shape[1])
+        loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(
+            out.gradient_force, f_lab.cuda())
+        loss.backward()
+        _, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, p.double(), cell.double(), batch,
+                                          e_lab.double(), f_lab.double())
+        err = nrm = 0.0
+        for name, prm in model.named_parameters():
+            if prm.requires_grad:
+                err += (prm.grad.detach().cpu().double() - want[name]).norm().item() ** 2
+                nrm += want[name].norm().item() ** 2
+        assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm), (scale, np.sqrt(err / nrm))
+    assert len(set(edges)) == 3 and edges[1] < edges[0] < edges[2], edges
+    assert len(model._train_ws) == 1 and model._train_ws[0].E >= max(edges[:2])      # one workspace served all three
