@@ -465,6 +465,54 @@ size_t nnhip_colsum_scratch_bytes(int32_t n);
 int nnhip_colsum_batch(const nnhip_colsum_problem* problems_dev, int32_t n, float* scratch, void* stream);
 
 /* --------------------------------------------------------------------------
+ * The two halves of a training step as single calls (what newtonnet_amd/train_fused.py:FusedEnergyForces runs in its forward
+ * and backward): the stages above in order, on one stream, nothing else.  `ws` holds DEVICE pointers to every buffer of the
+ * step (per-layer arrays indexed by layer; sizes as in the stage declarations; the host side owns and sizes them:
+ * newtonnet_amd/train_fused.py:TrainWorkspace).  Replaces: the forward + torch.autograd.grad(create_graph=True) of
+ * newtonnet/models/newtonnet.py:74-104 / output.py:66-73 (values), and loss.backward() through it, trainer.py:309 (grads).
+ *   nnhip_train_values: parameter-only preparation (transposes, filter tables), forward sweep, reverse sweep -> energy[B],
+ *                       forces[N][3], every intermediate kept in `ws`.
+ *   nnhip_train_grads : given g_energy[B] = dL/dE and g_forces[N][3] = dL/dF: tangent forward, tangent reverse, the batched
+ *                       weight-gradient / column-sum / per-element-sum launches; the parameter gradients land where the tables
+ *                       (ws->probs, ws->sums) and the g_* pointers say.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int32_t n_atoms, n_edges, n_mol, n_layers, n_basis, envelope, bf16_wgrad, pad_;
+  /* batch + graph (nnhip_graph_* / nnhip_edge_embed outputs; rbf / drbf are required) */
+  const int64_t* z; const float* pos; const float* cell; const int64_t* batch;
+  const int32_t* mol_ptr; const int32_t* row_ptr; const int32_t* col; const int32_t* rev; const int32_t* pid;
+  const int64_t* edge_index; const float* geo; const float* disp; const float* rbf; const float* drbf; const int32_t* xg;
+  /* parameter-only data rebuilt by nnhip_train_values */
+  float* wT[NNHIP_MAX_LAYERS][7]; float* headT[2]; float* ftab[NNHIP_MAX_LAYERS];
+  /* values, forward */
+  float* a0; float* hn[NNHIP_MAX_LAYERS]; float* m[NNHIP_MAX_LAYERS]; float* msg[NNHIP_MAX_LAYERS];
+  float* h1[NNHIP_MAX_LAYERS]; float* h2[NNHIP_MAX_LAYERS]; float* phi1[NNHIP_MAX_LAYERS]; float* phi2[NNHIP_MAX_LAYERS];
+  float* a_mid[NNHIP_MAX_LAYERS]; float* a_out[NNHIP_MAX_LAYERS]; float* f_out[NNHIP_MAX_LAYERS]; float* q[NNHIP_MAX_LAYERS];
+  float* e1; float* e2; float* g_e2; float* atom_energy; float* energy; float* forces;
+  /* values, reverse */
+  float* t_e1; float* GA[NNHIP_MAX_LAYERS]; float* gf[NNHIP_MAX_LAYERS]; float* Gf[2]; float* g_h12[NNHIP_MAX_LAYERS];
+  float* t1[NNHIP_MAX_LAYERS]; float* t2[NNHIP_MAX_LAYERS]; float* g_msg[NNHIP_MAX_LAYERS]; float* g_m[NNHIP_MAX_LAYERS];
+  float* t_n[NNHIP_MAX_LAYERS]; float* g_x; float* g_u; float* g_d;
+  /* tangents, forward */
+  float* tgeo; float* da_mid; float* da_out[NNHIP_MAX_LAYERS]; float* dhn[NNHIP_MAX_LAYERS]; float* dm[NNHIP_MAX_LAYERS];
+  float* dmsg[NNHIP_MAX_LAYERS]; float* dh1[NNHIP_MAX_LAYERS]; float* dh2[NNHIP_MAX_LAYERS]; float* dphi1[NNHIP_MAX_LAYERS];
+  float* dphi2[NNHIP_MAX_LAYERS]; float* df_out[NNHIP_MAX_LAYERS]; float* dq[NNHIP_MAX_LAYERS]; float* de1; float* de2;
+  /* tangents, reverse */
+  float* dg_e2; float* w4row; float* scal; float* dg_e1; float* dGA; float* dgf; float* dGf[2];
+  float* gq[NNHIP_MAX_LAYERS]; float* dgq[NNHIP_MAX_LAYERS]; float* dg_h12[NNHIP_MAX_LAYERS]; float* dg_h1[NNHIP_MAX_LAYERS];
+  float* dg_h2[NNHIP_MAX_LAYERS]; float* dg_msg; float* g_eps[NNHIP_MAX_LAYERS]; float* dg_eps[NNHIP_MAX_LAYERS];
+  float* dg_m[NNHIP_MAX_LAYERS]; float* dg_hn[NNHIP_MAX_LAYERS]; float* rb; const float* zeros_nf;
+  /* batched gradient launches and the outputs they do not cover */
+  const nnhip_wgrad_problem* probs; const nnhip_colsum_problem* sums; float* slabs; float* cs_scratch; float* sp_scratch;
+  int32_t n_probs, chunks, n_sums, pad2_;
+  float* g_embedding; float* g_scale; float* g_shift; float* g_head4_b;
+} nnhip_train_ws;
+size_t nnhip_train_ws_bytes(void); /* sizeof(nnhip_train_ws) of this build (bindings check their mirror against it) */
+int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws* ws, void* stream);
+int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws* ws, const float* g_energy, const float* g_forces,
+                      void* stream);
+
+/* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,

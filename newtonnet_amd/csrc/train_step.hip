@@ -1,0 +1,253 @@
+// The two halves of a training step as single C calls: the per-stage entry points of include/newtonnet_hip.h strung together
+// exactly as tests/tangent_ref.py states the algorithm (sweeps 1-2 = values, 3-4 = tangents + weight gradients; csrc/train.hip has
+// the kernels and the derivation).  Host code only: every line is a call to an exported stage; the buffers belong to the caller.
+#include <string.h>
+
+#include "common.h"
+
+#define TS_TRY(x)          \
+  do {                     \
+    int _r = (x);          \
+    if (_r) return _r;     \
+  } while (0)
+
+static nnhip_mlp_desc mlp_desc(int mode, const float* X, int ldx, const float* W1, const float* W2, float* H, float* Y, int M,
+                               int act) {
+  nnhip_mlp_desc d;
+  memset(&d, 0, sizeof(d));
+  d.X = X;
+  d.ldx = ldx;
+  d.W1 = W1;
+  d.W2 = W2;
+  d.H = H;
+  d.ldh = NF;
+  d.Y = Y;
+  d.ldy = NF;
+  d.M = M;
+  d.mode = mode;
+  d.activation = act;
+  return d;
+}
+static int run1(const nnhip_mlp_desc& d, void* s) { return d.M > 0 ? nnhip_mlp128_ex(&d, s) : NNHIP_OK; }
+static int run2(const nnhip_mlp_desc& a, const nnhip_mlp_desc& b, void* s) { return a.M > 0 ? nnhip_mlp128_pair_ex(&a, &b, s) : NNHIP_OK; }
+
+static int check(const nnhip_model* model, const nnhip_train_ws* w, const char* who) {
+  if (!model || !w || w->n_layers != model->n_layers || w->n_layers < 1 || w->n_layers > NNHIP_MAX_LAYERS || w->n_atoms < 0 ||
+      w->n_edges < 0 || (w->n_edges & 1) || model->n_features != NF || !w->rbf || !w->drbf) {
+    nnhip_set_error("%s: bad arguments", who);
+    return NNHIP_E_INVALID;
+  }
+  for (int l = 0; l < model->n_layers; ++l)
+    if (model->layer[l].ln_w) {
+      nnhip_set_error("%s: layer_norm=True is outside the fused training path", who);
+      return NNHIP_E_UNSUPPORTED;
+    }
+  return NNHIP_OK;
+}
+
+extern "C" size_t nnhip_train_ws_bytes(void) { return sizeof(nnhip_train_ws); }
+
+extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws* w, void* s) {
+  TS_TRY(check(model, w, "nnhip_train_values"));
+  const int N = w->n_atoms, E = w->n_edges, B = w->n_mol, L = w->n_layers, P = E / 2, act = model->activation;
+  if (N == 0) return NNHIP_OK;
+  // parameter-only data of this step: transposed weights, radial-filter tables
+  {
+    const float* src[40];
+    float* dst[40];
+    int c = 0;
+    for (int l = 0; l < L; ++l) {
+      const nnhip_layer_params& lp = model->layer[l];
+      const float* ws_[7] = {lp.node0_w, lp.node2_w, lp.eq1_0_w, lp.eq1_2_w, lp.eq2_0_w, lp.eq2_2_w, lp.update_w};
+      for (int k = 0; k < 7; ++k) {
+        if (c == 40) {
+          TS_TRY(nnhip_transpose128(src, dst, c, s));
+          c = 0;
+        }
+        src[c] = ws_[k];
+        dst[c++] = w->wT[l][k];
+      }
+    }
+    if (c + 2 > 40) {
+      TS_TRY(nnhip_transpose128(src, dst, c, s));
+      c = 0;
+    }
+    src[c] = model->head0_w;
+    dst[c++] = w->headT[0];
+    src[c] = model->head2_w;
+    dst[c++] = w->headT[1];
+    TS_TRY(nnhip_transpose128(src, dst, c, s));
+    const float* ew[NNHIP_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) ew[l] = model->layer[l].edge_w;
+    TS_TRY(nnhip_filter_tables(ew, w->ftab, L, model->frequencies, model->n_basis, model->envelope, s));
+  }
+  // ---- sweep 1: forward
+  TS_TRY(nnhip_embed(w->z, model->node_embedding, N, w->a0, s));
+  {
+    const nnhip_layer_params& l0 = model->layer[0];
+    nnhip_mlp_desc d = mlp_desc(MODE_FWD, w->a0, NF, l0.node0_w, l0.node2_w, w->hn[0], w->m[0], N, act);
+    d.b1 = l0.node0_b;
+    d.b2 = l0.node2_b;
+    TS_TRY(run1(d, s));
+  }
+  const float* a_in = w->a0;
+  const float* f_in = nullptr;
+  for (int l = 0; l < L; ++l) {
+    const nnhip_layer_params& lp = model->layer[l];
+    TS_TRY(nnhip_message_fwd(w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid, a_in, w->msg[l], w->a_mid[l], N, s));
+    const nnhip_mlp_desc d1 = mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->phi1[l], P, act);
+    if (l > 0)
+      TS_TRY(run2(d1, mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->phi2[l], P, act), s));
+    else
+      TS_TRY(run1(d1, s));
+    TS_TRY(nnhip_force_message_fwd(w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_in, w->f_out[l], N, s));
+    if (l + 1 < L) {
+      const nnhip_layer_params& nx = model->layer[l + 1];
+      TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nx.node0_w, nx.node0_b, nx.node2_w,
+                            nx.node2_b, w->hn[l + 1], w->m[l + 1], N, act, s));
+    } else {
+      TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], model->head0_w, model->head0_b,
+                            model->head2_w, model->head2_b, w->e1, w->e2, N, act, s));
+    }
+    a_in = w->a_out[l];
+    f_in = w->f_out[l];
+  }
+  TS_TRY(nnhip_head_out(w->e2, model->head4_w, model->head4_b, model->scale, model->shift, w->z, w->mol_ptr, N, B, act,
+                        w->atom_energy, w->g_e2, w->energy, s));
+  // ---- sweep 2: reverse (seed 1)
+  {
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act);
+    d.T = w->t_e1;
+    TS_TRY(run1(d, s));
+  }
+  TS_TRY(nnhip_node_bwd(nullptr, nullptr, nullptr, nullptr, w->GA[L - 1], 0, w->f_out[L - 1], w->q[L - 1], nullptr,
+                        w->wT[L - 1][6], w->gf[L - 1], N, act, s));
+  int pp = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    const float* f_prev = l > 0 ? w->f_out[l - 1] : nullptr;
+    float* Gf = w->Gf[pp];
+    TS_TRY(nnhip_force_message_bwd(w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_prev,
+                                   w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, s));
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act);
+    d1.T = w->t1[l];
+    if (l > 0) {
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->g_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->g_msg[l], P, act);
+      d2.T = w->t2[l];
+      d2.accumulate = 1;
+      TS_TRY(run2(d1, d2, s));
+    } else {
+      TS_TRY(run1(d1, s));
+    }
+    TS_TRY(nnhip_message_bwd(w->g_msg[l], w->GA[l], w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid,
+                             l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0 ? 1 : 0, s));
+    if (l > 0) {
+      HIP_TRY(hipMemcpyAsync(w->GA[l - 1], w->GA[l], sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->GA[l - 1], N, act);
+      d.T = w->t_n[l];
+      d.accumulate = 1;
+      TS_TRY(run1(d, s));
+      TS_TRY(nnhip_node_bwd(nullptr, nullptr, nullptr, nullptr, w->GA[l - 1], 0, w->f_out[l - 1], w->q[l - 1], Gf,
+                            w->wT[l - 1][6], w->gf[l - 1], N, act, s));
+    }
+    pp ^= 1;
+  }
+  return nnhip_edge_embed_bwd(w->g_x, w->g_u, w->geo, w->disp, w->pos, w->cell, w->row_ptr, w->col, w->rev, w->mol_ptr, N, E, B,
+                              L, model->cutoff, w->g_d, w->forces, nullptr, s);
+}
+
+extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws* w, const float* g_energy,
+                                 const float* g_forces, void* s) {
+  TS_TRY(check(model, w, "nnhip_train_grads"));
+  if (!g_energy || !g_forces) {
+    nnhip_set_error("nnhip_train_grads: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  const int N = w->n_atoms, E = w->n_edges, L = w->n_layers, P = E / 2, act = model->activation;
+  if (N == 0) return NNHIP_OK;
+  // ---- sweep 3: tangent forward along v = -dL/dF
+  TS_TRY(nnhip_edge_tangent_geom(g_forces, -1.0f, w->edge_index, w->geo, E, model->cutoff, w->tgeo, s));
+  for (int l = 0; l < L; ++l) {
+    const nnhip_layer_params& lp = model->layer[l];
+    const bool first = l == 0;
+    TS_TRY(nnhip_message_tan_fwd(w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo, w->ftab[l], w->row_ptr, w->col, w->pid,
+                                 first ? nullptr : w->da_out[l - 1], w->dmsg[l], w->da_mid, N, s));
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->dphi1[l], P, act);
+    d1.T = w->dh1[l];
+    if (!first) {
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->dphi2[l], P, act);
+      d2.T = w->dh2[l];
+      TS_TRY(run2(d1, d2, s));
+    } else {
+      TS_TRY(run1(d1, s));
+    }
+    TS_TRY(nnhip_force_message_tan_fwd(w->phi1[l], w->dphi1[l], w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr,
+                                       w->col, w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1],
+                                       w->df_out[l], N, s));
+    TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
+    TS_TRY(nnhip_update_tan_fwd(w->da_mid, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], N, w->da_out[l], s));
+    if (l + 1 < L) {
+      const nnhip_layer_params& nx = model->layer[l + 1];
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act);
+      d.T = w->dhn[l + 1];
+      TS_TRY(run1(d, s));
+    } else {
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, model->head0_w, model->head2_w, w->e1, w->de2, N, act);
+      d.T = w->de1;
+      TS_TRY(run1(d, s));
+    }
+  }
+  // ---- sweep 4: tangent reverse, seed tangent c = dL/dE
+  TS_TRY(nnhip_head_seed_tan(w->e2, w->de2, model->head4_w, model->head4_b, model->scale, w->z, w->batch, g_energy, N, act,
+                             w->dg_e2, w->w4row, w->scal, s));
+  {
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act);
+    d.T2 = w->t_e1;
+    d.Hd = w->de1;
+    d.G = w->dg_e1;
+    TS_TRY(run1(d, s));
+  }
+  const float* dGf = nullptr;
+  int pp = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    const bool first = l == 0;
+    TS_TRY(nnhip_update_tan_bwd(w->GA[l], w->dGA, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], dGf, N, w->gq[l], w->dgq[l],
+                                w->dgf, s));
+    TS_TRY(nnhip_linear128(w->dgq[l], NF, w->wT[l][6], w->dgf, NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_ACC, s));
+    float* nxt = w->dGf[pp];
+    TS_TRY(nnhip_force_message_tan_bwd(w->gf[l], w->dgf, w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr, w->col,
+                                       w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1], w->dg_h12[l],
+                                       first ? nullptr : nxt, N, s));
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN2, w->dg_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->dg_msg, P, act);
+    d1.T2 = w->t1[l];
+    d1.Hd = w->dh1[l];
+    d1.G = w->dg_h1[l];
+    if (!first) {
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN2, w->dg_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->dg_msg, P, act);
+      d2.T2 = w->t2[l];
+      d2.Hd = w->dh2[l];
+      d2.G = w->dg_h2[l];
+      d2.accumulate = 1;
+      TS_TRY(run2(d1, d2, s));
+    } else {
+      TS_TRY(run1(d1, s));
+    }
+    TS_TRY(nnhip_message_tan_bwd(w->g_msg[l], w->dg_msg, w->GA[l], w->dGA, w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo,
+                                 w->ftab[l], w->row_ptr, w->col, w->pid, w->dg_m[l], w->g_eps[l], w->dg_eps[l], N, s));
+    {
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->dGA, N, act);
+      d.T2 = first ? w->zeros_nf : w->t_n[l];
+      d.Hd = first ? w->zeros_nf : w->dhn[l];
+      d.G = w->dg_hn[l];
+      d.accumulate = 1;
+      TS_TRY(run1(d, s));
+    }
+    dGf = nxt;
+    pp ^= 1;
+  }
+  // ---- weight gradients: one batched split-K launch + its reduction, column sums, per-element sums
+  TS_TRY(nnhip_pair_rbf(w->rbf, w->drbf, w->tgeo, w->edge_index, w->pid, E, w->n_basis, w->rb, s));
+  TS_TRY(nnhip_wgrad_batch(w->probs, w->n_probs, w->chunks, w->slabs, w->bf16_wgrad, P, s));
+  TS_TRY(nnhip_colsum_batch(w->sums, w->n_sums, w->cs_scratch, s));
+  TS_TRY(nnhip_species_sum(w->dGA, NF, NF, w->z, N, w->sp_scratch, w->g_embedding, 0, NF, NF, nullptr, 0, 0, 0, nullptr, 0, s));
+  return nnhip_species_sum(w->scal, 4, 4, w->z, N, w->sp_scratch, w->g_scale, 0, 1, 1, w->g_shift, 1, 1, 1, w->g_head4_b, 2, s);
+}

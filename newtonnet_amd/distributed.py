@@ -36,9 +36,10 @@ def shard_molecules(atoms_per_molecule: Sequence[int], world_size: int) -> List[
 
 def allreduce_counts(n_energy: int, n_force: int, device, group=None) -> Tuple[float, float]:
     """Global number of energy / force-component elements in this step (one tiny all-reduce)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(n_energy), float(n_force)            # (no device work, no sync)
     t = torch.tensor([float(n_energy), float(n_force)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t[0]), float(t[1])
 
 
@@ -87,10 +88,55 @@ class TrainStep:
     loss = w_E * MSE(E) + w_F * MSE(F), clip_grad_norm_, optimizer.step -- data-parallel over molecules."""
     def __init__(self, model, optimizer, w_energy: float = 1.0, w_force: float = 50.0, clip_grad: float = 1.0,
                  group=None):
+        """optimizer: a torch optimizer (the step is then autograd through the model's fused node + torch clipping + the
+        optimizer), or a FusedClipAdam (its max_norm is the clipping; `clip_grad` is ignored): the step then runs with NO
+        autograd and no per-parameter tensors -- exact neighbor list, value sweeps, loss and its gradient, tangent sweeps,
+        weight gradients, one all-reduce of the flat gradient, clip + Adam -- for batches of any (changing) structure."""
         self.model, self.optimizer = model, optimizer
         self.w_energy, self.w_force, self.clip_grad, self.group = w_energy, w_force, clip_grad, group
+        self.fused = isinstance(optimizer, FusedClipAdam)
+        self._loss = self._gE = self._gF = None
+
+    def _call_fused(self, z, pos, cell, batch, energy_label, force_label):
+        from newtonnet_amd import hip, train_fused
+        model, dev = self.model, pos.device
+        if not model.training:
+            raise RuntimeError('TrainStep needs model.train()')
+        if not train_fused.supported(model, list(model.output_properties)):
+            raise NotImplementedError("FusedClipAdam / the fused step needs output_properties ['energy', 'gradient_force'] and "
+                                      'layer_norm=False')
+        emb = model.embedding_layers.edge_embedding
+        n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), dev, self.group)
+        zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
+        bc = batch.contiguous() if batch.dtype == torch.int64 else batch.long().contiguous()
+        pd, cd = hip._f32c(pos.detach(), 'pos'), hip._f32c(cell.detach(), 'cell')
+        e_lab, f_lab = hip._f32c(energy_label.detach(), 'energy_label'), hip._f32c(force_label.detach(), 'force_label')
+        N, B = pd.shape[0], cd.shape[0]
+        if e_lab.numel() != B or f_lab.numel() != 3 * N:
+            raise ValueError(f'labels of shape {tuple(energy_label.shape)}, {tuple(force_label.shape)} for {B} molecules, {N} atoms')
+        with torch.no_grad():
+            g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
+            ws = train_fused.acquire_workspace(model, g, dev)
+            if self._loss is None or self._loss.device != dev:
+                self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            if self._gE is None or self._gE.shape[0] != B or self._gF.shape[0] != N or self._gE.device != dev:
+                self._gE = torch.empty(B, dtype=torch.float32, device=dev)
+                self._gF = torch.empty(N, 3, dtype=torch.float32, device=dev)
+            norm = torch.tensor([self.w_energy / n_e, self.w_force / n_f], dtype=torch.float32).to(dev, non_blocking=True)
+            runner = train_fused.Runner(model, zc, pd, cd, bc, g, ws)
+            runner.values()
+            hip._check(hip.lib().nnhip_mse_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab),
+                                                     3 * N, hip._ptr(norm), hip._ptr(self._loss), hip._ptr(self._gE),
+                                                     hip._ptr(self._gF), hip._stream(dev)), 'nnhip_mse_loss_grad')
+            runner.grads(self._gE, self._gF)
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(ws.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.optimizer.step(ws.flat_grad)
+            return self._loss[0].clone()
 
     def __call__(self, z, pos, cell, batch, energy_label, force_label):
+        if self.fused:
+            return self._call_fused(z, pos, cell, batch, energy_label, force_label)
         self.optimizer.zero_grad(set_to_none=True)
         n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), pos.device, self.group)
         pos = pos.detach().clone().requires_grad_(True)

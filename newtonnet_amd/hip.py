@@ -71,6 +71,33 @@ class ColsumProblem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('out', C.c_void_p), ('rows', C.c_int32), ('pad_', C.c_int32)]
 
 
+def _train_ws_fields():
+    L, vp, i32 = NNHIP_MAX_LAYERS, C.c_void_p, C.c_int32
+    one = lambda *names: [(n, vp) for n in names]            # noqa: E731
+    per = lambda *names: [(n, vp * L) for n in names]        # noqa: E731
+    return ([(n, i32) for n in ('n_atoms', 'n_edges', 'n_mol', 'n_layers', 'n_basis', 'envelope', 'bf16_wgrad', 'pad_')]
+            + one('z', 'pos', 'cell', 'batch', 'mol_ptr', 'row_ptr', 'col', 'rev', 'pid', 'edge_index', 'geo', 'disp', 'rbf',
+                  'drbf', 'xg')
+            + [('wT', (vp * 7) * L), ('headT', vp * 2)] + per('ftab')
+            + one('a0') + per('hn', 'm', 'msg', 'h1', 'h2', 'phi1', 'phi2', 'a_mid', 'a_out', 'f_out', 'q')
+            + one('e1', 'e2', 'g_e2', 'atom_energy', 'energy', 'forces')
+            + one('t_e1') + per('GA', 'gf') + [('Gf', vp * 2)] + per('g_h12', 't1', 't2', 'g_msg', 'g_m', 't_n')
+            + one('g_x', 'g_u', 'g_d')
+            + one('tgeo', 'da_mid') + per('da_out', 'dhn', 'dm', 'dmsg', 'dh1', 'dh2', 'dphi1', 'dphi2', 'df_out', 'dq')
+            + one('de1', 'de2')
+            + one('dg_e2', 'w4row', 'scal', 'dg_e1', 'dGA', 'dgf') + [('dGf', vp * 2)]
+            + per('gq', 'dgq', 'dg_h12', 'dg_h1', 'dg_h2') + one('dg_msg') + per('g_eps', 'dg_eps', 'dg_m', 'dg_hn')
+            + one('rb', 'zeros_nf')
+            + one('probs', 'sums', 'slabs', 'cs_scratch', 'sp_scratch')
+            + [(n, i32) for n in ('n_probs', 'chunks', 'n_sums', 'pad2_')]
+            + one('g_embedding', 'g_scale', 'g_shift', 'g_head4_b'))
+
+
+class TrainWs(C.Structure):
+    """nnhip_train_ws: device pointers of one training step (newtonnet_amd/train_fused.py:TrainWorkspace fills it)."""
+    _fields_ = _train_ws_fields()
+
+
 MODE_FWD, MODE_BWD, MODE_TAN, MODE_TAN2 = 0, 1, 2, 3
 WG_PLAIN, WG_ACT, WG_TDACT = 0, 1, 2
 
@@ -164,12 +191,15 @@ def lib():
     L.nnhip_wgrad_slab_bytes.restype = sz
     L.nnhip_wgrad_batch.argtypes = [vp, i32, i32, vp, i32, i32, vp]
     L.nnhip_colsum_batch.argtypes = [vp, i32, vp, vp]
+    L.nnhip_train_values.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp]
+    L.nnhip_train_grads.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp, vp, vp]
+    L.nnhip_train_ws_bytes.restype = sz
     L.nnhip_mse_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.nnhip_clip_adam_scratch_bytes.restype = sz
     L.nnhip_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, f32, f32, f32, f32, f32, vp]
     for fn in STAGE_SYMBOLS:
         if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes', 'nnhip_species_scratch_bytes',
-                      'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes'):
+                      'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_ws_bytes'):
             getattr(L, fn).restype = C.c_int
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
@@ -187,7 +217,8 @@ STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables
                  'nnhip_message_tan_bwd', 'nnhip_update_tan_fwd', 'nnhip_update_tan_bwd', 'nnhip_head_seed_tan',
                  'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_species_scratch_bytes', 'nnhip_wgrad_slab_bytes',
                  'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad',
-                 'nnhip_clip_adam', 'nnhip_clip_adam_scratch_bytes')
+                 'nnhip_clip_adam', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_values', 'nnhip_train_grads',
+                 'nnhip_train_ws_bytes')
 
 EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',

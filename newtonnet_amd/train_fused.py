@@ -191,6 +191,37 @@ class TrainWorkspace:
         self.chunks = max(1, min(256, (max(P, N) + 31) // 32))
         self.slabs = torch.empty(hip.lib().nnhip_wgrad_slab_bytes(self.n_probs, self.chunks) // 4, dtype=torch.float32,
                                  device=device)
+        self._c_view(model, G)
+
+    def _c_view(self, model, G):
+        """nnhip_train_ws (include/newtonnet_hip.h): every buffer above by device pointer; the batch/graph fields are set per
+        step by Runner._bind."""
+        if C.sizeof(hip.TrainWs) != hip.lib().nnhip_train_ws_bytes():
+            raise RuntimeError('nnhip_train_ws: the ctypes mirror and the library disagree (stale libnewtonnet_hip.so?)')
+        c = self.c = hip.TrainWs()
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        emb = model.embedding_layers.edge_embedding
+        c.n_atoms, c.n_mol, c.n_layers, c.n_basis, c.envelope = self.N, self.B, self.L, emb.n_basis, emb.envelope_id
+        for name, _ in hip.TrainWs._fields_:
+            v = getattr(self, name, None)
+            if name in ('wT',):
+                for l in range(self.L):
+                    for k in range(7):
+                        c.wT[l][k] = ptr(self.wT[l][k])
+            elif isinstance(v, list):
+                arr = getattr(c, name)
+                for l, t in enumerate(v):
+                    arr[l] = ptr(t)
+            elif isinstance(v, torch.Tensor):
+                setattr(c, name, ptr(v))
+        c.probs, c.sums = ptr(self.prob_dev), ptr(self.sum_dev)
+        c.n_probs, c.chunks, c.n_sums = self.n_probs, self.chunks, self.n_sums
+        sc = model.scalers[list(model.output_properties).index('energy')]
+        c.g_embedding = ptr(G(model.embedding_layers.node_embedding.weight))
+        c.g_scale = ptr(G(sc.scale.weight)) if sc.scale is not None else None
+        c.g_shift = ptr(G(sc.shift.weight)) if sc.shift is not None else None
+        c.g_head4_b = ptr(self.g_head4_b)
+        self.model_c, self.model_key = None, None
 
 
 class Runner:
@@ -215,213 +246,33 @@ class Runner:
         """the CURRENT torch stream at the time of the call (a HIP-graph capture runs on its own stream)"""
         return hip._stream(self.pos.device)
 
-    # -- small helpers ------------------------------------------------------------------------------------------------
-    def _desc(self, mode, X, W1, W2, H, Y, M, *, ldx=F, b1=None, b2=None, accumulate=False, T=None, T2=None, Hd=None, G=None,
-              x_off=0):
-        d = hip.MlpDesc()
-        d.X, d.ldx = _p(X, x_off).value, ldx
-        d.W1, d.W2 = _p(W1).value, _p(W2).value
-        d.b1, d.b2 = (_p(b1).value if b1 is not None else None), (_p(b2).value if b2 is not None else None)
-        d.H, d.ldh, d.Y, d.ldy = _p(H).value, F, _p(Y).value, F
-        d.M, d.mode, d.accumulate, d.activation = M, mode, 1 if accumulate else 0, self.act
-        d.T = _p(T).value if T is not None else None
-        d.T2 = _p(T2).value if T2 is not None else None
-        d.Hd = _p(Hd).value if Hd is not None else None
-        d.G = _p(G).value if G is not None else None
-        return d
+    def _bind(self):
+        """The C view of this step: the workspace's table of device pointers + this batch's graph, and the model's parameters."""
+        ws, g, c = self.ws, self.g, self.ws.c
+        key = tuple(p.data_ptr() for p in ws.params)
+        if ws.model_key != key:           # (parameters re-allocated, e.g. by model.to(): rebuild the pointer table)
+            ws.model_c, ws.model_key = self.model._hip_model(self.energy_idx), key
+        c.n_edges = g.n_edges
+        c.bf16_wgrad = 1 if self.bf16 else 0
+        for name, t in (('z', self.z), ('pos', self.pos), ('cell', self.cell), ('batch', self.batch), ('mol_ptr', g.mol_ptr),
+                        ('row_ptr', g.row_ptr), ('col', g.col), ('rev', g.rev), ('pid', g.pid), ('edge_index', g.edge_index),
+                        ('geo', g.geo), ('disp', g.disp), ('rbf', g.rbf), ('drbf', g.drbf), ('xg', g.xg)):
+            setattr(c, name, t.data_ptr())
+        return C.byref(ws.model_c), C.byref(c)
 
-    def _mlp(self, mode, X, W1, W2, H, Y, M, **kw):
-        if M > 0:
-            _chk(hip.lib().nnhip_mlp128_ex(C.byref(self._desc(mode, X, W1, W2, H, Y, M, **kw)), self.st), 'nnhip_mlp128_ex')
-
-    def _mlp2(self, d0, d1):
-        """equiv_message1 | equiv_message2 (or their adjoints / tangents) over the same pair rows in one launch"""
-        if d0.M > 0:
-            _chk(hip.lib().nnhip_mlp128_pair_ex(C.byref(d0), C.byref(d1), self.st), 'nnhip_mlp128_pair_ex')
-
-    def _lin(self, A, W, out, M, acc=False):
-        if M > 0:
-            _chk(hip.lib().nnhip_linear128(_p(A), F, _p(W), _p(out), F, None, None, 0, M, hip.PRO_NONE,
-                                           hip.EPI_ACC if acc else hip.EPI_STORE, self.st), 'nnhip_linear128')
-
-    def _prepare(self):
-        """Parameter-only data of this step: transposed weights (one launch) and the radial-filter tables (one launch)."""
-        L_, ws, model = hip.lib(), self.ws, self.model
-        src, dst = [], []
-        for l, il in enumerate(model.interaction_layers):
-            for k, w in enumerate((il.message_nodepart[0].weight, il.message_nodepart[2].weight, il.equiv_message1[0].weight,
-                                   il.equiv_message1[2].weight, il.equiv_message2[0].weight, il.equiv_message2[2].weight,
-                                   il.equiv_update.weight)):
-                src.append(w)
-                dst.append(ws.wT[l][k])
-        head = model.output_layers[self.energy_idx].layers
-        src += [head[0].weight, head[2].weight]
-        dst += ws.headT
-        for o in range(0, len(src), 40):
-            n = min(40, len(src) - o)
-            a = (_vp * n)(*[t.data_ptr() for t in src[o:o + n]])
-            b = (_vp * n)(*[t.data_ptr() for t in dst[o:o + n]])
-            _chk(L_.nnhip_transpose128(a, b, n, self.st), 'nnhip_transpose128')
-        n = ws.L
-        ew = (_vp * n)(*[il.message_edgepart.weight.data_ptr() for il in model.interaction_layers])
-        tb = (_vp * n)(*[t.data_ptr() for t in ws.ftab])
-        emb = model.embedding_layers.edge_embedding
-        _chk(L_.nnhip_filter_tables(ew, tb, n, _p(emb.embedding.frequencies), emb.n_basis, emb.envelope_id, self.st),
-             'nnhip_filter_tables')
-
-    # -- sweeps 1 and 2: values ------------------------------------------------------------------------------------------
+    # -- sweeps 1 and 2: values (csrc/train_step.hip strings the stages together) ------------------------------------------
     def values(self):
-        L_, ws, g, model, st, act = hip.lib(), self.ws, self.g, self.model, self.st, self.act
-        N, B, L = ws.N, ws.B, ws.L
-        E, P = g.n_edges, g.n_edges // 2                     # this batch's own counts (the workspace holds capacities)
-        self._prepare()
-        layers = list(model.interaction_layers)
-        head = model.output_layers[self.energy_idx].layers
-        sc = model.scalers[self.energy_idx]
-        z = self.z
-        idx = (_p(g.row_ptr), _p(g.col), _p(g.pid))
-        _chk(L_.nnhip_embed(_p(z), _p(model.embedding_layers.node_embedding.weight), N, _p(ws.a0), st), 'nnhip_embed')
-        n0 = layers[0].message_nodepart
-        self._mlp(hip.MODE_FWD, ws.a0, n0[0].weight, n0[2].weight, ws.hn[0], ws.m[0], N, b1=n0[0].bias, b2=n0[2].bias)
-        a_in, f_in = ws.a0, None
-        for l, il in enumerate(layers):
-            _chk(L_.nnhip_message_fwd(_p(ws.m[l]), _p(g.xg), _p(ws.ftab[l]), *idx, _p(a_in), _p(ws.msg[l]), _p(ws.a_mid[l]), N, st),
-                 'nnhip_message_fwd')
-            e1w, e2w = il.equiv_message1, il.equiv_message2
-            if l > 0:
-                self._mlp2(self._desc(hip.MODE_FWD, ws.msg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.phi1[l], P),
-                           self._desc(hip.MODE_FWD, ws.msg[l], e2w[0].weight, e2w[2].weight, ws.h2[l], ws.phi2[l], P))
-            else:
-                self._mlp(hip.MODE_FWD, ws.msg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.phi1[l], P)
-            _chk(L_.nnhip_force_message_fwd(_p(ws.phi1[l]), _p(ws.phi2[l]), _p(g.geo), _p(g.xg), *idx, _p(f_in), _p(ws.f_out[l]),
-                                            N, st), 'nnhip_force_message_fwd')
-            if l + 1 < L:
-                nx = layers[l + 1].message_nodepart
-                nxt = (nx[0].weight, nx[0].bias, nx[2].weight, nx[2].bias, ws.hn[l + 1], ws.m[l + 1])
-            else:
-                nxt = (head[0].weight, head[0].bias, head[2].weight, head[2].bias, ws.e1, ws.e2)
-            _chk(L_.nnhip_node_fwd(_p(ws.f_out[l]), _p(ws.a_mid[l]), _p(il.equiv_update.weight), _p(ws.q[l]), _p(ws.a_out[l]),
-                                   *[_p(t) for t in nxt], N, act, st), 'nnhip_node_fwd')
-            a_in, f_in = ws.a_out[l], ws.f_out[l]
-        _chk(L_.nnhip_head_out(_p(ws.e2), _p(head[4].weight), _p(head[4].bias),
-                               _p(sc.scale.weight) if sc.scale is not None else None,
-                               _p(sc.shift.weight) if sc.shift is not None else None, _p(z), _p(g.mol_ptr), N, B, act,
-                               _p(ws.atom_energy), _p(ws.g_e2), _p(ws.energy), st), 'nnhip_head_out')
-        # ---- reverse (seed 1)
-        self._mlp(hip.MODE_TAN, ws.g_e2, ws.headT[1], ws.headT[0], ws.e1, ws.GA[L - 1], N, T=ws.t_e1)
-        _chk(L_.nnhip_node_bwd(None, None, None, None, _p(ws.GA[L - 1]), 0, _p(ws.f_out[L - 1]), _p(ws.q[L - 1]), None,
-                               _p(ws.wT[L - 1][6]), _p(ws.gf[L - 1]), N, act, st), 'nnhip_node_bwd')
-        pp = 0
-        for l in range(L - 1, -1, -1):
-            f_prev = ws.f_out[l - 1] if l > 0 else None
-            Gf = ws.Gf[pp]
-            _chk(L_.nnhip_force_message_bwd(_p(ws.gf[l]), _p(ws.phi1[l]), _p(ws.phi2[l]), _p(g.geo), _p(g.xg), *idx, _p(f_prev),
-                                            _p(ws.g_h12[l]), _p(ws.g_u, 4 * l * E), _p(Gf), N, st), 'nnhip_force_message_bwd')
-            d1 = self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.g_msg[l], P, ldx=2 * F, T=ws.t1[l])
-            if l > 0:
-                self._mlp2(d1, self._desc(hip.MODE_TAN, ws.g_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.g_msg[l], P, ldx=2 * F,
-                                          T=ws.t2[l], accumulate=True, x_off=F))
-            elif P > 0:
-                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
-            _chk(L_.nnhip_message_bwd(_p(ws.g_msg[l]), _p(ws.GA[l]), _p(ws.m[l]), _p(g.xg), _p(ws.ftab[l]), *idx,
-                                      _p(ws.g_m[l]) if l > 0 else None, _p(ws.g_x, l * E), N, 1 if l > 0 else 0, st),
-                 'nnhip_message_bwd')
-            if l > 0:
-                ws.GA[l - 1].copy_(ws.GA[l])
-                self._mlp(hip.MODE_TAN, ws.g_m[l], ws.wT[l][1], ws.wT[l][0], ws.hn[l], ws.GA[l - 1], N, T=ws.t_n[l],
-                          accumulate=True)
-                _chk(L_.nnhip_node_bwd(None, None, None, None, _p(ws.GA[l - 1]), 0, _p(ws.f_out[l - 1]), _p(ws.q[l - 1]), _p(Gf),
-                                       _p(ws.wT[l - 1][6]), _p(ws.gf[l - 1]), N, act, st), 'nnhip_node_bwd')
-            pp ^= 1
-        emb = model.embedding_layers.edge_embedding
-        _chk(L_.nnhip_edge_embed_bwd(_p(ws.g_x), _p(ws.g_u), _p(g.geo), _p(g.disp), _p(self.pos), _p(self.cell), _p(g.row_ptr),
-                                     _p(g.col), _p(g.rev), _p(g.mol_ptr), N, E, B, L, float(emb.cutoff), _p(ws.g_d),
-                                     _p(ws.forces), None, st), 'nnhip_edge_embed_bwd')
-        return ws.energy, ws.forces
+        m, c = self._bind()
+        _chk(hip.lib().nnhip_train_values(m, c, self.st), 'nnhip_train_values')
+        return self.ws.energy, self.ws.forces
 
     # -- sweeps 3 and 4: tangents, then the weight gradients ---------------------------------------------------------------
     def grads(self, g_energy: torch.Tensor, g_forces: torch.Tensor):
-        L_, ws, g, model, st, act = hip.lib(), self.ws, self.g, self.model, self.st, self.act
-        N, B, L = ws.N, ws.B, ws.L
-        E, P = g.n_edges, g.n_edges // 2
-        layers = list(model.interaction_layers)
-        head = model.output_layers[self.energy_idx].layers
-        sc = model.scalers[self.energy_idx]
-        emb = model.embedding_layers.edge_embedding
-        idx = (_p(g.row_ptr), _p(g.col), _p(g.pid))
-        g_forces = g_forces.reshape(N, 3).to(torch.float32).contiguous()
+        ws = self.ws
+        g_forces = g_forces.reshape(ws.N, 3).to(torch.float32).contiguous()
         g_energy = g_energy.to(torch.float32).contiguous()
-        # ---- sweep 3: tangent forward along v = -dL/dF
-        _chk(L_.nnhip_edge_tangent_geom(_p(g_forces), -1.0, _p(g.edge_index), _p(g.geo), E, float(emb.cutoff), _p(ws.tgeo), st),
-             'nnhip_edge_tangent_geom')
-        for l, il in enumerate(layers):
-            first = l == 0
-            da_in = None if first else ws.da_out[l - 1]
-            _chk(L_.nnhip_message_tan_fwd(_p(ws.m[l]), None if first else _p(ws.dm[l]), _p(g.xg), _p(ws.tgeo), _p(ws.ftab[l]), *idx,
-                                          _p(da_in), _p(ws.dmsg[l]), _p(ws.da_mid), N, st), 'nnhip_message_tan_fwd')
-            e1w, e2w = il.equiv_message1, il.equiv_message2
-            d1 = self._desc(hip.MODE_TAN, ws.dmsg[l], e1w[0].weight, e1w[2].weight, ws.h1[l], ws.dphi1[l], P, T=ws.dh1[l])
-            if not first:
-                self._mlp2(d1, self._desc(hip.MODE_TAN, ws.dmsg[l], e2w[0].weight, e2w[2].weight, ws.h2[l], ws.dphi2[l], P,
-                                          T=ws.dh2[l]))
-            elif P > 0:
-                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
-            _chk(L_.nnhip_force_message_tan_fwd(_p(ws.phi1[l]), _p(ws.dphi1[l]), _p(ws.phi2[l]), _p(ws.dphi2[l]), _p(g.geo),
-                                                _p(ws.tgeo), _p(g.xg), *idx, None if first else _p(ws.f_out[l - 1]),
-                                                None if first else _p(ws.df_out[l - 1]), _p(ws.df_out[l]), N, st),
-                 'nnhip_force_message_tan_fwd')
-            self._lin(ws.df_out[l], il.equiv_update.weight, ws.dq[l], 3 * N)
-            _chk(L_.nnhip_update_tan_fwd(_p(ws.da_mid), _p(ws.f_out[l]), _p(ws.df_out[l]), _p(ws.q[l]), _p(ws.dq[l]), N,
-                                         _p(ws.da_out[l]), st), 'nnhip_update_tan_fwd')
-            if l + 1 < L:
-                nx = layers[l + 1].message_nodepart
-                self._mlp(hip.MODE_TAN, ws.da_out[l], nx[0].weight, nx[2].weight, ws.hn[l + 1], ws.dm[l + 1], N, T=ws.dhn[l + 1])
-            else:
-                self._mlp(hip.MODE_TAN, ws.da_out[l], head[0].weight, head[2].weight, ws.e1, ws.de2, N, T=ws.de1)
-        # ---- sweep 4: tangent reverse, seed tangent c = dL/dE
-        _chk(L_.nnhip_head_seed_tan(_p(ws.e2), _p(ws.de2), _p(head[4].weight), _p(head[4].bias),
-                                    _p(sc.scale.weight) if sc.scale is not None else None, _p(self.z), _p(self.batch),
-                                    _p(g_energy), N, act, _p(ws.dg_e2), _p(ws.w4row), _p(ws.scal), st), 'nnhip_head_seed_tan')
-        self._mlp(hip.MODE_TAN2, ws.dg_e2, ws.headT[1], ws.headT[0], ws.e1, ws.dGA, N, T2=ws.t_e1, Hd=ws.de1, G=ws.dg_e1)
-        dGf, pp = None, 0
-        for l in range(L - 1, -1, -1):
-            first = l == 0
-            _chk(L_.nnhip_update_tan_bwd(_p(ws.GA[l]), _p(ws.dGA), _p(ws.f_out[l]), _p(ws.df_out[l]), _p(ws.q[l]), _p(ws.dq[l]),
-                                         _p(dGf), N, _p(ws.gq[l]), _p(ws.dgq[l]), _p(ws.dgf), st), 'nnhip_update_tan_bwd')
-            self._lin(ws.dgq[l], ws.wT[l][6], ws.dgf, 3 * N, acc=True)
-            nxt = ws.dGf[pp]
-            _chk(L_.nnhip_force_message_tan_bwd(_p(ws.gf[l]), _p(ws.dgf), _p(ws.phi2[l]), _p(ws.dphi2[l]), _p(g.geo), _p(ws.tgeo),
-                                                _p(g.xg), *idx, None if first else _p(ws.f_out[l - 1]),
-                                                None if first else _p(ws.df_out[l - 1]), _p(ws.dg_h12[l]),
-                                                None if first else _p(nxt), N, st), 'nnhip_force_message_tan_bwd')
-            d1 = self._desc(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][3], ws.wT[l][2], ws.h1[l], ws.dg_msg, P, ldx=2 * F, T2=ws.t1[l],
-                            Hd=ws.dh1[l], G=ws.dg_h1[l])
-            if not first:
-                self._mlp2(d1, self._desc(hip.MODE_TAN2, ws.dg_h12[l], ws.wT[l][5], ws.wT[l][4], ws.h2[l], ws.dg_msg, P, ldx=2 * F,
-                                          T2=ws.t2[l], Hd=ws.dh2[l], G=ws.dg_h2[l], accumulate=True, x_off=F))
-            elif P > 0:
-                _chk(L_.nnhip_mlp128_ex(C.byref(d1), st), 'nnhip_mlp128_ex')
-            _chk(L_.nnhip_message_tan_bwd(_p(ws.g_msg[l]), _p(ws.dg_msg), _p(ws.GA[l]), _p(ws.dGA), _p(ws.m[l]),
-                                          None if first else _p(ws.dm[l]), _p(g.xg), _p(ws.tgeo), _p(ws.ftab[l]), *idx,
-                                          _p(ws.dg_m[l]), _p(ws.g_eps[l]), _p(ws.dg_eps[l]), N, st), 'nnhip_message_tan_bwd')
-            self._mlp(hip.MODE_TAN2, ws.dg_m[l], ws.wT[l][1], ws.wT[l][0], ws.hn[l], ws.dGA, N,
-                      T2=ws.zeros_nf if first else ws.t_n[l], Hd=ws.zeros_nf if first else ws.dhn[l], G=ws.dg_hn[l], accumulate=True)
-            dGf = nxt
-            pp ^= 1
-        # ---- weight gradients: one batched split-K launch + its reduction, column sums, per-element sums
-        _chk(L_.nnhip_pair_rbf(_p(g.rbf), _p(g.drbf), _p(ws.tgeo), _p(g.edge_index), _p(g.pid), E, emb.n_basis, _p(ws.rb), st),
-             'nnhip_pair_rbf')
-        _chk(L_.nnhip_wgrad_batch(_p(ws.prob_dev), ws.n_probs, ws.chunks, _p(ws.slabs), 1 if self.bf16 else 0, P, st),
-             'nnhip_wgrad_batch')
-        _chk(L_.nnhip_colsum_batch(_p(ws.sum_dev), ws.n_sums, _p(ws.cs_scratch), st), 'nnhip_colsum_batch')
-        gmap = {id(p): gr for p, gr in zip(ws.params, ws.grads)}
-        _chk(L_.nnhip_species_sum(_p(ws.dGA), F, F, _p(self.z), N, _p(ws.sp_scratch),
-                                  _p(gmap[id(model.embedding_layers.node_embedding.weight)]), 0, F, F, None, 0, 0, 0, None, 0, st),
-             'nnhip_species_sum')
-        _chk(L_.nnhip_species_sum(_p(ws.scal), 4, 4, _p(self.z), N, _p(ws.sp_scratch),
-                                  _p(gmap[id(sc.scale.weight)]) if sc.scale is not None else None, 0, 1, 1,
-                                  _p(gmap[id(sc.shift.weight)]) if sc.shift is not None else None, 1, 1, 1,
-                                  _p(ws.g_head4_b), 2, st), 'nnhip_species_sum')
+        m, c = self._bind()
+        _chk(hip.lib().nnhip_train_grads(m, c, _p(g_energy), _p(g_forces), self.st), 'nnhip_train_grads')
         return ws.grads
 
 
@@ -455,6 +306,23 @@ class FusedEnergyForces(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
+def acquire_workspace(model, g: hip.Graph, device, static: bool = False) -> TrainWorkspace:
+    """A free workspace of the model's cache that fits the batch behind `g` (same N and B, at least its edge count, same
+    parameter objects), or a new one."""
+    cache = model.__dict__.setdefault('_train_ws', [])
+    params = trainable_parameters(model)
+    ws = next((w for w in cache if not w.busy and (w.N, w.B, w.energy.device) == (g.n_atoms, g.n_mol, device)
+               and g.n_edges <= w.E and all(a is b for a, b in zip(w.params, params))), None)
+    if ws is None:
+        # capacity: real batches differ in their edge count from step to step -- leave 12.5 % head room (even, >= 64) so that
+        # the next batches of the same shape reuse the buffers and the uploaded problem tables
+        e_cap = g.n_edges if static else ((g.n_edges + g.n_edges // 8 + 64) & ~1)
+        ws = TrainWorkspace(model, g.n_atoms, e_cap, g.n_mol, device)
+        cache[:] = [w for w in cache if w.busy or (w.N, w.B) != (ws.N, ws.B)][-3:]   # superseded capacities go, a few shapes stay
+        cache.append(ws)
+    return ws
+
+
 def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None):
     """Train-mode energy + gradient_force through the fused node.  `graph`: a static candidate list (GraphedTrainStep) whose
     geometry is refreshed at `pos`; otherwise the exact list is built (one host sync for the edge count).
@@ -469,17 +337,7 @@ def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None)
             g = hip.refresh_graph(graph, pd, cd, bc, emb.cutoff, emb.embedding.frequencies)
         else:
             g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
-    cache = model.__dict__.setdefault('_train_ws', [])
-    params = trainable_parameters(model)
-    ws = next((w for w in cache if not w.busy and (w.N, w.B, w.energy.device) == (g.n_atoms, g.n_mol, pos.device)
-               and g.n_edges <= w.E and all(a is b for a, b in zip(w.params, params))), None)
-    if ws is None:
-        # capacity: real batches differ in their edge count from step to step -- leave 12.5 % head room (even, >= 64) so that
-        # the next batches of the same shape reuse the buffers and the uploaded problem tables
-        e_cap = g.n_edges if graph is not None else ((g.n_edges + g.n_edges // 8 + 64) & ~1)
-        ws = TrainWorkspace(model, g.n_atoms, e_cap, g.n_mol, pos.device)
-        cache[:] = [w for w in cache if w.busy or (w.N, w.B) != (ws.N, ws.B)][-3:]   # superseded capacities go, a few shapes stay
-        cache.append(ws)
+    ws = acquire_workspace(model, g, pos.device, static=graph is not None)
     ws.busy = torch.is_grad_enabled()
     runner = Runner(model, zc, pd, cd, bc, g, ws)
     energy, forces = FusedEnergyForces.apply(pos, runner, *ws.params)

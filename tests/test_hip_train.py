@@ -408,6 +408,17 @@ def test_fully_fused_graphed_step_matches_torch_optimizer():
     for (k, a), b in zip(m_e.state_dict().items(), m_f.state_dict().values()):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4, err_msg=k)
     assert float(opt.state[0]) == len(seq)
+    # the same step without capture (TrainStep + FusedClipAdam: exact neighbor list every step, any structure)
+    torch.manual_seed(0)
+    m_n = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+    m_n.train()
+    plain = TrainStep(m_n, FusedClipAdam(m_n, lr=1e-3, max_norm=1.0), 1.0, 50.0)
+    assert plain.fused
+    l_n = [float(plain(*batch_of(B, s))) for B, s in seq]
+    np.testing.assert_allclose(l_n, l_e, rtol=2e-4)
+    for (k, a), b in zip(m_e.state_dict().items(), m_n.state_dict().values()):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=2e-4, err_msg=k)
+    assert len(m_n._train_ws) == 2          # one workspace per (N, B) shape, reused across the changing edge counts
     # the flat layout survives: every trainable parameter is a view of the one buffer the optimizer updates
     base = m_f._flat_params.data_ptr()
     assert all(base <= p.data_ptr() < base + 4 * m_f._flat_params.numel() for n, p in m_f.named_parameters() if 'frequencies' not in n)

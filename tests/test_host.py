@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.nnhip_version() >= 100
 
 
+def test_train_ws_mirror_matches_header():
+    """The ctypes mirror of nnhip_train_ws lists the header's members in the header's order, and has the library's size."""
+    import ctypes as C
+    from newtonnet_amd import hip
+    text = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'newtonnet_hip.h')).read()
+    body = text[:text.index('} nnhip_train_ws;')]
+    body = re.sub(r'/\*.*?\*/', '', body[body.rindex('typedef struct {'):], flags=re.S)
+    names = []
+    for stmt in body.split(';'):
+        stmt = stmt.replace('typedef struct {', '')
+        if not stmt.strip():
+            continue
+        # "const float* a, b_" / "float* hn[NNHIP_MAX_LAYERS]" / "int32_t n_atoms, n_edges"
+        decl = re.sub(r'^\s*(const\s+)?\w+\s*\*?\s*', '', stmt.strip())
+        names += [re.match(r'\*?\s*(\w+)', part.strip()).group(1) for part in decl.split(',')]
+    assert names == [n for n, _ in hip.TrainWs._fields_]
+    assert C.sizeof(hip.TrainWs) == hip.lib().nnhip_train_ws_bytes()
+
+
 def test_workspace_layout_is_consistent():
     from newtonnet_amd import hip
     lay = hip.workspace_layout(21504, 310406, 1024, 3)

@@ -75,6 +75,11 @@ def main():
         mf.train()
         fstep = GraphedTrainStep(mf, FusedClipAdam(mf, lr=1e-3, max_norm=1.0), 1.0, 50.0, assume_static=True)
         res['all_hip_graph'] = timeit(lambda: fstep(*args), 3, 30)
+        torch.manual_seed(0)
+        mn = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
+        mn.train()
+        nstep = TrainStep(mn, FusedClipAdam(mn, lr=1e-3, max_norm=1.0), 1.0, 50.0)
+        res['all_hip_eager'] = timeit(lambda: nstep(*args), 3, 30)
         os.environ['NNHIP_TRAIN_BF16'] = '1'           # bf16-operand weight-gradient products (fp32 everywhere else)
         torch.manual_seed(0)
         mb = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
