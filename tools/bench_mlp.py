@@ -21,6 +21,8 @@ for M in [int(a) for a in sys.argv[1:]] or [1000, 21504, 313006]:
     hip.mlp128(X, W1, W2, H, Y, 0)
     Hr = (X.double() @ W1.double().T); Yr = torch.nn.functional.silu(Hr) @ W2.double().T
     e_h, e_y = (H.double() - Hr).abs().max().item(), (Y.double() - Yr).abs().max().item()
+    rel = lambda a, b: ((a.double() - b).norm() / b.norm()).item()  # noqa: E731
+    r_h, r_y = rel(H, Hr), rel(Y, Yr)
     # adjoint: G = (Xg W1^T) * silu'(H), Yb = G W2^T (+ old)
     Xg = torch.randn(M, 256, device='cuda')[:, :128]          # strided view (ld = 256)
     Hd = Hr.float().contiguous(); Yb = torch.randn(M, 128, device='cuda'); Y0 = Yb.clone()
@@ -35,5 +37,5 @@ for M in [int(a) for a in sys.argv[1:]] or [1000, 21504, 313006]:
     t_b = timeit(lambda: hip.mlp128(Xg, W1, W2, Hd, Yb, 1))
     t_a = timeit(lambda: hip.mlp128(Xg, W1, W2, Hd, Yb, 1, accumulate=True))
     t_2 = timeit(lambda: (hip.linear128(X, W1, H), hip.linear128(H, W2, Y, prologue=hip.PRO_SILU)))
-    print(f'M={M:7d} err H {e_h:.1e} Y {e_y:.1e} bwd+acc {e_b:.1e} bwd {e_b2:.1e} | fwd {t_f:7.1f}us {fl/t_f/1e6:6.1f}TF | '
+    print(f'M={M:7d} rel-rms H {r_h:.2e} Y {r_y:.2e} bwd {rel(Yb, Ybr):.2e} | err H {e_h:.1e} Y {e_y:.1e} bwd+acc {e_b:.1e} bwd {e_b2:.1e} | fwd {t_f:7.1f}us {fl/t_f/1e6:6.1f}TF | '
           f'bwd {t_b:7.1f}us {fl/t_b/1e6:6.1f}TF | bwd+acc {t_a:7.1f}us | 2x lin128 {t_2:7.1f}us', flush=True)
