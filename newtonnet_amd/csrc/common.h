@@ -310,5 +310,20 @@ struct NodeBwdArgs {
 };
 int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s);
 int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
+// split-f16 forms (node128s.hip): the weights come as prepared (hi, lo) f16 images instead of the fp32 pointers of the arguments
+#define WIMG_BYTES (2 * NF * NF * 2 + 4)   // two f16 planes + the inverse scale
+#define WIMG_MAX_JOBS 40
+struct WeightImageJobs {
+  const float* src[WIMG_MAX_JOBS];
+  char* dst[WIMG_MAX_JOBS];
+};
+struct NodeImages {
+  const char *Wu, *W0, *W2;      // node_fwd: equiv_update, next message_nodepart / head (first, second linear)
+  const char *W2T, *W0T, *WuT;   // node_bwd: their transposes
+};
+int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s);
+int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_t s);
+int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_t s);
+bool split_products_enabled();   // mlp128.hip (NNHIP_MLP_SPLIT=0 turns every split-f16 kernel off)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -158,7 +158,7 @@ __device__ __forceinline__ f32x16 split_block(const char* wrow, const h8 (&bh)[8
   return acc;
 }
 
-template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
+template <int MODE, bool ACCUM_LAST>
 __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(const MlpPair P) {
   extern __shared__ __attribute__((aligned(16))) char img[];
   float* red = reinterpret_cast<float*>(img + 2 * SW_MAT);
@@ -252,14 +252,14 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
             }
           }
 #pragma unroll
-          for (int k = 0; k < 16; ++k) hs[nb][k] = GEN_ACT ? act_f(acc[k], P.a[0].act) : silu_f(acc[k]);
+          for (int k = 0; k < 16; ++k) hs[nb][k] = silu_f(acc[k]);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            hs[nb][4 * q] = acc[4 * q] * (GEN_ACT ? dact_f(hin[q].x, P.a[0].act) : dsilu_f(hin[q].x));
-            hs[nb][4 * q + 1] = acc[4 * q + 1] * (GEN_ACT ? dact_f(hin[q].y, P.a[0].act) : dsilu_f(hin[q].y));
-            hs[nb][4 * q + 2] = acc[4 * q + 2] * (GEN_ACT ? dact_f(hin[q].z, P.a[0].act) : dsilu_f(hin[q].z));
-            hs[nb][4 * q + 3] = acc[4 * q + 3] * (GEN_ACT ? dact_f(hin[q].w, P.a[0].act) : dsilu_f(hin[q].w));
+            hs[nb][4 * q] = acc[4 * q] * dsilu_f(hin[q].x);
+            hs[nb][4 * q + 1] = acc[4 * q + 1] * dsilu_f(hin[q].y);
+            hs[nb][4 * q + 2] = acc[4 * q + 2] * dsilu_f(hin[q].z);
+            hs[nb][4 * q + 3] = acc[4 * q + 3] * dsilu_f(hin[q].w);
           }
         }
       }
@@ -299,13 +299,13 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
       // ---------------- stage 2: Y^T = W2 . act^T
 #pragma unroll
       for (int nb2 = 0; nb2 < 4; ++nb2) {
+        const f32x16 acc = split_block(w2row + nb2 * 32 * SW_PITCH, bh, bl);
         float4 yold[4];
-        if (ACCUM_LAST) {
+        if (ACCUM_LAST) {   // (requested behind the MFMA chain: 16 more live registers across it would spill)
           const float4* yp = reinterpret_cast<const float4*>(p.Y + (size_t)ec * p.ldy + nb2 * 32 + 4 * h);
 #pragma unroll
           for (int q = 0; q < 4; ++q) yold[q] = accum ? yp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const f32x16 acc = split_block(w2row + nb2 * 32 * SW_PITCH, bh, bl);
         if (live) {
           float4* yp = reinterpret_cast<float4*>(p.Y + (size_t)e * p.ldy + nb2 * 32 + 4 * h);
 #pragma unroll
@@ -325,25 +325,24 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
   }
 }
 
-template <int MODE, bool ACCUM_LAST, bool GEN_ACT>
+template <int MODE, bool ACCUM_LAST>
 static int launch_split_t(const MlpPair& a, hipStream_t s) {
-  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp128s_kernel<MODE, ACCUM_LAST, GEN_ACT>,
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp128s_kernel<MODE, ACCUM_LAST>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, MLPS_LDS_BYTES);
   HIP_TRY(attr_rc);
   const int n_tiles = (a.a[0].M + 31) / 32;
   int blocks = cdiv(n_tiles, MLPS_WAVES);
   if (blocks > 256) blocks = 256;  // one persistent workgroup per CU (136 KiB of LDS each)
-  mlp128s_kernel<MODE, ACCUM_LAST, GEN_ACT><<<blocks, MLPS_THREADS, MLPS_LDS_BYTES, s>>>(a);
+  mlp128s_kernel<MODE, ACCUM_LAST><<<blocks, MLPS_THREADS, MLPS_LDS_BYTES, s>>>(a);
   LAUNCH_CHECK();
   return 0;
 }
 
-// (mlp128.hip: launch_mlp_dispatch) forward and adjoint modes of the persistent kernel
+// (mlp128.hip: launch_mlp_dispatch) forward and adjoint modes of the persistent kernel, SiLU
 int launch_mlp_split(int mode, bool accum_last, const MlpPair& P, hipStream_t s) {
-  const bool gen = P.a[0].act != NNHIP_ACT_SILU;
-  if (mode == MODE_FWD && !accum_last) return gen ? launch_split_t<MODE_FWD, false, true>(P, s) : launch_split_t<MODE_FWD, false, false>(P, s);
-  if (mode == MODE_BWD && !accum_last) return gen ? launch_split_t<MODE_BWD, false, true>(P, s) : launch_split_t<MODE_BWD, false, false>(P, s);
-  if (mode == MODE_BWD && accum_last) return gen ? launch_split_t<MODE_BWD, true, true>(P, s) : launch_split_t<MODE_BWD, true, false>(P, s);
+  if (mode == MODE_FWD && !accum_last) return launch_split_t<MODE_FWD, false>(P, s);
+  if (mode == MODE_BWD && !accum_last) return launch_split_t<MODE_BWD, false>(P, s);
+  if (mode == MODE_BWD && accum_last) return launch_split_t<MODE_BWD, true>(P, s);
   nnhip_set_error("launch_mlp_split: unsupported mode %d/%d", mode, (int)accum_last);
   return NNHIP_E_INVALID;
 }

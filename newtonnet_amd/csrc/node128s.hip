@@ -1,0 +1,345 @@
+// Row-local fused node kernels (node128.hip: node_fwd_kernel / node_bwd_kernel) with split-f16 products on the matrix cores.
+//
+// Same stages, same tiling (one 4-wave workgroup per 32 atom rows, wave w = output block w of every GEMM, hand-over through an
+// LDS tile) and the same results contract as the fp32 kernels; the products take the form of mlp128s.hip: every fp32 operand
+// as two scaled f16 pieces, hi_a hi_b + hi_a lo_b + lo_a hi_b on v_mfma_f32_32x32x16_f16 with fp32 accumulation (5.3x less
+// matrix-pipe time than the v_mfma_f32_32x32x2_f32 chain, and closer to fp64).
+//   weights : f16 (hi, lo) images prepared once per parameter set (weight_image_kernel; pipeline.hip keeps them in the
+//             prepared block), scaled per matrix, k-slots permuted to the fragment order -- a wave's A fragments of one GEMM are 16
+//             16-byte loads per lane, as before;
+//   rows    : scaled per row by the largest magnitude of the row.  A row's 128 values live in 8 lanes of 4 waves: each lane
+//             publishes the maximum of its 16 values in LDS BEFORE the barrier that already separates two uses of the tile, so the
+//             exchange costs no extra barrier; the (hi, lo) pieces are written to the LDS tile in fragment order.
+#include <string.h>
+
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define NS_PITCH 272                         // bytes per row of one plane of the LDS tile (128 f16 + 16 pad)
+#define NS_PLANE (32 * NS_PITCH)
+#define NS_LDS_BYTES (2 * NS_PLANE + 8 * 32 * 4)
+#define WIMG_PLANE (NF * NF * 2)             // one f16 plane of a weight image
+
+// ---- weight images ----------------------------------------------------------------------------------------------
+// src: fp32 [128][128] row-major (rows = output features of D^T = W . X^T).  dst: hi plane, lo plane ([out][k-slot] f16, slot
+// 16 T + 8 h + 4 j + c <-> input feature 16 T + 8 j + 4 h + c), then the inverse scale as one float.
+__device__ __forceinline__ void ns_pow2_scale(float m, float& S, float& inv) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  const bool ok = e >= 40 && e < 255;
+  S = ok ? __uint_as_float((unsigned)(268 - e) << 23) : 1.0f;
+  inv = ok ? __uint_as_float((unsigned)(e - 14) << 23) : 1.0f;
+}
+__global__ void __launch_bounds__(1024) weight_image_kernel(WeightImageJobs jobs) {
+  __shared__ float red[16];
+  const float* src = jobs.src[blockIdx.x];
+  char* dst = jobs.dst[blockIdx.x];
+  float4 v[4];
+  float m = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = reinterpret_cast<const float4*>(src)[threadIdx.x + 1024 * q];
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v[q].x)), fmaxf(fabsf(v[q].y), fabsf(v[q].z))), fabsf(v[q].w));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w]);
+  float S, inv;
+  ns_pow2_scale(m, S, inv);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = threadIdx.x + 1024 * q, o = idx >> 5, c = idx & 31;
+    const int off = 2 * (o * NF + (c >> 2) * 16 + (c & 1) * 8 + ((c >> 1) & 1) * 4);
+    const float s[4] = {v[q].x * S, v[q].y * S, v[q].z * S, v[q].w * S};
+    h4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const _Float16 a = (_Float16)s[j];
+      hi[j] = a;
+      lo[j] = (_Float16)(s[j] - (float)a);
+    }
+    *reinterpret_cast<h4*>(dst + off) = hi;
+    *reinterpret_cast<h4*>(dst + WIMG_PLANE + off) = lo;
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float*>(dst + 2 * WIMG_PLANE) = inv;
+}
+int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s) {
+  for (int o = 0; o < n; o += WIMG_MAX_JOBS) {
+    WeightImageJobs jobs;
+    const int c = n - o < WIMG_MAX_JOBS ? n - o : WIMG_MAX_JOBS;
+    for (int k = 0; k < c; ++k) {
+      jobs.src[k] = src[o + k];
+      jobs.dst[k] = dst[o + k];
+    }
+    weight_image_kernel<<<c, 1024, 0, s>>>(jobs);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- tile helpers -----------------------------------------------------------------------------------------------
+struct STile {
+  char* img;     // LDS: hi plane, lo plane of the 32-row tile
+  float* pmax;   // LDS [8][32]: per (wave, lane half) maxima of each row
+  int r, h, nb;
+};
+struct WFrag {
+  h8 hi[8], lo[8];
+  float inv;     // inverse scale of the matrix
+};
+
+// A fragments of output block nb (rows nb*32 + r of the image), fetched one GEMM ahead like node128.hip:load_w
+__device__ __forceinline__ void load_wimg(WFrag& w, const STile& t, const char* __restrict__ img) {
+  const char* p = img + ((size_t)(t.nb * 32 + t.r) * NF + 8 * t.h) * 2;
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    w.hi[T] = *reinterpret_cast<const h8*>(p + 32 * T);
+    w.lo[T] = *reinterpret_cast<const h8*>(p + WIMG_PLANE + 32 * T);
+  }
+  w.inv = *reinterpret_cast<const float*>(img + 2 * WIMG_PLANE);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ float row_amax16(const float (&v)[16]) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m = fmaxf(m, fabsf(v[k]));
+  return m;
+}
+// publish this lane's share of the row maximum (before the barrier that frees the tile)
+__device__ __forceinline__ void tile_publish(const float (&v)[16], const STile& t) { t.pmax[(t.nb * 2 + t.h) * 32 + t.r] = row_amax16(v); }
+// after that barrier: row scale, split, write the fragment-ordered planes; returns the inverse row scale.
+// v[4 q + c] = feature nb*32 + 8 q + 4 h + c  ->  k-slot (2 nb + (q >> 1)) * 16 + 8 h + 4 (q & 1) + c
+__device__ __forceinline__ float tile_commit(const float (&v)[16], const STile& t) {
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, t.pmax[j * 32 + t.r]);
+  float S, inv;
+  ns_pow2_scale(m, S, inv);
+  char* row = t.img + t.r * NS_PITCH + 2 * (t.nb * 32 + 8 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = v[4 * q + c] * S;
+      const _Float16 a = (_Float16)s;
+      hi[c] = a;
+      lo[c] = (_Float16)(s - (float)a);
+    }
+    const int off = 2 * ((q >> 1) * 16 + (q & 1) * 4);
+    *reinterpret_cast<h4*>(row + off) = hi;
+    *reinterpret_cast<h4*>(row + NS_PLANE + off) = lo;
+  }
+  return inv;
+}
+
+// block nb of D^T = W . X^T for the 32 rows of the LDS tile, scaled back: B fragments two triples ahead of their use
+__device__ __forceinline__ void tile_gemm_s(float (&out)[16], const STile& t, const WFrag& w, float inv_row) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const char* xr = t.img + t.r * NS_PITCH + 16 * t.h;
+  h8 bh0 = *reinterpret_cast<const h8*>(xr), bl0 = *reinterpret_cast<const h8*>(xr + NS_PLANE);
+  h8 bh1 = *reinterpret_cast<const h8*>(xr + 32), bl1 = *reinterpret_cast<const h8*>(xr + NS_PLANE + 32);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    h8 bh2, bl2;
+    if (T < 6) {
+      bh2 = *reinterpret_cast<const h8*>(xr + 32 * (T + 2));
+      bl2 = *reinterpret_cast<const h8*>(xr + NS_PLANE + 32 * (T + 2));
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bh0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bl0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[T], bh0, acc, 0, 0, 0);
+    bh0 = bh1;
+    bl0 = bl1;
+    if (T < 6) {
+      bh1 = bh2;
+      bl1 = bl2;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const float sc = inv_row * w.inv;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[k] = acc[k] * sc;
+}
+
+// this lane's 16 values of column block nb (features nb*32 + (k&3) + 8 (k>>2) + 4h) of one row
+__device__ __forceinline__ void sblk_load(float (&v)[16], const float* __restrict__ base, size_t row_off, const STile& t) {
+  const float4* p = reinterpret_cast<const float4*>(base + row_off + t.nb * 32 + 4 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 x = p[2 * q];
+    v[4 * q] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restrict__ base, size_t row_off, const STile& t) {
+  float4* p = reinterpret_cast<float4*>(base + row_off + t.nb * 32 + 4 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+#define NS_TILE_SETUP()                                                      \
+  __shared__ __attribute__((aligned(16))) char lds[NS_LDS_BYTES];            \
+  STile t;                                                                   \
+  t.img = lds;                                                               \
+  t.pmax = reinterpret_cast<float*>(lds + 2 * NS_PLANE);                     \
+  t.r = threadIdx.x & 31;                                                    \
+  t.h = (threadIdx.x >> 5) & 1;                                              \
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                   \
+  const int row = blockIdx.x * 32 + t.r;                                     \
+  const int rc = min(row, p.N - 1);                                          \
+  const bool live = row < p.N;
+
+// equiv_update + energy update + the next layer's message_nodepart (or the first two linears of the energy head)
+__global__ void __launch_bounds__(256, 2) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
+  NS_TILE_SETUP()
+  WFrag wf;
+  load_wimg(wf, t, im.Wu);
+  float upd[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) upd[k] = 0.f;
+  float xa[16], xb[16], a[16];
+  sblk_load(xa, p.f, ((size_t)rc * 3 + 0) * NF, t);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float (&cur)[16] = (c & 1) ? xb : xa;
+    float (&nxt)[16] = (c & 1) ? xa : xb;
+    float qv[16];
+    tile_publish(cur, t);
+    __syncthreads();            // every wave is done reading the previous tile; the row maxima are visible
+    const float inv = tile_commit(cur, t);
+    __syncthreads();
+    if (c < 2)
+      sblk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
+    else
+      sblk_load(a, p.a_mid, (size_t)rc * NF, t);
+    tile_gemm_s(qv, t, wf, inv);
+    if (c == 2 && p.W0) load_wimg(wf, t, im.W0);
+    if (live) sblk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] += upd[k];
+  if (live) sblk_store(a, p.a_out, (size_t)row * NF, t);
+  if (!p.W0) return;
+
+  // message_nodepart of the next layer
+  tile_publish(a, t);
+  __syncthreads();
+  float inv = tile_commit(a, t);
+  __syncthreads();
+  float hn[16], b0v[16], b2v[16];
+  sblk_load(b0v, p.b0, 0, t);
+  tile_gemm_s(hn, t, wf, inv);
+  load_wimg(wf, t, im.W2);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
+  if (live) sblk_store(hn, p.hn, (size_t)row * NF, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) hn[k] = silu_f(hn[k]);
+  tile_publish(hn, t);
+  __syncthreads();
+  inv = tile_commit(hn, t);
+  __syncthreads();
+  sblk_load(b2v, p.b2, 0, t);
+  float m[16];
+  tile_gemm_s(m, t, wf, inv);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] += b2v[k];
+  if (live) sblk_store(m, p.m, (size_t)row * NF, t);
+}
+
+// adjoint of the upper node MLP / head, then of the lower layer's update (see node128.hip:node_bwd_kernel)
+__global__ void __launch_bounds__(256, 2) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
+  NS_TILE_SETUP()
+  float ga[16];
+  WFrag wf;
+  if (p.W2T) {
+    load_wimg(wf, t, im.W2T);
+    float x[16], hpre[16], g[16];
+    sblk_load(x, p.g_top, (size_t)rc * NF, t);
+    sblk_load(hpre, p.h_top, (size_t)rc * NF, t);
+    tile_publish(x, t);
+    __syncthreads();
+    float inv = tile_commit(x, t);
+    __syncthreads();
+    tile_gemm_s(g, t, wf, inv);
+    load_wimg(wf, t, im.W0T);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
+    tile_publish(g, t);
+    __syncthreads();
+    inv = tile_commit(g, t);
+    __syncthreads();
+    tile_gemm_s(ga, t, wf, inv);
+    if (p.WuT) load_wimg(wf, t, im.WuT);
+    if (p.acc_ga) {
+      float old[16];
+      sblk_load(old, p.g_a, (size_t)rc * NF, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) ga[k] += old[k];
+    }
+    if (live) sblk_store(ga, p.g_a, (size_t)row * NF, t);
+  } else {
+    sblk_load(ga, p.g_a, (size_t)rc * NF, t);
+    if (p.WuT) load_wimg(wf, t, im.WuT);
+  }
+  if (!p.WuT) return;
+
+  // adjoint of the lower layer's update:  gf_k = G_f,k + g_a * q_k + (g_a * f'_k) W_u
+  float fa[16], fb[16];
+  sblk_load(fa, p.f, ((size_t)rc * 3 + 0) * NF, t);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float (&cur)[16] = (c & 1) ? fb : fa;
+    float (&nxt)[16] = (c & 1) ? fa : fb;
+    float out[16], qv[16], gin[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cur[k] *= ga[k];
+    tile_publish(cur, t);
+    __syncthreads();
+    const float inv = tile_commit(cur, t);
+    __syncthreads();
+    if (c < 2) sblk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
+    sblk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+    if (p.G_f) sblk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
+    tile_gemm_s(out, t, wf, inv);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qv[k], out[k]);
+    if (p.G_f) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] += gin[k];
+    }
+    if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
+  }
+}
+
+int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_LIN1, s);
+  node_fwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  LAUNCH_CHECK();
+  return 0;
+}
+int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  ScopedTimer t1(TC_LIN1, s);
+  node_bwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  LAUNCH_CHECK();
+  return 0;
+}

@@ -140,6 +140,9 @@ struct PrepLayout {
   size_t headT[2];                 // head0^T, head2^T
   size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
   size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values, then [FT_ROWS][F] d/dx
+  // split-f16 images (node128s.hip) of the node-level weights: update, node0, node2 and their transposes; head0, head2 (+ ^T)
+  size_t img[NNHIP_MAX_LAYERS][6];
+  size_t img_head[4];
   size_t total;
 };
 static size_t prep_bytes(int L);
@@ -164,6 +167,9 @@ static void make_prep_layout(int L, PrepLayout& q) {
   q.m_tab = carve(off, (size_t)128 * NF * 4);
   q.headT[0] = carve(off, NF * NF * 4);
   q.headT[1] = carve(off, NF * NF * 4);
+  for (int l = 0; l < L; ++l)
+    for (int k = 0; k < 6; ++k) q.img[l][k] = carve(off, WIMG_BYTES);
+  for (int k = 0; k < 4; ++k) q.img_head[k] = carve(off, WIMG_BYTES);
   q.total = off;
 }
 static size_t prep_bytes(int L) {
@@ -269,6 +275,26 @@ static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pba
     src[c] = model->head2_w;
     dst[c++] = Q(pq.headT[1]);
     TRY(launch_transposes(src, dst, c, s));
+  }
+  // split-f16 images of the node-level weights (after the transposes above: the reverse sweep's images are made from them)
+  if (split_products_enabled() && model->activation == NNHIP_ACT_SILU) {
+    const float* src[6 * NNHIP_MAX_LAYERS + 4];
+    char* dst[6 * NNHIP_MAX_LAYERS + 4];
+    int c = 0;
+    for (int l = 0; l < L; ++l) {
+      const nnhip_layer_params& lp = model->layer[l];
+      const float* ws_[6] = {lp.update_w, lp.node0_w, lp.node2_w, Q(pq.wT[l][6]), Q(pq.wT[l][0]), Q(pq.wT[l][1])};
+      for (int k = 0; k < 6; ++k) {
+        src[c] = ws_[k];
+        dst[c++] = pbase + pq.img[l][k];
+      }
+    }
+    const float* hs_[4] = {model->head0_w, model->head2_w, Q(pq.headT[0]), Q(pq.headT[1])};
+    for (int k = 0; k < 4; ++k) {
+      src[c] = hs_[k];
+      dst[c++] = pbase + pq.img_head[k];
+    }
+    TRY(launch_weight_images(src, dst, c, s));
   }
   // radial-filter tables, one per layer
   {
@@ -381,6 +407,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   char* pbase = prepared ? (char*)prepared : ws + w.prep;
   auto Q = [&](size_t off) { return (float*)(pbase + off); };
   if (!prepared) TRY(run_prepare(model, pq, pbase, s));
+  const bool split_nodes = split_products_enabled() && act == NNHIP_ACT_SILU;   // node128s.hip (images in the prepared block)
 
   // ------------------------------------------------------------------ forward sweep
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
@@ -441,7 +468,18 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       }
       na.N = N;
       na.act = act;
-      TRY(launch_node_fwd(na, s));
+      if (split_nodes) {
+        NodeImages im;
+        memset(&im, 0, sizeof(im));
+        im.Wu = pbase + pq.img[l][0];
+        if (na.W0) {
+          im.W0 = l + 1 < L ? pbase + pq.img[l + 1][1] : pbase + pq.img_head[0];
+          im.W2 = l + 1 < L ? pbase + pq.img[l + 1][2] : pbase + pq.img_head[1];
+        }
+        TRY(launch_node_fwd_split(na, im, s));
+      } else {
+        TRY(launch_node_fwd(na, s));
+      }
     }
     if (lp.ln_w) {   // layer_norm=True (newtonnet.py:228-231): normalise in place, then the next message_nodepart unfused
       TRY(launch_layer_norm_fwd(A_OUT(l), lp.ln_w, lp.ln_b, N, P(w.xhat[l]), P(w.rstd[l]), s));
@@ -464,6 +502,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   if (!want_forces) return NNHIP_OK;
 
   // ------------------------------------------------------------------ reverse sweep
+  auto node_bwd = [&](const NodeBwdArgs& a, const NodeImages& im) {
+    return split_nodes ? launch_node_bwd_split(a, im, s) : launch_node_bwd(a, s);
+  };
   // head adjoint (g_e1 = (g_e2 H2) * silu'(e1); g_a = g_e1 H0) + update adjoint of the last layer
   // (gf = g_a * q + (g_a * f) W_u; dE/d force_node after the last layer is zero): one row-local launch
   {
@@ -482,15 +523,20 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nb.gf = P(w.gf_mid);
     nb.N = N;
     nb.act = act;
+    NodeImages bim;
+    memset(&bim, 0, sizeof(bim));
+    bim.W2T = pbase + pq.img_head[3];
+    bim.W0T = pbase + pq.img_head[2];
+    bim.WuT = pbase + pq.img[L - 1][3];
     const nnhip_layer_params& top = model->layer[L - 1];
     if (top.ln_w) {   // the LayerNorm adjoint sits between the head adjoint and the update adjoint: three launches
       NodeBwdArgs head = nb;
       head.WuT = nullptr;
-      TRY(launch_node_bwd(head, s));
+      TRY(node_bwd(head, bim));
       TRY(launch_layer_norm_bwd(P(w.pub.g_a), top.ln_w, P(w.xhat[L - 1]), P(w.rstd[L - 1]), N, s));
       nb.W2T = nullptr;
     }
-    TRY(launch_node_bwd(nb, s));
+    TRY(node_bwd(nb, bim));
   }
   float* g_fbuf[2] = {P(w.pub.g_f), P(w.g_f2)};
   int pp = 0;
@@ -538,16 +584,20 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       nb.gf = P(w.gf_mid);
       nb.N = N;
       nb.act = act;
-    nb.act = act;
+      NodeImages bim;
+      memset(&bim, 0, sizeof(bim));
+      bim.W2T = pbase + pq.img[l][5];
+      bim.W0T = pbase + pq.img[l][4];
+      bim.WuT = pbase + pq.img[l - 1][3];
       const nnhip_layer_params& below = model->layer[l - 1];
       if (below.ln_w) {
         NodeBwdArgs mlp = nb;
         mlp.WuT = nullptr;
-        TRY(launch_node_bwd(mlp, s));
+        TRY(node_bwd(mlp, bim));
         TRY(launch_layer_norm_bwd(P(w.pub.g_a), below.ln_w, P(w.xhat[l - 1]), P(w.rstd[l - 1]), N, s));
         nb.W2T = nullptr;
       }
-      TRY(launch_node_bwd(nb, s));
+      TRY(node_bwd(nb, bim));
     }
     pp ^= 1;
   }
