@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def synthetic_aspirin(n_conf, seed, device):
@@ -338,15 +339,34 @@ def main():
         formula_gbs = (edge_fwd_b + edge_bwd_b) / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
         pair_b = pair_layout_bytes(N, E)
         edge_gbs = pair_b / (edge_ms * 1e-3) / 1e9 if edge_ms > 0 else 0.0
-        # dominant kernel: the fused two-layer edge MLP (mlp128_kernel, forward + adjoint launches)
-        mfma = {'bound': 'mfma', 'kernel': 'mlp128_kernel (fused Linear-SiLU-Linear over edges, fwd + adjoint)',
-                'achieved': round(mlp_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(mlp_tf / MFMA_F32_PEAK_TFLOPS, 4),
-                'traffic': None, 'traffic_note': 'PMC passes are separate runs: profiles/r01_*_pmc_{fetch,write}_size.txt',
-                'launches_per_step': mlp_n, 'avg_launch_us': round(1e3 * mlp_ms / mlp_n, 2),
-                'flops_per_launch': mlp_flops / mlp_n, 'ms_per_step': round(mlp_ms, 4),
-                'all_dense_kernels': {'achieved': round(lin_tf, 2), 'ms_per_step': round(lin_ms, 4),
-                                      'flops_per_step': lin_flops}}
+        # dominant kernel: the fused two-layer edge MLP (forward + adjoint launches).  Default build: mlp128s_kernel forms each
+        # fp32 product from split-f16 pieces (3 f16 MFMAs per 16 k-values) and is bound by its HBM traffic; NNHIP_MLP_SPLIT=0:
+        # mlp128_kernel on v_mfma_f32_32x32x2_f32, bound by the fp32 matrix pipe.
+        split = hip.split_products()
+        # algorithmic HBM bytes of one MLP phase over P pair rows, in units of 512 P: forward X in + hidden, output out = 3;
+        # adjoint g_phi, hidden in + g_msg out = 3, + g_msg in when accumulating = 4.  Per step (3 layers, phi2 skipped in
+        # layer 0): 5 forward phases, 3 plain + 2 accumulating adjoint phases
+        mlp_bytes = (E // 2) * 512.0 * (5 * 3 + 3 * 3 + 2 * 4)
+        mlp_gbs = mlp_bytes / (mlp_ms * 1e-3) / 1e9 if mlp_ms > 0 else 0.0
+        common = {'traffic': None, 'traffic_note': 'PMC passes are separate runs: profiles/*_pmc_{fetch,write}_size.txt',
+                  'launches_per_step': mlp_n, 'avg_launch_us': round(1e3 * mlp_ms / mlp_n, 2),
+                  'flops_per_launch': mlp_flops / mlp_n, 'algorithmic_bytes_per_launch': round(mlp_bytes / mlp_n),
+                  'ms_per_step': round(mlp_ms, 4),
+                  'all_dense_kernels': {'achieved': round(lin_tf, 2), 'unit': 'useful fp32 TFLOP/s', 'ms_per_step': round(lin_ms, 4),
+                                        'flops_per_step': lin_flops}}
+        if split:
+            mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel (fused Linear-SiLU-Linear over pair rows, fwd + adjoint; split-f16 '
+                                              'products, fp32 accumulate)',
+                    'achieved': round(mlp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(mlp_gbs / HBM_PEAK_GBS, 4),
+                    'matrix_pipe': {'useful_fp32_tflops': round(mlp_tf, 2), 'executed_f16_tflops': round(3 * mlp_tf, 2),
+                                    'peak_f16_tflops': MFMA_F16_PEAK_TFLOPS, 'frac': round(3 * mlp_tf / MFMA_F16_PEAK_TFLOPS, 4),
+                                    'note': '3 v_mfma_f32_32x32x16_f16 per 16 k-values (hi*hi + hi*lo + lo*hi); the same FLOPs on '
+                                            f'v_mfma_f32_32x32x2_f32 would need {round(mlp_tf / MFMA_F32_PEAK_TFLOPS, 2)} of its peak'}}
+        else:
+            mfma = {'bound': 'mfma', 'kernel': 'mlp128_kernel (fused Linear-SiLU-Linear over pair rows, fwd + adjoint; fp32 MFMA)',
+                    'achieved': round(mlp_tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(mlp_tf / MFMA_F32_PEAK_TFLOPS, 4)}
+        mfma.update(common)
         hbm = {'bound': 'hbm', 'kernel': 'msg_fwd/force_fwd/force_bwd/msg_bwd (edge kernels of one step)',
                'achieved': round(edge_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                'frac': round(edge_gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'ms_per_step': round(edge_ms, 4),
@@ -357,11 +377,7 @@ def main():
                                    'model, not achieved bandwidth)',
                'formula_bytes_per_step': edge_fwd_b + edge_bwd_b, 'frac_vs_formula': round(formula_gbs / HBM_PEAK_GBS, 4)}
         if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
-            # algorithmic HBM bytes of one MLP phase over P pair rows, in units of 512 P: forward X in + hidden, output out
-            # = 3; adjoint g_phi, hidden in + g_msg out = 3, + g_msg in when accumulating = 4.  Per step (3 layers, phi2
-            # skipped in layer 0): 5 forward phases, 3 plain + 2 accumulating adjoint phases
-            mfma['algorithmic_bytes_per_launch'] = round((E // 2) * 512.0 * (5 * 3 + 3 * 3 + 2 * 4) / mlp_n)
-            t, src = pmc_traffic(['void mlp128_kernel', 'mlp128_kernel'])
+            t, src = pmc_traffic(['void mlp128s_kernel', 'mlp128s_kernel'] if split else ['void mlp128_kernel', 'mlp128_kernel'])
             if t is not None:
                 mfma['traffic'], mfma['traffic_source'] = round(t), src
             t, src = pmc_traffic(['msg_fwd_kernel', 'void force_fwd_kernel', 'void force_bwd_kernel', 'void msg_bwd_kernel'])
@@ -372,7 +388,10 @@ def main():
                 cnt_gbs = t * n_edge / (edge_ms * 1e-3) / 1e9
                 hbm['achieved_counter_bytes'] = round(cnt_gbs, 1)
                 hbm['frac_vs_counter_bytes'] = round(cnt_gbs / HBM_PEAK_GBS, 4)
-        roofline, edge_roofline = (mfma, hbm) if lin_ms >= edge_ms else (hbm, mfma)
+        # `roofline` = the single kernel with the largest share of the step (the edge MLP kernel unless one of the four edge
+        # kernels outweighs it); the other object is reported as `roofline_secondary`
+        top_edge = max(classes[k]['ms_per_step'] for k in ('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd'))
+        roofline, edge_roofline = (mfma, hbm) if mlp_ms >= top_edge else (hbm, mfma)
 
     # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
     cpu_baseline = None

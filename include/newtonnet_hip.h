@@ -513,6 +513,14 @@ int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws* ws, const 
                       void* stream);
 
 /* --------------------------------------------------------------------------
+ * Product form of the dense kernels.  1 (default): the 128x128 linears of the hot path (edge MLPs, node MLPs, equiv_update
+ * and their adjoints / tangents, SiLU models) form each fp32 product from two scaled f16 pieces per operand on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation (csrc/mlp128s.hip, node128s.hip); 0 (environment NNHIP_MLP_SPLIT=0,
+ * read once per process): v_mfma_f32_32x32x2_f32 everywhere.  Inputs, outputs and accumulators are fp32 either way.
+ * ------------------------------------------------------------------------ */
+int nnhip_split_products(void);
+
+/* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,

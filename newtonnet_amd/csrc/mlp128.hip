@@ -340,14 +340,15 @@ int launch_mlp_split(int mode, bool accum_last, const MlpPair& P, hipStream_t s)
 
 // The forward / adjoint launches of the persistent kernel take the split-f16 product form (mlp128s.hip: 5x less matrix-pipe
 // time, and closer to fp64 than the fp32 MFMA chain below); NNHIP_MLP_SPLIT=0 keeps them on v_mfma_f32_32x32x2_f32 (tooling,
-// A/B).  The other activations of the factory and the training modes (MODE_TAN / MODE_TAN2) run the fp32 form.
+// A/B).  The other activations of the factory run the fp32 form.
+extern "C" int nnhip_split_products(void) { return split_products_enabled() ? 1 : 0; }
 bool split_products_enabled() {
   static const bool on = !(getenv("NNHIP_MLP_SPLIT") && atoi(getenv("NNHIP_MLP_SPLIT")) == 0);
   return on;
 }
 
 static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipStream_t s) {
-  if (split_products_enabled() && P.a[0].act == NNHIP_ACT_SILU && (mode == MODE_FWD || mode == MODE_BWD)) return launch_mlp_split(mode, accum_last, P, s);
+  if (split_products_enabled() && P.a[0].act == NNHIP_ACT_SILU) return launch_mlp_split(mode, accum_last, P, s);
   if (P.a[0].act != NNHIP_ACT_SILU) {
     if (mode == MODE_FWD && !accum_last) return launch_mlp_t<MODE_FWD, false, true>(P, s);
     if (mode == MODE_BWD && !accum_last) return launch_mlp_t<MODE_BWD, false, true>(P, s);

@@ -253,7 +253,31 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
           }
 #pragma unroll
           for (int k = 0; k < 16; ++k) hs[nb][k] = silu_f(acc[k]);
+        } else if (MODE == MODE_TAN2) {
+          // tangent of the adjoint: G = dT act'(H) + T2 act''(H) Hd, kept (row-major) for the weight-gradient products
+          const float* t2p = (ph ? P.a[1].T2 : P.a[0].T2) + (size_t)ec * p.ldh + nb * 32 + 4 * h;
+          const float* hdp = (ph ? P.a[1].Hd : P.a[0].Hd) + (size_t)ec * p.ldh + nb * 32 + 4 * h;
+          float* gp = (ph ? P.a[1].G : P.a[0].G) + (size_t)e * p.ldh + nb * 32 + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 t2 = ld4(t2p + 8 * q), hd = ld4(hdp + 8 * q);
+            float4 gv;
+            gv.x = fmaf(acc[4 * q], dsilu_f(hin[q].x), t2.x * d2silu_f(hin[q].x) * hd.x);
+            gv.y = fmaf(acc[4 * q + 1], dsilu_f(hin[q].y), t2.y * d2silu_f(hin[q].y) * hd.y);
+            gv.z = fmaf(acc[4 * q + 2], dsilu_f(hin[q].z), t2.z * d2silu_f(hin[q].z) * hd.z);
+            gv.w = fmaf(acc[4 * q + 3], dsilu_f(hin[q].w), t2.w * d2silu_f(hin[q].w) * hd.w);
+            hs[nb][4 * q] = gv.x;
+            hs[nb][4 * q + 1] = gv.y;
+            hs[nb][4 * q + 2] = gv.z;
+            hs[nb][4 * q + 3] = gv.w;
+            if (live) st4(gp + 8 * q, gv);
+          }
         } else {
+          if (MODE == MODE_TAN && live) {   // keep the stage-1 product (row-major): the tangent sweeps and weight gradients read it
+            float* tp = (ph ? P.a[1].T : P.a[0].T) + (size_t)e * p.ldh + nb * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st4(tp + 8 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             hs[nb][4 * q] = acc[4 * q] * dsilu_f(hin[q].x);
@@ -338,11 +362,15 @@ static int launch_split_t(const MlpPair& a, hipStream_t s) {
   return 0;
 }
 
-// (mlp128.hip: launch_mlp_dispatch) forward and adjoint modes of the persistent kernel, SiLU
+// (mlp128.hip: launch_mlp_dispatch) every mode of the persistent kernel, SiLU
 int launch_mlp_split(int mode, bool accum_last, const MlpPair& P, hipStream_t s) {
   if (mode == MODE_FWD && !accum_last) return launch_split_t<MODE_FWD, false>(P, s);
   if (mode == MODE_BWD && !accum_last) return launch_split_t<MODE_BWD, false>(P, s);
   if (mode == MODE_BWD && accum_last) return launch_split_t<MODE_BWD, true>(P, s);
+  if (mode == MODE_TAN && !accum_last) return launch_split_t<MODE_TAN, false>(P, s);
+  if (mode == MODE_TAN && accum_last) return launch_split_t<MODE_TAN, true>(P, s);
+  if (mode == MODE_TAN2 && !accum_last) return launch_split_t<MODE_TAN2, false>(P, s);
+  if (mode == MODE_TAN2 && accum_last) return launch_split_t<MODE_TAN2, true>(P, s);
   nnhip_set_error("launch_mlp_split: unsupported mode %d/%d", mode, (int)accum_last);
   return NNHIP_E_INVALID;
 }

@@ -225,7 +225,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
-                    'nnhip_prepare', 'nnhip_check_species')
+                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products')
 
 
 def _check(rc: int, what: str):
@@ -492,6 +492,11 @@ def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 def timers_enable(on: bool):
     _check(lib().nnhip_timers_enable(1 if on else 0), 'nnhip_timers_enable')
+
+
+def split_products() -> bool:
+    """True when the dense kernels use the split-f16 product form (default; NNHIP_MLP_SPLIT=0 selects fp32 MFMA)."""
+    return bool(lib().nnhip_split_products())
 
 
 def timers_read(reset: bool = True):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run a few training steps (fused path, HIP-graph replay unless --eager) for rocprofv3.
-usage: tools/profile_train.py [ethanol|aspirin] [B] [--eager | --fused] [--steps K]"""
+usage: tools/profile_train.py [ethanol|aspirin] [B] [--eager | --fused | --fused-eager] [--steps K]"""
 import os
 import sys
 
@@ -21,7 +21,9 @@ args = [t.cuda() for t in (aspirin_batch if kind == 'aspirin' else ethanol_batch
 torch.manual_seed(0)
 model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
 model.train()
-if '--fused' in sys.argv:
+if '--fused-eager' in sys.argv:       # no autograd, no capture: exact neighbor list every step
+    step = TrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0)
+elif '--fused' in sys.argv:
     step = GraphedTrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0, assume_static=True)
 elif eager:
     step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), 1.0, 50.0, 1.0)
