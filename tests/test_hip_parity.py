@@ -587,3 +587,97 @@ def test_other_envelopes(tag):
     o2 = model(z, pos.clone().requires_grad_(True), cell, batch)
     assert type(o2.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'
     check_forces(o2.gradient_force.detach().cpu().numpy(), c[f'{tag}_forces'])
+
+
+def _mlp_errors(M, x_scale, w_scale, seed=0):
+    """relative rms errors (H, Y, adjoint Y) of nnhip_mlp128 against float64 on M rows whose magnitudes span `x_scale` (per row)
+    and weights scaled by `w_scale`"""
+    from newtonnet_amd import hip
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(M, 128, generator=g) * x_scale
+    W1 = torch.randn(128, 128, generator=g) / 11 * w_scale[0]
+    W2 = torch.randn(128, 128, generator=g) / 11 * w_scale[1]
+    Xg = torch.randn(M, 128, generator=g) * x_scale
+    Xc, W1c, W2c, Xgc = (t.cuda() for t in (X, W1, W2, Xg))
+    H, Y, Yb = (torch.empty(M, 128, device='cuda') for _ in range(3))
+    hip.mlp128(Xc, W1c, W2c, H, Y, 0)
+    Hr = X.double() @ W1.double().T
+    Yr = torch.nn.functional.silu(Hr) @ W2.double().T
+    s = torch.sigmoid(Hr)
+    Gr = (Xg.double() @ W1.double().T) * (s * (1 + Hr * (1 - s)))
+    Ybr = Gr @ W2.double().T
+    hip.mlp128(Xgc, W1c, W2c, Hr.float().cuda(), Yb, 1)
+    rel = lambda a, b: ((a.cpu().double() - b).norm() / b.norm()).item()  # noqa: E731
+    rows = lambda a, b: ((a.cpu().double() - b).norm(dim=1) / b.norm(dim=1).clamp_min(1e-300)).max().item()  # noqa: E731
+    return rel(H, Hr), rel(Y, Yr), rel(Yb, Ybr), rows(H, Hr)
+
+
+def test_split_f16_products_are_fp32_grade():
+    """The persistent edge-MLP kernel forms fp32 products from split-f16 pieces (csrc/mlp128s.hip).  Against float64: plain
+    inputs, rows whose magnitudes differ by 12 orders (per-row scales), tiny / huge weight matrices (per-matrix scales) -- the
+    error stays at the fp32 rounding level for EVERY row, not only in the norm."""
+    from newtonnet_amd import hip
+    assert hip.split_products()
+    M = 65536                                     # > 49 152 rows: the persistent kernel (the row-local one serves smaller M)
+    e = _mlp_errors(M, torch.ones(M, 1), (1.0, 1.0))
+    print('plain            : H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
+    assert max(e[:3]) < 4e-7 and e[3] < 2e-6
+    span = 10.0 ** torch.linspace(-8, 4, M).view(M, 1)
+    # (rows of very different magnitude share a 32-row tile; rows are scaled one by one.  |X| up to 1e4 saturates silu: H only)
+    e = _mlp_errors(M, span[torch.randperm(M, generator=torch.Generator().manual_seed(1))], (1.0, 1.0))
+    print('rows 1e-8 .. 1e4 : H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
+    assert e[0] < 4e-7 and e[3] < 2e-6
+    e = _mlp_errors(M, torch.ones(M, 1), (1e-6, 1e5))
+    print('weights 1e-6, 1e5: H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
+    assert max(e[:3]) < 4e-7 and e[3] < 2e-6
+
+
+def test_fp32_mfma_form_still_serves(tmp_path):
+    """NNHIP_MLP_SPLIT=0 keeps every dense kernel on v_mfma_f32_32x32x2_f32 (own process: the switch is read once per
+    process).  512 aspirin conformers (78 k pair rows: the persistent kernels): both product forms against the float64 oracle
+    on the first 64 conformers, and against each other on all of them."""
+    import os
+    import subprocess
+    import sys
+    from oracle import newtonnet_ref as ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'run_case.py'
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np, torch\n"
+        "from tests import util\n"
+        "from tests.test_hip_parity import make_model\n"
+        "from newtonnet_amd import hip\n"
+        "assert hip.split_products() == (sys.argv[2] == '1')\n"
+        "a = util.load_npz('aspirin_frames.npz')\n"
+        "B, n = 512, 21\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "pos = torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=g)\n"
+        "z = torch.from_numpy(a['z']).long().repeat(B)\n"
+        "batch = torch.repeat_interleave(torch.arange(B), n)\n"
+        "model, _ = make_model('rand')\n"
+        "out = model(z.cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'), batch.cuda())\n"
+        "np.savez(sys.argv[1], energy=out.energy.cpu().numpy(), forces=out.gradient_force.cpu().numpy(), pos=pos.numpy(),\n"
+        "         z=z.numpy())\n")
+    res = {}
+    for split in ('0', '1'):
+        out = tmp_path / f'out{split}.npz'
+        env = dict(os.environ, NNHIP_MLP_SPLIT=split)
+        r = subprocess.run([sys.executable, str(script), str(out), split], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[split] = dict(np.load(out))
+    assert np.array_equal(res['0']['pos'], res['1']['pos'])
+    n_ref = 64 * 21
+    pos = torch.from_numpy(res['0']['pos'][:n_ref]).double()
+    z = torch.from_numpy(res['0']['z'][:n_ref])
+    batch = torch.repeat_interleave(torch.arange(64), 21)
+    sd = util.load_state('rand', torch.float64)
+    o = ref.energy_forces(sd, z, pos, torch.zeros(64, 3, 3, dtype=torch.float64), batch)
+    e_ref, f_ref = o['energy'], o['forces']
+    for split in ('0', '1'):
+        mae = np.abs(res[split]['forces'][:n_ref] - f_ref.numpy()).mean()
+        de = np.abs(res[split]['energy'][:64] - e_ref.numpy()).max()
+        print(f"NNHIP_MLP_SPLIT={split}: force MAE vs float64 oracle {mae:.2e} eV/A, max |dE| {de:.2e} eV")
+        assert mae <= util.FORCE_MAE_TOL and np.all(np.abs(res[split]['energy'][:64] - e_ref.numpy()) <= util.energy_tol(e_ref.numpy()))
+    assert np.abs(res['0']['forces'] - res['1']['forces']).max() <= 5e-6
