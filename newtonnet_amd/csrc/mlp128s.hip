@@ -14,7 +14,9 @@
 // Scales.  f16 has 5 exponent bits, so operands are scaled into [2^14, 2^15) by their row's largest magnitude before the
 // split: activations per ROW (a lane owns one pair row: its own 64 values + one cross-half exchange), weights per MATRIX (a
 // workgroup-wide maximum while the matrix is staged into LDS).  Both scales are powers of two: applying and removing them is
-// exact, and rows / matrices of any magnitude keep their 22 bits.
+// exact, and rows / matrices of any magnitude keep their 22 bits.  (The bound is relative to the row's and the matrix's LARGEST
+// element -- |error| <~ 2^-21 max|row| max|W| sqrt(K) per output, the class of the fp32 rounding of the dominant products;
+// elements far below their row's maximum are not resolved to 22 bits of their own.)
 //
 // LDS image of a weight matrix: two f16 planes (hi, lo) of [128 outputs][128 k-slots], 272-byte row pitch (conflict-free
 // ds_read_b128), with the k-slots permuted so that the 8 slots a lane feeds to one MFMA are contiguous AND match what that
@@ -158,6 +160,20 @@ __device__ __forceinline__ f32x16 split_block(const char* wrow, const h8 (&bh)[8
   return acc;
 }
 
+// The next tile's X request (a macro: placed at one of two points of the tile loop)
+#define MLPS_PREFETCH_X()                                                                  \
+  {                                                                                        \
+    const bool last = tile + tile_step >= n_tiles;                                         \
+    const float* xn = (last && more) ? P.a[1].X : p.X;                                     \
+    const int ldn = (last && more) ? P.a[1].ldx : p.ldx;                                   \
+    const int nt = last ? tile0 : tile + tile_step;                                        \
+    mlps_load_x(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);               \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  }
+#ifndef MLPS_EARLY_X
+#define MLPS_EARLY_X 0   // 1: forward mode requests the next X before stage 1 (a whole tile of cover; tooling A/B)
+#endif
+
 template <int MODE, bool ACCUM_LAST>
 __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(const MlpPair P) {
   extern __shared__ __attribute__((aligned(16))) char img[];
@@ -222,6 +238,7 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
           split8(v, S, bh[T], bl[T]);
         }
       }
+      if (MLPS_EARLY_X && MODE == MODE_FWD) MLPS_PREFETCH_X()
       // ---------------- stage 1: H^T = W1 . X^T  (4 blocks of 32 features)
       float hs[4][16];
 #pragma unroll
@@ -311,14 +328,7 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
 
       // X of the NEXT tile (of this phase, or the first tile of the next phase): requested once the stage-1 tile has been split
       // (the register budget of two waves per SIMD does not hold x, both operand sets and the stage-1 tile at once)
-      {
-        const bool last = tile + tile_step >= n_tiles;
-        const float* xn = (last && more) ? P.a[1].X : p.X;
-        const int ldn = (last && more) ? P.a[1].ldx : p.ldx;
-        const int nt = last ? tile0 : tile + tile_step;
-        mlps_load_x(x, xn, ldn, min((min(nt, n_tiles - 1) << 5) + r, M - 1), h);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (!(MLPS_EARLY_X && MODE == MODE_FWD)) MLPS_PREFETCH_X()
 
       // ---------------- stage 2: Y^T = W2 . act^T
 #pragma unroll

@@ -17,6 +17,9 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+#ifndef NS_WG_PER_CU
+#define NS_WG_PER_CU 2   // launch-bounds hint: workgroups per CU (tooling: 3 = every tile of config 2 resident at once, 168 VGPRs)
+#endif
 #define NS_PITCH 272                         // bytes per row of one plane of the LDS tile (128 f16 + 16 pad)
 #define NS_PLANE (32 * NS_PITCH)
 #define NS_LDS_BYTES (2 * NS_PLANE + 8 * 32 * 4)
@@ -203,7 +206,7 @@ __device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restri
   const bool live = row < p.N;
 
 // equiv_update + energy update + the next layer's message_nodepart (or the first two linears of the energy head)
-__global__ void __launch_bounds__(256, 2) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
+__global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
   NS_TILE_SETUP()
   WFrag wf;
   load_wimg(wf, t, im.Wu);
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) node_fwd_split_kernel(const NodeFwdArg
 }
 
 // adjoint of the upper node MLP / head, then of the lower layer's update (see node128.hip:node_bwd_kernel)
-__global__ void __launch_bounds__(256, 2) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
+__global__ void __launch_bounds__(256, NS_WG_PER_CU) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
   NS_TILE_SETUP()
   float ga[16];
   WFrag wf;

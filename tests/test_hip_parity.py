@@ -630,6 +630,12 @@ def test_split_f16_products_are_fp32_grade():
     e = _mlp_errors(M, torch.ones(M, 1), (1e-6, 1e5))
     print('weights 1e-6, 1e5: H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
     assert max(e[:3]) < 4e-7 and e[3] < 2e-6
+    # magnitudes spread over 6 orders INSIDE every row: the error bound is relative to the row's largest element (like the fp32
+    # rounding of the dominant products), which the per-row norms measure
+    inner = 10.0 ** (-6.0 * torch.rand(M, 128, generator=torch.Generator().manual_seed(2)))
+    e = _mlp_errors(M, inner, (1.0, 1.0))
+    print('1e-6 .. 1 in rows: H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
+    assert max(e[:3]) < 4e-7 and e[3] < 2e-6
 
 
 def test_fp32_mfma_form_still_serves(tmp_path):
