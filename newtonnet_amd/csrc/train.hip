@@ -838,8 +838,11 @@ colsum_final_kernel(const nnhip_colsum_problem* __restrict__ probs, const float*
 // walks its slice of atoms and accumulates rows into an LDS table [119][width] (thread = column: no conflicts, fixed order);
 // pass 2 adds the per-workgroup tables.  width <= 128.
 #define SP_CHUNKS 256
-static inline int species_chunks(int n_atoms) {   // ~64 atoms per workgroup, at most SP_CHUNKS
-  const int c = (n_atoms + 63) / 64;
+#ifndef SP_ATOMS
+#define SP_ATOMS 64
+#endif
+static inline int species_chunks(int n_atoms) {   // ~SP_ATOMS atoms per workgroup, at most SP_CHUNKS
+  const int c = (n_atoms + SP_ATOMS - 1) / SP_ATOMS;
   return c < 1 ? 1 : (c > SP_CHUNKS ? SP_CHUNKS : c);
 }
 __global__ void __launch_bounds__(NF)

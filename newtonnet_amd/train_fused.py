@@ -188,7 +188,11 @@ class TrainWorkspace:
         self.sum_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.cs_scratch = torch.empty(max(hip.lib().nnhip_colsum_scratch_bytes(self.n_sums) // 4, 1), dtype=torch.float32,
                                       device=device)
-        self.chunks = max(1, min(256, (max(P, N) + 31) // 32))
+        # split-K chunks of the weight-gradient launch: ~256 rows each (every chunk costs a 64 KiB slab written and read back),
+        # but at least 32 of them while 32 rows remain per chunk (24 problems x 32 chunks fill the chip), at most 256
+        # (tools/sweep_train_chunks.sh: mixed-32 step 1.15 -> 1.05 ms, aspirin-128 2.05 -> 1.93 ms against one chunk per 32 rows)
+        M = max(P, N)
+        self.chunks = max(1, min(256, max((M + 255) // 256, min(32, (M + 31) // 32))))
         self.slabs = torch.empty(hip.lib().nnhip_wgrad_slab_bytes(self.n_probs, self.chunks) // 4, dtype=torch.float32,
                                  device=device)
         self._c_view(model, G)
