@@ -379,8 +379,16 @@ typedef struct {
   float* Y; int32_t ldy;
   int32_t M, mode, accumulate, activation;
   float* T; const float* T2; const float* Hd; float* G;
+  /* optional: split-f16 images of W1 / W2 (nnhip_weight_images; both or neither).  With them the row-local form of the kernel
+   * (M <= 49 152 rows) takes the split-f16 product form instead of v_mfma_f32_32x32x2_f32; results agree to fp32 rounding. */
+  const void* W1_image; const void* W2_image;
 } nnhip_mlp_desc;
 int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
+/* Split-f16 image of a [128][128] fp32 matrix (rows = output features): two f16 planes (hi, lo) of the matrix scaled by a power
+ * of two into the f16 range, k-slots in MFMA fragment order, then the inverse scale (csrc/node128s.hip).  `count` matrices in
+ * one launch; each image takes nnhip_weight_image_bytes() bytes, 256-byte aligned. */
+size_t nnhip_weight_image_bytes(void);
+int nnhip_weight_images(const float* const* src, void* const* images, int32_t count, void* stream);
 /* two MLPs over the same M rows in one launch (same mode / activation; only the second may accumulate) */
 int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* desc0, const nnhip_mlp_desc* desc1, void* stream);
 
@@ -484,6 +492,9 @@ typedef struct {
   const int64_t* edge_index; const float* geo; const float* disp; const float* rbf; const float* drbf; const int32_t* xg;
   /* parameter-only data rebuilt by nnhip_train_values */
   float* wT[NNHIP_MAX_LAYERS][7]; float* headT[2]; float* ftab[NNHIP_MAX_LAYERS];
+  /* split-f16 images (nnhip_weight_images) of, per layer: update, node0, node2, their transposes, eq1_0, eq1_2, eq2_0, eq2_2,
+   * their transposes; of head0, head2 and their transposes */
+  void* wimg[NNHIP_MAX_LAYERS][14]; void* himg[4];
   /* values, forward */
   float* a0; float* hn[NNHIP_MAX_LAYERS]; float* m[NNHIP_MAX_LAYERS]; float* msg[NNHIP_MAX_LAYERS];
   float* h1[NNHIP_MAX_LAYERS]; float* h2[NNHIP_MAX_LAYERS]; float* phi1[NNHIP_MAX_LAYERS]; float* phi2[NNHIP_MAX_LAYERS];

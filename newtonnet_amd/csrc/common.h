@@ -273,6 +273,9 @@ struct MlpArgs {
   const float* T2;  // MODE_TAN2: [M][ldh] in, the T of the value sweep
   const float* Hd;  // MODE_TAN2: [M][ldh] in, tangent of H
   float* G;         // MODE_TAN2: [M][ldh] out, the hidden adjoint's tangent
+  // optional split-f16 images of W1 / W2 (node128s.hip:weight_image_kernel): the row-local kernel then takes the split-f16 form
+  const char* W1_img;
+  const char* W2_img;
 };
 struct MlpPair {      // up to two MLPs over the same M rows, run back to back by one persistent launch (mlp128.hip)
   MlpArgs a[2];
@@ -317,6 +320,10 @@ struct WeightImageJobs {
   const float* src[WIMG_MAX_JOBS];
   char* dst[WIMG_MAX_JOBS];
 };
+// images kept per layer (prepared block / training workspace), and of the energy head
+enum { IMG_UPDATE = 0, IMG_NODE0, IMG_NODE2, IMG_UPDATE_T, IMG_NODE0_T, IMG_NODE2_T, IMG_EQ1_0, IMG_EQ1_2, IMG_EQ2_0, IMG_EQ2_2,
+       IMG_EQ1_0_T, IMG_EQ1_2_T, IMG_EQ2_0_T, IMG_EQ2_2_T, IMG_PER_LAYER };
+enum { IMG_HEAD0 = 0, IMG_HEAD2, IMG_HEAD0_T, IMG_HEAD2_T, IMG_HEAD_COUNT };
 struct NodeImages {
   const char *Wu, *W0, *W2;      // node_fwd: equiv_update, next message_nodepart / head (first, second linear)
   const char *W2T, *W0T, *WuT;   // node_bwd: their transposes
@@ -324,6 +331,8 @@ struct NodeImages {
 int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s);
 int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_t s);
 int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_t s);
+int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s);      // needs a.W1_img / a.W2_img, SiLU
+int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s);
 bool split_products_enabled();   // mlp128.hip (NNHIP_MLP_SPLIT=0 turns every split-f16 kernel off)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

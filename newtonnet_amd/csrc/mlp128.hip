@@ -479,6 +479,12 @@ static int desc_to_args(const nnhip_mlp_desc* d, MlpArgs& a, const char* who) {
   a.T2 = d->T2;
   a.Hd = d->Hd;
   a.G = d->G;
+  if ((d->W1_image == nullptr) != (d->W2_image == nullptr)) {
+    nnhip_set_error("%s: W1_image / W2_image come together", who);
+    return NNHIP_E_INVALID;
+  }
+  a.W1_img = (const char*)d->W1_image;
+  a.W2_img = (const char*)d->W2_image;
   return NNHIP_OK;
 }
 extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {

@@ -396,7 +396,12 @@ int launch_lin_wide(const float* X, int ldx, const float* W, float* Y, int ldy, 
   return 0;
 }
 
+static bool wide_split(const MlpArgs& a) {
+  return a.W1_img && a.W2_img && a.act == NNHIP_ACT_SILU && split_products_enabled();
+}
+
 int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
+  if (wide_split(a)) return launch_mlp_wide_split(mode, accum, a, s);
   const int n_tiles = cdiv(a.M, 32);
   if (mode == MODE_FWD && !accum)
     mlp128_wide_kernel<MODE_FWD, false><<<n_tiles, 256, 0, s>>>(a);
@@ -419,6 +424,7 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
 }
 
 int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s) {
+  if (wide_split(P.a[0]) && wide_split(P.a[1])) return launch_mlp_wide_pair_split(mode, P, s);
   const int n_tiles = cdiv(P.a[0].M, 32);
   const bool par = !P.accum[1];   // two independent MLPs: side by side (blockIdx.y)
 #define WIDE_PAIR(M_)                                                                  \

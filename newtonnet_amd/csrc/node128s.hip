@@ -10,6 +10,7 @@
 //   rows    : scaled per row by the largest magnitude of the row.  A row's 128 values live in 8 lanes of 4 waves: each lane
 //             publishes the maximum of its 16 values in LDS BEFORE the barrier that already separates two uses of the tile, so the
 //             exchange costs no extra barrier; the (hi, lo) pieces are written to the LDS tile in fragment order.
+#include <stdint.h>
 #include <string.h>
 
 #include "common.h"
@@ -345,4 +346,151 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
   node_bwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
   LAUNCH_CHECK();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-local form of the fused edge / node MLP (node128.hip: mlp128_wide_kernel, same MlpArgs contract, SiLU) with split-f16
+// products: the weights come as prepared images (MlpArgs::W1_img / W2_img).  The single-molecule / MD-loop and small-batch
+// training regimes are chains of these launches; a GEMM stage is 24 MFMAs of 32 cycles instead of 64 of 64.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t) {
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, p.M - 1);
+  const bool live = row < p.M;
+
+  WFrag wf;
+  load_wimg(wf, t, p.W1_img);
+  float x[16], hv[16], hin[16];
+  sblk_load(x, p.X, (size_t)rc * p.ldx, t);
+  if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
+  tile_publish(x, t);
+  __syncthreads();
+  float inv = tile_commit(x, t);
+  __syncthreads();
+  tile_gemm_s(hv, t, wf, inv);
+  load_wimg(wf, t, p.W2_img);
+  if (MODE == MODE_FWD) {
+    if (p.b1) {
+      float b[16];
+      sblk_load(b, p.b1, 0, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) hv[k] += b[k];
+    }
+    if (live) sblk_store(hv, p.H, (size_t)row * p.ldh, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = silu_f(hv[k]);
+  } else if (MODE == MODE_TAN2) {
+    float t2[16], hd[16];
+    sblk_load(t2, p.T2, (size_t)rc * p.ldh, t);
+    sblk_load(hd, p.Hd, (size_t)rc * p.ldh, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] = fmaf(hv[k], dsilu_f(hin[k]), t2[k] * d2silu_f(hin[k]) * hd[k]);
+    if (live) sblk_store(hv, p.G, (size_t)row * p.ldh, t);
+  } else {
+    if (MODE == MODE_TAN && live) sblk_store(hv, p.T, (size_t)row * p.ldh, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
+  }
+  tile_publish(hv, t);
+  __syncthreads();
+  inv = tile_commit(hv, t);
+  __syncthreads();
+  float y[16];
+  tile_gemm_s(y, t, wf, inv);
+  if (MODE == MODE_FWD && p.b2) {
+    float b[16];
+    sblk_load(b, p.b2, 0, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += b[k];
+  }
+  if (accum) {   // uniform
+    float yold[16];
+    sblk_load(yold, p.Y, (size_t)rc * p.ldy, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += yold[k];
+  }
+  if (live) sblk_store(y, p.Y, (size_t)row * p.ldy, t);
+}
+
+#define NS_STILE_SETUP()                                                     \
+  __shared__ __attribute__((aligned(16))) char lds[NS_LDS_BYTES];            \
+  STile t;                                                                   \
+  t.img = lds;                                                               \
+  t.pmax = reinterpret_cast<float*>(lds + 2 * NS_PLANE);                     \
+  t.r = threadIdx.x & 31;                                                    \
+  t.h = (threadIdx.x >> 5) & 1;                                              \
+  t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+template <int MODE, bool ACCUM>
+__global__ void __launch_bounds__(256) mlp128_wide_split_kernel(const MlpArgs p) {
+  NS_STILE_SETUP()
+  mlp_wide_split_body<MODE>(p, ACCUM, t);
+}
+// two MLPs over the same rows in one launch (node128.hip:mlp128_wide_pair_kernel)
+template <int MODE, bool PAR>
+__global__ void __launch_bounds__(256) mlp128_wide_pair_split_kernel(const MlpPair P) {
+  NS_STILE_SETUP()
+  if (PAR) {
+    if (blockIdx.y == 0)
+      mlp_wide_split_body<MODE>(P.a[0], false, t);
+    else
+      mlp_wide_split_body<MODE>(P.a[1], false, t);
+  } else {
+    mlp_wide_split_body<MODE>(P.a[0], false, t);
+    __syncthreads();
+    mlp_wide_split_body<MODE>(P.a[1], P.accum[1] != 0, t);
+  }
+}
+
+int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
+  const int n_tiles = cdiv(a.M, 32);
+#define WIDE_S(M_, A_)                                                       \
+  if (mode == M_ && accum == A_) {                                           \
+    mlp128_wide_split_kernel<M_, A_><<<n_tiles, 256, 0, s>>>(a);             \
+    LAUNCH_CHECK();                                                          \
+    return 0;                                                                \
+  }
+  WIDE_S(MODE_FWD, false)
+  WIDE_S(MODE_BWD, false)
+  WIDE_S(MODE_BWD, true)
+  WIDE_S(MODE_TAN, false)
+  WIDE_S(MODE_TAN, true)
+  WIDE_S(MODE_TAN2, false)
+  WIDE_S(MODE_TAN2, true)
+#undef WIDE_S
+  return NNHIP_E_INVALID;
+}
+int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s) {
+  const int n_tiles = cdiv(P.a[0].M, 32);
+  const bool par = !P.accum[1];
+#define WIDE_PAIR_S(M_)                                                                  \
+  if (mode == M_) {                                                                      \
+    if (par)                                                                             \
+      mlp128_wide_pair_split_kernel<M_, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);       \
+    else                                                                                 \
+      mlp128_wide_pair_split_kernel<M_, false><<<n_tiles, 256, 0, s>>>(P);               \
+    LAUNCH_CHECK();                                                                      \
+    return 0;                                                                            \
+  }
+  WIDE_PAIR_S(MODE_FWD)
+  WIDE_PAIR_S(MODE_BWD)
+  WIDE_PAIR_S(MODE_TAN)
+  WIDE_PAIR_S(MODE_TAN2)
+#undef WIDE_PAIR_S
+  return NNHIP_E_INVALID;
+}
+
+extern "C" size_t nnhip_weight_image_bytes(void) { return ((size_t)WIMG_BYTES + 255) & ~(size_t)255; }
+extern "C" int nnhip_weight_images(const float* const* src, void* const* images, int32_t count, void* stream) {
+  if (!src || !images || count < 0) {
+    nnhip_set_error("nnhip_weight_images: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  for (int k = 0; k < count; ++k)
+    if (!src[k] || !images[k] || ((uintptr_t)images[k] & 15)) {
+      nnhip_set_error("nnhip_weight_images: matrix %d: null or misaligned pointer", k);
+      return NNHIP_E_INVALID;
+    }
+  return count ? launch_weight_images(src, reinterpret_cast<char* const*>(images), count, (hipStream_t)stream) : NNHIP_OK;
 }

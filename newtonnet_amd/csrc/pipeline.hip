@@ -140,9 +140,9 @@ struct PrepLayout {
   size_t headT[2];                 // head0^T, head2^T
   size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
   size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][F] values, then [FT_ROWS][F] d/dx
-  // split-f16 images (node128s.hip) of the node-level weights: update, node0, node2 and their transposes; head0, head2 (+ ^T)
-  size_t img[NNHIP_MAX_LAYERS][6];
-  size_t img_head[4];
+  // split-f16 images (node128s.hip) of every [128][128] weight and its transpose (IMG_* of common.h), and of the head's
+  size_t img[NNHIP_MAX_LAYERS][IMG_PER_LAYER];
+  size_t img_head[IMG_HEAD_COUNT];
   size_t total;
 };
 static size_t prep_bytes(int L);
@@ -168,8 +168,8 @@ static void make_prep_layout(int L, PrepLayout& q) {
   q.headT[0] = carve(off, NF * NF * 4);
   q.headT[1] = carve(off, NF * NF * 4);
   for (int l = 0; l < L; ++l)
-    for (int k = 0; k < 6; ++k) q.img[l][k] = carve(off, WIMG_BYTES);
-  for (int k = 0; k < 4; ++k) q.img_head[k] = carve(off, WIMG_BYTES);
+    for (int k = 0; k < IMG_PER_LAYER; ++k) q.img[l][k] = carve(off, WIMG_BYTES);
+  for (int k = 0; k < IMG_HEAD_COUNT; ++k) q.img_head[k] = carve(off, WIMG_BYTES);
   q.total = off;
 }
 static size_t prep_bytes(int L) {
@@ -278,19 +278,33 @@ static int run_prepare(const nnhip_model* model, const PrepLayout& pq, char* pba
   }
   // split-f16 images of the node-level weights (after the transposes above: the reverse sweep's images are made from them)
   if (split_products_enabled() && model->activation == NNHIP_ACT_SILU) {
-    const float* src[6 * NNHIP_MAX_LAYERS + 4];
-    char* dst[6 * NNHIP_MAX_LAYERS + 4];
+    const float* src[IMG_PER_LAYER * NNHIP_MAX_LAYERS + IMG_HEAD_COUNT];
+    char* dst[IMG_PER_LAYER * NNHIP_MAX_LAYERS + IMG_HEAD_COUNT];
     int c = 0;
     for (int l = 0; l < L; ++l) {
       const nnhip_layer_params& lp = model->layer[l];
-      const float* ws_[6] = {lp.update_w, lp.node0_w, lp.node2_w, Q(pq.wT[l][6]), Q(pq.wT[l][0]), Q(pq.wT[l][1])};
-      for (int k = 0; k < 6; ++k) {
+      const float* ws_[IMG_PER_LAYER];
+      ws_[IMG_UPDATE] = lp.update_w;
+      ws_[IMG_NODE0] = lp.node0_w;
+      ws_[IMG_NODE2] = lp.node2_w;
+      ws_[IMG_UPDATE_T] = Q(pq.wT[l][6]);
+      ws_[IMG_NODE0_T] = Q(pq.wT[l][0]);
+      ws_[IMG_NODE2_T] = Q(pq.wT[l][1]);
+      ws_[IMG_EQ1_0] = lp.eq1_0_w;
+      ws_[IMG_EQ1_2] = lp.eq1_2_w;
+      ws_[IMG_EQ2_0] = lp.eq2_0_w;
+      ws_[IMG_EQ2_2] = lp.eq2_2_w;
+      ws_[IMG_EQ1_0_T] = Q(pq.wT[l][2]);
+      ws_[IMG_EQ1_2_T] = Q(pq.wT[l][3]);
+      ws_[IMG_EQ2_0_T] = Q(pq.wT[l][4]);
+      ws_[IMG_EQ2_2_T] = Q(pq.wT[l][5]);
+      for (int k = 0; k < IMG_PER_LAYER; ++k) {
         src[c] = ws_[k];
         dst[c++] = pbase + pq.img[l][k];
       }
     }
-    const float* hs_[4] = {model->head0_w, model->head2_w, Q(pq.headT[0]), Q(pq.headT[1])};
-    for (int k = 0; k < 4; ++k) {
+    const float* hs_[IMG_HEAD_COUNT] = {model->head0_w, model->head2_w, Q(pq.headT[0]), Q(pq.headT[1])};
+    for (int k = 0; k < IMG_HEAD_COUNT; ++k) {
       src[c] = hs_[k];
       dst[c++] = pbase + pq.img_head[k];
     }
@@ -433,6 +447,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
       m1.act = m2.act = act;
+      if (split_nodes) {   // (used by the row-local form only: small pair counts)
+        m1.W1_img = pbase + pq.img[l][IMG_EQ1_0];
+        m1.W2_img = pbase + pq.img[l][IMG_EQ1_2];
+        m2.W1_img = pbase + pq.img[l][IMG_EQ2_0];
+        m2.W2_img = pbase + pq.img[l][IMG_EQ2_2];
+      }
       if (has_f)
         TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
       else
@@ -471,10 +491,10 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       if (split_nodes) {
         NodeImages im;
         memset(&im, 0, sizeof(im));
-        im.Wu = pbase + pq.img[l][0];
+        im.Wu = pbase + pq.img[l][IMG_UPDATE];
         if (na.W0) {
-          im.W0 = l + 1 < L ? pbase + pq.img[l + 1][1] : pbase + pq.img_head[0];
-          im.W2 = l + 1 < L ? pbase + pq.img[l + 1][2] : pbase + pq.img_head[1];
+          im.W0 = l + 1 < L ? pbase + pq.img[l + 1][IMG_NODE0] : pbase + pq.img_head[IMG_HEAD0];
+          im.W2 = l + 1 < L ? pbase + pq.img[l + 1][IMG_NODE2] : pbase + pq.img_head[IMG_HEAD2];
         }
         TRY(launch_node_fwd_split(na, im, s));
       } else {
@@ -525,9 +545,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     nb.act = act;
     NodeImages bim;
     memset(&bim, 0, sizeof(bim));
-    bim.W2T = pbase + pq.img_head[3];
-    bim.W0T = pbase + pq.img_head[2];
-    bim.WuT = pbase + pq.img[L - 1][3];
+    bim.W2T = pbase + pq.img_head[IMG_HEAD2_T];
+    bim.W0T = pbase + pq.img_head[IMG_HEAD0_T];
+    bim.WuT = pbase + pq.img[L - 1][IMG_UPDATE_T];
     const nnhip_layer_params& top = model->layer[L - 1];
     if (top.ln_w) {   // the LayerNorm adjoint sits between the head adjoint and the update adjoint: three launches
       NodeBwdArgs head = nb;
@@ -557,6 +577,12 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
       m1.act = m2.act = act;
+      if (split_nodes) {
+        m1.W1_img = pbase + pq.img[l][IMG_EQ1_2_T];
+        m1.W2_img = pbase + pq.img[l][IMG_EQ1_0_T];
+        m2.W1_img = pbase + pq.img[l][IMG_EQ2_2_T];
+        m2.W2_img = pbase + pq.img[l][IMG_EQ2_0_T];
+      }
       if (has_f)
         TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
       else
@@ -586,9 +612,9 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       nb.act = act;
       NodeImages bim;
       memset(&bim, 0, sizeof(bim));
-      bim.W2T = pbase + pq.img[l][5];
-      bim.W0T = pbase + pq.img[l][4];
-      bim.WuT = pbase + pq.img[l - 1][3];
+      bim.W2T = pbase + pq.img[l][IMG_NODE2_T];
+      bim.W0T = pbase + pq.img[l][IMG_NODE0_T];
+      bim.WuT = pbase + pq.img[l - 1][IMG_UPDATE_T];
       const nnhip_layer_params& below = model->layer[l - 1];
       if (below.ln_w) {
         NodeBwdArgs mlp = nb;

@@ -12,7 +12,7 @@
   } while (0)
 
 static nnhip_mlp_desc mlp_desc(int mode, const float* X, int ldx, const float* W1, const float* W2, float* H, float* Y, int M,
-                               int act) {
+                               int act, const void* img1 = nullptr, const void* img2 = nullptr) {
   nnhip_mlp_desc d;
   memset(&d, 0, sizeof(d));
   d.X = X;
@@ -26,10 +26,65 @@ static nnhip_mlp_desc mlp_desc(int mode, const float* X, int ldx, const float* W
   d.M = M;
   d.mode = mode;
   d.activation = act;
+  d.W1_image = img1;     // (both NULL when the split-f16 form is off: train_images)
+  d.W2_image = img2;
   return d;
 }
 static int run1(const nnhip_mlp_desc& d, void* s) { return d.M > 0 ? nnhip_mlp128_ex(&d, s) : NNHIP_OK; }
 static int run2(const nnhip_mlp_desc& a, const nnhip_mlp_desc& b, void* s) { return a.M > 0 ? nnhip_mlp128_pair_ex(&a, &b, s) : NNHIP_OK; }
+
+// the split-f16 product form of the row-local kernels: SiLU models, images present in the workspace, NNHIP_MLP_SPLIT != 0
+static bool train_images(const nnhip_model* model, const nnhip_train_ws* w) {
+  return split_products_enabled() && model->activation == NNHIP_ACT_SILU && w->himg[0] != nullptr;
+}
+#define LIMG(l, k) (img_on ? w->wimg[l][k] : nullptr)
+#define HIMG(k) (img_on ? w->himg[k] : nullptr)
+
+static int node_fwd_any(bool img_on, const nnhip_train_ws* w, int l, bool to_head, const float* f, const float* a_mid, const float* Wu,
+                        float* q, float* a_out, const float* W0, const float* b0, const float* W2, const float* b2, float* hn,
+                        float* m, int N, int act, void* s) {
+  if (!img_on) return nnhip_node_fwd(f, a_mid, Wu, q, a_out, W0, b0, W2, b2, hn, m, N, act, s);
+  NodeFwdArgs na;
+  memset(&na, 0, sizeof(na));
+  na.f = f;
+  na.a_mid = a_mid;
+  na.Wu = Wu;
+  na.q = q;
+  na.a_out = a_out;
+  na.W0 = W0;
+  na.b0 = b0;
+  na.W2 = W2;
+  na.b2 = b2;
+  na.hn = hn;
+  na.m = m;
+  na.N = N;
+  na.act = act;
+  NodeImages im;
+  memset(&im, 0, sizeof(im));
+  im.Wu = (const char*)w->wimg[l][IMG_UPDATE];
+  im.W0 = (const char*)(to_head ? w->himg[IMG_HEAD0] : w->wimg[l + 1][IMG_NODE0]);
+  im.W2 = (const char*)(to_head ? w->himg[IMG_HEAD2] : w->wimg[l + 1][IMG_NODE2]);
+  return launch_node_fwd_split(na, im, (hipStream_t)s);
+}
+// update adjoint only (the node-MLP adjoint of the training sweeps is a separate MODE_TAN launch that keeps its hidden product)
+static int node_bwd_update_any(bool img_on, const nnhip_train_ws* w, int l, float* g_a, const float* f, const float* q, const float* G_f,
+                               const float* WuT, float* gf, int N, int act, void* s) {
+  if (!img_on) return nnhip_node_bwd(nullptr, nullptr, nullptr, nullptr, g_a, 0, f, q, G_f, WuT, gf, N, act, s);
+  NodeBwdArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.g_a = g_a;
+  nb.f = f;
+  nb.q = q;
+  nb.G_f = G_f;
+  nb.WuT = WuT;
+  nb.gf = gf;
+  nb.N = N;
+  nb.act = act;
+  NodeImages im;
+  memset(&im, 0, sizeof(im));
+  im.WuT = (const char*)w->wimg[l][IMG_UPDATE_T];
+  return launch_node_bwd_split(nb, im, (hipStream_t)s);
+}
 
 static int check(const nnhip_model* model, const nnhip_train_ws* w, const char* who) {
   if (!model || !w || w->n_layers != model->n_layers || w->n_layers < 1 || w->n_layers > NNHIP_MAX_LAYERS || w->n_atoms < 0 ||
@@ -51,6 +106,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   TS_TRY(check(model, w, "nnhip_train_values"));
   const int N = w->n_atoms, E = w->n_edges, B = w->n_mol, L = w->n_layers, P = E / 2, act = model->activation;
   if (N == 0) return NNHIP_OK;
+  const bool img_on = train_images(model, w);
   // parameter-only data of this step: transposed weights, radial-filter tables
   {
     const float* src[40];
@@ -77,6 +133,39 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     src[c] = model->head2_w;
     dst[c++] = w->headT[1];
     TS_TRY(nnhip_transpose128(src, dst, c, s));
+    if (train_images(model, w)) {   // split-f16 images of every weight and transpose (the weights change every step)
+      const float* isrc[IMG_PER_LAYER * NNHIP_MAX_LAYERS + IMG_HEAD_COUNT];
+      void* idst[IMG_PER_LAYER * NNHIP_MAX_LAYERS + IMG_HEAD_COUNT];
+      int n = 0;
+      for (int l = 0; l < L; ++l) {
+        const nnhip_layer_params& lp = model->layer[l];
+        const float* m_[IMG_PER_LAYER];
+        m_[IMG_UPDATE] = lp.update_w;
+        m_[IMG_NODE0] = lp.node0_w;
+        m_[IMG_NODE2] = lp.node2_w;
+        m_[IMG_UPDATE_T] = w->wT[l][6];
+        m_[IMG_NODE0_T] = w->wT[l][0];
+        m_[IMG_NODE2_T] = w->wT[l][1];
+        m_[IMG_EQ1_0] = lp.eq1_0_w;
+        m_[IMG_EQ1_2] = lp.eq1_2_w;
+        m_[IMG_EQ2_0] = lp.eq2_0_w;
+        m_[IMG_EQ2_2] = lp.eq2_2_w;
+        m_[IMG_EQ1_0_T] = w->wT[l][2];
+        m_[IMG_EQ1_2_T] = w->wT[l][3];
+        m_[IMG_EQ2_0_T] = w->wT[l][4];
+        m_[IMG_EQ2_2_T] = w->wT[l][5];
+        for (int k = 0; k < IMG_PER_LAYER; ++k) {
+          isrc[n] = m_[k];
+          idst[n++] = w->wimg[l][k];
+        }
+      }
+      const float* h_[IMG_HEAD_COUNT] = {model->head0_w, model->head2_w, w->headT[0], w->headT[1]};
+      for (int k = 0; k < IMG_HEAD_COUNT; ++k) {
+        isrc[n] = h_[k];
+        idst[n++] = w->himg[k];
+      }
+      TS_TRY(nnhip_weight_images(isrc, idst, n, s));
+    }
     const float* ew[NNHIP_MAX_LAYERS];
     for (int l = 0; l < L; ++l) ew[l] = model->layer[l].edge_w;
     TS_TRY(nnhip_filter_tables(ew, w->ftab, L, model->frequencies, model->n_basis, model->envelope, s));
@@ -85,7 +174,8 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   TS_TRY(nnhip_embed(w->z, model->node_embedding, N, w->a0, s));
   {
     const nnhip_layer_params& l0 = model->layer[0];
-    nnhip_mlp_desc d = mlp_desc(MODE_FWD, w->a0, NF, l0.node0_w, l0.node2_w, w->hn[0], w->m[0], N, act);
+    nnhip_mlp_desc d = mlp_desc(MODE_FWD, w->a0, NF, l0.node0_w, l0.node2_w, w->hn[0], w->m[0], N, act, LIMG(0, IMG_NODE0),
+                                LIMG(0, IMG_NODE2));
     d.b1 = l0.node0_b;
     d.b2 = l0.node2_b;
     TS_TRY(run1(d, s));
@@ -95,19 +185,21 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   for (int l = 0; l < L; ++l) {
     const nnhip_layer_params& lp = model->layer[l];
     TS_TRY(nnhip_message_fwd(w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid, a_in, w->msg[l], w->a_mid[l], N, s));
-    const nnhip_mlp_desc d1 = mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->phi1[l], P, act);
+    const nnhip_mlp_desc d1 = mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->phi1[l], P, act,
+                                       LIMG(l, IMG_EQ1_0), LIMG(l, IMG_EQ1_2));
     if (l > 0)
-      TS_TRY(run2(d1, mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->phi2[l], P, act), s));
+      TS_TRY(run2(d1, mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->phi2[l], P, act, LIMG(l, IMG_EQ2_0),
+                               LIMG(l, IMG_EQ2_2)), s));
     else
       TS_TRY(run1(d1, s));
     TS_TRY(nnhip_force_message_fwd(w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_in, w->f_out[l], N, s));
     if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
-      TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nx.node0_w, nx.node0_b, nx.node2_w,
-                            nx.node2_b, w->hn[l + 1], w->m[l + 1], N, act, s));
+      TS_TRY(node_fwd_any(img_on, w, l, false, w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nx.node0_w, nx.node0_b,
+                          nx.node2_w, nx.node2_b, w->hn[l + 1], w->m[l + 1], N, act, s));
     } else {
-      TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], model->head0_w, model->head0_b,
-                            model->head2_w, model->head2_b, w->e1, w->e2, N, act, s));
+      TS_TRY(node_fwd_any(img_on, w, l, true, w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], model->head0_w,
+                          model->head0_b, model->head2_w, model->head2_b, w->e1, w->e2, N, act, s));
     }
     a_in = w->a_out[l];
     f_in = w->f_out[l];
@@ -116,22 +208,25 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
                         w->atom_energy, w->g_e2, w->energy, s));
   // ---- sweep 2: reverse (seed 1)
   {
-    nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act);
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act, HIMG(IMG_HEAD2_T),
+                                HIMG(IMG_HEAD0_T));
     d.T = w->t_e1;
     TS_TRY(run1(d, s));
   }
-  TS_TRY(nnhip_node_bwd(nullptr, nullptr, nullptr, nullptr, w->GA[L - 1], 0, w->f_out[L - 1], w->q[L - 1], nullptr,
-                        w->wT[L - 1][6], w->gf[L - 1], N, act, s));
+  TS_TRY(node_bwd_update_any(img_on, w, L - 1, w->GA[L - 1], w->f_out[L - 1], w->q[L - 1], nullptr, w->wT[L - 1][6], w->gf[L - 1], N,
+                             act, s));
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const float* f_prev = l > 0 ? w->f_out[l - 1] : nullptr;
     float* Gf = w->Gf[pp];
     TS_TRY(nnhip_force_message_bwd(w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_prev,
                                    w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, s));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act);
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act,
+                                 LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T = w->t1[l];
     if (l > 0) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->g_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->g_msg[l], P, act);
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->g_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->g_msg[l], P, act,
+                                   LIMG(l, IMG_EQ2_2_T), LIMG(l, IMG_EQ2_0_T));
       d2.T = w->t2[l];
       d2.accumulate = 1;
       TS_TRY(run2(d1, d2, s));
@@ -142,12 +237,13 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
                              l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0 ? 1 : 0, s));
     if (l > 0) {
       HIP_TRY(hipMemcpyAsync(w->GA[l - 1], w->GA[l], sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->GA[l - 1], N, act);
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->GA[l - 1], N, act,
+                                  LIMG(l, IMG_NODE2_T), LIMG(l, IMG_NODE0_T));
       d.T = w->t_n[l];
       d.accumulate = 1;
       TS_TRY(run1(d, s));
-      TS_TRY(nnhip_node_bwd(nullptr, nullptr, nullptr, nullptr, w->GA[l - 1], 0, w->f_out[l - 1], w->q[l - 1], Gf,
-                            w->wT[l - 1][6], w->gf[l - 1], N, act, s));
+      TS_TRY(node_bwd_update_any(img_on, w, l - 1, w->GA[l - 1], w->f_out[l - 1], w->q[l - 1], Gf, w->wT[l - 1][6], w->gf[l - 1], N, act,
+                                 s));
     }
     pp ^= 1;
   }
@@ -164,6 +260,7 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
   }
   const int N = w->n_atoms, E = w->n_edges, L = w->n_layers, P = E / 2, act = model->activation;
   if (N == 0) return NNHIP_OK;
+  const bool img_on = train_images(model, w);
   // ---- sweep 3: tangent forward along v = -dL/dF
   TS_TRY(nnhip_edge_tangent_geom(g_forces, -1.0f, w->edge_index, w->geo, E, model->cutoff, w->tgeo, s));
   for (int l = 0; l < L; ++l) {
@@ -171,10 +268,12 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     const bool first = l == 0;
     TS_TRY(nnhip_message_tan_fwd(w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo, w->ftab[l], w->row_ptr, w->col, w->pid,
                                  first ? nullptr : w->da_out[l - 1], w->dmsg[l], w->da_mid, N, s));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->dphi1[l], P, act);
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->dphi1[l], P, act, LIMG(l, IMG_EQ1_0),
+                                 LIMG(l, IMG_EQ1_2));
     d1.T = w->dh1[l];
     if (!first) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->dphi2[l], P, act);
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->dphi2[l], P, act,
+                                   LIMG(l, IMG_EQ2_0), LIMG(l, IMG_EQ2_2));
       d2.T = w->dh2[l];
       TS_TRY(run2(d1, d2, s));
     } else {
@@ -187,11 +286,13 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     TS_TRY(nnhip_update_tan_fwd(w->da_mid, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], N, w->da_out[l], s));
     if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act);
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act,
+                                  LIMG(l + 1, IMG_NODE0), LIMG(l + 1, IMG_NODE2));
       d.T = w->dhn[l + 1];
       TS_TRY(run1(d, s));
     } else {
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, model->head0_w, model->head2_w, w->e1, w->de2, N, act);
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, model->head0_w, model->head2_w, w->e1, w->de2, N, act, HIMG(IMG_HEAD0),
+                                  HIMG(IMG_HEAD2));
       d.T = w->de1;
       TS_TRY(run1(d, s));
     }
@@ -200,7 +301,8 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
   TS_TRY(nnhip_head_seed_tan(w->e2, w->de2, model->head4_w, model->head4_b, model->scale, w->z, w->batch, g_energy, N, act,
                              w->dg_e2, w->w4row, w->scal, s));
   {
-    nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act);
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act, HIMG(IMG_HEAD2_T),
+                                HIMG(IMG_HEAD0_T));
     d.T2 = w->t_e1;
     d.Hd = w->de1;
     d.G = w->dg_e1;
@@ -217,12 +319,14 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     TS_TRY(nnhip_force_message_tan_bwd(w->gf[l], w->dgf, w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr, w->col,
                                        w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1], w->dg_h12[l],
                                        first ? nullptr : nxt, N, s));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN2, w->dg_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->dg_msg, P, act);
+    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN2, w->dg_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->dg_msg, P, act,
+                                 LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T2 = w->t1[l];
     d1.Hd = w->dh1[l];
     d1.G = w->dg_h1[l];
     if (!first) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN2, w->dg_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->dg_msg, P, act);
+      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN2, w->dg_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->dg_msg, P, act,
+                                   LIMG(l, IMG_EQ2_2_T), LIMG(l, IMG_EQ2_0_T));
       d2.T2 = w->t2[l];
       d2.Hd = w->dh2[l];
       d2.G = w->dg_h2[l];
@@ -234,7 +338,8 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     TS_TRY(nnhip_message_tan_bwd(w->g_msg[l], w->dg_msg, w->GA[l], w->dGA, w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo,
                                  w->ftab[l], w->row_ptr, w->col, w->pid, w->dg_m[l], w->g_eps[l], w->dg_eps[l], N, s));
     {
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->dGA, N, act);
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->dGA, N, act,
+                                  LIMG(l, IMG_NODE2_T), LIMG(l, IMG_NODE0_T));
       d.T2 = first ? w->zeros_nf : w->t_n[l];
       d.Hd = first ? w->zeros_nf : w->dhn[l];
       d.G = w->dg_hn[l];

@@ -56,7 +56,8 @@ class MlpDesc(C.Structure):
     _fields_ = [('X', C.c_void_p), ('ldx', C.c_int32), ('W1', C.c_void_p), ('W2', C.c_void_p), ('b1', C.c_void_p),
                 ('b2', C.c_void_p), ('H', C.c_void_p), ('ldh', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32),
                 ('M', C.c_int32), ('mode', C.c_int32), ('accumulate', C.c_int32), ('activation', C.c_int32),
-                ('T', C.c_void_p), ('T2', C.c_void_p), ('Hd', C.c_void_p), ('G', C.c_void_p)]
+                ('T', C.c_void_p), ('T2', C.c_void_p), ('Hd', C.c_void_p), ('G', C.c_void_p),
+                ('W1_image', C.c_void_p), ('W2_image', C.c_void_p)]
 
 
 class WgradProblem(C.Structure):
@@ -78,7 +79,7 @@ def _train_ws_fields():
     return ([(n, i32) for n in ('n_atoms', 'n_edges', 'n_mol', 'n_layers', 'n_basis', 'envelope', 'bf16_wgrad', 'pad_')]
             + one('z', 'pos', 'cell', 'batch', 'mol_ptr', 'row_ptr', 'col', 'rev', 'pid', 'edge_index', 'geo', 'disp', 'rbf',
                   'drbf', 'xg')
-            + [('wT', (vp * 7) * L), ('headT', vp * 2)] + per('ftab')
+            + [('wT', (vp * 7) * L), ('headT', vp * 2)] + per('ftab') + [('wimg', (vp * 14) * L), ('himg', vp * 4)]
             + one('a0') + per('hn', 'm', 'msg', 'h1', 'h2', 'phi1', 'phi2', 'a_mid', 'a_out', 'f_out', 'q')
             + one('e1', 'e2', 'g_e2', 'atom_energy', 'energy', 'forces')
             + one('t_e1') + per('GA', 'gf') + [('Gf', vp * 2)] + per('g_h12', 't1', 't2', 'g_msg', 'g_m', 't_n')
@@ -194,12 +195,15 @@ def lib():
     L.nnhip_train_values.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp]
     L.nnhip_train_grads.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp, vp, vp]
     L.nnhip_train_ws_bytes.restype = sz
+    L.nnhip_weight_image_bytes.restype = sz
+    L.nnhip_weight_images.argtypes = [vp, vp, i32, vp]
     L.nnhip_mse_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     L.nnhip_clip_adam_scratch_bytes.restype = sz
     L.nnhip_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, f32, f32, f32, f32, f32, vp]
     for fn in STAGE_SYMBOLS:
         if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes', 'nnhip_species_scratch_bytes',
-                      'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_ws_bytes'):
+                      'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_ws_bytes',
+                      'nnhip_weight_image_bytes'):
             getattr(L, fn).restype = C.c_int
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
@@ -218,7 +222,7 @@ STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables
                  'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_species_scratch_bytes', 'nnhip_wgrad_slab_bytes',
                  'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad',
                  'nnhip_clip_adam', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_values', 'nnhip_train_grads',
-                 'nnhip_train_ws_bytes')
+                 'nnhip_train_ws_bytes', 'nnhip_weight_image_bytes', 'nnhip_weight_images')
 
 EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',

@@ -110,6 +110,9 @@ class TrainWorkspace:
         # ---- parameter-only data rebuilt every step: transposed weights, radial-filter tables
         self.wT = [[buf(F, F) for _ in range(7)] for _ in range(L)]
         self.headT = [buf(F, F), buf(F, F)]
+        n_img = hip.lib().nnhip_weight_image_bytes() // 4              # split-f16 images of every weight / transpose (csrc/node128s.hip)
+        self.wimg = [[buf(n_img) for _ in range(14)] for _ in range(L)]
+        self.himg = [buf(n_img) for _ in range(4)]
         n_tab = hip.lib().nnhip_filter_table_bytes() // 4
         self.ftab = [buf(n_tab) for _ in range(L)]
         # ---- gradient outputs (zero-initialised once: the parameters the path never touches keep an exact zero gradient)
@@ -208,10 +211,10 @@ class TrainWorkspace:
         c.n_atoms, c.n_mol, c.n_layers, c.n_basis, c.envelope = self.N, self.B, self.L, emb.n_basis, emb.envelope_id
         for name, _ in hip.TrainWs._fields_:
             v = getattr(self, name, None)
-            if name in ('wT',):
+            if name in ('wT', 'wimg'):
                 for l in range(self.L):
-                    for k in range(7):
-                        c.wT[l][k] = ptr(self.wT[l][k])
+                    for k in range(len(v[l])):
+                        getattr(c, name)[l][k] = ptr(v[l][k])
             elif isinstance(v, list):
                 arr = getattr(c, name)
                 for l, t in enumerate(v):
