@@ -333,6 +333,7 @@ int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_
 int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_t s);
 int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s);      // needs a.W1_img / a.W2_img, SiLU
 int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s);
+int launch_lin_wide_split(const float* X, int ldx, const char* img, float* Y, int ldy, int M, bool acc, hipStream_t s);
 bool split_products_enabled();   // mlp128.hip (NNHIP_MLP_SPLIT=0 turns every split-f16 kernel off)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

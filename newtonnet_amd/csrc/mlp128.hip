@@ -335,6 +335,8 @@ int launch_mlp_wide(int mode, bool accum, const MlpArgs& a, hipStream_t s);   //
 int launch_mlp_wide_pair(int mode, const MlpPair& P, hipStream_t s);
 
 #define MLP_WIDE_MAX_TILES 1536   // up to ~49k rows one workgroup per tile beats the persistent form (tools/bench_mlp.py)
+#define MLPS_WIDE_MAX_TILES 832   // ... ~27k rows with split-f16 products (config-2 recipe: 611 tiles 0.189 vs 0.220 ms per step
+                                  // row-local vs persistent, 1223 tiles 0.309 vs 0.242)
 
 int launch_mlp_split(int mode, bool accum_last, const MlpPair& P, hipStream_t s);   // mlp128s.hip
 
@@ -370,7 +372,9 @@ static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipS
 }
 
 static bool mlp_use_wide(const MlpArgs& a) {
-  static const int wide_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : MLP_WIDE_MAX_TILES;
+  static const int env_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : -1;
+  const int wide_max = env_max >= 0 ? env_max
+                                    : (split_products_enabled() && a.act == NNHIP_ACT_SILU ? MLPS_WIDE_MAX_TILES : MLP_WIDE_MAX_TILES);
   return cdiv(a.M, 32) <= wide_max || a.b1 || a.b2;
 }
 

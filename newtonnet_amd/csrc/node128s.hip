@@ -494,3 +494,37 @@ extern "C" int nnhip_weight_images(const float* const* src, void* const* images,
     }
   return count ? launch_weight_images(src, reinterpret_cast<char* const*>(images), count, (hipStream_t)stream) : NNHIP_OK;
 }
+
+// One dense linear Y (+)= X W^T, row-local, split-f16 products (node128.hip:lin128_wide_kernel with a weight image)
+template <bool ACC>
+__global__ void __launch_bounds__(256)
+lin128_wide_split_kernel(const float* __restrict__ X, int ldx, const char* __restrict__ img, float* __restrict__ Y, int ldy, int M) {
+  NS_STILE_SETUP()
+  const int row = blockIdx.x * 32 + t.r;
+  const int rc = min(row, M - 1);
+  WFrag wf;
+  load_wimg(wf, t, img);
+  float x[16], y[16];
+  sblk_load(x, X, (size_t)rc * ldx, t);
+  tile_publish(x, t);
+  __syncthreads();
+  const float inv = tile_commit(x, t);
+  __syncthreads();
+  if (ACC) sblk_load(x, Y, (size_t)rc * ldy, t);
+  tile_gemm_s(y, t, wf, inv);
+  if (ACC) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] += x[k];
+  }
+  if (row < M) sblk_store(y, Y, (size_t)row * ldy, t);
+}
+int launch_lin_wide_split(const float* X, int ldx, const char* img, float* Y, int ldy, int M, bool acc, hipStream_t s) {
+  if (M <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  if (acc)
+    lin128_wide_split_kernel<true><<<cdiv(M, 32), 256, 0, s>>>(X, ldx, img, Y, ldy, M);
+  else
+    lin128_wide_split_kernel<false><<<cdiv(M, 32), 256, 0, s>>>(X, ldx, img, Y, ldy, M);
+  LAUNCH_CHECK();
+  return 0;
+}

@@ -282,7 +282,10 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     TS_TRY(nnhip_force_message_tan_fwd(w->phi1[l], w->dphi1[l], w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr,
                                        w->col, w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1],
                                        w->df_out[l], N, s));
-    TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
+    if (img_on)
+      TS_TRY(launch_lin_wide_split(w->df_out[l], NF, (const char*)w->wimg[l][IMG_UPDATE], w->dq[l], NF, 3 * N, false, (hipStream_t)s));
+    else
+      TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
     TS_TRY(nnhip_update_tan_fwd(w->da_mid, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], N, w->da_out[l], s));
     if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
@@ -314,7 +317,10 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     const bool first = l == 0;
     TS_TRY(nnhip_update_tan_bwd(w->GA[l], w->dGA, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], dGf, N, w->gq[l], w->dgq[l],
                                 w->dgf, s));
-    TS_TRY(nnhip_linear128(w->dgq[l], NF, w->wT[l][6], w->dgf, NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_ACC, s));
+    if (img_on)
+      TS_TRY(launch_lin_wide_split(w->dgq[l], NF, (const char*)w->wimg[l][IMG_UPDATE_T], w->dgf, NF, 3 * N, true, (hipStream_t)s));
+    else
+      TS_TRY(nnhip_linear128(w->dgq[l], NF, w->wT[l][6], w->dgf, NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_ACC, s));
     float* nxt = w->dGf[pp];
     TS_TRY(nnhip_force_message_tan_bwd(w->gf[l], w->dgf, w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr, w->col,
                                        w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1], w->dg_h12[l],
