@@ -883,6 +883,54 @@ species_total_kernel(const float* __restrict__ part, int chunks, int width, int 
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// Small batches (the launch-bound regime): the same sums in ONE launch, no table -- workgroup zz first lists the atoms of its
+// element (each of its two waves scans a strided half of z with coalesced loads and compacts its hits by ballot: fixed order),
+// then adds their rows; workgroup 119 forms the plain total.
+#define SP_DIRECT_MAX_ATOMS 1024
+__global__ void __launch_bounds__(NF)
+species_direct_kernel(const float* __restrict__ x, int ldx, int width, const int64_t* __restrict__ z, int n_atoms,
+                      float* __restrict__ out0, int c0, int cols0, int ldo0, float* __restrict__ out1, int c1, int cols1, int ldo1,
+                      float* __restrict__ total, int c_total) {
+  const int zz = blockIdx.x, c = threadIdx.x;
+  if (zz < NNHIP_N_ELEMENTS) {
+    __shared__ unsigned short list[2][SP_DIRECT_MAX_ATOMS];
+    __shared__ int cnt[2];
+    const int wave = c >> 6, lane = c & 63;
+    int n = 0;   // wave-uniform
+    for (int base = wave * 64; base < n_atoms; base += NF) {
+      const int i = base + lane;
+      const bool hit = i < n_atoms && (int)z[i] == zz;
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[wave][n + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+      n += __popcll(m);
+    }
+    if (lane == 0) cnt[wave] = n;
+    __syncthreads();
+    float s = 0.f;
+    if (c < width) {
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int m = cnt[w];
+#pragma unroll 4
+        for (int k = 0; k < m; ++k) s += x[(size_t)list[w][k] * ldx + c];
+      }
+    }
+    if (out0 && c >= c0 && c < c0 + cols0) out0[(size_t)zz * ldo0 + (c - c0)] = s;
+    if (out1 && c >= c1 && c < c1 + cols1) out1[(size_t)zz * ldo1 + (c - c1)] = s;
+  } else if (total) {
+    __shared__ float sh[NF];
+    float s = 0.f;
+    for (int i = c; i < n_atoms; i += NF) s += x[(size_t)i * ldx + c_total];
+    sh[c] = s;
+    __syncthreads();
+    for (int o = NF / 2; o > 0; o >>= 1) {
+      if (c < o) sh[c] += sh[c + o];
+      __syncthreads();
+    }
+    if (c == 0) total[0] = sh[0];
+  }
+}
+
 // out[i][:] = table[z[i]][:]   (node embedding lookup, newtonnet.py:142)
 __global__ void __launch_bounds__(256)
 embed_rows_kernel(const int64_t* __restrict__ z, const float* __restrict__ table, int n_atoms, float* __restrict__ out) {
@@ -1144,6 +1192,12 @@ extern "C" int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, con
   ARG_CHECK(n_atoms >= 0 && x && z && scratch && width >= 1 && width <= NF && ldx >= width && (!out0 || (c0 >= 0 && c0 + cols0 <= width)) &&
                 (!out1 || (c1 >= 0 && c1 + cols1 <= width)) && (!total || (c_total >= 0 && c_total < width)), "nnhip_species_sum");
   hipStream_t s = (hipStream_t)stream;
+  if (n_atoms <= SP_DIRECT_MAX_ATOMS) {
+    species_direct_kernel<<<NNHIP_N_ELEMENTS + (total ? 1 : 0), NF, 0, s>>>(x, ldx, width, z, n_atoms, out0, c0, cols0, ldo0, out1, c1,
+                                                                          cols1, ldo1, total, c_total);
+    LAUNCH_CHECK();
+    return NNHIP_OK;
+  }
   const int chunks = species_chunks(n_atoms);
   species_partial_kernel<<<chunks, NF, NNHIP_N_ELEMENTS * width * sizeof(float), s>>>(x, ldx, width, z, n_atoms, scratch);
   LAUNCH_CHECK();

@@ -328,12 +328,14 @@ class GraphedTrainStep:
         """(w_E / n_E, w_F / n_F) with the GLOBAL element counts as a device tensor, and whether ANY rank's batch structure
         changed -- one small all-reduce per step under torch.distributed (every rank must take the same re-capture decision,
         or the collectives inside the capture's warm-up would be unmatched)."""
+        if not (dist.is_available() and dist.is_initialized()):       # nothing to agree on: no device work
+            return torch.tensor([self.w_energy / max(energy_label.numel(), 1), self.w_force / max(force_label.numel(), 1)],
+                                dtype=torch.float32), changed
         counts = torch.tensor([float(energy_label.numel()), float(force_label.numel()), 1.0 if changed else 0.0],
                               dtype=torch.float32, device=dev)
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
-            if not (self.assume_static and self._st is not None):
-                changed = bool(counts[2].item() > 0)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        if not (self.assume_static and self._st is not None):
+            changed = bool(counts[2].item() > 0)
         w = torch.tensor([self.w_energy, self.w_force], dtype=torch.float32, device=dev)
         return w / counts[:2], changed
 
@@ -342,7 +344,7 @@ class GraphedTrainStep:
         dev = pos.device
         emb = self.model.embedding_layers.edge_embedding
         st = dict(z=z.clone(), cell=cell.clone(), batch=batch.clone(), pos=pos.detach().clone().requires_grad_(True),
-                  e=energy_label.detach().clone(), f=force_label.detach().clone(), norm=norm.clone())
+                  e=energy_label.detach().clone(), f=force_label.detach().clone(), norm=norm.to(dev).clone())
         # static candidate list: every ordered pair of every molecule (minimum image when periodic)
         st['graph'] = hip.build_graph(st['pos'].detach(), st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies,
                                       want_rbf=True, envelope=emb.envelope_id)
