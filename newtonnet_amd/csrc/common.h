@@ -310,7 +310,34 @@ struct NodeBwdArgs {
   int N;
   int acc_ga;
   int act;
+  // training (split-f16 kernel only): keep the hidden product t = g_top W2 before the act' factor; read the running g_a from
+  // another buffer than the one written (the value sweep keeps g_a of every layer)
+  float* T;
+  const float* g_a_in;
 };
+// tangent forms of the two node kernels (node128s.hip; training sweeps 3 and 4, csrc/train.hip)
+struct NodeTanFwdArgs {
+  const float *df, *f, *q;   // [N][3][F] tangent / value of force_node after the edge phase, equiv_update(force_node)
+  const float* da_mid;       // [N][F]
+  const float* hn;           // [N][F] pre-activation of the next message_nodepart / head (value sweep)
+  float* dq;                 // [N][3][F] out
+  float* da_out;             // [N][F] out
+  float *T, *Y;              // [N][F] out: tangent of hn, tangent of the next m (or of e2)
+  int N;
+};
+struct NodeTanBwdArgs {
+  // part A (g_top != NULL): tangent of the upper node-MLP / head adjoint
+  const float *g_top, *h_top, *t2_top, *hd_top;   // dg_m, hn, t_n, dhn (t2 / hd NULL = 0)
+  float* G;                  // [N][F] out: tangent of the hidden adjoint
+  float* dga;                // [N][F] running tangent of dE/d atom_node (acc_dga: +=, else =; part A absent: input only)
+  int acc_dga;
+  // part B (f != NULL): tangent of the lower layer's update adjoint
+  const float *ga, *f, *df, *q, *dq, *dgf_in;
+  float *gq, *dgq, *dgf;     // [N][3][F] out
+  int N;
+};
+int launch_node_tan_fwd_split(const NodeTanFwdArgs& a, const struct NodeImages& im, hipStream_t s);
+int launch_node_tan_bwd_split(const NodeTanBwdArgs& a, const struct NodeImages& im, hipStream_t s);
 int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s);
 int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 // split-f16 forms (node128s.hip): the weights come as prepared (hi, lo) f16 images instead of the fp32 pointers of the arguments

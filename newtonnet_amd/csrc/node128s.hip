@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_bwd_split_kernel(const
     __syncthreads();
     tile_gemm_s(g, t, wf, inv);
     load_wimg(wf, t, im.W0T);
+    if (p.T && live) sblk_store(g, p.T, (size_t)row * NF, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
     tile_publish(g, t);
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_bwd_split_kernel(const
     if (p.WuT) load_wimg(wf, t, im.WuT);
     if (p.acc_ga) {
       float old[16];
-      sblk_load(old, p.g_a, (size_t)rc * NF, t);
+      sblk_load(old, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
 #pragma unroll
       for (int k = 0; k < 16; ++k) ga[k] += old[k];
     }
@@ -329,6 +330,159 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_bwd_split_kernel(const
     }
     if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
   }
+}
+
+// Tangent of node_fwd (training sweep 3): dq_k = df_k W_u^T;  da_out = da_mid + sum_k (df_k q_k + f_k dq_k);
+// T = da_out W0^T (tangent of hn);  Y = (T silu'(hn)) W2^T (tangent of the next m / of e2).  Images: Wu, W0, W2.
+__global__ void __launch_bounds__(256, 2) node_tan_fwd_split_kernel(const NodeTanFwdArgs p, const NodeImages im) {
+  NS_TILE_SETUP()
+  WFrag wf;
+  load_wimg(wf, t, im.Wu);
+  float upd[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) upd[k] = 0.f;
+  float xa[16], xb[16], a[16];
+  sblk_load(xa, p.df, ((size_t)rc * 3 + 0) * NF, t);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float (&cur)[16] = (c & 1) ? xb : xa;
+    float (&nxt)[16] = (c & 1) ? xa : xb;
+    float dqv[16], fv[16], qv[16];
+    tile_publish(cur, t);
+    __syncthreads();
+    const float inv = tile_commit(cur, t);
+    __syncthreads();
+    if (c < 2)
+      sblk_load(nxt, p.df, ((size_t)rc * 3 + c + 1) * NF, t);
+    else
+      sblk_load(a, p.da_mid, (size_t)rc * NF, t);
+    sblk_load(fv, p.f, ((size_t)rc * 3 + c) * NF, t);
+    sblk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+    tile_gemm_s(dqv, t, wf, inv);
+    if (c == 2) load_wimg(wf, t, im.W0);
+    if (live) sblk_store(dqv, p.dq, ((size_t)row * 3 + c) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], fmaf(fv[k], dqv[k], upd[k]));
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] += upd[k];
+  if (live) sblk_store(a, p.da_out, (size_t)row * NF, t);
+
+  tile_publish(a, t);
+  __syncthreads();
+  float inv = tile_commit(a, t);
+  __syncthreads();
+  float hn[16], tv[16];
+  sblk_load(hn, p.hn, (size_t)rc * NF, t);
+  tile_gemm_s(tv, t, wf, inv);
+  load_wimg(wf, t, im.W2);
+  if (live) sblk_store(tv, p.T, (size_t)row * NF, t);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tv[k] *= dsilu_f(hn[k]);
+  tile_publish(tv, t);
+  __syncthreads();
+  inv = tile_commit(tv, t);
+  __syncthreads();
+  float y[16];
+  tile_gemm_s(y, t, wf, inv);
+  if (live) sblk_store(y, p.Y, (size_t)row * NF, t);
+}
+
+// Tangent of node_bwd (training sweep 4).  Part A, tangent of the upper node-MLP / head adjoint (images W2T, W0T):
+//   dT = g_top W2;  G = dT silu'(h) + t2 silu''(h) hd (stored);  dGA (+)= G W0.
+// Part B, tangent of the lower layer's update adjoint (image WuT), with the dGA part A just produced:
+//   gq_k = GA f_k;  dgq_k = dGA f_k + GA df_k;  dgf_k = dG_f,k + dGA q_k + GA dq_k + dgq_k W_u.
+__global__ void __launch_bounds__(256, 2) node_tan_bwd_split_kernel(const NodeTanBwdArgs p, const NodeImages im) {
+  NS_TILE_SETUP()
+  float dga[16];
+  WFrag wf;
+  if (p.g_top) {
+    load_wimg(wf, t, im.W2T);
+    float x[16], hpre[16], g[16];
+    sblk_load(x, p.g_top, (size_t)rc * NF, t);
+    sblk_load(hpre, p.h_top, (size_t)rc * NF, t);
+    tile_publish(x, t);
+    __syncthreads();
+    float inv = tile_commit(x, t);
+    __syncthreads();
+    tile_gemm_s(g, t, wf, inv);
+    load_wimg(wf, t, im.W0T);
+    if (p.t2_top) {   // (uniform)
+      float t2[16], hd[16];
+      sblk_load(t2, p.t2_top, (size_t)rc * NF, t);
+      sblk_load(hd, p.hd_top, (size_t)rc * NF, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) g[k] = fmaf(g[k], dsilu_f(hpre[k]), t2[k] * d2silu_f(hpre[k]) * hd[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
+    }
+    if (live) sblk_store(g, p.G, (size_t)row * NF, t);
+    tile_publish(g, t);
+    __syncthreads();
+    inv = tile_commit(g, t);
+    __syncthreads();
+    tile_gemm_s(dga, t, wf, inv);
+    if (p.f) load_wimg(wf, t, im.WuT);
+    if (p.acc_dga) {
+      float old[16];
+      sblk_load(old, p.dga, (size_t)rc * NF, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dga[k] += old[k];
+    }
+    if (live) sblk_store(dga, p.dga, (size_t)row * NF, t);
+  } else {
+    sblk_load(dga, p.dga, (size_t)rc * NF, t);
+    if (p.f) load_wimg(wf, t, im.WuT);
+  }
+  if (!p.f) return;
+
+  float ga[16];
+  sblk_load(ga, p.ga, (size_t)rc * NF, t);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t off = ((size_t)rc * 3 + c) * NF, ooff = ((size_t)row * 3 + c) * NF;
+    float fv[16], dfv[16], v[16], out[16];
+    sblk_load(fv, p.f, off, t);
+    sblk_load(dfv, p.df, off, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = ga[k] * fv[k];
+    if (live) sblk_store(v, p.gq, ooff, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = fmaf(dga[k], fv[k], ga[k] * dfv[k]);
+    if (live) sblk_store(v, p.dgq, ooff, t);
+    tile_publish(v, t);
+    __syncthreads();
+    const float inv = tile_commit(v, t);
+    __syncthreads();
+    sblk_load(fv, p.q, off, t);       // (fv, dfv reused for q, dq: consumed after the GEMM)
+    sblk_load(dfv, p.dq, off, t);
+    tile_gemm_s(out, t, wf, inv);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] += fmaf(dga[k], fv[k], ga[k] * dfv[k]);
+    if (p.dgf_in) {
+      float gin[16];
+      sblk_load(gin, p.dgf_in, off, t);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] += gin[k];
+    }
+    if (live) sblk_store(out, p.dgf, ooff, t);
+  }
+}
+
+int launch_node_tan_fwd_split(const NodeTanFwdArgs& a, const NodeImages& im, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  node_tan_fwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  LAUNCH_CHECK();
+  return 0;
+}
+int launch_node_tan_bwd_split(const NodeTanBwdArgs& a, const NodeImages& im, hipStream_t s) {
+  if (a.N <= 0) return 0;
+  ScopedTimer t0(TC_LIN, s);
+  node_tan_bwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_t s) {

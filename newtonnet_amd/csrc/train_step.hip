@@ -86,6 +86,34 @@ static int node_bwd_update_any(bool img_on, const nnhip_train_ws* w, int l, floa
   return launch_node_bwd_split(nb, im, (hipStream_t)s);
 }
 
+// value reverse sweep, split form: node-MLP / head adjoint of the upper level (keeps its hidden product T, reads the running g_a
+// from `ga_in`, writes `ga_out`) + update adjoint of layer `lo` in ONE launch (node128s.hip:node_bwd_split_kernel)
+static int node_bwd_fused(const nnhip_train_ws* w, const float* g_top, const float* h_top, const void* img_w2t, const void* img_w0t,
+                          float* T, const float* ga_in, float* ga_out, int lo, const float* G_f, int N, int act, void* s) {
+  NodeBwdArgs nb;
+  memset(&nb, 0, sizeof(nb));
+  nb.g_top = g_top;
+  nb.h_top = h_top;
+  nb.W2T = nb.W0T = w->wT[lo][6];   // (non-NULL: the split kernel takes its weights from the images below)
+  nb.g_a = ga_out;
+  nb.g_a_in = ga_in;
+  nb.acc_ga = ga_in != nullptr;
+  nb.T = T;
+  nb.f = w->f_out[lo];
+  nb.q = w->q[lo];
+  nb.G_f = G_f;
+  nb.WuT = w->wT[lo][6];
+  nb.gf = w->gf[lo];
+  nb.N = N;
+  nb.act = act;
+  NodeImages im;
+  memset(&im, 0, sizeof(im));
+  im.W2T = (const char*)img_w2t;
+  im.W0T = (const char*)img_w0t;
+  im.WuT = (const char*)w->wimg[lo][IMG_UPDATE_T];
+  return launch_node_bwd_split(nb, im, (hipStream_t)s);
+}
+
 static int check(const nnhip_model* model, const nnhip_train_ws* w, const char* who) {
   if (!model || !w || w->n_layers != model->n_layers || w->n_layers < 1 || w->n_layers > NNHIP_MAX_LAYERS || w->n_atoms < 0 ||
       w->n_edges < 0 || (w->n_edges & 1) || model->n_features != NF || !w->rbf || !w->drbf) {
@@ -207,14 +235,16 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   TS_TRY(nnhip_head_out(w->e2, model->head4_w, model->head4_b, model->scale, model->shift, w->z, w->mol_ptr, N, B, act,
                         w->atom_energy, w->g_e2, w->energy, s));
   // ---- sweep 2: reverse (seed 1)
-  {
-    nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act, HIMG(IMG_HEAD2_T),
-                                HIMG(IMG_HEAD0_T));
+  if (img_on) {
+    TS_TRY(node_bwd_fused(w, w->g_e2, w->e1, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T], w->t_e1, nullptr, w->GA[L - 1], L - 1,
+                          nullptr, N, act, s));
+  } else {
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act);
     d.T = w->t_e1;
     TS_TRY(run1(d, s));
+    TS_TRY(node_bwd_update_any(false, w, L - 1, w->GA[L - 1], w->f_out[L - 1], w->q[L - 1], nullptr, w->wT[L - 1][6], w->gf[L - 1], N,
+                               act, s));
   }
-  TS_TRY(node_bwd_update_any(img_on, w, L - 1, w->GA[L - 1], w->f_out[L - 1], w->q[L - 1], nullptr, w->wT[L - 1][6], w->gf[L - 1], N,
-                             act, s));
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const float* f_prev = l > 0 ? w->f_out[l - 1] : nullptr;
@@ -235,14 +265,16 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     }
     TS_TRY(nnhip_message_bwd(w->g_msg[l], w->GA[l], w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid,
                              l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0 ? 1 : 0, s));
-    if (l > 0) {
+    if (l > 0 && img_on) {
+      TS_TRY(node_bwd_fused(w, w->g_m[l], w->hn[l], w->wimg[l][IMG_NODE2_T], w->wimg[l][IMG_NODE0_T], w->t_n[l], w->GA[l],
+                            w->GA[l - 1], l - 1, Gf, N, act, s));
+    } else if (l > 0) {
       HIP_TRY(hipMemcpyAsync(w->GA[l - 1], w->GA[l], sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->GA[l - 1], N, act,
-                                  LIMG(l, IMG_NODE2_T), LIMG(l, IMG_NODE0_T));
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->GA[l - 1], N, act);
       d.T = w->t_n[l];
       d.accumulate = 1;
       TS_TRY(run1(d, s));
-      TS_TRY(node_bwd_update_any(img_on, w, l - 1, w->GA[l - 1], w->f_out[l - 1], w->q[l - 1], Gf, w->wT[l - 1][6], w->gf[l - 1], N, act,
+      TS_TRY(node_bwd_update_any(false, w, l - 1, w->GA[l - 1], w->f_out[l - 1], w->q[l - 1], Gf, w->wT[l - 1][6], w->gf[l - 1], N, act,
                                  s));
     }
     pp ^= 1;
@@ -282,20 +314,37 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     TS_TRY(nnhip_force_message_tan_fwd(w->phi1[l], w->dphi1[l], w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr,
                                        w->col, w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1],
                                        w->df_out[l], N, s));
-    if (img_on)
-      TS_TRY(launch_lin_wide_split(w->df_out[l], NF, (const char*)w->wimg[l][IMG_UPDATE], w->dq[l], NF, 3 * N, false, (hipStream_t)s));
-    else
-      TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
+    if (img_on) {   // equiv_update tangent + energy-update tangent + tangent of the next message_nodepart / head: one launch
+      const bool last = l + 1 == L;
+      NodeTanFwdArgs a;
+      memset(&a, 0, sizeof(a));
+      a.df = w->df_out[l];
+      a.f = w->f_out[l];
+      a.q = w->q[l];
+      a.da_mid = w->da_mid;
+      a.hn = last ? w->e1 : w->hn[l + 1];
+      a.dq = w->dq[l];
+      a.da_out = w->da_out[l];
+      a.T = last ? w->de1 : w->dhn[l + 1];
+      a.Y = last ? w->de2 : w->dm[l + 1];
+      a.N = N;
+      NodeImages im;
+      memset(&im, 0, sizeof(im));
+      im.Wu = (const char*)w->wimg[l][IMG_UPDATE];
+      im.W0 = (const char*)(last ? w->himg[IMG_HEAD0] : w->wimg[l + 1][IMG_NODE0]);
+      im.W2 = (const char*)(last ? w->himg[IMG_HEAD2] : w->wimg[l + 1][IMG_NODE2]);
+      TS_TRY(launch_node_tan_fwd_split(a, im, (hipStream_t)s));
+      continue;
+    }
+    TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
     TS_TRY(nnhip_update_tan_fwd(w->da_mid, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], N, w->da_out[l], s));
     if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act,
-                                  LIMG(l + 1, IMG_NODE0), LIMG(l + 1, IMG_NODE2));
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act);
       d.T = w->dhn[l + 1];
       TS_TRY(run1(d, s));
     } else {
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, model->head0_w, model->head2_w, w->e1, w->de2, N, act, HIMG(IMG_HEAD0),
-                                  HIMG(IMG_HEAD2));
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, model->head0_w, model->head2_w, w->e1, w->de2, N, act);
       d.T = w->de1;
       TS_TRY(run1(d, s));
     }
@@ -303,9 +352,42 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
   // ---- sweep 4: tangent reverse, seed tangent c = dL/dE
   TS_TRY(nnhip_head_seed_tan(w->e2, w->de2, model->head4_w, model->head4_b, model->scale, w->z, w->batch, g_energy, N, act,
                              w->dg_e2, w->w4row, w->scal, s));
-  {
-    nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act, HIMG(IMG_HEAD2_T),
-                                HIMG(IMG_HEAD0_T));
+  // split form: the tangent of a node-MLP (or head) adjoint and the tangent of the update adjoint BELOW it share one launch
+  // (node128s.hip:node_tan_bwd_split_kernel): "A(level) + B(layer)"
+  auto tan_bwd_fused = [&](const float* g_top, const float* h_top, const float* t2, const float* hd, float* G, int acc,
+                           const void* img_w2t, const void* img_w0t, int lo, const float* dgf_in) -> int {
+    NodeTanBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g_top = g_top;
+    a.h_top = h_top;
+    a.t2_top = t2;
+    a.hd_top = hd;
+    a.G = G;
+    a.dga = w->dGA;
+    a.acc_dga = acc;
+    a.N = N;
+    NodeImages im;
+    memset(&im, 0, sizeof(im));
+    im.W2T = (const char*)img_w2t;
+    im.W0T = (const char*)img_w0t;
+    if (lo >= 0) {
+      a.ga = w->GA[lo];
+      a.f = w->f_out[lo];
+      a.df = w->df_out[lo];
+      a.q = w->q[lo];
+      a.dq = w->dq[lo];
+      a.dgf_in = dgf_in;
+      a.gq = w->gq[lo];
+      a.dgq = w->dgq[lo];
+      a.dgf = w->dgf;
+      im.WuT = (const char*)w->wimg[lo][IMG_UPDATE_T];
+    }
+    return launch_node_tan_bwd_split(a, im, (hipStream_t)s);
+  };
+  if (img_on) {
+    TS_TRY(tan_bwd_fused(w->dg_e2, w->e1, w->t_e1, w->de1, w->dg_e1, 0, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T], L - 1, nullptr));
+  } else {
+    nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act);
     d.T2 = w->t_e1;
     d.Hd = w->de1;
     d.G = w->dg_e1;
@@ -315,12 +397,11 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const bool first = l == 0;
-    TS_TRY(nnhip_update_tan_bwd(w->GA[l], w->dGA, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], dGf, N, w->gq[l], w->dgq[l],
-                                w->dgf, s));
-    if (img_on)
-      TS_TRY(launch_lin_wide_split(w->dgq[l], NF, (const char*)w->wimg[l][IMG_UPDATE_T], w->dgf, NF, 3 * N, true, (hipStream_t)s));
-    else
+    if (!img_on) {
+      TS_TRY(nnhip_update_tan_bwd(w->GA[l], w->dGA, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], dGf, N, w->gq[l], w->dgq[l],
+                                  w->dgf, s));
       TS_TRY(nnhip_linear128(w->dgq[l], NF, w->wT[l][6], w->dgf, NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_ACC, s));
+    }
     float* nxt = w->dGf[pp];
     TS_TRY(nnhip_force_message_tan_bwd(w->gf[l], w->dgf, w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr, w->col,
                                        w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1], w->dg_h12[l],
@@ -343,9 +424,11 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     }
     TS_TRY(nnhip_message_tan_bwd(w->g_msg[l], w->dg_msg, w->GA[l], w->dGA, w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo,
                                  w->ftab[l], w->row_ptr, w->col, w->pid, w->dg_m[l], w->g_eps[l], w->dg_eps[l], N, s));
-    {
-      nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->dGA, N, act,
-                                  LIMG(l, IMG_NODE2_T), LIMG(l, IMG_NODE0_T));
+    if (img_on) {
+      TS_TRY(tan_bwd_fused(w->dg_m[l], w->hn[l], first ? nullptr : w->t_n[l], first ? nullptr : w->dhn[l], w->dg_hn[l], 1,
+                           w->wimg[l][IMG_NODE2_T], w->wimg[l][IMG_NODE0_T], l - 1, first ? nullptr : nxt));
+    } else {
+      nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_m[l], NF, w->wT[l][1], w->wT[l][0], w->hn[l], w->dGA, N, act);
       d.T2 = first ? w->zeros_nf : w->t_n[l];
       d.Hd = first ? w->zeros_nf : w->dhn[l];
       d.G = w->dg_hn[l];
