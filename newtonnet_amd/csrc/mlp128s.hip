@@ -75,6 +75,9 @@ __device__ __forceinline__ void split4(const float4& v, float S, h4& hi, h4& lo)
 }
 
 __device__ __forceinline__ void mlps_load_x(float4 (&x)[16], const float* X, int ldx, int row, int h) {
+#ifdef MLPS_ABL_X   // tooling (wrong results): every tile reads the first 32 rows -- the price of streaming X from HBM
+  row &= 31;
+#endif
   const float4* xp = reinterpret_cast<const float4*>(X + (size_t)row * ldx + 4 * h);
 #pragma unroll
   for (int t = 0; t < 16; ++t) x[t] = xp[2 * t];   // features 8t + 4h + {0..3}
