@@ -859,14 +859,22 @@ species_partial_kernel(const float* __restrict__ x, int ldx, int width, const in
   __syncthreads();
   for (int k = col; k < NNHIP_N_ELEMENTS * width; k += NF) part[(size_t)blockIdx.x * NNHIP_N_ELEMENTS * width + k] = tab[k];
 }
-// out[zz][c] (pitch ldo) = sum over chunks; `cols` columns starting at part column c0
-__global__ void __launch_bounds__(NF)
+// out[zz][c] (pitch ldo) = sum over chunks; `cols` columns starting at part column c0.  1024 threads: 8 groups walk the chunks
+// 8 apart, the group sums are added in a fixed order.
+__global__ void __launch_bounds__(1024)
 species_final_kernel(const float* __restrict__ part, int chunks, int width, int c0, int cols, float* __restrict__ out, int ldo) {
-  const int zz = blockIdx.x, c = threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float sh[8][NF];
+  const int zz = blockIdx.x, c = threadIdx.x & (NF - 1), g = threadIdx.x >> 7;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += part[((size_t)k * NNHIP_N_ELEMENTS + zz) * width + c0 + c];
-  out[(size_t)zz * ldo + c] = s;
+  if (c < cols)
+    for (int k = g; k < chunks; k += 8) s += part[((size_t)k * NNHIP_N_ELEMENTS + zz) * width + c0 + c];
+  sh[g][c] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += sh[q][c];
+    out[(size_t)zz * ldo + c] = s;
+  }
 }
 // out[0] = sum over chunks and elements of column c0 (a plain sum over atoms, e.g. dL/d b4); fixed order
 __global__ void __launch_bounds__(1024)
@@ -1202,11 +1210,11 @@ extern "C" int nnhip_species_sum(const float* x, int32_t ldx, int32_t width, con
   species_partial_kernel<<<chunks, NF, NNHIP_N_ELEMENTS * width * sizeof(float), s>>>(x, ldx, width, z, n_atoms, scratch);
   LAUNCH_CHECK();
   if (out0) {
-    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, chunks, width, c0, cols0, out0, ldo0);
+    species_final_kernel<<<NNHIP_N_ELEMENTS, 1024, 0, s>>>(scratch, chunks, width, c0, cols0, out0, ldo0);
     LAUNCH_CHECK();
   }
   if (out1) {
-    species_final_kernel<<<NNHIP_N_ELEMENTS, NF, 0, s>>>(scratch, chunks, width, c1, cols1, out1, ldo1);
+    species_final_kernel<<<NNHIP_N_ELEMENTS, 1024, 0, s>>>(scratch, chunks, width, c1, cols1, out1, ldo1);
     LAUNCH_CHECK();
   }
   if (total) {
