@@ -222,6 +222,8 @@ class GraphedTrainStep:
     all-reduce runs eagerly (allreduce_gradients), so the same class serves one GPU and DDP.  A new structure (e.g. the last,
     smaller batch of an epoch) re-captures; optimizers must be capture-safe (torch.optim.Adam(..., capturable=True)).
     """
+    EAGER_ABOVE_ATOMS = 8192     # fused mode: batches at least this large run eagerly on the exact neighbor list
+
     def __init__(self, model, optimizer, w_energy: float = 1.0, w_force: float = 50.0, clip_grad: float = 1.0,
                  group=None, assume_static: bool = False):
         """optimizer: a capturable torch optimizer (the step is then torch autograd + torch optimizer, captured), or a
@@ -233,6 +235,7 @@ class GraphedTrainStep:
         self.assume_static = assume_static
         self.fused = isinstance(optimizer, FusedClipAdam)
         self._st = None
+        self._eager = None
         self.captures = 0
 
     # -- fully fused mode ------------------------------------------------------------------------------------
@@ -288,6 +291,12 @@ class GraphedTrainStep:
         structure changed (then all ranks re-capture together: a rank-local decision would leave collectives unmatched) -- with
         one tiny all-reduce; (2) replay forward + loss + gradients; (3) all-reduce the flat gradient; (4) replay clip + Adam."""
         distributed = dist.is_available() and dist.is_initialized()
+        if pos.shape[0] >= self.EAGER_ABOVE_ATOMS:
+            # device-bound sizes: replay saves nothing, and the static all-pairs candidate list is larger than the exact one
+            # (1024 aspirin conformers: 8.7 ms replayed vs 7.2 ms eager) -- run the same step eagerly on the exact list
+            if self._eager is None:
+                self._eager = TrainStep(self.model, self.optimizer, self.w_energy, self.w_force, self.clip_grad, self.group)
+            return self._eager(z, pos, cell, batch, energy_label, force_label)
         changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
         norm, changed = self._global_norm(energy_label, force_label, changed, pos.device)
         if changed:
