@@ -419,9 +419,15 @@ __device__ __forceinline__ float comp(const float4& v, int w) { return w == 0 ? 
 // B rows as stored ([row][128]), A rows split by output-feature class ([class][row][32]) so that wave w reads its class
 // with unit stride.  Two LDS buffers: the next trip's rows are requested before this trip's MFMAs and written behind them.
 #define WG_R 16
-struct WgStage {   // what one thread fetched for the next trip: rows (t >> 5) and (t >> 5) + 8, lane column c = t & 31
-  float4 a1[2], a2[2], b1[2], b2[2], ha[2];   // raw as loaded (b1 / b2 hold hB / dhB for WG_ACT); wg_finish applies the prologue
-  bool live[2];
+#ifndef WG_WAVES
+#define WG_WAVES 4   // 4: wave = output class, 4 column blocks each; 8 (tooling): two waves per class, 2 column blocks each
+#endif
+#define WG_THREADS (64 * WG_WAVES)
+#define WG_Q (WG_R * 32 / WG_THREADS)   // rows a thread fetches per trip
+#define WG_NACC (16 / WG_WAVES)         // accumulator blocks per wave
+struct WgStage {   // what one thread fetched for the next trip: rows (t >> 5) + (WG_THREADS / 32) q, lane column c = t & 31
+  float4 a1[WG_Q], a2[WG_Q], b1[WG_Q], b2[WG_Q], ha[WG_Q];   // raw as loaded (b1 / b2 hold hB / dhB for WG_ACT); wg_finish applies the prologue
+  bool live[WG_Q];
 };
 struct WgLds {
   float a1[4][WG_R][32], a2[4][WG_R][32];
@@ -434,8 +440,8 @@ template <int TYPE, bool TWO, bool NB32>
 __device__ __forceinline__ void wg_fetch(const WgProb& P, int r0, int r_end, int r_safe, WgStage& g) {
   const int c = threadIdx.x & 31;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int r = r0 + (threadIdx.x >> 5) + 8 * q;
+  for (int q = 0; q < WG_Q; ++q) {
+    const int r = r0 + (threadIdx.x >> 5) + (WG_THREADS / 32) * q;
     g.live[q] = r < r_end;
     const int rr = g.live[q] ? r : r_safe;
     g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
@@ -461,7 +467,7 @@ __device__ __forceinline__ void wg_finish(const WgProb& P, WgStage& g) {
   const int act = P.activation;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < WG_Q; ++q) {
     if (!NB32 && TYPE == WG_ACT) {
       const float4 hv = g.b1[q], dh = g.b2[q];
       g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
@@ -484,8 +490,8 @@ template <bool TWO, bool NB32>
 __device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g) {
   const int c = threadIdx.x & 31;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = (threadIdx.x >> 5) + 8 * q;
+  for (int q = 0; q < WG_Q; ++q) {
+    const int row = (threadIdx.x >> 5) + (WG_THREADS / 32) * q;
     L.a1[0][row][c] = g.a1[q].x;
     L.a1[1][row][c] = g.a1[q].y;
     L.a1[2][row][c] = g.a1[q].z;
@@ -508,7 +514,7 @@ __device__ __forceinline__ void wg_commit(WgLds& L, const WgStage& g) {
 }
 
 template <int TYPE, bool TWO, bool NB32>
-__device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[4]) {
+__device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[WG_NACC]) {
   WgStage g;
   wg_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
   wg_finish<TYPE, TWO, NB32>(P, g);
@@ -523,11 +529,14 @@ __device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, i
 #pragma unroll
     for (int kk = 0; kk < WG_R / 2; ++kk) {
       const int row = 2 * kk + h;
-      const float a1 = L.a1[w][row][c];
+      const float a1 = L.a1[w & 3][row][c];
       if (NB32) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.b1[row][c], acc[0], 0, 0, 0);
-        if (TWO) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.a2[w][row][c], L.b2[row][c], acc[0], 0, 0, 0);
+        if (WG_WAVES == 4 || w < 4) {   // (8-wave form: the second wave of a class idles on 32-column problems)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.b1[row][c], acc[0], 0, 0, 0);
+          if (TWO) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.a2[w & 3][row][c], L.b2[row][c], acc[0], 0, 0, 0);
+        }
       } else {
+#if WG_WAVES == 4
         const float4 b1 = *reinterpret_cast<const float4*>(&L.b1[row][4 * c]);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1], 0, 0, 0);
@@ -541,6 +550,18 @@ __device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, i
           acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.z, acc[2], 0, 0, 0);
           acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.w, acc[3], 0, 0, 0);
         }
+#else
+        const int hf = 2 * (w >> 2);
+        const float2 b1 = *reinterpret_cast<const float2*>(&L.b1[row][4 * c + hf]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1], 0, 0, 0);
+        if (TWO) {
+          const float a2 = L.a2[w & 3][row][c];
+          const float2 b2 = *reinterpret_cast<const float2*>(&L.b2[row][4 * c + hf]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2.y, acc[1], 0, 0, 0);
+        }
+#endif
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -553,7 +574,7 @@ __device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, i
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(WG_THREADS)
 wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
   WgLds* lds = reinterpret_cast<WgLds*>(wg_lds_raw);   // [2]
@@ -571,9 +592,9 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
   // rows of this workgroup: contiguous, a multiple of the trip size
   const int per = ((M + WG_R * chunks - 1) / (WG_R * chunks)) * WG_R;
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
-  f32x16 acc[4];
+  f32x16 acc[WG_NACC];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < WG_NACC; ++q)
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[q][k] = 0.f;
   const bool two = P.A2 != nullptr;
@@ -598,11 +619,19 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
-    const int o = 4 * row + w;
+    const int o = 4 * row + (w & 3);
+#if WG_WAVES == 4
     if (nb32)
       slab[(size_t)o * NF + c] = acc[0][k];     // input "feature" c = basis index
     else
       st4(slab + (size_t)o * NF + 4 * c, make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]));
+#else
+    if (nb32) {
+      if (w < 4) slab[(size_t)o * NF + c] = acc[0][k];
+    } else {
+      *reinterpret_cast<float2*>(slab + (size_t)o * NF + 4 * c + 2 * (w >> 2)) = make_float2(acc[0][k], acc[1][k]);
+    }
+#endif
   }
 }
 
@@ -1245,7 +1274,7 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
   if (bf16_operands)
     wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   else
-    wgrad_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
+    wgrad_kernel<<<dim3(chunks, n_problems), WG_THREADS, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   LAUNCH_CHECK();
   wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();
