@@ -16,14 +16,14 @@ def global_batch():
     return synthetic_md17_mixed(12, 7, 'cpu')
 
 
-def run(z, pos, cell, batch, e_lab, f_lab, steps, group_ok):
-    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep
+def run(z, pos, cell, batch, e_lab, f_lab, steps, group_ok, mode='graph'):
+    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep, TrainStep
     from newtonnet_amd.models import NewtonNet
     torch.manual_seed(0)
     model = NewtonNet(output_properties=['energy', 'gradient_force']).cuda()
     model.train()
     opt = FusedClipAdam(model, lr=1e-3, max_norm=1.0)
-    step = GraphedTrainStep(model, opt, 1.0, 50.0)
+    step = GraphedTrainStep(model, opt, 1.0, 50.0) if mode == 'graph' else TrainStep(model, opt, 1.0, 50.0)   # captured / eager
     args = [t.cuda() for t in (z, pos, cell, batch, e_lab, f_lab)]
     losses = [float(step(*args)) for _ in range(steps)]
     torch.cuda.synchronize()
@@ -32,6 +32,7 @@ def run(z, pos, cell, batch, e_lab, f_lab, steps, group_ok):
 
 def main():
     out, backend, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    mode = sys.argv[4] if len(sys.argv) > 4 else 'graph'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(0)
     if backend == 'nccl':
@@ -43,7 +44,7 @@ def main():
     sizes = torch.bincount(batch).tolist()
     m0, m1 = shard_molecules(sizes, world)[rank]
     a0, a1 = sum(sizes[:m0]), sum(sizes[:m1])
-    flat, losses, gnorm = run(z[a0:a1], pos[a0:a1], cell[m0:m1], batch[a0:a1] - m0, e_lab[m0:m1], f_lab[a0:a1], steps, True)
+    flat, losses, gnorm = run(z[a0:a1], pos[a0:a1], cell[m0:m1], batch[a0:a1] - m0, e_lab[m0:m1], f_lab[a0:a1], steps, True, mode)
     torch.save(dict(flat=flat, losses=losses, gnorm=gnorm, shard=(m0, m1)), os.path.join(out, f'rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()

@@ -424,7 +424,7 @@ def test_fully_fused_graphed_step_matches_torch_optimizer():
     assert all(base <= p.data_ptr() < base + 4 * m_f._flat_params.numel() for n, p in m_f.named_parameters() if 'frequencies' not in n)
 
 
-def _run_ddp(tmp_path, backend, steps=3, timeout=300, nproc=2):
+def _run_ddp(tmp_path, backend, steps=3, timeout=300, nproc=2, mode='graph'):
     import socket
     import subprocess
     import sys
@@ -434,7 +434,7 @@ def _run_ddp(tmp_path, backend, steps=3, timeout=300, nproc=2):
     s.close()
     root = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), __import__('os').path.join(root, 'tests', 'ddp_worker.py'), str(tmp_path), backend, str(steps)]
+           '--master-port', str(port), __import__('os').path.join(root, 'tests', 'ddp_worker.py'), str(tmp_path), backend, str(steps), mode]
     env = dict(__import__('os').environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True, env=env)
     try:
@@ -446,8 +446,8 @@ def _run_ddp(tmp_path, backend, steps=3, timeout=300, nproc=2):
     return p.returncode, out
 
 
-@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
-def test_two_rank_training_equals_single_process(tmp_path, backend):
+@pytest.mark.parametrize('backend,mode', [('gloo', 'graph'), ('nccl', 'graph'), ('gloo', 'eager')])
+def test_two_rank_training_equals_single_process(tmp_path, backend, mode):
     """BASELINE configs[3] on its real code path: two ranks (one process each, here sharing the single GPU of the test box),
     each with its molecule shard of a mixed MD17-shaped batch, run the fully fused HIP-graph train step with the flat-gradient
     all-reduce and the global loss normalisation; after 3 steps every rank must hold the parameters of a single process that
@@ -456,14 +456,14 @@ def test_two_rank_training_equals_single_process(tmp_path, backend):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from tests import ddp_worker
-    rc, log = _run_ddp(tmp_path, backend)
+    rc, log = _run_ddp(tmp_path, backend, mode=mode)      # mode: HIP-graph replay / the eager TrainStep + FusedClipAdam
     if backend == 'nccl' and rc != 0:
         pytest.skip('RCCL did not accept two ranks on one device on this box: ' + log.strip().splitlines()[-1][:300])
     assert rc == 0, log[-3000:]
     r0, r1 = (torch.load(tmp_path / f'rank{r}.pt') for r in (0, 1))
     assert torch.equal(r0['flat'], r1['flat'])                      # replicas stay bit-identical
     z, pos, cell, batch, e_lab, f_lab = ddp_worker.global_batch()
-    flat, losses, gnorm = ddp_worker.run(z, pos, cell, batch, e_lab, f_lab, 3, False)
+    flat, losses, gnorm = ddp_worker.run(z, pos, cell, batch, e_lab, f_lab, 3, False, mode)
     scale = float(flat.abs().max())
     assert float((r0['flat'] - flat).abs().max()) <= 2e-5 * scale, float((r0['flat'] - flat).abs().max())
     # each rank reports its share of the global loss: the shares add up to the single-process loss
