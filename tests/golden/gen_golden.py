@@ -592,3 +592,47 @@ def main_cosine():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'cosine':
     main_cosine()
+
+
+def main_train():
+    """The reference's training objective and its parameter gradients (train/trainer.py:299-313): the reference model in train
+    mode (derivative heads with create_graph, models/newtonnet.py:106-113), seeded weights, the mixed-molecule case, the loss
+    factory of the reference itself with the published weights (train/loss.py:5-52, scripts/config.yml:45-51: MSE(E) + 50 MSE(F)),
+    seeded labels, loss.backward() -> case_train_mixed.npz (loss + every parameter gradient, float64 run stored as float32)."""
+    import types as _types
+    NewtonNet = import_reference()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_ref_loss', f'{REF}/newtonnet/train/loss.py')   # (the package __init__ pulls in wandb)
+    _ref_loss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(_ref_loss)
+    get_loss_by_string = _ref_loss.get_loss_by_string
+    rnd = {k: torch.from_numpy(v).double() for k, v in np.load(f'{OUT}/rand_state_seed0.npz').items()}
+    c = np.load(f'{OUT}/case_mixed_rand.npz')
+    z, pos = torch.from_numpy(c['z']).long(), torch.from_numpy(c['pos']).double()
+    cell, batch = torch.from_numpy(c['cell']).double(), torch.from_numpy(c['batch']).long()
+    g = torch.Generator().manual_seed(3)
+    e_lab = torch.randn(cell.shape[0], generator=g)            # float32 draws (the GPU tests draw the same), widened
+    f_lab = torch.randn(pos.shape[0], 3, generator=g)
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    model.to(torch.float64)
+    model.load_state_dict(rnd, strict=True)
+    model.train()
+    main_loss, _ = get_loss_by_string({'energy': {'weight': 1.0, 'mode': 'mse'}, 'gradient_force': {'weight': 50.0, 'mode': 'mse'}})
+    data = _types.SimpleNamespace(z=z, batch=batch, energy=e_lab.double(), force=f_lab.double())
+    pred = model(z, pos.clone(), cell, batch)
+    loss = main_loss(pred, data)
+    loss.backward()
+    rec = dict(loss=np.float64(loss.item()), energy_label=e_lab.numpy(), force_label=f_lab.numpy(),
+               energy=pred.energy.detach().numpy(), forces=pred.gradient_force.detach().numpy())
+    n = 0
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            rec['grad.' + name] = p.grad.detach().numpy().astype(np.float32)
+            rec['gnorm.' + name] = np.float64(p.grad.detach().norm().item())
+            n += 1
+    print('train fixture: loss', loss.item(), n, 'parameter gradients')
+    np.savez_compressed(f'{OUT}/case_train_mixed.npz', **rec)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train':
+    main_train()

@@ -520,3 +520,41 @@ def test_workspace_is_reused_across_batches_with_different_edge_counts():
         assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm), (scale, np.sqrt(err / nrm))
     assert len(set(edges)) == 3 and edges[1] < edges[0] < edges[2], edges
     assert len(model._train_ws) == 1 and model._train_ws[0].E >= max(edges[:2])      # one workspace served all three
+
+
+def test_training_gradients_against_reference_fixture():
+    """Row T pinned to the reference itself: tests/golden/case_train_mixed.npz holds the loss and every parameter gradient the
+    REFERENCE produces (its model in train mode, its loss factory with the published weights, loss.backward()).  The mirror's
+    train-mode forward + the same loss + backward run on the hand-written training kernels; the all-HIP step reports the
+    same loss."""
+    from newtonnet_amd.distributed import FusedClipAdam, TrainStep
+    from newtonnet_amd.models import NewtonNet
+    c = util.load_npz('case_train_mixed.npz')
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    e_lab, f_lab = torch.from_numpy(c['energy_label']).cuda(), torch.from_numpy(c['force_label']).cuda()
+    model = NewtonNet(output_properties=['energy', 'gradient_force'])
+    model.load_state_dict(util.load_state('rand', torch.float32))
+    model = model.cuda()
+    model.train()
+    out = model(z.cuda(), pos.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab) + 50.0 * torch.nn.functional.mse_loss(out.gradient_force, f_lab)
+    loss.backward()
+    assert abs(loss.item() - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))
+    np.testing.assert_allclose(out.energy.detach().cpu().numpy(), c['energy'], rtol=0, atol=2e-5)
+    assert np.abs(out.gradient_force.detach().cpu().numpy() - c['forces']).max() <= 5e-5
+    err = nrm = 0.0
+    n = 0
+    for name, prm in model.named_parameters():
+        if 'grad.' + name in c:
+            want = c['grad.' + name].astype(np.float64)
+            err += float(((prm.grad.detach().cpu().double().numpy() - want) ** 2).sum())
+            nrm += float((want ** 2).sum())
+            n += 1
+    assert n == 39
+    print(f'gradients vs the reference: relative error {np.sqrt(err / nrm):.2e}')
+    assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm)
+    # the step without autograd evaluates the same objective
+    step = TrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0)
+    l2 = float(step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab))
+    assert abs(l2 - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))

@@ -172,3 +172,22 @@ def test_oracle_other_envelopes_pinned(tag, name, p):
     np.testing.assert_allclose(out['dist_edge'].numpy(), c[f'{tag}_dist_edge'], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(out['energy'].numpy(), c[f'{tag}_energy'], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(out['forces'].numpy(), c[f'{tag}_forces'], rtol=1e-10, atol=1e-12)
+
+
+def test_oracle_training_gradients_pinned_to_reference():
+    """The training objective and every parameter gradient of the REFERENCE (its own model in train mode, its own loss factory
+    with the published weights, loss.backward(): trainer.py:299-313; generated by tests/golden/gen_golden.py train) against the
+    oracle's restatement -- pins the checker of the hand-written training path (row T)."""
+    c = util.load_npz('case_train_mixed.npz')
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float64)
+    sd = util.load_state('rand', torch.float64)
+    loss, grads = ref.training_loss_grads(sd, z, pos, cell, batch, torch.from_numpy(c['energy_label']).double(),
+                                          torch.from_numpy(c['force_label']).double())
+    assert abs(loss.item() - float(c['loss'])) <= 1e-10 * abs(float(c['loss']))
+    names = [k[5:] for k in c if k.startswith('grad.')]
+    assert len(names) == 39
+    for name in names:
+        want, nrm = c['grad.' + name].astype(np.float64), float(c['gnorm.' + name])
+        got = grads[name].numpy()
+        assert abs(np.linalg.norm(got) - nrm) <= 1e-9 * max(nrm, 1e-30), name                      # the float64 norm
+        assert np.abs(got - want).max() <= 2e-7 * max(np.abs(want).max(), 1e-30), name              # float32-stored entries
