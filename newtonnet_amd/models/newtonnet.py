@@ -80,6 +80,14 @@ class NewtonNet(nn.Module):
             self.aggregators.append(get_aggregator_by_string(key))
 
     # ------------------------------------------------------------------------------------------
+    def __getstate__(self):
+        """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
+        state = self.__dict__.copy()
+        for k in ('_train_ws', '_static_train_graph'):
+            state.pop(k, None)
+        return state
+
+    # ------------------------------------------------------------------------------------------
     def train(self, mode=True):
         """As the reference (newtonnet.py:106-113): flips create_graph on derivative heads; returns None."""
         super().train(mode)

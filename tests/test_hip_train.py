@@ -558,3 +558,26 @@ def test_training_gradients_against_reference_fixture():
     step = TrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0)
     l2 = float(step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab))
     assert abs(l2 - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))
+
+
+def test_trained_module_pickles_without_its_workspaces(tmp_path):
+    """trainer.py:219 saves the whole module after training steps: the pickle must carry parameters and structure only, not the
+    training workspaces hanging off the module."""
+    from newtonnet_amd.distributed import TrainStep
+    from newtonnet_amd.models import NewtonNet
+    z, pos, cell, batch, _ = util.case_inputs('ethanol4_rand', torch.float32)
+    torch.manual_seed(0)
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).cuda()
+    model.train()
+    step = TrainStep(model, torch.optim.Adam(model.parameters(), lr=1e-3), 1.0, 50.0, 1.0)
+    g = torch.Generator().manual_seed(3)
+    step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), torch.randn(cell.shape[0], generator=g).cuda(),
+         torch.randn(pos.shape[0], 3, generator=g).cuda())
+    assert model._train_ws                     # the step left a workspace on the module
+    path = tmp_path / 'model.pt'
+    torch.save(model, path)
+    assert path.stat().st_size < 4_000_000     # 401 k parameters, not hundreds of MB of buffers
+    back = torch.load(path, weights_only=False)
+    assert '_train_ws' not in back.__dict__
+    for (k, a), b in zip(model.state_dict().items(), back.state_dict().values()):
+        assert torch.equal(a, b), k
