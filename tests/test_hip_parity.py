@@ -687,3 +687,40 @@ def test_fp32_mfma_form_still_serves(tmp_path):
         print(f"NNHIP_MLP_SPLIT={split}: force MAE vs float64 oracle {mae:.2e} eV/A, max |dE| {de:.2e} eV")
         assert mae <= util.FORCE_MAE_TOL and np.all(np.abs(res[split]['energy'][:64] - e_ref.numpy()) <= util.energy_tol(e_ref.numpy()))
     assert np.abs(res['0']['forces'] - res['1']['forces']).max() <= 5e-6
+
+
+def test_split_products_properties_at_full_size():
+    """Size-independent properties of the persistent edge-MLP kernel at the config-2 row count (156 503 pair rows), no oracle
+    needed: (1) the per-row power-of-two scales are exact -- multiplying input rows by powers of two multiplies the linear
+    outputs (forward H, adjoint Y) by the same powers BITWISE; (2) the adjoint is linear in its input to fp32 rounding; (3) rows
+    are independent -- permuting the rows permutes the outputs bitwise (tiles and lanes carry no cross-row state)."""
+    from newtonnet_amd import hip
+    M = 156503
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(M, 128, generator=g).cuda()
+    X2 = torch.randn(M, 128, generator=g).cuda()
+    W1, W2 = (torch.randn(128, 128, generator=g) / 11).cuda(), (torch.randn(128, 128, generator=g) / 11).cuda()
+    Hpre = torch.randn(M, 128, generator=g).cuda()
+    pw = torch.pow(2.0, torch.randint(-20, 21, (M, 1), generator=g).float()).cuda()
+
+    def fwd(x):
+        H, Y = torch.empty(M, 128, device='cuda'), torch.empty(M, 128, device='cuda')
+        hip.mlp128(x, W1, W2, H, Y, 0)
+        return H, Y
+
+    def adj(x):
+        Y = torch.empty(M, 128, device='cuda')
+        hip.mlp128(x, W1, W2, Hpre, Y, 1)
+        return Y
+    H0, Y0 = fwd(X)
+    H1, _ = fwd(X * pw)
+    assert torch.equal(H1, H0 * pw)                                   # (1) forward pre-activations
+    A0 = adj(X)
+    assert torch.equal(adj(X * pw), A0 * pw)                          # (1) adjoint output
+    A2 = adj(X2)
+    lin = adj(0.75 * X - 1.5 * X2)
+    err = (lin - (0.75 * A0 - 1.5 * A2)).abs().max().item()
+    assert err <= 2e-5 * A0.abs().max().item(), err                   # (2)
+    perm = torch.randperm(M, generator=g).cuda()
+    Hp, Yp = fwd(X[perm].contiguous())
+    assert torch.equal(Hp, H0[perm]) and torch.equal(Yp, Y0[perm])    # (3)
