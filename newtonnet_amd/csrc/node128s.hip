@@ -267,7 +267,10 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
 }
 
 // adjoint of the upper node MLP / head, then of the lower layer's update (see node128.hip:node_bwd_kernel)
-__global__ void __launch_bounds__(256, NS_WG_PER_CU) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
+#ifndef NS_WG_PER_CU_BWD
+#define NS_WG_PER_CU_BWD NS_WG_PER_CU
+#endif
+__global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
   NS_TILE_SETUP()
   float ga[16];
   WFrag wf;
