@@ -617,7 +617,8 @@ def test_split_f16_products_are_fp32_grade():
     inputs, rows whose magnitudes differ by 12 orders (per-row scales), tiny / huge weight matrices (per-matrix scales) -- the
     error stays at the fp32 rounding level for EVERY row, not only in the norm."""
     from newtonnet_amd import hip
-    assert hip.split_products()
+    if not hip.split_products():
+        pytest.skip('NNHIP_MLP_SPLIT=0: the fp32 MFMA form is running')
     M = 65536                                     # > 49 152 rows: the persistent kernel (the row-local one serves smaller M)
     e = _mlp_errors(M, torch.ones(M, 1), (1.0, 1.0))
     print('plain            : H %.2e  Y %.2e  adjoint %.2e  worst row %.2e' % e)
