@@ -24,6 +24,11 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define NS_PITCH 272                         // bytes per row of one plane of the LDS tile (128 f16 + 16 pad)
 #define NS_PLANE (32 * NS_PITCH)
 #define NS_LDS_BYTES (2 * NS_PLANE + 8 * 32 * 4)
+#ifndef NS_MERGE3
+#define NS_MERGE3 0   // 1 (tooling): the three components of equiv_update (and of its adjoint) share ONE publish / commit / barrier
+                      // round -- three LDS tiles, three GEMMs behind the same weight fragments.  Measured 3 % SLOWER (0.308 vs
+                      // 0.298 ms per step for the six launches): the kernels are bound by their HBM streams, not the stage count
+#endif
 #define WIMG_PLANE (NF * NF * 2)             // one f16 plane of a weight image
 
 // ---- weight images ----------------------------------------------------------------------------------------------
@@ -195,7 +200,7 @@ __device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restri
 }
 
 #define NS_TILE_SETUP()                                                      \
-  __shared__ __attribute__((aligned(16))) char lds[NS_LDS_BYTES];            \
+  __shared__ __attribute__((aligned(16))) char lds[(NS_MERGE3 ? 3 : 1) * NS_LDS_BYTES]; \
   STile t;                                                                   \
   t.img = lds;                                                               \
   t.pmax = reinterpret_cast<float*>(lds + 2 * NS_PLANE);                     \
@@ -214,7 +219,41 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
   float upd[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) upd[k] = 0.f;
-  float xa[16], xb[16], a[16];
+  float a[16];
+#if NS_MERGE3
+  {
+    STile t1 = t, t2 = t;
+    t1.img = lds + NS_LDS_BYTES;
+    t1.pmax = reinterpret_cast<float*>(lds + NS_LDS_BYTES + 2 * NS_PLANE);
+    t2.img = lds + 2 * NS_LDS_BYTES;
+    t2.pmax = reinterpret_cast<float*>(lds + 2 * NS_LDS_BYTES + 2 * NS_PLANE);
+    float x0[16], x1[16], x2[16], qv[16];
+    sblk_load(x0, p.f, ((size_t)rc * 3 + 0) * NF, t);
+    sblk_load(x1, p.f, ((size_t)rc * 3 + 1) * NF, t);
+    sblk_load(x2, p.f, ((size_t)rc * 3 + 2) * NF, t);
+    tile_publish(x0, t);
+    tile_publish(x1, t1);
+    tile_publish(x2, t2);
+    __syncthreads();
+    const float inv0 = tile_commit(x0, t), inv1 = tile_commit(x1, t1), inv2 = tile_commit(x2, t2);
+    __syncthreads();
+    sblk_load(a, p.a_mid, (size_t)rc * NF, t);
+    tile_gemm_s(qv, t, wf, inv0);
+    if (live) sblk_store(qv, p.q, ((size_t)row * 3 + 0) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = x0[k] * qv[k];
+    tile_gemm_s(qv, t1, wf, inv1);
+    if (live) sblk_store(qv, p.q, ((size_t)row * 3 + 1) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(x1[k], qv[k], upd[k]);
+    tile_gemm_s(qv, t2, wf, inv2);
+    if (p.W0) load_wimg(wf, t, im.W0);
+    if (live) sblk_store(qv, p.q, ((size_t)row * 3 + 2) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) upd[k] = fmaf(x2[k], qv[k], upd[k]);
+  }
+#else
+  float xa[16], xb[16];
   sblk_load(xa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -235,6 +274,7 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
+#endif
 #pragma unroll
   for (int k = 0; k < 16; ++k) a[k] += upd[k];
   if (live) sblk_store(a, p.a_out, (size_t)row * NF, t);
@@ -308,6 +348,45 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
   if (!p.WuT) return;
 
   // adjoint of the lower layer's update:  gf_k = G_f,k + g_a * q_k + (g_a * f'_k) W_u
+#if NS_MERGE3
+  {
+    STile t1 = t, t2 = t;
+    t1.img = lds + NS_LDS_BYTES;
+    t1.pmax = reinterpret_cast<float*>(lds + NS_LDS_BYTES + 2 * NS_PLANE);
+    t2.img = lds + 2 * NS_LDS_BYTES;
+    t2.pmax = reinterpret_cast<float*>(lds + 2 * NS_LDS_BYTES + 2 * NS_PLANE);
+    float x0[16], x1[16], x2[16];
+    sblk_load(x0, p.f, ((size_t)rc * 3 + 0) * NF, t);
+    sblk_load(x1, p.f, ((size_t)rc * 3 + 1) * NF, t);
+    sblk_load(x2, p.f, ((size_t)rc * 3 + 2) * NF, t);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      x0[k] *= ga[k];
+      x1[k] *= ga[k];
+      x2[k] *= ga[k];
+    }
+    tile_publish(x0, t);
+    tile_publish(x1, t1);
+    tile_publish(x2, t2);
+    __syncthreads();
+    const float inv0 = tile_commit(x0, t), inv1 = tile_commit(x1, t1), inv2 = tile_commit(x2, t2);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float out[16], qv[16], gin[16];
+      sblk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+      if (p.G_f) sblk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
+      tile_gemm_s(out, c == 0 ? t : (c == 1 ? t1 : t2), wf, c == 0 ? inv0 : (c == 1 ? inv1 : inv2));
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qv[k], out[k]);
+      if (p.G_f) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] += gin[k];
+      }
+      if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
+    }
+  }
+#else
   float fa[16], fb[16];
   sblk_load(fa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
@@ -333,6 +412,7 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
     }
     if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
   }
+#endif
 }
 
 // Tangent of node_fwd (training sweep 3): dq_k = df_k W_u^T;  da_out = da_mid + sum_k (df_k q_k + f_k dq_k);
