@@ -152,6 +152,9 @@ def train_leg(device, dist, backend, world, rank, steps, warmup, molecules=32):
             'atoms_total': n_atoms, 'ms_per_step': round(1e3 * dt / steps, 4),
             'atom_steps_per_s': round(n_atoms * steps / dt, 1), 'molecule_steps_per_s': round(world * molecules * steps / dt, 1),
             'gradient_bytes': int(flat.numel() * 4), 'allreduce_us': None if ar_us is None else round(ar_us, 1),
+            'collectives_per_step': 0 if dist is None else 1,
+            'collectives_note': 'one all-reduce of the flat fp32 gradient per step; the global loss normalisation (element counts) '
+                                'is agreed once, on the first step (assume_static: the structure never changes)',
             'replicas_in_sync': in_sync, 'first_loss': round(loss0, 5), 'last_loss': round(float(loss), 5)}
 
 
@@ -190,42 +193,134 @@ def pair_layout_bytes(N, E, L=3, F=128):
     return total
 
 
-def pmc_traffic(kernel_prefixes):
+def _profile_table(path):
+    """Rows of a tools/rocpd_{stats,pmc}.py summary: {kernel name: {(grid_x, grid_y): [numeric columns]}} + header comments."""
+    rows, notes = {}, []
+    with open(path) as f:
+        for line in f:
+            if line.startswith('#'):
+                notes.append(line[1:].strip())
+                continue
+            parts = line.split()
+            k = len(parts)
+            while k > 0 and parts[k - 1].replace('.', '', 1).replace('-', '', 1).isdigit():
+                k -= 1
+            if k == 0 or len(parts) - k < 4:
+                continue
+            nums = [float(v) for v in parts[k:]]
+            rows.setdefault(' '.join(parts[:k]), {})[(int(nums[0]), int(nums[1]))] = nums[2:]
+    return rows, notes
+
+
+def _largest_grid(grids):
+    """the config-2 batch's launches of a kernel: the row with the most workgroups (summaries that also hold the small
+    training-leg launches of the same kernels list them under their own, smaller grids)"""
+    return grids[max(grids, key=lambda g: g[0] * g[1])]
+
+
+def _kernel_match(name, want):
+    base = name[5:] if name.startswith('void ') else name
+    return base == want or base.startswith(want + '<')
+
+
+def pmc_traffic(kernels):
     """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes of this same command
     (profiles/<latest>_pmc_{fetch,write}_size.txt; FETCH_SIZE / WRITE_SIZE are in KiB and FETCH_SIZE under-reports wide
     reads by 2x on gfx950 -- MI355X_MICROARCH.md).  Counters cannot be collected from inside the timed process, so this is
-    the stored measurement, named in `traffic_source`; None when the files are missing."""
+    the stored measurement, named in the returned source.  Rows are keyed on kernel name AND grid: only the largest grid of a
+    kernel (the config-2 batch) counts.  Returns ({kernel row name: (launches, bytes per launch)}, source) or (None, None)."""
     import glob
     fetch = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')))
     write = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')))
     if not fetch or not write:
         return None, None
-
-    def table(path):
-        rows = {}
-        with open(path) as f:
-            head = next(f)
-            if head.startswith('#'):          # "# tree <sha>": the commit the counters were collected on
-                sha.append(head[1:].strip())
-                next(f)
-            for line in f:
-                parts = line.split()
-                if len(parts) < 4:
-                    continue
-                name = ' '.join(parts[:-3])
-                rows[name] = (int(parts[-3]), float(parts[-1]))      # launches, KiB per launch
-        return rows
-    sha = []
-    tf, tw = table(fetch[-1]), table(write[-1])
-    n = by = 0.0
-    for name, (cnt, kib) in tf.items():
-        if any(name.startswith(p) or (' ' + p) in name for p in kernel_prefixes) and name in tw:
-            n += cnt
-            by += cnt * (2.0 * kib + tw[name][1]) * 1024.0
-    if n == 0:
+    (tf, notes), (tw, _) = _profile_table(fetch[-1]), _profile_table(write[-1])
+    out = {}
+    for name, grids in tf.items():
+        if any(_kernel_match(name, k) for k in kernels) and name in tw:
+            n, _us, kib = _largest_grid(grids)[:3]
+            out[name] = (int(n), (2.0 * kib + _largest_grid(tw[name])[2]) * 1024.0)
+    if not out:
         return None, None
-    return by / n, (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
-                    + (f' [{sha[0]}]' if sha else ' [round-1 tree]'))
+    return out, (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
+                 + (f' [{notes[0]}]' if notes else ' [round-1 tree]'))
+
+
+EDGE_KERNELS = ('msg_fwd_kernel', 'force_fwd_kernel', 'force_bwd_kernel', 'msg_bwd_kernel')
+ROCPROF_CLASSES = {'edge_msg_fwd': ('msg_fwd_kernel',), 'edge_force_fwd': ('force_fwd_kernel',),
+                   'edge_force_bwd': ('force_bwd_kernel',), 'edge_msg_bwd': ('msg_bwd_kernel',),
+                   'mlp128': ('mlp128s_kernel', 'mlp128_kernel'),
+                   'node': ('node_fwd_split_kernel', 'node_bwd_split_kernel', 'node_fwd_kernel', 'node_bwd_kernel')}
+
+
+def rocprof_classes():
+    """Per-class kernel time per step from the committed rocprofv3 --kernel-trace summary of this command
+    (profiles/<latest>_kernel_stats.txt, per kernel name x grid; largest grid of each kernel = the config-2 batch).  The
+    instrumented pass of this script brackets every launch with HIP events, which inflates each class by 8-19 %: these are the
+    un-instrumented durations of the same kernels.  `other` and the total are only formed for summaries taken with
+    --no-train-leg (header note), where every row belongs to the inference step."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.txt')))
+    files = [f for f in files if 'train' not in os.path.basename(f)]
+    if not files:
+        return None
+    rows, notes = _profile_table(files[-1])
+    steps = None
+    for name, grids in rows.items():
+        if _kernel_match(name, 'msg_fwd_kernel'):
+            steps = _largest_grid(grids)[0] / 3.0          # three interaction layers: three launches per step
+    if not steps:
+        return None
+    out, named = {}, 0.0
+    for cls, kernels in ROCPROF_CLASSES.items():
+        ms = n = 0.0
+        for name, grids in rows.items():
+            if any(_kernel_match(name, k) for k in kernels):
+                calls, total_ms = _largest_grid(grids)[:2]
+                ms += total_ms / steps
+                n += calls / steps
+        out[cls] = {'ms_per_step': round(ms, 4), 'launches_per_step': round(n, 2)}
+        named += ms
+    pure = any('no-train-leg' in t for t in notes)
+    if pure:
+        total = sum(v[1] for grids in rows.values() for v in grids.values()) / steps
+        out['other'] = {'ms_per_step': round(total - named, 4)}
+        out['sum_ms_per_step'] = round(total, 4)
+    else:
+        out['sum_ms_per_step_named_classes'] = round(named, 4)
+    out['source'] = os.path.relpath(files[-1], ROOT) + (f' [{"; ".join(notes)}]' if notes else '')
+    return out
+
+
+def edge_kernel_bytes(N, E, L=3, F=128):
+    """pair_layout_bytes split over the four edge kernels, per step (sum over the L layers; k = 1 in layer 0, else 2):
+    msg_fwd   msg write P, node rows m / a_in / a_mid 3 N, 16 B per edge;     force_fwd  phi reads k P, f_in / f_out 6 N, 16 B;
+    force_bwd phi reads k P + g_phi writes k P, gf / f / g_fin 9 N, 32 B;     msg_bwd    g_msg read P, m / g_a / g_m 3 N, 32 B."""
+    P, row = E // 2, 4 * F
+    out = dict.fromkeys(('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd'), 0)
+    for l in range(L):
+        k = 1 if l == 0 else 2
+        out['edge_msg_fwd'] += P * row + 3 * row * N + 16 * E
+        out['edge_force_fwd'] += k * P * row + 6 * row * N + 16 * E
+        out['edge_force_bwd'] += 2 * k * P * row + 9 * row * N + 32 * E
+        out['edge_msg_bwd'] += P * row + 3 * row * N + 32 * E
+    return out
+
+
+def self_launch(n):
+    """Run this script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` as a child process (rendezvous
+    on 127.0.0.1, a free port), relay its output -- rank 0's single JSON line on stdout -- and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -247,9 +342,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  Nothing in this process has touched the
+        # GPU yet (importing torch does not), and the ranks are CHILD processes -- never an exec of a GPU-initialised one.
+        raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} '
-                         f'(WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     # One process per GPU.  (BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo lets several ranks share one device: used only to
     # exercise this launch path on a 1-GPU box.)
     n_dev = torch.cuda.device_count()
@@ -376,16 +474,32 @@ def main():
                                    "Decomposition A's per-directed-edge formula, which this layout undercuts (an upper-bound "
                                    'model, not achieved bandwidth)',
                'formula_bytes_per_step': edge_fwd_b + edge_bwd_b, 'frac_vs_formula': round(formula_gbs / HBM_PEAK_GBS, 4)}
+        # per-kernel fractions of the four edge kernels on the bytes the pair-once layout must move (names the weakest one)
+        per_kernel = {}
+        for cls, by in edge_kernel_bytes(N, E).items():
+            ms = classes[cls]['ms_per_step']
+            per_kernel[cls] = {'algorithmic_bytes_per_step': by, 'ms_per_step': round(ms, 4),
+                               'frac_pair_bytes': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+        hbm['per_kernel'] = per_kernel
         if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
-            t, src = pmc_traffic(['void mlp128s_kernel', 'mlp128s_kernel'] if split else ['void mlp128_kernel', 'mlp128_kernel'])
+            t, src = pmc_traffic(['mlp128s_kernel'] if split else ['mlp128_kernel'])
             if t is not None:
-                mfma['traffic'], mfma['traffic_source'] = round(t), src
-            t, src = pmc_traffic(['msg_fwd_kernel', 'void force_fwd_kernel', 'void force_bwd_kernel', 'void msg_bwd_kernel'])
+                n_l = sum(n for n, _ in t.values())
+                mfma['traffic'] = round(sum(n * b for n, b in t.values()) / n_l)
+                mfma['traffic_source'] = src
+                mfma['traffic_per_instantiation'] = {k: round(b) for k, (n, b) in t.items()}
+            t, src = pmc_traffic(EDGE_KERNELS)
             if t is not None:
+                # launches of one step: every row of the table saw the same number of steps; msg_fwd runs once per layer
+                steps_seen = max(n for k, (n, b) in t.items() if _kernel_match(k, 'msg_fwd_kernel')) / 3.0
+                step_bytes = sum(n * b for n, b in t.values()) / steps_seen
                 n_edge = max(classes['edge_all']['launches_per_step'], 1)
-                hbm['traffic'], hbm['traffic_source'] = round(t), src
-                hbm['traffic_note'] = f'average HBM bytes per edge-kernel launch from the PMC passes ({n_edge:.0f} launches per step)'
-                cnt_gbs = t * n_edge / (edge_ms * 1e-3) / 1e9
+                hbm['traffic'], hbm['traffic_source'] = round(step_bytes / n_edge), src
+                hbm['traffic_note'] = (f'average HBM bytes per edge-kernel launch from the PMC passes ({n_edge:.0f} launches per '
+                                       'step; rows keyed on kernel name and grid)')
+                hbm['counter_bytes_per_step'] = round(step_bytes)
+                hbm['traffic_per_instantiation'] = {k: round(b) for k, (n, b) in t.items()}
+                cnt_gbs = step_bytes / (edge_ms * 1e-3) / 1e9
                 hbm['achieved_counter_bytes'] = round(cnt_gbs, 1)
                 hbm['frac_vs_counter_bytes'] = round(cnt_gbs / HBM_PEAK_GBS, 4)
         # `roofline` = the single kernel with the largest share of the step (the edge MLP kernel unless one of the four edge
@@ -448,7 +562,7 @@ def main():
         try:
             train = train_leg(device, dist, backend, world, rank, max(args.steps, 10), args.warmup)
         except Exception as exc:  # noqa: BLE001 -- the headline line must survive a failure of the secondary leg; it is REPORTED
-            if args.mode == 'train':
+            if args.mode == 'train' or world > 1:   # with several ranks the others would wait in the leg's collectives: fail the run
                 raise
             train = {'error': f'{type(exc).__name__}: {exc}'[:400], 'allreduce_us': None}
             print(f'[bench rank {rank}] train leg failed: {train["error"]}', file=sys.stderr, flush=True)
@@ -477,6 +591,11 @@ def main():
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,
+            'kernel_classes_note': ('event-timed in a separate instrumented pass: every launch is bracketed by HIP events, which '
+                                    f'inflates the classes (their sum {sum(classes[k]["ms_per_step"] for k in ("edge_all", "linear_mfma", "other", "graph")) if classes else 0:.3f} ms vs '
+                                    f'ms_per_step {1e3 * dt / args.steps:.3f}); kernel_classes_rocprof holds the un-instrumented '
+                                    'durations of the same kernels from the committed rocprofv3 trace'),
+            'kernel_classes_rocprof': rocprof_classes() if (args.workload == 'aspirin' and args.conformers == 1024) else None,
             'cpu_baseline': cpu_baseline,
         }
         if cpu_baseline:

@@ -61,6 +61,9 @@ enum {
 };
 
 int nnhip_version(void);
+/* bit 0: tooling build (compiled with extra flags, e.g. an ablation switch that changes results); the Python package refuses
+ * to load such a library unless NNHIP_ALLOW_TOOLING_LIB=1 */
+int nnhip_build_flags(void);
 const char* nnhip_last_error(void);
 
 /* --------------------------------------------------------------------------
@@ -455,18 +458,31 @@ size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks);
  * number of pairs changes from batch to batch, the table does not) */
 int nnhip_wgrad_batch(const nnhip_wgrad_problem* problems_dev, int32_t n_problems, int32_t chunks, float* slabs,
                       int32_t bf16_operands, int32_t pair_rows, void* stream);
-/* Training objective of the reference (newtonnet/train/loss.py:48,72,96; scripts/config.yml:45-51) and its gradient:
- *   loss = w[0] sum (E - E*)^2 + w[1] sum (F - F*)^2;  g_energy = 2 w[0] (E - E*);  g_forces = 2 w[1] (F - F*)
- * weights_dev[2] = (w_E / n_E, w_F / n_F) lives in DEVICE memory (a data-parallel run refreshes the global counts there). */
+/* Training objective of the reference (newtonnet/train/loss.py:5-50 factory, :53-103 BaseLoss with nn.MSELoss / nn.L1Loss /
+ * nn.HuberLoss(delta), mean reduction; scripts/config.yml:45-51) and its gradient:
+ *   loss = w[0] sum l_E(E - E*) + w[1] sum l_F(F - F*);  g_energy = w[0] l_E'(E - E*);  g_forces = w[1] l_F'(F - F*)
+ * weights_dev[2] = (w_E / n_E, w_F / n_F) lives in DEVICE memory (a data-parallel run refreshes the global counts there).
+ * `forces` is whichever force the loss is on (gradient_force, or direct_force for DirectForceLoss, loss.py:41-47). */
+enum { NNHIP_LOSS_MSE = 0, NNHIP_LOSS_MAE = 1, NNHIP_LOSS_HUBER = 2 };
+int nnhip_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
+                    const float* force_label, int32_t n_force, const float* weights_dev, int32_t mode_energy, int32_t mode_force,
+                    float delta_energy, float delta_force, float* loss, float* g_energy, float* g_forces, void* stream);
+/* the 'mse' / 'mse' case of nnhip_loss_grad */
 int nnhip_mse_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
                         const float* force_label, int32_t n_force, const float* weights_dev, float* loss, float* g_energy,
                         float* g_forces, void* stream);
 /* clip_grad_norm_(max_norm) + torch.optim.Adam step (trainer.py:311-313; no weight decay / amsgrad) on flat buffers of n
  * floats.  state[2] (device) = (step count, last gradient norm); scratch: nnhip_clip_adam_scratch_bytes().  max_norm <= 0:
- * no clipping. */
+ * no clipping.
+ * nnhip_clip_adam_dev: the hyper-parameters (lr, beta1, beta2, eps, max_norm) are read from DEVICE memory at run time -- a
+ * captured HIP graph then follows a learning-rate schedule (trainer.py:190,254: ReduceLROnPlateau on optimizer.param_groups) --
+ * and mask_dev (n bytes, optional) marks frozen elements (0 = requires_grad False, newtonnet_train.py:69-81 freeze_*): they
+ * stay out of the norm and are not updated. */
 size_t nnhip_clip_adam_scratch_bytes(void);
 int nnhip_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
                     float* state, float lr, float beta1, float beta2, float eps, float max_norm, void* stream);
+int nnhip_clip_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                        float* state, const float* hyper_dev, const uint8_t* mask_dev, void* stream);
 /* out[c] = sum_r src[r][c] for [rows][128] arrays (bias gradients); device table */
 typedef struct { const float* src; float* out; int32_t rows; int32_t pad_; } nnhip_colsum_problem;
 size_t nnhip_colsum_scratch_bytes(int32_t n);

@@ -5,6 +5,17 @@
 
 #include "../../include/newtonnet_hip.h"
 
+// Every compile-time switch that changes RESULTS (the ablations of tools/ablate_*.sh) may only be defined in a tooling build
+// (build.sh adds -DNNHIP_TOOLING to any build with extra flags; nnhip_build_flags() bit 0 reports it and newtonnet_amd.hip
+// refuses to load such a library unless NNHIP_ALLOW_TOOLING_LIB=1).
+#if (defined(EDGE_ABL_SELF) || defined(EDGE_ABL_PAIR) || defined(EDGE_ABL_TABLE) || defined(EDGE_ABL_STORE) ||              \
+     defined(EDGE_ABL_NO_TABLE) || defined(MLPS_ABL_X) || defined(ABL_NO_SILU) || defined(ABL_NO_STORE) ||                  \
+     (defined(LIN_ABLATE_NO_LOAD) && LIN_ABLATE_NO_LOAD) || (defined(LIN_ABLATE_NO_STORE) && LIN_ABLATE_NO_STORE) ||         \
+     (defined(LIN_ABLATE_NO_MFMA) && LIN_ABLATE_NO_MFMA) || (defined(LIN_ABLATE_NO_LDS) && LIN_ABLATE_NO_LDS)) &&            \
+    !defined(NNHIP_TOOLING)
+#error "ablation switches produce wrong results: build through csrc/build.sh (it marks the library with -DNNHIP_TOOLING)"
+#endif
+
 #define NF NNHIP_F    // 128 features: one wave = 64 lanes x float2
 #define NB NNHIP_NB   // 20 radial basis functions (default; 1..NNHIP_MAX_NB supported)
 #define WAVE 64

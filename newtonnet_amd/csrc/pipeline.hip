@@ -51,7 +51,15 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 100; }
+extern "C" int nnhip_version(void) { return 101; }
+// bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
+extern "C" int nnhip_build_flags(void) {
+#ifdef NNHIP_TOOLING
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 // ---- timers ------------------------------------------------------------------------------------------
 struct TimerRec {

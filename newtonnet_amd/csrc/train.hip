@@ -978,27 +978,48 @@ embed_rows_kernel(const int64_t* __restrict__ z, const float* __restrict__ table
 }
 
 // ---------------------------------------------------------------------------------------------
-// The reference's training objective and its gradient in one launch (newtonnet/train/loss.py:48,72,96; scripts/config.yml:45-51):
-//   loss = w[0] sum_b (E_b - E*_b)^2 + w[1] sum_{i,k} (F_ik - F*_ik)^2       w = (w_E / n_E, w_F / n_F) read from DEVICE memory
-//   gE = 2 w[0] (E - E*),  gF = 2 w[1] (F - F*)                               (data-parallel runs refresh the global counts there)
+// The reference's training objective and its gradient in one launch (newtonnet/train/loss.py:53-103: BaseLoss with
+// nn.MSELoss / nn.L1Loss / nn.HuberLoss, mean reduction; scripts/config.yml:45-51):
+//   loss = w[0] sum_b l_E(E_b - E*_b) + w[1] sum_{i,k} l_F(F_ik - F*_ik)    w = (w_E / n_E, w_F / n_F) read from DEVICE memory
+//   gE = w[0] l_E'(E - E*),  gF = w[1] l_F'(F - F*)                          (data-parallel runs refresh the global counts there)
+//   mse: l = d^2; mae: l = |d| (l'(0) = 0 like torch.sign); huber(delta): l = d^2/2 for |d| <= delta, delta (|d| - delta/2) beyond
 // One workgroup, fixed summation order (the arrays are a few thousand elements; the step is launch-bound at that size).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float loss_term(float d, int mode, float delta, float& dl) {
+  const float a = fabsf(d);
+  if (mode == NNHIP_LOSS_MAE) {
+    dl = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return a;
+  }
+  if (mode == NNHIP_LOSS_HUBER) {
+    if (a <= delta) {
+      dl = d;
+      return 0.5f * d * d;
+    }
+    dl = d > 0.f ? delta : -delta;
+    return delta * (a - 0.5f * delta);
+  }
+  dl = 2.f * d;
+  return d * d;
+}
 __global__ void __launch_bounds__(1024)
-mse_loss_grad_kernel(const float* __restrict__ e, const float* __restrict__ e_lab, int n_e, const float* __restrict__ f,
-                     const float* __restrict__ f_lab, int n_f, const float* __restrict__ w, float* __restrict__ loss,
-                     float* __restrict__ g_e, float* __restrict__ g_f) {
+loss_grad_kernel(const float* __restrict__ e, const float* __restrict__ e_lab, int n_e, const float* __restrict__ f,
+                 const float* __restrict__ f_lab, int n_f, const float* __restrict__ w, int mode_e, int mode_f, float delta_e,
+                 float delta_f, float* __restrict__ loss, float* __restrict__ g_e, float* __restrict__ g_f) {
   __shared__ double sh[1024];
   const float we = w[0], wf = w[1];
   double s = 0.0;
   for (int k = threadIdx.x; k < n_e; k += 1024) {
-    const float d = e[k] - e_lab[k];
-    g_e[k] = 2.f * we * d;
-    s += (double)we * d * d;
+    float dl;
+    const float l = loss_term(e[k] - e_lab[k], mode_e, delta_e, dl);
+    g_e[k] = we * dl;
+    s += (double)we * l;
   }
   for (int k = threadIdx.x; k < n_f; k += 1024) {
-    const float d = f[k] - f_lab[k];
-    g_f[k] = 2.f * wf * d;
-    s += (double)wf * d * d;
+    float dl;
+    const float l = loss_term(f[k] - f_lab[k], mode_f, delta_f, dl);
+    g_f[k] = wf * dl;
+    s += (double)wf * l;
   }
   sh[threadIdx.x] = s;
   __syncthreads();
@@ -1017,15 +1038,20 @@ mse_loss_grad_kernel(const float* __restrict__ e, const float* __restrict__ e_la
 //           g' = clip g;  m = b1 m + (1 - b1) g';  v = b2 v + (1 - b2) g'^2;
 //           p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // state[0] = step t (float), state[1] = last total norm (for logging).  max_norm <= 0: no clipping.
+// hyper (DEVICE, optional): (lr, beta1, beta2, eps, max_norm) read at run time, so a captured HIP graph follows a learning-rate
+// schedule; NULL: the by-value arguments.  mask (DEVICE bytes, optional): elements with mask == 0 are frozen parameters
+// (requires_grad False): they do not enter the norm and are not updated, like parameters the optimizer was never given.
 // ---------------------------------------------------------------------------------------------
 #define OPT_BLOCKS 256
 __global__ void __launch_bounds__(256)
-gradnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part, float* __restrict__ state) {
+gradnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part, float* __restrict__ state,
+                        const uint8_t* __restrict__ mask) {
   __shared__ double sh[256];
   const long per = (n + OPT_BLOCKS - 1) / OPT_BLOCKS;
   const long k0 = blockIdx.x * per, k1 = min(n, k0 + per);
   double s = 0.0;
-  for (long k = k0 + threadIdx.x; k < k1; k += 256) s += (double)g[k] * (double)g[k];
+  for (long k = k0 + threadIdx.x; k < k1; k += 256)
+    if (!mask || mask[k]) s += (double)g[k] * (double)g[k];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -1040,8 +1066,15 @@ gradnorm_partial_kernel(const float* __restrict__ g, long n, float* __restrict__
 __global__ void __launch_bounds__(256)
 clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                  const float* __restrict__ part, float* __restrict__ state, float lr, float b1, float b2, float eps,
-                 float max_norm) {
+                 float max_norm, const float* __restrict__ hyper, const uint8_t* __restrict__ mask) {
   __shared__ float s_clip, s_c1, s_c2;
+  if (hyper) {
+    lr = hyper[0];
+    b1 = hyper[1];
+    b2 = hyper[2];
+    eps = hyper[3];
+    max_norm = hyper[4];
+  }
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int k = 0; k < OPT_BLOCKS; ++k) tot += (double)part[k];
@@ -1057,6 +1090,7 @@ clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
   const long per = (n + OPT_BLOCKS - 1) / OPT_BLOCKS;
   const long k0 = blockIdx.x * per, k1 = min(n, k0 + per);
   for (long k = k0 + threadIdx.x; k < k1; k += 256) {
+    if (mask && !mask[k]) continue;
     const float gk = g[k] * clip;
     const float mk = fmaf(b1, m[k], (1.0f - b1) * gk);
     const float vk = fmaf(b2, v[k], (1.0f - b2) * gk * gk);
@@ -1292,28 +1326,48 @@ extern "C" int nnhip_colsum_batch(const nnhip_colsum_problem* probs_dev, int32_t
   return NNHIP_OK;
 }
 
-extern "C" int nnhip_mse_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
-                                   const float* force_label, int32_t n_force, const float* weights_dev, float* loss,
-                                   float* g_energy, float* g_forces, void* stream) {
+extern "C" int nnhip_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
+                               const float* force_label, int32_t n_force, const float* weights_dev, int32_t mode_energy,
+                               int32_t mode_force, float delta_energy, float delta_force, float* loss, float* g_energy,
+                               float* g_forces, void* stream) {
   ARG_CHECK(n_energy >= 0 && n_force >= 0 && energy && energy_label && forces && force_label && weights_dev && loss && g_energy &&
-                g_forces, "nnhip_mse_loss_grad");
-  mse_loss_grad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(energy, energy_label, n_energy, forces, force_label, n_force,
-                                                            weights_dev, loss, g_energy, g_forces);
+                g_forces && mode_energy >= 0 && mode_energy <= NNHIP_LOSS_HUBER && mode_force >= 0 &&
+                mode_force <= NNHIP_LOSS_HUBER && delta_energy > 0.f && delta_force > 0.f, "nnhip_loss_grad");
+  loss_grad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(energy, energy_label, n_energy, forces, force_label, n_force, weights_dev,
+                                                        mode_energy, mode_force, delta_energy, delta_force, loss, g_energy,
+                                                        g_forces);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
+extern "C" int nnhip_mse_loss_grad(const float* energy, const float* energy_label, int32_t n_energy, const float* forces,
+                                   const float* force_label, int32_t n_force, const float* weights_dev, float* loss,
+                                   float* g_energy, float* g_forces, void* stream) {
+  return nnhip_loss_grad(energy, energy_label, n_energy, forces, force_label, n_force, weights_dev, NNHIP_LOSS_MSE, NNHIP_LOSS_MSE,
+                         1.f, 1.f, loss, g_energy, g_forces, stream);
+}
 
 extern "C" size_t nnhip_clip_adam_scratch_bytes(void) { return OPT_BLOCKS * sizeof(float); }
+static int clip_adam_launch(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
+                            float* state, float lr, float beta1, float beta2, float eps, float max_norm, const float* hyper,
+                            const uint8_t* mask, hipStream_t s) {
+  if (n == 0) return NNHIP_OK;
+  gradnorm_partial_kernel<<<OPT_BLOCKS, 256, 0, s>>>(grads, (long)n, scratch, state, mask);
+  LAUNCH_CHECK();
+  clip_adam_kernel<<<OPT_BLOCKS, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, (long)n, scratch, state, lr, beta1, beta2, eps,
+                                              max_norm, hyper, mask);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
 extern "C" int nnhip_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float* scratch,
                                float* state, float lr, float beta1, float beta2, float eps, float max_norm, void* stream) {
   ARG_CHECK(n >= 0 && params && grads && exp_avg && exp_avg_sq && scratch && state && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f &&
                 beta2 >= 0.f && beta2 < 1.f, "nnhip_clip_adam");
-  if (n == 0) return NNHIP_OK;
-  hipStream_t s = (hipStream_t)stream;
-  gradnorm_partial_kernel<<<OPT_BLOCKS, 256, 0, s>>>(grads, (long)n, scratch, state);
-  LAUNCH_CHECK();
-  clip_adam_kernel<<<OPT_BLOCKS, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, (long)n, scratch, state, lr, beta1, beta2, eps,
-                                              max_norm);
-  LAUNCH_CHECK();
-  return NNHIP_OK;
+  return clip_adam_launch(params, grads, exp_avg, exp_avg_sq, n, scratch, state, lr, beta1, beta2, eps, max_norm, nullptr, nullptr,
+                          (hipStream_t)stream);
+}
+extern "C" int nnhip_clip_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   float* scratch, float* state, const float* hyper_dev, const uint8_t* mask_dev, void* stream) {
+  ARG_CHECK(n >= 0 && params && grads && exp_avg && exp_avg_sq && scratch && state && hyper_dev, "nnhip_clip_adam_dev");
+  return clip_adam_launch(params, grads, exp_avg, exp_avg_sq, n, scratch, state, 0.f, 0.f, 0.f, 0.f, 0.f, hyper_dev, mask_dev,
+                          (hipStream_t)stream);
 }

@@ -35,12 +35,62 @@ def shard_molecules(atoms_per_molecule: Sequence[int], world_size: int) -> List[
 
 
 def allreduce_counts(n_energy: int, n_force: int, device, group=None) -> Tuple[float, float]:
-    """Global number of energy / force-component elements in this step (one tiny all-reduce)."""
+    """Global number of energy / force-component elements in this step as host floats (one tiny all-reduce + a host sync: the
+    torch-autograd step uses it; the all-HIP steps keep the counts on the device, `_CountReduce`)."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(n_energy), float(n_force)            # (no device work, no sync)
     t = torch.tensor([float(n_energy), float(n_force)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t[0]), float(t[1])
+
+
+class _CountReduce:
+    """(w_E / n_E, w_F / n_F) with GLOBAL element counts as a DEVICE tensor, without a host sync: the two local counts go to the
+    device, their all-reduce is issued asynchronously at the top of the step (it runs on the collective's own stream while the
+    value sweeps execute) and `norm()` joins it right before the loss kernel, the first consumer.  Off the critical path, exact
+    for batches whose sizes differ from rank to rank and from step to step (mixed MD17)."""
+
+    def __init__(self, w_energy: float, w_force: float, group=None):
+        self.w, self.group = (float(w_energy), float(w_force)), group
+        self._w_dev = None
+
+    def start(self, n_energy: int, n_force: int, device):
+        self._local = (max(int(n_energy), 1), max(int(n_force), 1))
+        self._work = self._counts = None
+        if dist.is_available() and dist.is_initialized():
+            self._counts = torch.tensor([float(n_energy), float(n_force)], dtype=torch.float64).to(device, non_blocking=True)
+            self._work = dist.all_reduce(self._counts, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._device = device
+
+    def norm(self) -> torch.Tensor:
+        if self._counts is None:
+            return torch.tensor([self.w[0] / self._local[0], self.w[1] / self._local[1]],
+                                dtype=torch.float32).to(self._device, non_blocking=True)
+        self._work.wait()                       # (stream-side join for RCCL; gloo completes on the host)
+        if self._w_dev is None or self._w_dev.device != self._counts.device:
+            self._w_dev = torch.tensor(self.w, dtype=torch.float64, device=self._counts.device)
+        return (self._w_dev / self._counts.clamp_min(1.0)).float()
+
+
+def _loss_spec(loss_modes, huber_delta):
+    """('mse' | 'mae' | 'huber') for the energy and the force term (newtonnet/train/loss.py:53-103) -> ids of the C ABI."""
+    from newtonnet_amd import hip
+    modes = (loss_modes, loss_modes) if isinstance(loss_modes, str) else tuple(loss_modes)
+    deltas = (huber_delta, huber_delta) if isinstance(huber_delta, (int, float)) else tuple(huber_delta)
+    for m in modes:
+        if m not in hip.LOSS_MODES:
+            raise ValueError(f'loss mode {m} not implemented')          # (the reference's message, loss.py:77)
+    return modes, (hip.LOSS_MODES[modes[0]], hip.LOSS_MODES[modes[1]]), (float(deltas[0]), float(deltas[1]))
+
+
+def _torch_loss_sum(pred, label, mode, delta):
+    """sum over elements of the reference's elementwise loss (the caller divides by the global element count)"""
+    d = pred - label
+    if mode == 'mse':
+        return d.pow(2).sum()
+    if mode == 'mae':
+        return d.abs().sum()
+    return torch.nn.functional.huber_loss(pred, label, reduction='sum', delta=delta)
 
 
 def _flat_view_of(params) -> Optional[torch.Tensor]:
@@ -84,18 +134,22 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None) -> Opt
 
 
 class TrainStep:
-    """One optimisation step with the reference's loss (scripts/config.yml:45-51; trainer.py:301-313):
-    loss = w_E * MSE(E) + w_F * MSE(F), clip_grad_norm_, optimizer.step -- data-parallel over molecules."""
+    """One optimisation step with the reference's loss (scripts/config.yml:45-51; trainer.py:301-313; loss.py:5-103):
+    loss = w_E * l_E(E) + w_F * l_F(F) with l = MSE / MAE / Huber (mean reduction), clip_grad_norm_, optimizer.step --
+    data-parallel over molecules."""
     def __init__(self, model, optimizer, w_energy: float = 1.0, w_force: float = 50.0, clip_grad: float = 1.0,
-                 group=None):
+                 group=None, loss_modes='mse', huber_delta=1.0):
         """optimizer: a torch optimizer (the step is then autograd through the model's fused node + torch clipping + the
         optimizer), or a FusedClipAdam (its max_norm is the clipping; `clip_grad` is ignored): the step then runs with NO
         autograd and no per-parameter tensors -- exact neighbor list, value sweeps, loss and its gradient, tangent sweeps,
-        weight gradients, one all-reduce of the flat gradient, clip + Adam -- for batches of any (changing) structure."""
+        weight gradients, one all-reduce of the flat gradient, clip + Adam -- for batches of any (changing) structure.
+        loss_modes: 'mse' | 'mae' | 'huber', or a pair (energy term, force term); huber_delta likewise."""
         self.model, self.optimizer = model, optimizer
         self.w_energy, self.w_force, self.clip_grad, self.group = w_energy, w_force, clip_grad, group
+        self.loss_modes, self._mode_ids, self.huber_delta = _loss_spec(loss_modes, huber_delta)
         self.fused = isinstance(optimizer, FusedClipAdam)
         self._loss = self._gE = self._gF = None
+        self._counts = _CountReduce(w_energy, w_force, group)
 
     def _call_fused(self, z, pos, cell, batch, energy_label, force_label):
         from newtonnet_amd import hip, train_fused
@@ -106,7 +160,9 @@ class TrainStep:
             raise NotImplementedError("FusedClipAdam / the fused step needs output_properties ['energy', 'gradient_force'] and "
                                       'layer_norm=False')
         emb = model.embedding_layers.edge_embedding
-        n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), dev, self.group)
+        # the step's two collectives: the 2-scalar count all-reduce starts NOW and overlaps the value sweeps (joined before the
+        # loss kernel, no host sync); the flat gradient all-reduce is the one on the critical path
+        self._counts.start(energy_label.numel(), force_label.numel(), dev)
         zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
         bc = batch.contiguous() if batch.dtype == torch.int64 else batch.long().contiguous()
         pd, cd = hip._f32c(pos.detach(), 'pos'), hip._f32c(cell.detach(), 'cell')
@@ -122,12 +178,13 @@ class TrainStep:
             if self._gE is None or self._gE.shape[0] != B or self._gF.shape[0] != N or self._gE.device != dev:
                 self._gE = torch.empty(B, dtype=torch.float32, device=dev)
                 self._gF = torch.empty(N, 3, dtype=torch.float32, device=dev)
-            norm = torch.tensor([self.w_energy / n_e, self.w_force / n_f], dtype=torch.float32).to(dev, non_blocking=True)
             runner = train_fused.Runner(model, zc, pd, cd, bc, g, ws)
             runner.values()
-            hip._check(hip.lib().nnhip_mse_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab),
-                                                     3 * N, hip._ptr(norm), hip._ptr(self._loss), hip._ptr(self._gE),
-                                                     hip._ptr(self._gF), hip._stream(dev)), 'nnhip_mse_loss_grad')
+            norm = self._counts.norm()
+            hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab),
+                                                 3 * N, hip._ptr(norm), self._mode_ids[0], self._mode_ids[1],
+                                                 self.huber_delta[0], self.huber_delta[1], hip._ptr(self._loss),
+                                                 hip._ptr(self._gE), hip._ptr(self._gF), hip._stream(dev)), 'nnhip_loss_grad')
             runner.grads(self._gE, self._gF)
             if dist.is_available() and dist.is_initialized():
                 dist.all_reduce(ws.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
@@ -141,13 +198,13 @@ class TrainStep:
         n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), pos.device, self.group)
         pos = pos.detach().clone().requires_grad_(True)
         out = self.model(z, pos, cell, batch)
-        sse_e = (out.energy - energy_label).pow(2).sum()
-        sse_f = (out.gradient_force - force_label).pow(2).sum()
-        loss = self.w_energy * sse_e / n_e + self.w_force * sse_f / n_f      # this rank's share of the global loss
+        sum_e = _torch_loss_sum(out.energy, energy_label, self.loss_modes[0], self.huber_delta[0])
+        sum_f = _torch_loss_sum(out.gradient_force, force_label, self.loss_modes[1], self.huber_delta[1])
+        loss = self.w_energy * sum_e / n_e + self.w_force * sum_f / n_f      # this rank's share of the global loss
         loss.backward()
         allreduce_gradients(self.model.parameters(), self.group)
         if self.clip_grad:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.clip_grad)
         self.optimizer.step()
         return loss.detach()
 
@@ -175,39 +232,93 @@ def flatten_parameters(model) -> torch.Tensor:
     return flat
 
 
-class FusedClipAdam:
+class FusedClipAdam(torch.optim.Optimizer):
     """clip_grad_norm_(max_norm) + Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; trainer.py:311-313) as two HIP
-    launches over the model's flat parameter buffer (csrc/train.hip: gradnorm_partial_kernel, clip_adam_kernel).  The step
-    counter lives on the device, so the update captures into a HIP graph."""
+    launches over the model's flat parameter buffer (csrc/train.hip: gradnorm_partial_kernel, clip_adam_kernel).
+
+    A torch.optim.Optimizer: `param_groups[0]['lr']` is the learning rate the next step uses, so the reference's schedulers
+    (ReduceLROnPlateau etc., trainer.py:190,254) and its `lr <= min_lr` stop criterion drive it unchanged.  The step counter AND
+    the hyper-parameters (lr, betas, eps, max_norm) live in device memory, so an update captured into a HIP graph follows the
+    schedule: `sync()` refreshes them (a 20-byte copy when something changed) and GraphedTrainStep calls it before every replay.
+    Parameters with requires_grad False (the freeze_* switches of scripts/newtonnet_train.py:69-81) are masked on the device:
+    they do not enter the clipping norm and are not updated, like parameters a torch optimizer was never given.
+    `step(flat_grad)` takes the flat gradient of the fused training path; `step()` gathers the parameters' .grad tensors."""
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0):
         from newtonnet_amd import hip
-        self.model, self.lr, self.betas, self.eps, self.max_norm = model, float(lr), betas, float(eps), float(max_norm or 0.0)
+        from newtonnet_amd.train_fused import trainable_parameters
+        self.model = model
         self.flat = flatten_parameters(model)
+        self._params = trainable_parameters(model)
+        super().__init__(self._params, dict(lr=float(lr), betas=tuple(betas), eps=float(eps), max_norm=float(max_norm or 0.0)))
         dev = self.flat.device
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        self.state = torch.zeros(2, dtype=torch.float32, device=dev)          # (step, last gradient norm)
+        self.dev_state = torch.zeros(2, dtype=torch.float32, device=dev)      # (step, last gradient norm)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)          # (lr, beta1, beta2, eps, max_norm)
+        self.mask = torch.ones(self.flat.numel(), dtype=torch.uint8, device=dev)
         self.scratch = torch.empty(hip.lib().nnhip_clip_adam_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+        self._hyper_host = self._mask_key = None
+        self.sync()
 
-    def step(self, flat_grad: torch.Tensor):
+    # plain attributes of the round-2 API, now views of the param group
+    lr = property(lambda self: self.param_groups[0]['lr'], lambda self, v: self.param_groups[0].__setitem__('lr', float(v)))
+    betas = property(lambda self: self.param_groups[0]['betas'])
+    eps = property(lambda self: self.param_groups[0]['eps'])
+    max_norm = property(lambda self: self.param_groups[0]['max_norm'],
+                        lambda self, v: self.param_groups[0].__setitem__('max_norm', float(v or 0.0)))
+
+    def sync(self):
+        """Bring the device-side hyper-parameters and the frozen-parameter mask up to date with param_groups / requires_grad
+        (host compare; device copies only on change).  Not capturable: call it outside a graph capture."""
+        g = self.param_groups[0]
+        h = (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['max_norm'] or 0.0))
+        if not (h[0] >= 0.0 and 0.0 <= h[1] < 1.0 and 0.0 <= h[2] < 1.0):
+            raise ValueError(f'FusedClipAdam: invalid hyper-parameters lr={h[0]}, betas=({h[1]}, {h[2]})')
+        if h != self._hyper_host:
+            self.hyper.copy_(torch.tensor(h + (0.0, 0.0, 0.0), dtype=torch.float32), non_blocking=False)
+            self._hyper_host = h
+        key = tuple(p.requires_grad for p in self._params)
+        if key != self._mask_key:
+            m = torch.cat([torch.full((p.numel(),), 1 if p.requires_grad else 0, dtype=torch.uint8) for p in self._params])
+            self.mask.copy_(m)
+            self._mask_key = key
+            self._masked = not all(key)
+
+    def _gather_grads(self) -> torch.Tensor:
+        flat = _flat_view_of([p for p in self._params]) if all(p.grad is not None for p in self._params) else None
+        if flat is not None:
+            return flat
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32)
+                          for p in self._params])
+
+    def step(self, flat_grad: Optional[torch.Tensor] = None, closure=None):
         from newtonnet_amd import hip
-        self.flat = flatten_parameters(self.model)
+        if closure is not None:
+            raise NotImplementedError('FusedClipAdam.step does not take a closure')
+        if flat_grad is None:
+            flat_grad = self._gather_grads()
+        if not torch.cuda.is_current_stream_capturing():
+            self.flat = flatten_parameters(self.model)
+            self.sync()
         if flat_grad.numel() != self.flat.numel() or flat_grad.dtype != torch.float32 or not flat_grad.is_contiguous():
             raise ValueError('FusedClipAdam.step needs the flat fp32 gradient of the model (train_fused.TrainWorkspace.flat_grad)')
-        hip._check(hip.lib().nnhip_clip_adam(hip._ptr(self.flat), hip._ptr(flat_grad), hip._ptr(self.exp_avg),
-                                             hip._ptr(self.exp_avg_sq), self.flat.numel(), hip._ptr(self.scratch),
-                                             hip._ptr(self.state), self.lr, self.betas[0], self.betas[1], self.eps, self.max_norm,
-                                             hip._stream(self.flat.device)), 'nnhip_clip_adam')
+        hip._check(hip.lib().nnhip_clip_adam_dev(hip._ptr(self.flat), hip._ptr(flat_grad), hip._ptr(self.exp_avg),
+                                                 hip._ptr(self.exp_avg_sq), self.flat.numel(), hip._ptr(self.scratch),
+                                                 hip._ptr(self.dev_state), hip._ptr(self.hyper), hip._ptr(self.mask),
+                                                 hip._stream(self.flat.device)), 'nnhip_clip_adam_dev')
 
     def state_dict(self):
-        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), state=self.state.clone(), lr=self.lr,
-                    betas=self.betas, eps=self.eps, max_norm=self.max_norm)
+        g = self.param_groups[0]
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), state=self.dev_state.clone(), lr=g['lr'],
+                    betas=g['betas'], eps=g['eps'], max_norm=g['max_norm'])
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.state.copy_(sd['state'])
-        self.lr, self.betas, self.eps, self.max_norm = sd['lr'], sd['betas'], sd['eps'], sd['max_norm']
+        self.dev_state.copy_(sd['state'])
+        g = self.param_groups[0]
+        g['lr'], g['betas'], g['eps'], g['max_norm'] = sd['lr'], tuple(sd['betas']), sd['eps'], sd['max_norm']
+        self.sync()
 
 
 class GraphedTrainStep:
@@ -225,17 +336,21 @@ class GraphedTrainStep:
     EAGER_ABOVE_ATOMS = 8192     # fused mode: batches at least this large run eagerly on the exact neighbor list
 
     def __init__(self, model, optimizer, w_energy: float = 1.0, w_force: float = 50.0, clip_grad: float = 1.0,
-                 group=None, assume_static: bool = False):
+                 group=None, assume_static: bool = False, loss_modes='mse', huber_delta=1.0):
         """optimizer: a capturable torch optimizer (the step is then torch autograd + torch optimizer, captured), or a
         FusedClipAdam (its max_norm is the clipping; `clip_grad` is ignored): the whole step then runs on hand-written kernels
         with NO autograd -- value sweeps, the loss and its gradient, tangent sweeps, weight gradients, clip + Adam.
-        assume_static: skip the per-step check that z / batch / cell are unchanged (it costs a device->host sync)."""
+        assume_static: the structure (z / batch / cell, hence the global element counts) never changes after the first step on
+        any rank: no per-step structure check (a device->host sync) and no per-step count all-reduce -- ONE collective per step,
+        the flat gradient.  loss_modes / huber_delta: as TrainStep."""
         self.model, self.optimizer = model, optimizer
         self.w_energy, self.w_force, self.clip_grad, self.group = w_energy, w_force, clip_grad, group
+        self.loss_modes, self._mode_ids, self.huber_delta = _loss_spec(loss_modes, huber_delta)
         self.assume_static = assume_static
         self.fused = isinstance(optimizer, FusedClipAdam)
         self._st = None
         self._eager = None
+        self._use_eager = None
         self.captures = 0
 
     # -- fully fused mode ------------------------------------------------------------------------------------
@@ -265,9 +380,10 @@ class GraphedTrainStep:
         def body():
             hip.refresh_graph(g, st['pos'], st['cell'], st['batch'], emb.cutoff, emb.embedding.frequencies)
             runner.values()
-            hip._check(L_.nnhip_mse_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(ws.forces), hip._ptr(st['f']),
-                                              3 * N, hip._ptr(st['norm']), hip._ptr(st['loss']), hip._ptr(st['gE']),
-                                              hip._ptr(st['gF']), hip._stream(dev)), 'nnhip_mse_loss_grad')
+            hip._check(L_.nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(ws.forces), hip._ptr(st['f']),
+                                          3 * N, hip._ptr(st['norm']), self._mode_ids[0], self._mode_ids[1], self.huber_delta[0],
+                                          self.huber_delta[1], hip._ptr(st['loss']), hip._ptr(st['gE']), hip._ptr(st['gF']),
+                                          hip._stream(dev)), 'nnhip_loss_grad')
             runner.grads(st['gE'], st['gF'])
         self._st = st
         st['norm'].copy_(norm)
@@ -286,29 +402,48 @@ class GraphedTrainStep:
             self.optimizer.step(ws.flat_grad)
         self.captures += 1
 
+    def _agree_eager(self, n_atoms: int, dev) -> bool:
+        """Eager (exact list) or replay (static candidate list)?  Decided ONCE, on the first call, from the LARGEST per-rank atom
+        count (one MAX all-reduce): every rank takes the same path -- the two paths issue different collectives, so a rank-local
+        decision with uneven shards around the threshold would leave them unmatched."""
+        if self._use_eager is None:
+            n = n_atoms
+            if dist.is_available() and dist.is_initialized():
+                t = torch.tensor([float(n_atoms)], dtype=torch.float32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                n = int(t.item())
+            self._use_eager = n >= self.EAGER_ABOVE_ATOMS
+        return self._use_eager
+
     def _call_fused(self, z, pos, cell, batch, energy_label, force_label):
-        """Per step: (1) agree on the global loss normalisation -- and, unless assume_static, on whether ANY rank's batch
-        structure changed (then all ranks re-capture together: a rank-local decision would leave collectives unmatched) -- with
-        one tiny all-reduce; (2) replay forward + loss + gradients; (3) all-reduce the flat gradient; (4) replay clip + Adam."""
+        """Per step: (1) unless assume_static: agree on the global loss normalisation and on whether ANY rank's batch structure
+        changed (then all ranks re-capture together: a rank-local decision would leave collectives unmatched) with one tiny
+        all-reduce -- with assume_static the normalisation of the first step is kept and there is no such collective;
+        (2) replay forward + loss + gradients; (3) all-reduce the flat gradient; (4) replay clip + Adam."""
         distributed = dist.is_available() and dist.is_initialized()
-        if pos.shape[0] >= self.EAGER_ABOVE_ATOMS:
+        if self._agree_eager(pos.shape[0], pos.device):
             # device-bound sizes: replay saves nothing, and the static all-pairs candidate list is larger than the exact one
             # (1024 aspirin conformers: 8.7 ms replayed vs 7.2 ms eager) -- run the same step eagerly on the exact list
             if self._eager is None:
-                self._eager = TrainStep(self.model, self.optimizer, self.w_energy, self.w_force, self.clip_grad, self.group)
+                self._eager = TrainStep(self.model, self.optimizer, self.w_energy, self.w_force, self.clip_grad, self.group,
+                                        self.loss_modes, self.huber_delta)
             return self._eager(z, pos, cell, batch, energy_label, force_label)
-        changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
-        norm, changed = self._global_norm(energy_label, force_label, changed, pos.device)
-        if changed:
-            self._capture_fused(z, pos, cell, batch, energy_label, force_label, norm)
-        st = self._st
-        st['norm'].copy_(norm)
+        if self.assume_static and self._st is not None:
+            st = self._st                     # structure and global counts are those of the capture: nothing to agree on
+        else:
+            changed = self._st is None or not (self.assume_static or self._same_structure(z, cell, batch))
+            norm, changed = self._global_norm(energy_label, force_label, changed, pos.device)
+            if changed:
+                self._capture_fused(z, pos, cell, batch, energy_label, force_label, norm)
+            st = self._st
+            st['norm'].copy_(norm)
         st['pos'].copy_(pos.detach(), non_blocking=True)
         st['e'].copy_(energy_label.detach(), non_blocking=True)
         st['f'].copy_(force_label.detach(), non_blocking=True)
         st['g1'].replay()
         if distributed:
             dist.all_reduce(st['ws'].flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.optimizer.sync()                 # learning-rate schedule / freeze switches reach the captured update
         st['g2'].replay()
         return st['loss'][0].clone()
 
@@ -316,15 +451,15 @@ class GraphedTrainStep:
     def _fwd_bwd(self, st):
         self.optimizer.zero_grad(set_to_none=True)
         out = self.model(st['z'], st['pos'], st['cell'], st['batch'])
-        sse_e = (out.energy - st['e']).pow(2).sum()
-        sse_f = (out.gradient_force - st['f']).pow(2).sum()
+        sse_e = _torch_loss_sum(out.energy, st['e'], self.loss_modes[0], self.huber_delta[0])
+        sse_f = _torch_loss_sum(out.gradient_force, st['f'], self.loss_modes[1], self.huber_delta[1])
         loss = st['norm'][0] * sse_e + st['norm'][1] * sse_f      # (w_E / n_E, w_F / n_F): a DEVICE tensor, refreshed every step
         loss.backward()
         return loss.detach()
 
     def _update(self):
         if self.clip_grad:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.clip_grad)
         self.optimizer.step()
 
     def _same_structure(self, z, cell, batch) -> bool:

@@ -100,6 +100,7 @@ class TrainWs(C.Structure):
 
 
 MODE_FWD, MODE_BWD, MODE_TAN, MODE_TAN2 = 0, 1, 2, 3
+LOSS_MODES = {'mse': 0, 'mae': 1, 'huber': 2}          # newtonnet/train/loss.py:53-103
 WG_PLAIN, WG_ACT, WG_TDACT = 0, 1, 2
 
 
@@ -110,9 +111,10 @@ class HipLibraryError(RuntimeError):
 _lib = None
 
 
-def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into newtonnet_amd/lib/libnewtonnet_hip.so."""
-    r = subprocess.run(['bash', BUILD_SCRIPT], capture_output=True, text=True)
+def build(verbose: bool = False, force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into newtonnet_amd/lib/libnewtonnet_hip.so (force: every source, not only the
+    stale ones)."""
+    r = subprocess.run(['bash', BUILD_SCRIPT] + (['--force'] if force else []), capture_output=True, text=True)
     if r.returncode != 0:
         raise HipLibraryError(f'hipcc build failed:\n{r.stdout}\n{r.stderr}')
     if verbose:
@@ -132,6 +134,11 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
     L.nnhip_version.restype = C.c_int
+    L.nnhip_build_flags.restype = C.c_int
+    if L.nnhip_build_flags() & 1 and os.environ.get('NNHIP_ALLOW_TOOLING_LIB') != '1':
+        raise HipLibraryError(f'{LIB_PATH} is a TOOLING build (compiled with extra flags such as an ablation switch: its results '
+                              'may be wrong).  Rebuild with `bash newtonnet_amd/csrc/build.sh --force`, or set '
+                              'NNHIP_ALLOW_TOOLING_LIB=1 for measurements.')
     L.nnhip_last_error.restype = C.c_char_p
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
@@ -198,6 +205,8 @@ def lib():
     L.nnhip_weight_image_bytes.restype = sz
     L.nnhip_weight_images.argtypes = [vp, vp, i32, vp]
     L.nnhip_mse_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.nnhip_loss_grad.argtypes = [vp, vp, i32, vp, vp, i32, vp, i32, i32, f32, f32, vp, vp, vp, vp]
+    L.nnhip_clip_adam_dev.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     L.nnhip_clip_adam_scratch_bytes.restype = sz
     L.nnhip_clip_adam.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, f32, f32, f32, f32, f32, vp]
     for fn in STAGE_SYMBOLS:
@@ -220,8 +229,8 @@ STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables
                  'nnhip_message_tan_fwd', 'nnhip_force_message_tan_fwd', 'nnhip_force_message_tan_bwd',
                  'nnhip_message_tan_bwd', 'nnhip_update_tan_fwd', 'nnhip_update_tan_bwd', 'nnhip_head_seed_tan',
                  'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_species_scratch_bytes', 'nnhip_wgrad_slab_bytes',
-                 'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad',
-                 'nnhip_clip_adam', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_values', 'nnhip_train_grads',
+                 'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad', 'nnhip_loss_grad',
+                 'nnhip_clip_adam', 'nnhip_clip_adam_dev', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_values', 'nnhip_train_grads',
                  'nnhip_train_ws_bytes', 'nnhip_weight_image_bytes', 'nnhip_weight_images')
 
 EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
@@ -229,7 +238,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
-                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products')
+                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags')
 
 
 def _check(rc: int, what: str):
@@ -269,27 +278,19 @@ def prepare(model: Model, device) -> torch.Tensor:
     return buf
 
 
-_box_cache = [None, None]   # (key, box lengths or None) of the last single-box cell inspected by build_graph
-
-
 def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
     """Box lengths (3 floats) when `cell` ([1,3,3]) is an axis-aligned periodic box of at least 3 cutoffs per side -- the
-    precondition of the O(N) cell-list kernels -- else None.  Inspecting a device tensor costs one device->host sync, so
-    the answer is cached on the tensor's identity (storage pointer + in-place version counter: the same cell tensor passed
-    step after step is looked at once), and callers that hold the cell on the host (the ASE calculator) pass it in."""
+    precondition of the O(N) cell-list kernels -- else None.  The CURRENT contents of the cell decide, every call: a device
+    tensor is read back (36 bytes, one round trip of ~30 us on a step that takes milliseconds at the >= 2048-atom sizes this
+    path serves); callers that hold the cell on the host (the ASE calculator) pass it in and skip the round trip.  Nothing is
+    cached on tensor identity: a fresh cell tensor per NPT frame reuses the allocator's block and its version counter."""
     if cell_host is not None:
         c = torch.as_tensor(cell_host, dtype=torch.float32).reshape(3, 3)
     else:
-        key = (cell.data_ptr(), cell._version, str(cell.device), float(cutoff))
-        if _box_cache[0] == key:
-            return _box_cache[1]
         c = cell.reshape(3, 3).cpu()
     diag = torch.diagonal(c)
     ok = bool((c - torch.diag(diag) == 0).all()) and bool((diag >= 3.0003 * cutoff).all())
-    box = tuple(float(v) for v in diag) if ok else None
-    if cell_host is None:
-        _box_cache[0], _box_cache[1] = key, box
-    return box
+    return tuple(float(v) for v in diag) if ok else None
 
 
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,

@@ -58,6 +58,10 @@ class Gather(torch.autograd.Function):
 
 
 def _envelope(x, p=9):
+    """PolynomialCutoff(p) (representations.py:155-171) for p > 0, CosineCutoff (:177-203) for p == -1: the selector of the
+    C ABI (EdgeEmbedding.envelope_id), so this path trains against the function the inference kernels evaluate."""
+    if p == -1:
+        return 0.5 * (1.0 + torch.cos(torch.pi * x))
     return 1.0 - 0.5 * (p + 1) * (p + 2) * x.pow(p) + p * (p + 2) * x.pow(p + 1) - 0.5 * p * (p + 1) * x.pow(p + 2)
 
 
@@ -111,7 +115,7 @@ def forward_train(model, z, pos, cell, batch, energy_idx: int, graph=None):
     r = disp.norm(dim=-1, keepdim=True)
     u = disp / r
     x = r / ee.cutoff
-    rbf = _envelope(x) * (torch.sin(ee.embedding.frequencies * x) / x)
+    rbf = _envelope(x, ee.envelope_id) * (torch.sin(ee.embedding.frequencies * x) / x)
     inside = None
     if static:   # candidates outside the cutoff: rbf -> 0 AND phi -> 0 (phi = W2 act(0) vanishes by itself only if act(0) = 0)
         inside = (r.detach().float() < ee.cutoff).to(rbf.dtype)

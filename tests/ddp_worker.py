@@ -27,7 +27,7 @@ def run(z, pos, cell, batch, e_lab, f_lab, steps, group_ok, mode='graph'):
     args = [t.cuda() for t in (z, pos, cell, batch, e_lab, f_lab)]
     losses = [float(step(*args)) for _ in range(steps)]
     torch.cuda.synchronize()
-    return model._flat_params.detach().cpu(), losses, float(opt.state[1])
+    return model._flat_params.detach().cpu(), losses, float(opt.dev_state[1])
 
 
 def main():

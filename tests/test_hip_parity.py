@@ -362,6 +362,35 @@ def test_cell_list_equals_all_pairs():
     assert torch.equal(g1.edge_index, g2.edge_index) and torch.equal(g1.disp, g2.disp)
 
 
+def test_fresh_cell_tensor_each_frame_is_read_every_call():
+    """NPT-style frames: every call gets a NEW cell tensor (the caching allocator hands the freed block back, version counter 0)
+    with different box lengths, then a triclinic one.  The cell-list path must bin with the CURRENT box: each frame's graph equals
+    the all-pairs kernels' graph of that frame."""
+    from newtonnet_amd import hip
+    z, pos, cell, batch = periodic_lattice(15, 3000, seed=4)
+    freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
+    pos_d, batch_d = pos.cuda(), batch.cuda()
+    old = hip.CELL_LIST_MIN_ATOMS
+    frames = [cell * s for s in (1.0, 0.62, 1.31, 0.55)]
+    tri = cell.clone()
+    tri[0, 1, 0] = 3.0                                    # sheared: not eligible for the cell list, must fall back
+    frames.append(tri)
+    try:
+        for c in frames:
+            hip.CELL_LIST_MIN_ATOMS = 1
+            cd = torch.tensor(c.numpy()).cuda()           # fresh device tensor per frame
+            g_cell = hip.build_graph(pos_d, cd, batch_d, 5.0, freq)
+            ptr = cd.data_ptr()
+            del cd
+            hip.CELL_LIST_MIN_ATOMS = 1 << 30
+            g_all = hip.build_graph(pos_d, c.cuda(), batch_d, 5.0, freq)
+            assert g_all.n_edges == g_cell.n_edges > 0, (float(c[0, 0, 0]), g_all.n_edges, g_cell.n_edges)
+            assert torch.equal(g_all.edge_index, g_cell.edge_index) and torch.equal(g_all.disp, g_cell.disp)
+    finally:
+        hip.CELL_LIST_MIN_ATOMS = old
+    assert ptr                                            # (frames really were separate tensors)
+
+
 def test_triclinic_cell_follows_reference_formula():
     """Triclinic box: the reference's image shift is d -= cell @ round(solve(cell^T, d)) (representations.py:92-93), which
     differs from the true minimum image for non-symmetric cells; the HIP path must reproduce the reference, not physics."""

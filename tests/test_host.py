@@ -145,3 +145,29 @@ def test_model_surgery_like_ase_interface():
     assert len(model.output_layers) == 2 and model.scalers[1].scale is None
     with pytest.raises(NotImplementedError):
         get_output_by_string('hessian')
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N without a launcher starts `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` as a
+    CHILD process (rendezvous on 127.0.0.1) and returns its exit code -- it never execs, and it does so before any GPU call."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1'])
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert not torch.cuda.is_initialized()
