@@ -20,11 +20,14 @@
 #define NB NNHIP_NB   // 20 radial basis functions (default; 1..NNHIP_MAX_NB supported)
 #define WAVE 64
 #ifndef FT_G
-#define FT_G 2048            // radial-filter table: intervals on x = r/cutoff in [0, 1)
+#define FT_G 3072            // radial-filter table: intervals on x = r/cutoff in [0, 1)
 #endif
-#define FT_ROWS (FT_G + 7)   // rows for x_g = (g - 1) / FT_G (4-point stencil at both ends) + 4 all-zero rows: the stencil of
-                            // a candidate edge at or beyond the cutoff (Verlet-skin lists, nnhip_edge_disp) points there
-#define FT_ZERO_ROW (FT_G + 3)
+// Table nodes x_g = g / FT_G, g = 0 .. FT_G, each node = three rows [T | S | D] of F floats (edge_common.h); behind them
+// all-zero nodes: the stencil (nodes g, g + 1) of a candidate edge at or beyond the cutoff (Verlet-skin lists,
+// nnhip_edge_disp) points at FT_ZERO_ROW
+#define FT_ROWS (FT_G + 4)
+#define FT_ZERO_ROW (FT_G + 1)
+#define FT_PITCH (3 * NNHIP_F)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -69,52 +69,47 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
   return tile * EDGE_ROWS + wave;
 }
 
-// Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx by cubic interpolation of
-// per-layer table planes T[g][f] = eps_f(x_g), D[g][f] = eps_f'(x_g) (graph.hip:filter_table_kernel, FT_G = 2048 intervals,
-// built in fp64 on every call).  Evaluating the 20-term contraction per (edge, feature) on the VALU was the
-// bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the tables turn it into
-// coalesced row reads from L2 and a handful of FMAs.  Interpolation error ~ h^4 |d4f/dx4| / 24 ~ 2e-8 relative
-// (h = 1/2048, fourth derivative ~ (20 pi)^4): below the fp32 rounding of the table entries themselves -- measured
-// against fp64 evaluation the value / derivative errors are 4e-8 / 5e-8 of the maximum at 2048 and at 4096 intervals
-// alike (1.4e-7 / 2.5e-7 at 1024), so 2048 is the smallest table that costs nothing; it keeps T + D of a layer at 2 MB.
+// Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx from per-layer tables
+// (graph.hip:filter_table_kernel, FT_G intervals, built in fp64 on every call).  Evaluating the 20-term contraction per
+// (edge, feature) on the VALU was the bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the
+// tables turn it into coalesced row reads from L2 and a handful of FMAs.
+//
+// Node g holds three rows: T[g] = eps(x_g), S[g] = (eps(x_g+1) - eps(x_g)) FT_G (the secant slope, formed in fp64 BEFORE the
+// one rounding -- differencing the fp32 values would amplify their rounding by FT_G) and D[g] = eps'(x_g).  On the interval
+// [x_g, x_g+1], u in [0, 1), h = 1 / FT_G, the cubic Hermite interpolant through (T, D) at both ends is
+//   eps(u)  = T_g + h ( u^2 (3 - 2u) S_g + u (1 - u)^2 D_g + u^2 (u - 1) D_g+1 )
+//   eps'(u) = 6 u (1 - u) S_g + (1 - u)(1 - 3u) D_g + u (3u - 2) D_g+1
+// FOUR row reads (T_g, S_g, D_g: 1.5 KiB contiguous; D_g+1) give the value AND the derivative; the 4-point Lagrange form of
+// rounds 1-2 read 4 + 4 rows of two planes, and the message adjoint was bound by those L2 requests (24 of ~36 per edge).
+// Against fp64 evaluation: value 3e-8 of the maximum (fp32 rounding of T), derivative 8e-8 at FT_G = 3072 (truncation
+// 0.008 h^3 |d4 eps/dx4| = 4e-8 + rounding; 1.6e-7 at 2048, 6e-8 at 4096): the force tolerances are unchanged.
 struct FilterW {
-  float w[4];   // value weights at nodes -1, 0, 1, 2
+  float a, b, c;      // value:      T_g + a S_g + b D_g + c D_g+1
+  float da, db, dc;   // derivative:       da S_g + db D_g + dc D_g+1
 };
 __device__ __forceinline__ FilterW filter_weights(float u) {
   FilterW f;
-  const float um1 = u - 1.f, um2 = u - 2.f, up1 = u + 1.f;
-  f.w[0] = -u * um1 * um2 * (1.f / 6.f);
-  f.w[1] = up1 * um1 * um2 * 0.5f;
-  f.w[2] = -up1 * u * um2 * 0.5f;
-  f.w[3] = up1 * u * um1 * (1.f / 6.f);
+  const float h = 1.0f / (float)FT_G, v = 1.f - u, uu = u * u;
+  f.a = h * uu * (3.f - 2.f * u);
+  f.b = h * u * v * v;
+  f.c = -h * uu * v;
+  f.da = 6.f * u * v;
+  f.db = v * (1.f - 3.f * u);
+  f.dc = u * (3.f * u - 2.f);
   return f;
 }
 __device__ __forceinline__ float4 filter_value(const float* __restrict__ table, int g0, int c4, const FilterW& fw) {
-  float4 t[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = ld4(table + (size_t)(g0 + k) * NF + c4);
-  float4 eps = mul4(t[0], fw.w[0]);
-#pragma unroll
-  for (int k = 1; k < 4; ++k) eps = fma4(t[k], fw.w[k], eps);
-  return eps;
+  const float* __restrict__ node = table + (size_t)g0 * FT_PITCH + c4;
+  const float4 t0 = ld4(node), s0 = ld4(node + NF), d0 = ld4(node + 2 * NF), d1 = ld4(node + FT_PITCH + 2 * NF);
+  return fma4(d1, fw.c, fma4(d0, fw.b, fma4(s0, fw.a, t0)));
 }
-// value and derivative: the derivative plane follows the value plane
+// value and derivative from the same four rows
 __device__ __forceinline__ void filter_value_deriv(const float* __restrict__ table, int g0, int c4, const FilterW& fw,
                                                    float4& eps, float4& deps) {
-  const float* dt = table + (size_t)FT_ROWS * NF;
-  float4 t[4], d[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    t[k] = ld4(table + (size_t)(g0 + k) * NF + c4);
-    d[k] = ld4(dt + (size_t)(g0 + k) * NF + c4);
-  }
-  eps = mul4(t[0], fw.w[0]);
-  deps = mul4(d[0], fw.w[0]);
-#pragma unroll
-  for (int k = 1; k < 4; ++k) {
-    eps = fma4(t[k], fw.w[k], eps);
-    deps = fma4(d[k], fw.w[k], deps);
-  }
+  const float* __restrict__ node = table + (size_t)g0 * FT_PITCH + c4;
+  const float4 t0 = ld4(node), s0 = ld4(node + NF), d0 = ld4(node + 2 * NF), d1 = ld4(node + FT_PITCH + 2 * NF);
+  eps = fma4(d1, fw.c, fma4(d0, fw.b, fma4(s0, fw.a, t0)));
+  deps = fma4(d1, fw.dc, fma4(d0, fw.db, mul4(s0, fw.da)));
 }
 
 // First edge of row i whose sender is above i (cols ascend within a row: [beg, mid) are the pairs owned by the other

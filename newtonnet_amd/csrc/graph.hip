@@ -405,13 +405,12 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   return NNHIP_OK;
 }
 
-// Radial-filter tables of one layer, x_g = (g - 1) / FT_G, g = 0 .. FT_G + 2 (fp64 evaluation, one rounding):
-//   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)          (values)
-//   D[g][f] = sum_n W_e[f][n] d rbf_n/dx (x_g)    (derivatives, tabulated separately: differentiating the fp32 value
-//             table would amplify its rounding by FT_G)
-// stored as two planes, table[0 .. FT_ROWS)[F] = T followed by [FT_ROWS][F] = D: with four features per lane every
-// row read of either plane is one coalesced 16-byte-per-lane instruction.  The message kernels interpolate both with the
-// same 4-point cubic weights (edge.hip).
+// Radial-filter tables of one layer, nodes x_g = g / FT_G, g = 0 .. FT_G (fp64 evaluation, one rounding per entry):
+//   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)                         (values)
+//   S[g][f] = (eps_f(x_g+1) - eps_f(x_g)) FT_G                   (secant slopes, differenced in fp64)
+//   D[g][f] = sum_n W_e[f][n] d rbf_n/dx (x_g)                   (derivatives)
+// stored node-major, table[g][T | S | D][F]: the four rows of one cubic Hermite evaluation (edge_common.h) are 1.5 KiB
+// contiguous + the D row of the next node; every row read is one coalesced 16-byte-per-lane instruction.
 struct FilterTableArgs {
   const float* edge_w[NNHIP_MAX_LAYERS];
   float* table[NNHIP_MAX_LAYERS];
@@ -419,42 +418,53 @@ struct FilterTableArgs {
   int nb;
   int env;
 };
-__global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
-  __shared__ double rb[NNHIP_MAX_NB], drb[NNHIP_MAX_NB];
-  const int nb = a.nb;
-  const int g = blockIdx.x, l = blockIdx.y;
-  if (g >= FT_ZERO_ROW) {   // the all-zero rows behind the table proper
-    a.table[l][(size_t)g * NF + threadIdx.x] = 0.f;
-    a.table[l][(size_t)(FT_ROWS + g) * NF + threadIdx.x] = 0.f;
+__device__ __forceinline__ void radial_basis_f64(double x, double w, int env_id, double& rb, double& drb) {
+  if (x >= 1.0) {   // at and beyond the cutoff the filter is identically zero (the polynomial envelope itself is not)
+    rb = drb = 0.0;
     return;
   }
-  const double x = (double)(g - 1) / (double)FT_G;
+  double env, denv;
+  envelope_eval(x, env_id, env, denv);
+  double bes, dbes;
+  if (x == 0.0) {
+    bes = w;       // sin(wx)/x -> w
+    dbes = 0.0;    // even function of x
+  } else {
+    double sn, cs;
+    sincos(w * x, &sn, &cs);
+    bes = sn / x;
+    dbes = (w * cs - bes) / x;
+  }
+  rb = env * bes;
+  drb = denv * bes + env * dbes;
+}
+__global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
+  __shared__ double rb[NNHIP_MAX_NB], drb[NNHIP_MAX_NB], rb1[NNHIP_MAX_NB];
+  const int nb = a.nb;
+  const int g = blockIdx.x, l = blockIdx.y;
+  float* __restrict__ node = a.table[l] + (size_t)g * FT_PITCH + threadIdx.x;
+  if (g > FT_G) {   // the all-zero nodes behind the table proper
+    node[0] = node[NF] = node[2 * NF] = 0.f;
+    return;
+  }
   if (threadIdx.x < nb) {
     const double w = (double)a.freq[threadIdx.x];
-    double env, denv;
-    envelope_eval(x, a.env, env, denv);
-    double bes, dbes;
-    if (x == 0.0) {
-      bes = w;       // sin(wx)/x -> w
-      dbes = 0.0;    // even function of x
-    } else {
-      double sn, cs;
-      sincos(w * x, &sn, &cs);
-      bes = sn / x;
-      dbes = (w * cs - bes) / x;
-    }
-    rb[threadIdx.x] = env * bes;
-    drb[threadIdx.x] = denv * bes + env * dbes;
+    double unused;
+    radial_basis_f64((double)g / (double)FT_G, w, a.env, rb[threadIdx.x], drb[threadIdx.x]);
+    radial_basis_f64((double)(g + 1) / (double)FT_G, w, a.env, rb1[threadIdx.x], unused);
   }
   __syncthreads();
   const float* __restrict__ we = a.edge_w[l] + (size_t)threadIdx.x * nb;
-  double acc = 0.0, dacc = 0.0;
+  double acc = 0.0, dacc = 0.0, sacc = 0.0;
   for (int n = 0; n < nb; ++n) {
-    acc += (double)we[n] * rb[n];
-    dacc += (double)we[n] * drb[n];
+    const double wn = (double)we[n];
+    acc += wn * rb[n];
+    dacc += wn * drb[n];
+    sacc += wn * (rb1[n] - rb[n]);
   }
-  a.table[l][(size_t)g * NF + threadIdx.x] = (float)acc;
-  a.table[l][(size_t)(FT_ROWS + g) * NF + threadIdx.x] = (float)dacc;
+  node[0] = (float)acc;
+  node[NF] = (float)(sacc * (double)FT_G);
+  node[2 * NF] = (float)dacc;
 }
 
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,

@@ -636,3 +636,35 @@ def main_train():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train':
     main_train()
+
+
+def main_triclinic_fuzz(n=100000, seed=2024):
+    """Expected neighbor bits of the triclinic fuzz (tests/util.py:triclinic_fuzz_inputs): the reference's own RadiusGraph in
+    fp32 on n two-atom cells, run in chunks (its per-molecule Python loop is O(B N)).  The fixture stores ONLY the expected
+    bits (is 0 -> 1 an edge, is 1 -> 0 an edge) and a checksum of the regenerated inputs; the inputs come from the seed."""
+    import hashlib
+    import_reference()
+    from newtonnet.layers.representations import RadiusGraph
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tests import util
+    r = 5.0
+    rg = RadiusGraph(r)
+    pos, cells, batch, kinds = util.triclinic_fuzz_inputs(n, seed, r)
+    bits = np.zeros((n, 2), dtype=np.uint8)
+    chunk = 1000
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        p = torch.from_numpy(pos[2 * c0:2 * c1])
+        ei, _ = rg(p, torch.from_numpy(cells[c0:c1]), torch.from_numpy(batch[2 * c0:2 * c1] - c0))
+        ei = ei.numpy()
+        for i, j in ei.T:
+            bits[c0 + i // 2, i % 2] = 1
+    digest = hashlib.sha256(pos.tobytes() + cells.tobytes()).hexdigest()
+    np.savez_compressed(f'{OUT}/case_triclinic_fuzz.npz', n=n, seed=seed, cutoff=r, bits=np.packbits(bits.reshape(-1)),
+                        input_sha256=np.array(digest), kinds=np.bincount(kinds, minlength=3))
+    print('triclinic fuzz:', n, 'cells,', int(bits[:, 0].sum()), 'edges 0->1,', int(bits[:, 1].sum()), 'edges 1->0,',
+          int((bits[:, 0] != bits[:, 1]).sum()), 'asymmetric; kinds', np.bincount(kinds, minlength=3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'triclinic_fuzz':
+    main_triclinic_fuzz()

@@ -171,3 +171,30 @@ def test_bench_self_launch_command(monkeypatch):
     assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     assert not torch.cuda.is_initialized()
+
+
+def test_tooling_builds_are_marked_and_refused(tmp_path):
+    """A library compiled with any extra flag (the ablation switches of tools/ablate_*.sh produce WRONG results) carries
+    nnhip_build_flags() bit 0 and the package refuses to load it; the shipped library is unmarked; defining an ablation switch
+    without the marker does not compile at all."""
+    import subprocess
+    import sys
+    from newtonnet_amd import hip
+    assert hip.lib().nnhip_build_flags() == 0
+    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-std=c++17', '-fsyntax-only', '-DEDGE_ABL_TABLE',
+                        os.path.join(ROOT, 'newtonnet_amd', 'csrc', 'edge.hip')], capture_output=True, text=True)
+    assert r.returncode != 0 and 'ablation switches produce wrong results' in r.stderr
+    # a marked library: one small translation unit is enough to show the load-time refusal
+    src = tmp_path / 'marked.cpp'
+    src.write_text('extern "C" int nnhip_version(void) { return 101; }\nextern "C" int nnhip_build_flags(void) { return 1; }\n')
+    so = os.path.join(ROOT, 'newtonnet_amd', 'lib', 'libmarked_test.so')
+    try:
+        subprocess.run(['g++', '-shared', '-fPIC', str(src), '-o', so], check=True)
+        code = ("import os, sys; sys.path.insert(0, %r); os.environ['NNHIP_LIB_NAME'] = 'libmarked_test.so'\n"
+                "from newtonnet_amd import hip\n"
+                "try:\n    hip.lib()\nexcept hip.HipLibraryError as e:\n    print('REFUSED' if 'TOOLING build' in str(e) else e)\n" % ROOT)
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+        assert 'REFUSED' in out.stdout, out.stdout + out.stderr
+    finally:
+        if os.path.exists(so):
+            os.remove(so)

@@ -191,3 +191,26 @@ def test_oracle_training_gradients_pinned_to_reference():
         got = grads[name].numpy()
         assert abs(np.linalg.norm(got) - nrm) <= 1e-9 * max(nrm, 1e-30), name                      # the float64 norm
         assert np.abs(got - want).max() <= 2e-7 * max(np.abs(want).max(), 1e-30), name              # float32-stored entries
+
+
+def _fuzz_bits(edge_index, n):
+    bits = np.zeros((n, 2), dtype=np.uint8)
+    ei = edge_index.cpu().numpy()
+    bits[ei[0] // 2, ei[0] % 2] = 1
+    return bits
+
+
+def test_oracle_triclinic_fuzz_fp32():
+    """General triclinic cells at the decision boundaries (tests/util.py:triclinic_fuzz_inputs; expected bits from the
+    reference's own RadiusGraph, gen_golden.py triclinic_fuzz): the inputs regenerate bit for bit from the seed and the oracle's
+    radius graph -- the same torch CPU ops -- agrees with the reference on every one of the first 20 000 cells."""
+    import hashlib
+    c = util.load_npz('case_triclinic_fuzz.npz')
+    n = int(c['n'])
+    pos, cells, batch, kinds = util.triclinic_fuzz_inputs(n, int(c['seed']), float(c['cutoff']))
+    assert hashlib.sha256(pos.tobytes() + cells.tobytes()).hexdigest() == str(c['input_sha256'])
+    want = np.unpackbits(c['bits'])[:2 * n].reshape(n, 2)
+    m = 20000
+    ei, _ = ref.radius_graph(torch.from_numpy(pos[:2 * m]), torch.from_numpy(cells[:m]), torch.from_numpy(batch[:2 * m]),
+                             float(c['cutoff']))
+    assert np.array_equal(_fuzz_bits(ei, m), want[:m])
