@@ -158,6 +158,64 @@ def train_leg(device, dist, backend, world, rank, steps, warmup, molecules=32):
             'replicas_in_sync': in_sync, 'first_loss': round(loss0, 5), 'last_loss': round(float(loss), 5)}
 
 
+def train_roofline(device, conformers=1024, reps=5):
+    """Roofline of the dominant kernel of a LARGE-batch training step (the 32-molecule data-parallel leg is launch-latency bound:
+    no kernel of it is near any roofline).  One rank, no collective: value sweeps + MSE loss + tangent sweeps + weight gradients of
+    `conformers` aspirin conformers through the same C entry points the step uses (nnhip_train_values / nnhip_loss_grad /
+    nnhip_train_grads), timed with the library's HIP-event hook.  Dominant = wgrad_kernel, ALL weight gradients of the step in one
+    batched split-K launch on v_mfma_f32_32x32x2_f32: FLOPs and operand bytes from the problem table (TrainWorkspace.wgrad_cost)."""
+    from newtonnet_amd import hip, train_fused
+    from newtonnet_amd.models import NewtonNet
+    z, pos, cell, batch = synthetic_aspirin(conformers, seed=0, device=device)
+    g = torch.Generator().manual_seed(1)
+    e_lab, f_lab = torch.randn(conformers, generator=g).to(device), torch.randn(pos.shape[0], 3, generator=g).to(device)
+    torch.manual_seed(0)
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).to(device)
+    model.train()
+    emb = model.embedding_layers.edge_embedding
+    N, B = pos.shape[0], conformers
+    norm = torch.tensor([1.0 / B, 50.0 / (3 * N)], dtype=torch.float32, device=device)
+    loss, gE, gF = torch.zeros(1, device=device), torch.empty(B, device=device), torch.empty(N, 3, device=device)
+    with torch.no_grad():
+        gr = hip.build_graph(pos, cell, batch, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=z, envelope=emb.envelope_id)
+        ws = train_fused.acquire_workspace(model, gr, device, static=True)
+        runner = train_fused.Runner(model, z, pos, cell, batch, gr, ws)
+
+        def one():
+            runner.values()
+            hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab), 3 * N,
+                                                 hip._ptr(norm), 0, 0, 1.0, 1.0, hip._ptr(loss), hip._ptr(gE), hip._ptr(gF),
+                                                 hip._stream(device)), 'nnhip_loss_grad')
+            runner.grads(gE, gF)
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        torch.cuda.synchronize()
+        ms_step = 1e3 * (time.perf_counter() - t0) / reps
+        hip.timers_enable(True)
+        for _ in range(reps):
+            one()
+        torch.cuda.synchronize()
+        tm = hip.timers_read(reset=True)
+        hip.timers_enable(False)
+    wg_ms, wg_n = tm['wgrad'][0] / max(tm['wgrad'][1], 1), tm['wgrad'][1] / reps
+    flops, by = ws.wgrad_cost(gr.n_edges // 2)
+    tf = flops / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
+    model.__dict__.pop('_train_ws', None)
+    return {'bound': 'mfma', 'kernel': 'wgrad_kernel (all 24 weight-gradient problems of a step in one batched split-K launch, '
+                                       'fp32 MFMA; operands through LDS with their activation prologue)',
+            'workload': f'{conformers} aspirin conformers (N = {N}, pairs = {gr.n_edges // 2}), value + tangent sweeps + weight '
+                        'gradients, fp32, one rank, no collective',
+            'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            'flops_per_launch': flops, 'operand_bytes_per_launch': by, 'avg_launch_us': round(1e3 * wg_ms, 1),
+            'launches_per_step': wg_n, 'operand_gbs': round(by / (wg_ms * 1e-3) / 1e9, 1) if wg_ms > 0 else None,
+            'traffic': None, 'traffic_note': 'PMC passes: profiles/r03_train_aspirin1024_pmc_{fetch,write}_size.txt',
+            'step_ms_without_optimizer': round(ms_step, 3),
+            'share_of_step': round(wg_ms * wg_n / ms_step, 3) if ms_step > 0 else None}
+
+
 def algorithmic_counts(N, E, L=3, F=128):
     """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step.
     The edge MLPs are evaluated once per undirected pair (P = E/2 rows): the FLOP counts below are the FLOPs actually
@@ -337,6 +395,7 @@ def main():
                     help='inference (default): the headline metric, with the data-parallel train step reported beside it in '
                          '"train"; train: the train step (BASELINE configs[3]) is the reported value')
     ap.add_argument('--no-train-leg', action='store_true')
+    ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -566,6 +625,13 @@ def main():
                 raise
             train = {'error': f'{type(exc).__name__}: {exc}'[:400], 'allreduce_us': None}
             print(f'[bench rank {rank}] train leg failed: {train["error"]}', file=sys.stderr, flush=True)
+        if rank == 0 and train is not None and 'error' not in train and not args.no_train_roofline:
+            try:
+                train['roofline'] = train_roofline(device)
+            except Exception as exc:  # noqa: BLE001 -- reported, never fatal: a secondary measurement
+                train['roofline'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+        if dist is not None:
+            dist.barrier()
 
     if rank == 0 and args.mode == 'train':
         print(json.dumps({
@@ -575,7 +641,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': train['workload'], 'parallelism': f'dp{world}: replicas + one flat-gradient all-reduce per step'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
-            'allreduce_us': train['allreduce_us'], 'train': train}))
+            'allreduce_us': train['allreduce_us'], 'roofline': train.get('roofline'), 'train': train}))
     elif rank == 0:
         line = {
             'metric': 'atom-steps/sec (energy+force) on batched MD17 aspirin',

@@ -539,6 +539,24 @@ size_t nnhip_train_ws_bytes(void); /* sizeof(nnhip_train_ws) of this build (bind
 int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws* ws, void* stream);
 int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws* ws, const float* g_energy, const float* g_forces,
                       void* stream);
+/* The same with adjoint seeds at the final node states: seed_a [N][F] = dL/d atom_node, seed_f [N][3][F] = dL/d force_node of
+ * loss terms that read them directly (the direct_force head below; either may be NULL).  With g_forces = 0 and no seeds this is
+ * plain back-propagation of an energy-only loss (output_properties ['energy'], trainer.py:299-313). */
+int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_train_ws* ws, const float* g_energy, const float* g_forces,
+                             const float* seed_a, const float* seed_f, void* stream);
+/* First-order adjoint of the direct_force head (output.py:115-132, scalers.py:55-56; DirectForceLoss loss.py:41-47), given
+ * g_out [N][3] = dL/d direct_force.  keep: the scratch of the forward nnhip_direct_force call, left untouched by the caller
+ * ([3][N][F]: pre-activations of the first two linears, output of the third).  work
+ * (nnhip_direct_force_bwd_work_floats(N) floats) receives g_d3 | g_pre2 | t1 | g_pre1 ([N][F] each, in this order): the rows of
+ * the head's weight-gradient products  dW4 = g_d3^T act(pre2), dW2 = g_pre2^T act(pre1), dW0 = g_pre1^T atom_node  and of its
+ * bias column sums, which the caller's nnhip_wgrad_batch / nnhip_colsum_batch tables reference.  seed_a / seed_f: outputs for
+ * nnhip_train_grads_seeded.  g_scale [119] (NULL without a scale): gradient of scalers.k.scale.weight; sc4 [N][4] and
+ * sp_scratch (nnhip_species_scratch_bytes(4)): scratch. */
+size_t nnhip_direct_force_bwd_work_floats(int32_t n_atoms);
+int nnhip_direct_force_bwd(const float* g_out, const float* force_node, const int64_t* z, const float* w0, const float* w2,
+                           const float* w4, const float* scale, int32_t activation, int32_t n_atoms, const float* keep,
+                           float* work, float* seed_a, float* seed_f, float* sc4, float* sp_scratch, float* g_scale,
+                           void* stream);
 
 /* --------------------------------------------------------------------------
  * Product form of the dense kernels.  1 (default): the 128x128 linears of the hot path (edge MLPs, node MLPs, equiv_update
@@ -553,9 +571,10 @@ int nnhip_split_products(void);
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,
  *          3-6 = msg_fwd / force_fwd / force_bwd / msg_bwd, 7 = graph build, 8 = fused edge-MLP kernel (mlp128),
- *          9 = single linears (lin128).  Disabled (0) by default.
+ *          9 = single linears (lin128), 10 = the batched weight-gradient kernel of training (wgrad_kernel, without its
+ *          slab reduction).  Disabled (0) by default.
  * ------------------------------------------------------------------------ */
-#define NNHIP_N_TIMER_CLASSES 10
+#define NNHIP_N_TIMER_CLASSES 11
 int nnhip_timers_enable(int32_t on);
 int nnhip_timers_read(double* ms_per_class, int64_t* launches_per_class, int32_t reset);
 

@@ -1305,10 +1305,13 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
   static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(WbLds));
   HIP_TRY(attr_rc2);
-  if (bf16_operands)
-    wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs, pair_rows);
-  else
-    wgrad_kernel<<<dim3(chunks, n_problems), WG_THREADS, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
+  {
+    ScopedTimer t1(TC_WGRAD, s);
+    if (bf16_operands)
+      wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs, pair_rows);
+    else
+      wgrad_kernel<<<dim3(chunks, n_problems), WG_THREADS, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
+  }
   LAUNCH_CHECK();
   wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
   LAUNCH_CHECK();

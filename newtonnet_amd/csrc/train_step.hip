@@ -285,6 +285,15 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
 
 extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws* w, const float* g_energy,
                                  const float* g_forces, void* s) {
+  return nnhip_train_grads_seeded(model, w, g_energy, g_forces, nullptr, nullptr, s);
+}
+
+// seed_a [N][F] / seed_f [N][3][F] (either may be NULL): dL/d atom_node, dL/d force_node of loss terms that read the final node
+// states directly (the direct_force head, csrc/heads.hip).  They enter the epsilon-part of the reverse sweep at its top: that
+// sweep is the tangent of the value adjoint and is linear in its seeds, so every weight-gradient product below picks up the
+// plain back-propagation of these terms next to the tangent-over-reverse terms of the energy / gradient-force loss.
+extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_train_ws* w, const float* g_energy,
+                                        const float* g_forces, const float* seed_a, const float* seed_f, void* s) {
   TS_TRY(check(model, w, "nnhip_train_grads"));
   if (!g_energy || !g_forces) {
     nnhip_set_error("nnhip_train_grads: bad arguments");
@@ -384,16 +393,20 @@ extern "C" int nnhip_train_grads(const nnhip_model* model, const nnhip_train_ws*
     }
     return launch_node_tan_bwd_split(a, im, (hipStream_t)s);
   };
+  if (seed_a)
+    HIP_TRY(hipMemcpyAsync(w->dGA, seed_a, sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
   if (img_on) {
-    TS_TRY(tan_bwd_fused(w->dg_e2, w->e1, w->t_e1, w->de1, w->dg_e1, 0, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T], L - 1, nullptr));
+    TS_TRY(tan_bwd_fused(w->dg_e2, w->e1, w->t_e1, w->de1, w->dg_e1, seed_a ? 1 : 0, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T],
+                         L - 1, seed_f));
   } else {
     nnhip_mlp_desc d = mlp_desc(MODE_TAN2, w->dg_e2, NF, w->headT[1], w->headT[0], w->e1, w->dGA, N, act);
     d.T2 = w->t_e1;
     d.Hd = w->de1;
     d.G = w->dg_e1;
+    d.accumulate = seed_a ? 1 : 0;
     TS_TRY(run1(d, s));
   }
-  const float* dGf = nullptr;
+  const float* dGf = img_on ? nullptr : seed_f;
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const bool first = l == 0;

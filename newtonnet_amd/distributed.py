@@ -133,6 +133,18 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None) -> Opt
     return flat
 
 
+_UNSUPPORTED_FUSED = ("FusedClipAdam / the fused step serves output_properties within {'energy', 'gradient_force', 'direct_force'} "
+                      "(with 'energy') and layer_norm=False")
+
+
+def _force_key(model):
+    """The force the step's loss is on: 'gradient_force' when the model has that head, else 'direct_force', else None (an
+    energy-only model, loss.py:30-47).  (A model with BOTH force heads trains the gradient force here; any other combination of
+    terms goes through the model's train-mode forward and a torch loss -- the same kernels behind one autograd node.)"""
+    keys = list(getattr(model, 'output_properties', ('energy', 'gradient_force')))
+    return 'gradient_force' if 'gradient_force' in keys else ('direct_force' if 'direct_force' in keys else None)
+
+
 class TrainStep:
     """One optimisation step with the reference's loss (scripts/config.yml:45-51; trainer.py:301-313; loss.py:5-103):
     loss = w_E * l_E(E) + w_F * l_F(F) with l = MSE / MAE / Huber (mean reduction), clip_grad_norm_, optimizer.step --
@@ -157,18 +169,19 @@ class TrainStep:
         if not model.training:
             raise RuntimeError('TrainStep needs model.train()')
         if not train_fused.supported(model, list(model.output_properties)):
-            raise NotImplementedError("FusedClipAdam / the fused step needs output_properties ['energy', 'gradient_force'] and "
-                                      'layer_norm=False')
+            raise NotImplementedError(_UNSUPPORTED_FUSED)
         emb = model.embedding_layers.edge_embedding
+        force_key = _force_key(model)
         # the step's two collectives: the 2-scalar count all-reduce starts NOW and overlaps the value sweeps (joined before the
         # loss kernel, no host sync); the flat gradient all-reduce is the one on the critical path
-        self._counts.start(energy_label.numel(), force_label.numel(), dev)
+        self._counts.start(energy_label.numel(), force_label.numel() if force_key else 0, dev)
         zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
         bc = batch.contiguous() if batch.dtype == torch.int64 else batch.long().contiguous()
         pd, cd = hip._f32c(pos.detach(), 'pos'), hip._f32c(cell.detach(), 'cell')
-        e_lab, f_lab = hip._f32c(energy_label.detach(), 'energy_label'), hip._f32c(force_label.detach(), 'force_label')
         N, B = pd.shape[0], cd.shape[0]
-        if e_lab.numel() != B or f_lab.numel() != 3 * N:
+        e_lab = hip._f32c(energy_label.detach(), 'energy_label')
+        f_lab = hip._f32c(force_label.detach(), 'force_label') if force_key else None
+        if e_lab.numel() != B or (f_lab is not None and f_lab.numel() != 3 * N):
             raise ValueError(f'labels of shape {tuple(energy_label.shape)}, {tuple(force_label.shape)} for {B} molecules, {N} atoms')
         with torch.no_grad():
             g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
@@ -181,11 +194,14 @@ class TrainStep:
             runner = train_fused.Runner(model, zc, pd, cd, bc, g, ws)
             runner.values()
             norm = self._counts.norm()
-            hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab),
-                                                 3 * N, hip._ptr(norm), self._mode_ids[0], self._mode_ids[1],
+            pred_f = ws.df_out if force_key == 'direct_force' else ws.forces      # the force the loss is on (loss.py:36-47)
+            hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(pred_f),
+                                                 hip._ptr(f_lab if f_lab is not None else pred_f), 3 * N if force_key else 0,
+                                                 hip._ptr(norm), self._mode_ids[0], self._mode_ids[1],
                                                  self.huber_delta[0], self.huber_delta[1], hip._ptr(self._loss),
                                                  hip._ptr(self._gE), hip._ptr(self._gF), hip._stream(dev)), 'nnhip_loss_grad')
-            runner.grads(self._gE, self._gF)
+            runner.grads(self._gE, self._gF if force_key == 'gradient_force' else None,
+                         self._gF if force_key == 'direct_force' else None)
             if dist.is_available() and dist.is_initialized():
                 dist.all_reduce(ws.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             self.optimizer.step(ws.flat_grad)
@@ -198,9 +214,11 @@ class TrainStep:
         n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), pos.device, self.group)
         pos = pos.detach().clone().requires_grad_(True)
         out = self.model(z, pos, cell, batch)
-        sum_e = _torch_loss_sum(out.energy, energy_label, self.loss_modes[0], self.huber_delta[0])
-        sum_f = _torch_loss_sum(out.gradient_force, force_label, self.loss_modes[1], self.huber_delta[1])
-        loss = self.w_energy * sum_e / n_e + self.w_force * sum_f / n_f      # this rank's share of the global loss
+        force_key = _force_key(self.model)
+        loss = self.w_energy * _torch_loss_sum(out.energy, energy_label, self.loss_modes[0], self.huber_delta[0]) / n_e
+        if force_key:                                                        # this rank's share of the global loss
+            loss = loss + self.w_force * _torch_loss_sum(getattr(out, force_key), force_label, self.loss_modes[1],
+                                                         self.huber_delta[1]) / n_f
         loss.backward()
         allreduce_gradients(self.model.parameters(), self.group)
         if self.clip_grad:
@@ -358,8 +376,8 @@ class GraphedTrainStep:
         from newtonnet_amd import hip, train_fused
         model = self.model
         if not train_fused.supported(model, list(model.output_properties)):
-            raise NotImplementedError("FusedClipAdam / the fused step needs output_properties ['energy', 'gradient_force'] and "
-                                      'layer_norm=False')
+            raise NotImplementedError(_UNSUPPORTED_FUSED)
+        force_key = _force_key(model)
         dev = pos.device
         emb = model.embedding_layers.edge_embedding
         flatten_parameters(model)
@@ -380,11 +398,13 @@ class GraphedTrainStep:
         def body():
             hip.refresh_graph(g, st['pos'], st['cell'], st['batch'], emb.cutoff, emb.embedding.frequencies)
             runner.values()
-            hip._check(L_.nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(ws.forces), hip._ptr(st['f']),
-                                          3 * N, hip._ptr(st['norm']), self._mode_ids[0], self._mode_ids[1], self.huber_delta[0],
-                                          self.huber_delta[1], hip._ptr(st['loss']), hip._ptr(st['gE']), hip._ptr(st['gF']),
-                                          hip._stream(dev)), 'nnhip_loss_grad')
-            runner.grads(st['gE'], st['gF'])
+            pred_f = ws.df_out if force_key == 'direct_force' else ws.forces
+            hip._check(L_.nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(pred_f), hip._ptr(st['f']),
+                                          3 * N if force_key else 0, hip._ptr(st['norm']), self._mode_ids[0], self._mode_ids[1],
+                                          self.huber_delta[0], self.huber_delta[1], hip._ptr(st['loss']), hip._ptr(st['gE']),
+                                          hip._ptr(st['gF']), hip._stream(dev)), 'nnhip_loss_grad')
+            runner.grads(st['gE'], st['gF'] if force_key == 'gradient_force' else None,
+                         st['gF'] if force_key == 'direct_force' else None)
         self._st = st
         st['norm'].copy_(norm)
         cur = torch.cuda.current_stream(dev)
@@ -452,8 +472,10 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         out = self.model(st['z'], st['pos'], st['cell'], st['batch'])
         sse_e = _torch_loss_sum(out.energy, st['e'], self.loss_modes[0], self.huber_delta[0])
-        sse_f = _torch_loss_sum(out.gradient_force, st['f'], self.loss_modes[1], self.huber_delta[1])
-        loss = st['norm'][0] * sse_e + st['norm'][1] * sse_f      # (w_E / n_E, w_F / n_F): a DEVICE tensor, refreshed every step
+        force_key = _force_key(self.model)
+        loss = st['norm'][0] * sse_e                               # (w_E / n_E, w_F / n_F): a DEVICE tensor, refreshed every step
+        if force_key:
+            loss = loss + st['norm'][1] * _torch_loss_sum(getattr(out, force_key), st['f'], self.loss_modes[1], self.huber_delta[1])
         loss.backward()
         return loss.detach()
 

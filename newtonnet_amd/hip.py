@@ -24,9 +24,9 @@ NNHIP_MAX_NB = 32
 ACTIVATION_IDS = {'swish': 0, 'silu': 0, 'relu': 1, 'elu': 2, 'leaky_relu': 3, 'tanh': 4, 'sigmoid': 5, 'softplus': 6,
                   'gelu': 7, 'ssp': 8}
 NNHIP_MAX_LAYERS = 8
-N_TIMER_CLASSES = 10
+N_TIMER_CLASSES = 11
 TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',
-                 'edge_msg_bwd', 'graph', 'mlp128', 'lin128')
+                 'edge_msg_bwd', 'graph', 'mlp128', 'lin128', 'wgrad')
 
 _fp = C.POINTER(C.c_float)
 
@@ -201,6 +201,10 @@ def lib():
     L.nnhip_colsum_batch.argtypes = [vp, i32, vp, vp]
     L.nnhip_train_values.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp]
     L.nnhip_train_grads.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp, vp, vp]
+    L.nnhip_train_grads_seeded.argtypes = [C.POINTER(Model), C.POINTER(TrainWs), vp, vp, vp, vp, vp]
+    L.nnhip_direct_force_bwd_work_floats.argtypes = [i32]
+    L.nnhip_direct_force_bwd_work_floats.restype = sz
+    L.nnhip_direct_force_bwd.argtypes = [vp] * 7 + [i32, i32] + [vp] * 8
     L.nnhip_train_ws_bytes.restype = sz
     L.nnhip_weight_image_bytes.restype = sz
     L.nnhip_weight_images.argtypes = [vp, vp, i32, vp]
@@ -212,7 +216,7 @@ def lib():
     for fn in STAGE_SYMBOLS:
         if fn not in ('nnhip_filter_table_bytes', 'nnhip_wgrad_slab_bytes', 'nnhip_species_scratch_bytes',
                       'nnhip_colsum_scratch_bytes', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_ws_bytes',
-                      'nnhip_weight_image_bytes'):
+                      'nnhip_weight_image_bytes', 'nnhip_direct_force_bwd_work_floats'):
             getattr(L, fn).restype = C.c_int
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
@@ -231,7 +235,8 @@ STAGE_SYMBOLS = ('nnhip_embed', 'nnhip_filter_table_bytes', 'nnhip_filter_tables
                  'nnhip_pair_rbf', 'nnhip_species_sum', 'nnhip_species_scratch_bytes', 'nnhip_wgrad_slab_bytes',
                  'nnhip_wgrad_batch', 'nnhip_colsum_batch', 'nnhip_colsum_scratch_bytes', 'nnhip_mse_loss_grad', 'nnhip_loss_grad',
                  'nnhip_clip_adam', 'nnhip_clip_adam_dev', 'nnhip_clip_adam_scratch_bytes', 'nnhip_train_values', 'nnhip_train_grads',
-                 'nnhip_train_ws_bytes', 'nnhip_weight_image_bytes', 'nnhip_weight_images')
+                 'nnhip_train_ws_bytes', 'nnhip_weight_image_bytes', 'nnhip_weight_images', 'nnhip_train_grads_seeded',
+                 'nnhip_direct_force_bwd', 'nnhip_direct_force_bwd_work_floats')
 
 EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed',
                     'nnhip_workspace_bytes', 'nnhip_workspace_layout', 'nnhip_energy_forces', 'nnhip_timers_enable',

@@ -232,14 +232,18 @@ class NewtonNet(nn.Module):
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
         static = getattr(self, '_static_train_graph', None)
         if train_fused.supported(self, keys) and os.environ.get('NNHIP_TRAIN_PATH', 'fused') == 'fused':
-            # energy + gradient_force: ONE autograd node on the hand-written kernels (tangent-over-reverse, csrc/train.hip)
-            energy, forces, g, ws = train_fused.forward_train(self, z, pos, cell, batch, graph=static)
+            # every head set without LayerNorm: ONE autograd node on the hand-written kernels (tangent-over-reverse,
+            # csrc/train.hip; direct_force head csrc/heads.hip)
+            energy, forces, direct, g, ws = train_fused.forward_train(self, z, pos, cell, batch, graph=static)
             outputs = CustomOutputSet(z=z, pos=pos, edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
             outputs.lazy('atom_node', lambda: ws.a_out[-1].clone())
             outputs.lazy('force_node', lambda: ws.f_out[-1].clone())
             outputs.energy = energy
-            outputs.gradient_force = forces
-            outputs.lazy('pos_grad', lambda: -forces)
+            if 'gradient_force' in keys:
+                outputs.gradient_force = forces
+                outputs.lazy('pos_grad', lambda: -forces)
+            if 'direct_force' in keys:
+                outputs.direct_force = direct
             return outputs
         energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx, graph=static)
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=atom_node, force_node=force_node, edge_index=g.edge_index,

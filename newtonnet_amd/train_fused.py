@@ -9,9 +9,11 @@ the reverse sweep differentiated once more in forward mode along v = -d (csrc/tr
 split-K MFMA weight-gradient products.  Every kernel is an entry point of include/newtonnet_hip.h ("Per-stage entry points");
 this file only owns buffers and order.  tests/tangent_ref.py states the same four sweeps in fp64 torch.
 
-Supported: output_properties {'energy', 'gradient_force'}, layer_norm=False, every fused activation.  Other head sets
-(energy only, direct_force, layer_norm=True) keep the torch-graph path of train_ops.py.  dL/dpos is not produced (None): the
-reference would return it, no trainer uses it.
+Supported: every trainable head set of the reference -- ['energy'], ['energy', 'gradient_force'], ['energy', 'direct_force'],
+all three (trainer.py:299-313, loss.py:30-47) -- with layer_norm=False and every fused activation.  An energy-only loss is the
+d = 0 case of the formula above; the direct_force head is an ordinary function of the final node states and back-propagates
+once (csrc/heads.hip), its adjoint seeds entering the epsilon-part of the reverse sweep.  layer_norm=True keeps the torch-graph
+path of train_ops.py.  dL/dpos is not produced (None): the reference would return it, no trainer uses it.
 """
 from __future__ import annotations
 
@@ -42,8 +44,9 @@ def trainable_parameters(model) -> List[torch.nn.Parameter]:
 
 
 def supported(model, keys) -> bool:
-    return (sorted(keys) == ['energy', 'gradient_force'] and all(il.layer_norm is None for il in model.interaction_layers)
-            and model.embedding_layers.n_features == F)
+    keys = list(keys)
+    return ('energy' in keys and set(keys) <= {'energy', 'gradient_force', 'direct_force'} and len(set(keys)) == len(keys)
+            and all(il.layer_norm is None for il in model.interaction_layers) and model.embedding_layers.n_features == F)
 
 
 class TrainWorkspace:
@@ -125,6 +128,14 @@ class TrainWorkspace:
             self.grads.append(self.flat_grad[off:off + p.numel()].view(p.shape))
             off += p.numel()
         self.sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(F) // 4)
+        # ---- direct_force head (output.py:115-132), when the model has one: forward intermediates kept for its adjoint, the
+        # adjoint's rows (operands of three more weight-gradient problems / column sums) and the seeds it hands to sweep 4
+        self.df_idx = list(model.output_properties).index('direct_force') if 'direct_force' in model.output_properties else None
+        if self.df_idx is not None:
+            self.df_keep, self.df_out = buf(3, N, F), buf(N, 3)
+            self.df_work = torch.zeros(hip.lib().nnhip_direct_force_bwd_work_floats(N), dtype=torch.float32, device=device)
+            self.df_seed_a, self.df_seed_f, self.df_sc4 = buf(N, F), buf(N, 3, F), buf(N, 4)
+            self.df_sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(4) // 4)
         self._tables(model, device)
 
     # device-resident tables of the batched launches (pointer lists of the transposes / filter tables stay on the host)
@@ -134,6 +145,7 @@ class TrainWorkspace:
         gmap = {id(p): g for p, g in zip(self.params, self.grads)}
         G = lambda prm: gmap[id(prm)]  # noqa: E731
         probs, sums = [], []
+        self.wgrad_cost_rows = []
 
         def add(out, M, A1, B1=None, A2=None, B2=None, typ=hip.WG_PLAIN, hA=None, hB=None, dhB=None, lda1=0, lda2=0, ldb1=0,
                 ldb2=0, cols32=False, ldo=0, ncols=0, a1_off=0, a2_off=0, b2_off=0):
@@ -148,6 +160,15 @@ class TrainWorkspace:
             q.M, q.lda1, q.lda2, q.ldb1, q.ldb2, q.ldh = M, lda1, lda2, ldb1, ldb2, 0
             q.type, q.b_cols32, q.activation, q.ldo, q.ncols = typ, 1 if cols32 else 0, act, ldo, ncols
             probs.append(q)
+            # cost model of the batched launch (bench.py: roofline of wgrad_kernel): products of [M x 128]^T [M x bw], and the
+            # operand arrays (each read once per launch) in floats per row
+            bw = 32 if cols32 else F
+            n_prod = 1 + (A2 is not None)
+            b_arrays = (1 if (B1 is not None or hB is not None) else 0) + (1 if (B2 is not None or dhB is not None) else 0)
+            row_floats = F * n_prod + bw * b_arrays + F * ((hA is not None) + (hB is not None and B1 is not None))
+            if typ == hip.WG_ACT:
+                row_floats = F * n_prod + F * (1 + (dhB is not None))       # A1 (, A2), hB (, dhB)
+            self.wgrad_cost_rows.append((M, n_prod, bw, row_floats))
 
         def colsum(out, src, rows):
             c = hip.ColsumProblem()
@@ -184,6 +205,18 @@ class TrainWorkspace:
         colsum(G(head[0].bias), self.dg_e1, N)
         colsum(G(head[4].weight), self.w4row, N)
         self.g_head4_b = G(head[4].bias)
+        if self.df_idx is not None and N > 0:      # the direct_force head's own parameters (rows written by nnhip_direct_force_bwd)
+            dh = model.output_layers[self.df_idx].layers
+            nf = N * F
+            g_d3, g_pre2, g_pre1 = self.df_work[:nf], self.df_work[nf:2 * nf], self.df_work[3 * nf:4 * nf]
+            add(G(dh[4].weight), N, g_d3, typ=hip.WG_ACT, hB=self.df_keep[1])
+            add(G(dh[2].weight), N, g_pre2, typ=hip.WG_ACT, hB=self.df_keep[0])
+            add(G(dh[0].weight), N, g_pre1, B1=self.a_out[L - 1])
+            colsum(G(dh[4].bias), g_d3, N)
+            colsum(G(dh[2].bias), g_pre2, N)
+            colsum(G(dh[0].bias), g_pre1, N)
+            sc = model.scalers[self.df_idx]
+            self.df_g_scale = G(sc.scale.weight) if sc.scale is not None else None
         self.n_probs, self.n_sums = len(probs), len(sums)
         arr = (hip.WgradProblem * len(probs))(*probs)
         self.prob_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
@@ -199,6 +232,15 @@ class TrainWorkspace:
         self.slabs = torch.empty(hip.lib().nnhip_wgrad_slab_bytes(self.n_probs, self.chunks) // 4, dtype=torch.float32,
                                  device=device)
         self._c_view(model, G)
+
+    def wgrad_cost(self, n_pairs: int):
+        """(FLOPs, operand bytes) of one batched weight-gradient launch when the step has `n_pairs` pair rows."""
+        fl = by = 0
+        for M, n_prod, bw, row_floats in self.wgrad_cost_rows:
+            m = n_pairs if M < 0 else M
+            fl += 2 * m * F * bw * n_prod
+            by += 4 * m * row_floats
+        return fl, by
 
     def _c_view(self, model, G):
         """nnhip_train_ws (include/newtonnet_hip.h): every buffer above by device pointer; the batch/graph fields are set per
@@ -268,40 +310,76 @@ class Runner:
         return C.byref(ws.model_c), C.byref(c)
 
     # -- sweeps 1 and 2: values (csrc/train_step.hip strings the stages together) ------------------------------------------
+    def _df_head(self):
+        ws, model = self.ws, self.model
+        head = model.output_layers[ws.df_idx].layers
+        sc = model.scalers[ws.df_idx].scale
+        return head, (sc.weight if sc is not None else None)
+
     def values(self):
+        """energy [B], gradient force [N,3] (and ws.df_out [N,3] when the model has a direct_force head)"""
         m, c = self._bind()
+        ws = self.ws
         _chk(hip.lib().nnhip_train_values(m, c, self.st), 'nnhip_train_values')
-        return self.ws.energy, self.ws.forces
+        if ws.df_idx is not None and ws.N > 0:
+            head, scale = self._df_head()
+            _chk(hip.lib().nnhip_direct_force(_p(ws.a_out[-1]), _p(ws.f_out[-1]), _p(self.z), _p(head[0].weight), _p(head[0].bias),
+                                              _p(head[2].weight), _p(head[2].bias), _p(head[4].weight), _p(head[4].bias), _p(scale),
+                                              self.act, ws.N, _p(ws.df_keep), _p(ws.df_out), self.st), 'nnhip_direct_force')
+        return ws.energy, ws.forces
 
     # -- sweeps 3 and 4: tangents, then the weight gradients ---------------------------------------------------------------
-    def grads(self, g_energy: torch.Tensor, g_forces: torch.Tensor):
+    def grads(self, g_energy: torch.Tensor, g_forces: Optional[torch.Tensor], g_direct: Optional[torch.Tensor] = None):
+        """dL/dparameters into ws.flat_grad given dL/dE [B], dL/d gradient_force [N,3] (None = 0: the loss has no gradient-force
+        term) and, for models with a direct_force head, dL/d direct_force [N,3] (None = 0)."""
         ws = self.ws
+        if g_forces is None:
+            if getattr(ws, '_zero_gf', None) is None:
+                ws._zero_gf = torch.zeros(ws.N, 3, dtype=torch.float32, device=ws.energy.device)
+            g_forces = ws._zero_gf
         g_forces = g_forces.reshape(ws.N, 3).to(torch.float32).contiguous()
         g_energy = g_energy.to(torch.float32).contiguous()
         m, c = self._bind()
-        _chk(hip.lib().nnhip_train_grads(m, c, _p(g_energy), _p(g_forces), self.st), 'nnhip_train_grads')
+        seed_a = seed_f = None
+        if ws.df_idx is not None and ws.N > 0:
+            if g_direct is None:      # the head exists but is not in the loss: its rows of the gradient launch are zeros
+                ws.df_work[:4 * ws.N * F].zero_()
+                if ws.df_g_scale is not None:
+                    ws.df_g_scale.zero_()
+            else:
+                head, scale = self._df_head()
+                g_direct = g_direct.reshape(ws.N, 3).to(torch.float32).contiguous()
+                _chk(hip.lib().nnhip_direct_force_bwd(_p(g_direct), _p(ws.f_out[-1]), _p(self.z), _p(head[0].weight),
+                                                      _p(head[2].weight), _p(head[4].weight), _p(scale), self.act, ws.N,
+                                                      _p(ws.df_keep), _p(ws.df_work), _p(ws.df_seed_a), _p(ws.df_seed_f),
+                                                      _p(ws.df_sc4), _p(ws.df_sp_scratch), _p(ws.df_g_scale), self.st),
+                     'nnhip_direct_force_bwd')
+                seed_a, seed_f = ws.df_seed_a, ws.df_seed_f
+        _chk(hip.lib().nnhip_train_grads_seeded(m, c, _p(g_energy), _p(g_forces), _p(seed_a), _p(seed_f), self.st),
+             'nnhip_train_grads_seeded')
         return ws.grads
 
 
 class FusedEnergyForces(torch.autograd.Function):
-    """(pos, *parameters) -> (energy [B], forces [N,3]); backward returns dL/dparameters (dL/dpos is not produced)."""
+    """(pos, *parameters) -> (energy [B], gradient force [N,3], direct force [N,3] or an empty tensor); backward returns
+    dL/dparameters (dL/dpos is not produced)."""
 
     @staticmethod
     def forward(ctx, pos, runner, *params):
         energy, forces = runner.values()
         ctx.runner = runner
         ctx.n_params = len(params)
-        return energy.clone(), forces.clone()      # (fresh tensors: autograd attaches this node to what forward returns)
+        ws = runner.ws
+        direct = ws.df_out.clone() if ws.df_idx is not None else energy.new_zeros(0)
+        return energy.clone(), forces.clone(), direct      # (fresh tensors: autograd attaches this node to what forward returns)
 
     @staticmethod
-    def backward(ctx, g_energy, g_forces):
+    def backward(ctx, g_energy, g_forces, g_direct):
         r = ctx.runner
         ws = r.ws
         if g_energy is None:
             g_energy = torch.zeros(ws.B, dtype=torch.float32, device=ws.energy.device)
-        if g_forces is None:
-            g_forces = torch.zeros(ws.N, 3, dtype=torch.float32, device=ws.energy.device)
-        r.grads(g_energy, g_forces)
+        r.grads(g_energy, g_forces, g_direct if ws.df_idx is not None else None)
         ws.busy = False
         # one copy of the flat gradient; autograd receives views of it (AccumulateGrad keeps them as the .grad tensors), and
         # distributed.allreduce_gradients recognises the flat layout and reduces it in place
@@ -333,7 +411,7 @@ def acquire_workspace(model, g: hip.Graph, device, static: bool = False) -> Trai
 def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None):
     """Train-mode energy + gradient_force through the fused node.  `graph`: a static candidate list (GraphedTrainStep) whose
     geometry is refreshed at `pos`; otherwise the exact list is built (one host sync for the edge count).
-    Returns (energy, forces, graph, workspace).  The outputs live in the workspace: valid until the next forward that reuses it (a
+    Returns (energy, gradient force, direct force or None, graph, workspace).  The outputs live in the workspace: valid until the next forward that reuses it (a
     workspace is reused only after its backward ran)."""
     emb = model.embedding_layers.edge_embedding
     zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
@@ -347,5 +425,5 @@ def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None)
     ws = acquire_workspace(model, g, pos.device, static=graph is not None)
     ws.busy = torch.is_grad_enabled()
     runner = Runner(model, zc, pd, cd, bc, g, ws)
-    energy, forces = FusedEnergyForces.apply(pos, runner, *ws.params)
-    return energy, forces, g, ws
+    energy, forces, direct = FusedEnergyForces.apply(pos, runner, *ws.params)
+    return energy, forces, (direct if ws.df_idx is not None else None), g, ws

@@ -668,3 +668,54 @@ def main_triclinic_fuzz(n=100000, seed=2024):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'triclinic_fuzz':
     main_triclinic_fuzz()
+
+
+def main_train_direct():
+    """The reference's training objective for a model WITHOUT a derivative head (trainer.py:299-313, loss.py:30-47): output
+    properties ['energy', 'direct_force'], its own loss factory {'energy': mse x 1, 'direct_force': mse x 20}, loss.backward().
+    Shared parameters = rand_state_seed0.npz; the direct_force head and its scaler are drawn by the reference's own constructor
+    under torch.manual_seed(5) and stored (float32) next to the loss and every parameter gradient -> case_train_direct.npz."""
+    import types as _types
+    NewtonNet = import_reference()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_ref_loss', f'{REF}/newtonnet/train/loss.py')
+    _ref_loss = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(_ref_loss)
+    rnd = {k: torch.from_numpy(v).double() for k, v in np.load(f'{OUT}/rand_state_seed0.npz').items()}
+    c = np.load(f'{OUT}/case_mixed_rand.npz')
+    z, pos = torch.from_numpy(c['z']).long(), torch.from_numpy(c['pos']).double()
+    cell, batch = torch.from_numpy(c['cell']).double(), torch.from_numpy(c['batch']).long()
+    g = torch.Generator().manual_seed(3)
+    e_lab = torch.randn(cell.shape[0], generator=g)
+    f_lab = torch.randn(pos.shape[0], 3, generator=g)
+    torch.manual_seed(5)
+    model = NewtonNet(output_properties=['energy', 'direct_force'])
+    with torch.no_grad():      # a non-trivial per-element scale (the constructor's is all ones)
+        model.scalers[1].scale.weight.copy_(1.0 + 0.25 * torch.randn(model.scalers[1].scale.weight.shape))
+    head_sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()
+               if k.startswith('output_layers.1.') or k.startswith('scalers.1.')}
+    sd = {k: (rnd[k] if k in rnd else head_sd[k].double()) for k in model.state_dict().keys()}
+    model.to(torch.float64)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    main_loss, _ = _ref_loss.get_loss_by_string({'energy': {'weight': 1.0, 'mode': 'mse'},
+                                                 'direct_force': {'weight': 20.0, 'mode': 'mse'}})
+    data = _types.SimpleNamespace(z=z, batch=batch, energy=e_lab.double(), force=f_lab.double())
+    pred = model(z, pos.clone(), cell, batch)
+    loss = main_loss(pred, data)
+    loss.backward()
+    rec = dict(loss=np.float64(loss.item()), energy_label=e_lab.numpy(), force_label=f_lab.numpy(),
+               energy=pred.energy.detach().numpy(), direct_force=pred.direct_force.detach().numpy())
+    for k, v in head_sd.items():
+        rec['state.' + k] = v.numpy()
+    n = 0
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            rec['grad.' + name] = p.grad.detach().numpy().astype(np.float32)
+            n += 1
+    print('train-direct fixture: loss', loss.item(), n, 'parameter gradients')
+    np.savez_compressed(f'{OUT}/case_train_direct.npz', **rec)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'train_direct':
+    main_train_direct()

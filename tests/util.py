@@ -90,3 +90,14 @@ def triclinic_fuzz_inputs(n, seed=2024, cutoff=5.0):
         kinds[b] = kind
     batch = np.repeat(np.arange(n, dtype=np.int64), 2)
     return pos, cells, batch, kinds
+
+
+def direct_train_state(dtype=torch.float64):
+    """state_dict of the ['energy', 'direct_force'] model behind tests/golden/case_train_direct.npz: the seeded shared parameters
+    + the direct_force head / scaler the reference's constructor drew (stored in the fixture)."""
+    c = load_npz('case_train_direct.npz')
+    sd = load_state('rand', dtype)
+    for k, v in c.items():
+        if k.startswith('state.'):
+            sd[k[6:]] = torch.from_numpy(v).to(dtype)
+    return sd, c
