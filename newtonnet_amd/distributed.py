@@ -194,7 +194,7 @@ class TrainStep:
             runner = train_fused.Runner(model, zc, pd, cd, bc, g, ws)
             runner.values()
             norm = self._counts.norm()
-            pred_f = ws.df_out if force_key == 'direct_force' else ws.forces      # the force the loss is on (loss.py:36-47)
+            pred_f = ws.dfh_out if force_key == 'direct_force' else ws.forces      # the force the loss is on (loss.py:36-47)
             hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(pred_f),
                                                  hip._ptr(f_lab if f_lab is not None else pred_f), 3 * N if force_key else 0,
                                                  hip._ptr(norm), self._mode_ids[0], self._mode_ids[1],
@@ -398,7 +398,7 @@ class GraphedTrainStep:
         def body():
             hip.refresh_graph(g, st['pos'], st['cell'], st['batch'], emb.cutoff, emb.embedding.frequencies)
             runner.values()
-            pred_f = ws.df_out if force_key == 'direct_force' else ws.forces
+            pred_f = ws.dfh_out if force_key == 'direct_force' else ws.forces
             hip._check(L_.nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(st['e']), B, hip._ptr(pred_f), hip._ptr(st['f']),
                                           3 * N if force_key else 0, hip._ptr(st['norm']), self._mode_ids[0], self._mode_ids[1],
                                           self.huber_delta[0], self.huber_delta[1], hip._ptr(st['loss']), hip._ptr(st['gE']),

@@ -130,12 +130,12 @@ class TrainWorkspace:
         self.sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(F) // 4)
         # ---- direct_force head (output.py:115-132), when the model has one: forward intermediates kept for its adjoint, the
         # adjoint's rows (operands of three more weight-gradient problems / column sums) and the seeds it hands to sweep 4
-        self.df_idx = list(model.output_properties).index('direct_force') if 'direct_force' in model.output_properties else None
-        if self.df_idx is not None:
-            self.df_keep, self.df_out = buf(3, N, F), buf(N, 3)
-            self.df_work = torch.zeros(hip.lib().nnhip_direct_force_bwd_work_floats(N), dtype=torch.float32, device=device)
-            self.df_seed_a, self.df_seed_f, self.df_sc4 = buf(N, F), buf(N, 3, F), buf(N, 4)
-            self.df_sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(4) // 4)
+        self.dfh_idx = list(model.output_properties).index('direct_force') if 'direct_force' in model.output_properties else None
+        if self.dfh_idx is not None:
+            self.dfh_keep, self.dfh_out = buf(3, N, F), buf(N, 3)
+            self.dfh_work = torch.zeros(hip.lib().nnhip_direct_force_bwd_work_floats(N), dtype=torch.float32, device=device)
+            self.dfh_seed_a, self.dfh_seed_f, self.dfh_sc4 = buf(N, F), buf(N, 3, F), buf(N, 4)
+            self.dfh_sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(4) // 4)
         self._tables(model, device)
 
     # device-resident tables of the batched launches (pointer lists of the transposes / filter tables stay on the host)
@@ -205,18 +205,18 @@ class TrainWorkspace:
         colsum(G(head[0].bias), self.dg_e1, N)
         colsum(G(head[4].weight), self.w4row, N)
         self.g_head4_b = G(head[4].bias)
-        if self.df_idx is not None and N > 0:      # the direct_force head's own parameters (rows written by nnhip_direct_force_bwd)
-            dh = model.output_layers[self.df_idx].layers
+        if self.dfh_idx is not None and N > 0:      # the direct_force head's own parameters (rows written by nnhip_direct_force_bwd)
+            dh = model.output_layers[self.dfh_idx].layers
             nf = N * F
-            g_d3, g_pre2, g_pre1 = self.df_work[:nf], self.df_work[nf:2 * nf], self.df_work[3 * nf:4 * nf]
-            add(G(dh[4].weight), N, g_d3, typ=hip.WG_ACT, hB=self.df_keep[1])
-            add(G(dh[2].weight), N, g_pre2, typ=hip.WG_ACT, hB=self.df_keep[0])
+            g_d3, g_pre2, g_pre1 = self.dfh_work[:nf], self.dfh_work[nf:2 * nf], self.dfh_work[3 * nf:4 * nf]
+            add(G(dh[4].weight), N, g_d3, typ=hip.WG_ACT, hB=self.dfh_keep[1])
+            add(G(dh[2].weight), N, g_pre2, typ=hip.WG_ACT, hB=self.dfh_keep[0])
             add(G(dh[0].weight), N, g_pre1, B1=self.a_out[L - 1])
             colsum(G(dh[4].bias), g_d3, N)
             colsum(G(dh[2].bias), g_pre2, N)
             colsum(G(dh[0].bias), g_pre1, N)
-            sc = model.scalers[self.df_idx]
-            self.df_g_scale = G(sc.scale.weight) if sc.scale is not None else None
+            sc = model.scalers[self.dfh_idx]
+            self.dfh_g_scale = G(sc.scale.weight) if sc.scale is not None else None
         self.n_probs, self.n_sums = len(probs), len(sums)
         arr = (hip.WgradProblem * len(probs))(*probs)
         self.prob_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
@@ -312,20 +312,20 @@ class Runner:
     # -- sweeps 1 and 2: values (csrc/train_step.hip strings the stages together) ------------------------------------------
     def _df_head(self):
         ws, model = self.ws, self.model
-        head = model.output_layers[ws.df_idx].layers
-        sc = model.scalers[ws.df_idx].scale
+        head = model.output_layers[ws.dfh_idx].layers
+        sc = model.scalers[ws.dfh_idx].scale
         return head, (sc.weight if sc is not None else None)
 
     def values(self):
-        """energy [B], gradient force [N,3] (and ws.df_out [N,3] when the model has a direct_force head)"""
+        """energy [B], gradient force [N,3] (and ws.dfh_out [N,3] when the model has a direct_force head)"""
         m, c = self._bind()
         ws = self.ws
         _chk(hip.lib().nnhip_train_values(m, c, self.st), 'nnhip_train_values')
-        if ws.df_idx is not None and ws.N > 0:
+        if ws.dfh_idx is not None and ws.N > 0:
             head, scale = self._df_head()
             _chk(hip.lib().nnhip_direct_force(_p(ws.a_out[-1]), _p(ws.f_out[-1]), _p(self.z), _p(head[0].weight), _p(head[0].bias),
                                               _p(head[2].weight), _p(head[2].bias), _p(head[4].weight), _p(head[4].bias), _p(scale),
-                                              self.act, ws.N, _p(ws.df_keep), _p(ws.df_out), self.st), 'nnhip_direct_force')
+                                              self.act, ws.N, _p(ws.dfh_keep), _p(ws.dfh_out), self.st), 'nnhip_direct_force')
         return ws.energy, ws.forces
 
     # -- sweeps 3 and 4: tangents, then the weight gradients ---------------------------------------------------------------
@@ -341,20 +341,20 @@ class Runner:
         g_energy = g_energy.to(torch.float32).contiguous()
         m, c = self._bind()
         seed_a = seed_f = None
-        if ws.df_idx is not None and ws.N > 0:
+        if ws.dfh_idx is not None and ws.N > 0:
             if g_direct is None:      # the head exists but is not in the loss: its rows of the gradient launch are zeros
-                ws.df_work[:4 * ws.N * F].zero_()
-                if ws.df_g_scale is not None:
-                    ws.df_g_scale.zero_()
+                ws.dfh_work[:4 * ws.N * F].zero_()
+                if ws.dfh_g_scale is not None:
+                    ws.dfh_g_scale.zero_()
             else:
                 head, scale = self._df_head()
                 g_direct = g_direct.reshape(ws.N, 3).to(torch.float32).contiguous()
                 _chk(hip.lib().nnhip_direct_force_bwd(_p(g_direct), _p(ws.f_out[-1]), _p(self.z), _p(head[0].weight),
                                                       _p(head[2].weight), _p(head[4].weight), _p(scale), self.act, ws.N,
-                                                      _p(ws.df_keep), _p(ws.df_work), _p(ws.df_seed_a), _p(ws.df_seed_f),
-                                                      _p(ws.df_sc4), _p(ws.df_sp_scratch), _p(ws.df_g_scale), self.st),
+                                                      _p(ws.dfh_keep), _p(ws.dfh_work), _p(ws.dfh_seed_a), _p(ws.dfh_seed_f),
+                                                      _p(ws.dfh_sc4), _p(ws.dfh_sp_scratch), _p(ws.dfh_g_scale), self.st),
                      'nnhip_direct_force_bwd')
-                seed_a, seed_f = ws.df_seed_a, ws.df_seed_f
+                seed_a, seed_f = ws.dfh_seed_a, ws.dfh_seed_f
         _chk(hip.lib().nnhip_train_grads_seeded(m, c, _p(g_energy), _p(g_forces), _p(seed_a), _p(seed_f), self.st),
              'nnhip_train_grads_seeded')
         return ws.grads
@@ -370,7 +370,7 @@ class FusedEnergyForces(torch.autograd.Function):
         ctx.runner = runner
         ctx.n_params = len(params)
         ws = runner.ws
-        direct = ws.df_out.clone() if ws.df_idx is not None else energy.new_zeros(0)
+        direct = ws.dfh_out.clone() if ws.dfh_idx is not None else energy.new_zeros(0)
         return energy.clone(), forces.clone(), direct      # (fresh tensors: autograd attaches this node to what forward returns)
 
     @staticmethod
@@ -379,7 +379,7 @@ class FusedEnergyForces(torch.autograd.Function):
         ws = r.ws
         if g_energy is None:
             g_energy = torch.zeros(ws.B, dtype=torch.float32, device=ws.energy.device)
-        r.grads(g_energy, g_forces, g_direct if ws.df_idx is not None else None)
+        r.grads(g_energy, g_forces, g_direct if ws.dfh_idx is not None else None)
         ws.busy = False
         # one copy of the flat gradient; autograd receives views of it (AccumulateGrad keeps them as the .grad tensors), and
         # distributed.allreduce_gradients recognises the flat layout and reduces it in place
@@ -426,4 +426,4 @@ def forward_train(model, z, pos, cell, batch, graph: Optional[hip.Graph] = None)
     ws.busy = torch.is_grad_enabled()
     runner = Runner(model, zc, pd, cd, bc, g, ws)
     energy, forces, direct = FusedEnergyForces.apply(pos, runner, *ws.params)
-    return energy, forces, (direct if ws.df_idx is not None else None), g, ws
+    return energy, forces, (direct if ws.dfh_idx is not None else None), g, ws
