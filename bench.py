@@ -288,8 +288,8 @@ def pmc_traffic(kernels):
     the stored measurement, named in the returned source.  Rows are keyed on kernel name AND grid: only the largest grid of a
     kernel (the config-2 batch) counts.  Returns ({kernel row name: (launches, bytes per launch)}, source) or (None, None)."""
     import glob
-    fetch = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')))
-    write = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')))
+    fetch = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')) if 'train' not in os.path.basename(f))
+    write = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')) if 'train' not in os.path.basename(f))
     if not fetch or not write:
         return None, None
     (tf, notes), (tw, _) = _profile_table(fetch[-1]), _profile_table(write[-1])

@@ -316,9 +316,10 @@ int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_out, int32_t
 int nnhip_embed(const int64_t* z, const float* table, int32_t n_atoms, float* out, void* stream);
 
 /* Radial-filter tables of `n_layers` layers (message_edgepart applied to the Bessel basis, newtonnet.py:186,210): for each
- * layer FT_ROWS nodes x_g = g / FT_G (FT_G = 3072 intervals of x = r/cutoff), each node three rows of F floats -- value,
- * secant slope to the next node (differenced in fp64), d/dx; tables[l] needs nnhip_filter_table_bytes() bytes.  The message
- * kernels evaluate the cubic Hermite interpolant (value and derivative from four rows) instead of contracting rbf per edge. */
+ * layer three planes of FT_ROWS rows of F floats over the nodes x_g = g / FT_G (FT_G = 3072 intervals of x = r/cutoff; row =
+ * g + 1) -- value, secant slope to the next node (differenced in fp64), d/dx; tables[l] needs nnhip_filter_table_bytes() bytes.
+ * The message kernels interpolate (value: 4-point Lagrange on the value plane; value and derivative: cubic Hermite from four
+ * rows) instead of contracting rbf per edge. */
 size_t nnhip_filter_table_bytes(void);
 int nnhip_filter_tables(const float* const* edge_w_host_array, float* const* tables_host_array, int32_t n_layers,
                         const float* frequencies, int32_t n_basis, int32_t envelope, void* stream);

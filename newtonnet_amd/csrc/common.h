@@ -22,12 +22,12 @@
 #ifndef FT_G
 #define FT_G 3072            // radial-filter table: intervals on x = r/cutoff in [0, 1)
 #endif
-// Table nodes x_g = g / FT_G, g = 0 .. FT_G, each node = three rows [T | S | D] of F floats (edge_common.h); behind them
-// all-zero nodes: the stencil (nodes g, g + 1) of a candidate edge at or beyond the cutoff (Verlet-skin lists,
-// nnhip_edge_disp) points at FT_ZERO_ROW
-#define FT_ROWS (FT_G + 4)
-#define FT_ZERO_ROW (FT_G + 1)
-#define FT_PITCH (3 * NNHIP_F)
+// Three planes T | S | D of FT_ROWS rows each; row = node + 1, nodes x_g = g / FT_G for g = -1 .. FT_G + 6 (zero beyond the
+// cutoff).  A candidate edge at or beyond the cutoff (Verlet-skin lists, nnhip_edge_disp) carries the node index FT_ZERO_ROW:
+// every row either stencil touches from there is all-zero (edge_common.h)
+#define FT_ROWS (FT_G + 8)
+#define FT_ZERO_ROW (FT_G + 3)
+#define FT_PLANE ((size_t)FT_ROWS * NNHIP_F)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

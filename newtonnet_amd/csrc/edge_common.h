@@ -74,21 +74,32 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
 // (edge, feature) on the VALU was the bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the
 // tables turn it into coalesced row reads from L2 and a handful of FMAs.
 //
-// Node g holds three rows: T[g] = eps(x_g), S[g] = (eps(x_g+1) - eps(x_g)) FT_G (the secant slope, formed in fp64 BEFORE the
-// one rounding -- differencing the fp32 values would amplify their rounding by FT_G) and D[g] = eps'(x_g).  On the interval
-// [x_g, x_g+1], u in [0, 1), h = 1 / FT_G, the cubic Hermite interpolant through (T, D) at both ends is
-//   eps(u)  = T_g + h ( u^2 (3 - 2u) S_g + u (1 - u)^2 D_g + u^2 (u - 1) D_g+1 )
-//   eps'(u) = 6 u (1 - u) S_g + (1 - u)(1 - 3u) D_g + u (3u - 2) D_g+1
-// FOUR row reads (T_g, S_g, D_g: 1.5 KiB contiguous; D_g+1) give the value AND the derivative; the 4-point Lagrange form of
-// rounds 1-2 read 4 + 4 rows of two planes, and the message adjoint was bound by those L2 requests (24 of ~36 per edge).
-// Against fp64 evaluation: value 3e-8 of the maximum (fp32 rounding of T), derivative 8e-8 at FT_G = 3072 (truncation
-// 0.008 h^3 |d4 eps/dx4| = 4e-8 + rounding; 1.6e-7 at 2048, 6e-8 at 4096): the force tolerances are unchanged.
+// Three planes over the nodes x_g = g / FT_G (row = g + 1): T[g] = eps(x_g), S[g] = (eps(x_g+1) - eps(x_g)) FT_G (the secant
+// slope, formed in fp64 BEFORE the one rounding -- differencing the fp32 values would amplify their rounding by FT_G) and
+// D[g] = eps'(x_g).  On the interval [x_g, x_g+1], u in [0, 1), h = 1 / FT_G:
+//   * value only (message forward; the adjoint's pairs owned by the other endpoint): 4-point cubic Lagrange on the T plane
+//     alone, rows g-1 .. g+2 -- 2 KiB contiguous, and the kernels that need no derivative touch a 1.5 MB plane that stays
+//     resident in the 4 MB L2 of an XCD (interleaving the planes made msg_fwd fetch 3.7x more from the fabric);
+//   * value AND derivative (the adjoint's own pairs, the tangent kernels of training): cubic Hermite through (T, D) at both ends
+//       eps(u)  = T_g + h ( u^2 (3 - 2u) S_g + u (1 - u)^2 D_g + u^2 (u - 1) D_g+1 )
+//       eps'(u) = 6 u (1 - u) S_g + (1 - u)(1 - 3u) D_g + u (3u - 2) D_g+1
+//     from FOUR rows (T_g, S_g, D_g, D_g+1); the Lagrange form of rounds 1-2 read 4 + 4 rows (T and D planes), and the message
+//     adjoint was bound by those L2 requests (24 of ~36 per edge).
+// Against fp64 evaluation (tests/test_hip_parity.py::test_radial_filter_tables_against_float64): value 3-4e-8 of the maximum
+// with either form (the fp32 rounding of T), Hermite derivative 8e-8 at FT_G = 3072 (truncation 0.008 h^3 |d4 eps/dx4| = 4e-8 +
+// rounding; 1.6e-7 at 2048, 6e-8 at 4096).
 struct FilterW {
-  float a, b, c;      // value:      T_g + a S_g + b D_g + c D_g+1
-  float da, db, dc;   // derivative:       da S_g + db D_g + dc D_g+1
+  float w[4];         // Lagrange value weights at nodes g-1, g, g+1, g+2
+  float a, b, c;      // Hermite value:      T_g + a S_g + b D_g + c D_g+1
+  float da, db, dc;   // Hermite derivative:       da S_g + db D_g + dc D_g+1
 };
 __device__ __forceinline__ FilterW filter_weights(float u) {
   FilterW f;
+  const float um1 = u - 1.f, um2 = u - 2.f, up1 = u + 1.f;
+  f.w[0] = -u * um1 * um2 * (1.f / 6.f);
+  f.w[1] = up1 * um1 * um2 * 0.5f;
+  f.w[2] = -up1 * u * um2 * 0.5f;
+  f.w[3] = up1 * u * um1 * (1.f / 6.f);
   const float h = 1.0f / (float)FT_G, v = 1.f - u, uu = u * u;
   f.a = h * uu * (3.f - 2.f * u);
   f.b = h * u * v * v;
@@ -98,16 +109,21 @@ __device__ __forceinline__ FilterW filter_weights(float u) {
   f.dc = u * (3.f * u - 2.f);
   return f;
 }
+// value only: the T plane (rows g0 .. g0 + 3 = nodes g0 - 1 .. g0 + 2)
 __device__ __forceinline__ float4 filter_value(const float* __restrict__ table, int g0, int c4, const FilterW& fw) {
-  const float* __restrict__ node = table + (size_t)g0 * FT_PITCH + c4;
-  const float4 t0 = ld4(node), s0 = ld4(node + NF), d0 = ld4(node + 2 * NF), d1 = ld4(node + FT_PITCH + 2 * NF);
-  return fma4(d1, fw.c, fma4(d0, fw.b, fma4(s0, fw.a, t0)));
+  float4 t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = ld4(table + (size_t)(g0 + k) * NF + c4);
+  float4 eps = mul4(t[0], fw.w[0]);
+#pragma unroll
+  for (int k = 1; k < 4; ++k) eps = fma4(t[k], fw.w[k], eps);
+  return eps;
 }
-// value and derivative from the same four rows
+// value and derivative from four rows of the three planes
 __device__ __forceinline__ void filter_value_deriv(const float* __restrict__ table, int g0, int c4, const FilterW& fw,
                                                    float4& eps, float4& deps) {
-  const float* __restrict__ node = table + (size_t)g0 * FT_PITCH + c4;
-  const float4 t0 = ld4(node), s0 = ld4(node + NF), d0 = ld4(node + 2 * NF), d1 = ld4(node + FT_PITCH + 2 * NF);
+  const float* __restrict__ node = table + (size_t)(g0 + 1) * NF + c4;
+  const float4 t0 = ld4(node), s0 = ld4(node + FT_PLANE), d0 = ld4(node + 2 * FT_PLANE), d1 = ld4(node + 2 * FT_PLANE + NF);
   eps = fma4(d1, fw.c, fma4(d0, fw.b, fma4(s0, fw.a, t0)));
   deps = fma4(d1, fw.dc, fma4(d0, fw.db, mul4(s0, fw.da)));
 }

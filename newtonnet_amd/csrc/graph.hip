@@ -405,12 +405,11 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
   return NNHIP_OK;
 }
 
-// Radial-filter tables of one layer, nodes x_g = g / FT_G, g = 0 .. FT_G (fp64 evaluation, one rounding per entry):
-//   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)                         (values)
+// Radial-filter tables of one layer, nodes x_g = g / FT_G (row = g + 1; fp64 evaluation, one rounding per entry):
+//   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)                         (values; node -1 = the analytic continuation to x < 0)
 //   S[g][f] = (eps_f(x_g+1) - eps_f(x_g)) FT_G                   (secant slopes, differenced in fp64)
 //   D[g][f] = sum_n W_e[f][n] d rbf_n/dx (x_g)                   (derivatives)
-// stored node-major, table[g][T | S | D][F]: the four rows of one cubic Hermite evaluation (edge_common.h) are 1.5 KiB
-// contiguous + the D row of the next node; every row read is one coalesced 16-byte-per-lane instruction.
+// three planes of FT_ROWS rows (edge_common.h says who reads what); every row read is one coalesced 16-byte-per-lane instruction.
 struct FilterTableArgs {
   const float* edge_w[NNHIP_MAX_LAYERS];
   float* table[NNHIP_MAX_LAYERS];
@@ -441,10 +440,10 @@ __device__ __forceinline__ void radial_basis_f64(double x, double w, int env_id,
 __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
   __shared__ double rb[NNHIP_MAX_NB], drb[NNHIP_MAX_NB], rb1[NNHIP_MAX_NB];
   const int nb = a.nb;
-  const int g = blockIdx.x, l = blockIdx.y;
-  float* __restrict__ node = a.table[l] + (size_t)g * FT_PITCH + threadIdx.x;
-  if (g > FT_G) {   // the all-zero nodes behind the table proper
-    node[0] = node[NF] = node[2 * NF] = 0.f;
+  const int row = blockIdx.x, l = blockIdx.y, g = row - 1;
+  float* __restrict__ out = a.table[l] + (size_t)row * NF + threadIdx.x;
+  if (g > FT_G) {   // beyond the cutoff: all-zero rows
+    out[0] = out[FT_PLANE] = out[2 * FT_PLANE] = 0.f;
     return;
   }
   if (threadIdx.x < nb) {
@@ -462,9 +461,9 @@ __global__ void __launch_bounds__(NF) filter_table_kernel(FilterTableArgs a) {
     dacc += wn * drb[n];
     sacc += wn * (rb1[n] - rb[n]);
   }
-  node[0] = (float)acc;
-  node[NF] = (float)(sacc * (double)FT_G);
-  node[2 * NF] = (float)dacc;
+  out[0] = (float)acc;
+  out[FT_PLANE] = (float)(sacc * (double)FT_G);
+  out[2 * FT_PLANE] = (float)dacc;
 }
 
 int launch_filter_tables(const float* const* edge_w, float* const* tables, int n_layers, const float* freq, int nb,

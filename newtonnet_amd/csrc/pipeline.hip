@@ -147,7 +147,7 @@ struct PrepLayout {
   size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
   size_t headT[2];                 // head0^T, head2^T
   size_t hn_tab, m_tab;            // [128][F] message_nodepart of layer 0 evaluated on the embedding rows (per element)
-  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: [FT_ROWS][T | S | D][F] (graph.hip:filter_table_kernel)
+  size_t ftab[NNHIP_MAX_LAYERS];   // radial-filter tables of each layer: planes T | S | D of [FT_ROWS][F] (graph.hip:filter_table_kernel)
   // split-f16 images (node128s.hip) of every [128][128] weight and its transpose (IMG_* of common.h), and of the head's
   size_t img[NNHIP_MAX_LAYERS][IMG_PER_LAYER];
   size_t img_head[IMG_HEAD_COUNT];
@@ -169,7 +169,7 @@ static void make_prep_layout(int L, PrepLayout& q) {
   size_t off = 0;
   for (int l = 0; l < L; ++l) {
     for (int k = 0; k < 7; ++k) q.wT[l][k] = carve(off, NF * NF * 4);
-    q.ftab[l] = carve(off, (size_t)FT_ROWS * FT_PITCH * 4);
+    q.ftab[l] = carve(off, 3 * FT_PLANE * 4);
   }
   q.hn_tab = carve(off, (size_t)128 * NF * 4);   // message_nodepart of layer 0 per element (119 rows, padded)
   q.m_tab = carve(off, (size_t)128 * NF * 4);
@@ -641,7 +641,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
 }
 
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----
-extern "C" size_t nnhip_filter_table_bytes(void) { return (size_t)FT_ROWS * FT_PITCH * sizeof(float); }
+extern "C" size_t nnhip_filter_table_bytes(void) { return 3 * FT_PLANE * sizeof(float); }
 extern "C" int nnhip_filter_tables(const float* const* edge_w, float* const* tables, int32_t n_layers, const float* freq,
                                    int32_t nb, int32_t envelope, void* stream) {
   if (!edge_w || !tables || !freq || n_layers < 1 || n_layers > NNHIP_MAX_LAYERS || nb < 1 || nb > NNHIP_MAX_NB ||

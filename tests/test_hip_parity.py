@@ -695,8 +695,8 @@ def _mlp_errors(M, x_scale, w_scale, seed=0):
 @pytest.mark.parametrize('envelope', [9, -1])
 def test_radial_filter_tables_against_float64(envelope):
     """The radial filter eps = W_e rbf(x) (newtonnet.py:186,210; representations.py:155-171,223-235) and its derivative as the
-    message kernels evaluate them: nnhip_filter_tables builds [node][T | S | D][F] rows and the kernels take the cubic Hermite
-    interpolant of edge_common.h from four of them.  The same formula in float64 on the device-built fp32 table against direct
+    message kernels evaluate them: nnhip_filter_tables builds the planes T | S | D and the kernels take the cubic Hermite
+    interpolant (value + derivative) or the 4-point Lagrange value of edge_common.h from four rows.  The same formula in float64 on the device-built fp32 table against direct
     float64 evaluation at 50 000 random x in (0.02, 1): value and derivative within 1e-7 of their maxima."""
     import ctypes as C
     from newtonnet_amd import hip
@@ -712,9 +712,9 @@ def test_radial_filter_tables_against_float64(envelope):
     hip._check(L.nnhip_filter_tables((vp * 1)(Wd.data_ptr()), (vp * 1)(table.data_ptr()), 1, hip._ptr(freq), nb, envelope,
                                      hip._stream(Wd.device)), 'nnhip_filter_tables')
     rows = n // (3 * 128)
-    G = rows - 4
-    tab = table.cpu().double().view(rows, 3, 128).numpy()
-    assert np.all(tab[G + 1:] == 0.0) and np.all(tab[G, 0] == 0.0)          # the all-zero nodes; eps(1) = 0
+    G = rows - 8
+    tab = table.cpu().double().view(3, rows, 128).numpy()                   # planes T | S | D, row = node + 1
+    assert np.all(tab[:, G + 2:] == 0.0) and np.all(tab[0, G + 1] == 0.0)   # all-zero rows beyond the cutoff; eps(1) = 0
     Wn, w = Wd.cpu().double().numpy(), freq.cpu().double().numpy()
     x = np.random.default_rng(3).uniform(0.02, 1.0, 50000)
     xc = x[:, None]
@@ -731,10 +731,16 @@ def test_radial_filter_tables_against_float64(envelope):
     g0 = np.minimum(np.floor(t).astype(int), G - 1)
     u = (t - g0)[:, None]
     h = 1.0 / G
-    T0, S0, D0, D1 = tab[g0, 0], tab[g0, 1], tab[g0, 2], tab[g0 + 1, 2]
+    T0, S0, D0, D1 = tab[0, g0 + 1], tab[1, g0 + 1], tab[2, g0 + 1], tab[2, g0 + 2]
     val = T0 + h * (u * u * (3 - 2 * u) * S0 + u * (1 - u) ** 2 * D0 + u * u * (u - 1) * D1)
     der = 6 * u * (1 - u) * S0 + (1 - u) * (1 - 3 * u) * D0 + u * (3 * u - 2) * D1
     ev, ed = np.abs(val - f_ref).max() / np.abs(f_ref).max(), np.abs(der - d_ref).max() / np.abs(d_ref).max()
+    # the value-only readers: 4-point Lagrange on the T plane, rows g0 .. g0 + 3
+    lw = [-u * (u - 1) * (u - 2) / 6, (u + 1) * (u - 1) * (u - 2) / 2, -(u + 1) * u * (u - 2) / 2, (u + 1) * u * (u - 1) / 6]
+    val_l = sum(lw[k] * tab[0, g0 + k] for k in range(4))
+    el = np.abs(val_l - f_ref).max() / np.abs(f_ref).max()
+    print(f'radial-filter table, Lagrange value on the T plane: {el:.2e} of the maximum')
+    assert el <= 1e-7
     print(f'radial-filter table, {G} intervals, envelope {envelope}: value {ev:.2e}, derivative {ed:.2e} of the maximum')
     assert ev <= 1e-7 and ed <= 1e-7
 
