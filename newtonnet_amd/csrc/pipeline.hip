@@ -431,6 +431,77 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   if (!prepared) TRY(run_prepare(model, pq, pbase, s));
   const bool split_nodes = split_products_enabled() && act == NNHIP_ACT_SILU;   // node128s.hip (images in the prepared block)
 
+  // ------------------------------------------------------------------ small systems: the whole step in ONE launch (small.hip)
+  {
+    const bool small_on = !(getenv("NNHIP_SMALL_STEP") && atoi(getenv("NNHIP_SMALL_STEP")) == 0);   // A-B switch (read per call)
+    bool plain = split_nodes && small_on && !virial && N <= SMALL_MAX_ATOMS && E <= SMALL_MAX_EDGES;
+    for (int l = 0; l < L; ++l) plain = plain && !model->layer[l].ln_w;
+    if (plain) {
+      SmallArgs a;
+      memset(&a, 0, sizeof(a));
+      a.z = z;
+      a.mol_ptr = mol_ptr;
+      a.row_ptr = row_ptr;
+      a.col = col;
+      a.rev = rev;
+      a.pid = pid;
+      a.geo = geo;
+      a.xg = reinterpret_cast<const int2*>(xg);
+      a.N = N;
+      a.E = E;
+      a.B = B;
+      a.L = L;
+      a.inv_rc = 1.0f / model->cutoff;
+      a.emb = model->node_embedding;
+      a.m_tab = Q(pq.m_tab);
+      for (int l = 0; l < L; ++l) {
+        a.ftab[l] = Q(pq.ftab[l]);
+        for (int k = 0; k < IMG_PER_LAYER; ++k) a.img[l][k] = pbase + pq.img[l][k];
+        a.node0_b[l] = model->layer[l].node0_b;
+        a.node2_b[l] = model->layer[l].node2_b;
+        a.m[l] = P(w.pub.m[l]);
+        a.hn[l] = P(w.pub.hn[l]);
+        a.msg[l] = P(w.pub.msg[l]);
+        a.h1[l] = P(w.pub.h12[l]);
+        a.h2[l] = P(w.pub.h12[l]) + h2_off;
+        a.phi1[l] = P(w.pub.phi1[l]);
+        a.phi2[l] = P(w.pub.phi2[l]);
+        a.a_mid[l] = P(w.pub.a_mid[l]);
+        a.a_out[l] = P(w.pub.a_out[l]);
+        a.f_out[l] = P(w.pub.f_out[l]);
+        a.q[l] = P(w.pub.q[l]);
+      }
+      for (int k = 0; k < IMG_HEAD_COUNT; ++k) a.img_head[k] = pbase + pq.img_head[k];
+      a.head0_b = model->head0_b;
+      a.head2_b = model->head2_b;
+      a.w4 = model->head4_w;
+      a.b4 = model->head4_b;
+      a.scale = model->scale;
+      a.shift = model->shift;
+      a.a0 = P(w.pub.a0);
+      a.e1 = P(w.pub.e1);
+      a.e2 = P(w.pub.e2);
+      a.g_e = P(w.g_e);
+      a.g_a = P(w.pub.g_a);
+      a.g_f[0] = P(w.pub.g_f);
+      a.g_f[1] = P(w.g_f2);
+      a.gf = P(w.gf_mid);
+      a.g_phi1 = P(w.g_h12);
+      a.g_phi2 = P(w.g_h12) + (size_t)((E + 1) / 2) * NF;
+      a.g_msg = P(w.g_msg);
+      a.g_m = P(w.g_m);
+      a.g_x = P(w.pub.g_x);
+      a.g_u = P(w.pub.g_u);
+      a.g_d = P(w.g_d);
+      a.energy = energy;
+      a.forces = forces;
+      a.atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
+      a.atom_node_out = atom_node_out;
+      a.force_node_out = force_node_out;
+      return launch_small_step(a, s);
+    }
+  }
+
   // ------------------------------------------------------------------ forward sweep
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
   // atoms' rows up, instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is not kept: its
