@@ -433,7 +433,11 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
 
   // ------------------------------------------------------------------ small systems: the whole step in ONE launch (small.hip)
   {
-    const bool small_on = !(getenv("NNHIP_SMALL_STEP") && atoi(getenv("NNHIP_SMALL_STEP")) == 0);   // A-B switch (read per call)
+    // OFF by default: measured on MI355X (profiles/r03_md_latency.txt) the single workgroup takes 905 us for the 21-atom step
+    // against 278 us for the 31 dependent launches below -- one CU serialises ~50 phases whose loads each pay the full L2 latency
+    // (two rounds of 14 dependent edge iterations per row phase, two to three rounds of GEMM units per dense phase).
+    // NNHIP_SMALL_STEP=1 selects it (read per call); tests keep it parity-checked.
+    const bool small_on = getenv("NNHIP_SMALL_STEP") && atoi(getenv("NNHIP_SMALL_STEP")) == 1;
     bool plain = split_nodes && small_on && !virial && N <= SMALL_MAX_ATOMS && E <= SMALL_MAX_EDGES;
     for (int l = 0; l < L; ++l) plain = plain && !model->layer[l].ln_w;
     if (plain) {

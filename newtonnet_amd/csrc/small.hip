@@ -14,6 +14,15 @@
 // v_mfma_f32_32x32x16_f16 per 16 k-values, fp32 accumulation).  The edge phases are one wave per receiver row with the same
 // pair-once layout, ownership rule and formulas as edge.hip.  Deterministic: fixed summation orders, no atomics.
 //
+// STATUS (round 3, measured): correct (parity tests against the oracle and against the multi-kernel path) but SLOWER than the
+// launches it replaces -- 905 us vs 278 us for the 21-atom aspirin step (tools/bench_latency.py) -- so pipeline.hip selects it
+// only under NNHIP_SMALL_STEP=1.  Why: one CU runs ~50 barrier-separated phases, and inside a phase nothing hides the L2 latency
+// (~1 us per dependent access): a row phase is two rounds of ~14 dependent edge iterations, a dense phase two to three rounds of
+// GEMM units whose operands come from L2.  The matrix work itself (~570 units x 24 MFMAs) is ~50 us on one CU; reaching it
+// needs (a) per-tile fusion of consecutive GEMMs with register hand-over as in mlp128s.hip, (b) node-level state in LDS,
+// (c) edge loops with their indices preloaded and two rows per wave -- DESIGN.md section 7 has the estimate (150 us at best,
+// i.e. not the 2x over the multi-kernel path that would justify it).
+//
 // Scope: SiLU models without LayerNorm, at most SMALL_MAX_ATOMS atoms and SMALL_MAX_EDGES directed edges in the whole batch,
 // energy + forces (no virial); everything else takes the multi-kernel path.  Throughput is not the point of this kernel.
 #include <string.h>

@@ -158,7 +158,9 @@ def test_skin_list_equals_exact_list_for_every_activation(activation):
             n_cand = fast._md['g'].n_edges
             fs = max(1.0, float(np.abs(exact.results['forces']).max()))
             assert np.abs(fast.results['forces'] - exact.results['forces']).max() < 5e-6 * fs, (activation, t, sub)
-            assert abs(float(fast.results['energy']) - float(exact.results['energy'])) <= 2e-6 * max(
+            # (the skin list sums a row's pairs in a different order than the exact list; softplus never vanishes and blows the
+            # seeded model's energy up to 3e8 eV, where that fp32 reordering alone shows at a few 1e-6 relative)
+            assert abs(float(fast.results['energy']) - float(exact.results['energy'])) <= 5e-6 * max(
                 1.0, abs(float(exact.results['energy'])))
     assert n_cand > 306           # the skin list really holds candidates beyond the cutoff (exact list of frame 0: 306)
 

@@ -175,9 +175,9 @@ def test_properties_config2_size():
 
 @pytest.mark.parametrize('case', ['aspirin1_rand', 'aspirin1_ckpt', 'ethanol4_rand'])
 def test_single_launch_small_step_equals_the_multi_kernel_path(case):
-    """Batches of at most 64 atoms run the whole step in ONE launch (csrc/small.hip): against the oracle like every other path
-    (test_golden_case covers these cases too), and against the multi-kernel path of the same library (NNHIP_SMALL_STEP=0) to fp32
-    rounding -- energies, forces, per-atom energies, final node states."""
+    """Batches of at most 64 atoms can run the whole step in ONE launch of one workgroup (csrc/small.hip; opt-in with
+    NNHIP_SMALL_STEP=1 -- measured slower than the multi-kernel path, kept parity-checked): against the oracle, and against the
+    multi-kernel path of the same library to fp32 rounding -- energies, forces, final node states."""
     import os
     model, sd = make_model('ckpt' if case.endswith('ckpt') else 'rand')
     z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
