@@ -535,6 +535,11 @@ typedef struct {
   const nnhip_wgrad_problem* probs; const nnhip_colsum_problem* sums; float* slabs; float* cs_scratch; float* sp_scratch;
   int32_t n_probs, chunks, n_sums, pad2_;
   float* g_embedding; float* g_scale; float* g_shift; float* g_head4_b;
+  /* layer_norm=True only (NULL otherwise): x_hat [N][F] and 1/sigma [N] of the value sweep, their tangents, the gradient at the
+   * LayerNorm OUTPUT kept by the value reverse sweep, and the rows whose column sums are d gamma / d beta */
+  float* ln_xhat[NNHIP_MAX_LAYERS]; float* ln_rstd[NNHIP_MAX_LAYERS]; float* ln_dxhat[NNHIP_MAX_LAYERS];
+  float* ln_drstd[NNHIP_MAX_LAYERS]; float* ln_gy[NNHIP_MAX_LAYERS]; float* ln_row_w[NNHIP_MAX_LAYERS];
+  float* ln_row_b[NNHIP_MAX_LAYERS];
 } nnhip_train_ws;
 size_t nnhip_train_ws_bytes(void); /* sizeof(nnhip_train_ws) of this build (bindings check their mirror against it) */
 int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws* ws, void* stream);

@@ -1100,6 +1100,67 @@ clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm in the tangent sweeps (layer_norm=True, newtonnet.py:202-205,228-231; values: edge.hip:layer_norm_fwd/bwd_kernel).
+// One wave per atom row, F = 128 features; x_hat and r = 1/sigma are those of the value sweep.
+//   tangent forward   s = mean(x_hat dx);  dx_hat = r (dx - mean(dx) - x_hat s);  dr = -r^2 s;  dy = gamma dx_hat
+//   tangent of the adjoint g_x = r A,  A = g' - mean(g') - x_hat c,  g' = gamma g_y,  c = mean(g' x_hat):
+//                     dA = dg' - mean(dg') - dx_hat c - x_hat mean(dg' x_hat + g' dx_hat);   dg_x = dr A + r dA
+//   and the rows whose column sums are the parameter gradients (the epsilon-part of  g_gamma = sum g_y x_hat,  g_beta = sum g_y):
+//                     row_w = dg_y x_hat + g_y dx_hat;   row_b = dg_y
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+layer_norm_tan_fwd_kernel(float* __restrict__ da /*in: tangent of the pre-norm row, out: of the normalised row*/,
+                          const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                          int n_atoms, float* __restrict__ dxhat, float* __restrict__ drstd) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const float2 dx = ld2(da + (size_t)i * NF + 2 * lane), xh = ld2(xhat + (size_t)i * NF + 2 * lane);
+  const float r = rstd[i];
+  const float md = wave_sum(dx.x + dx.y) * (1.0f / NF);
+  const float sm = wave_sum(fmaf(xh.x, dx.x, xh.y * dx.y)) * (1.0f / NF);
+  const float2 dxh = make_float2(r * (dx.x - md - xh.x * sm), r * (dx.y - md - xh.y * sm));
+  const float2 g = ld2(gamma + 2 * lane);
+  st2(dxhat + (size_t)i * NF + 2 * lane, dxh);
+  st2(da + (size_t)i * NF + 2 * lane, make_float2(g.x * dxh.x, g.y * dxh.y));
+  if (lane == 0) drstd[i] = -r * r * sm;
+}
+__global__ void __launch_bounds__(256)
+layer_norm_tan_bwd_kernel(const float* __restrict__ gy, float* __restrict__ dga /*in: dg_y, out: dg_x*/,
+                          const float* __restrict__ xhat, const float* __restrict__ rstd, const float* __restrict__ dxhat,
+                          const float* __restrict__ drstd, const float* __restrict__ gamma, int n_atoms,
+                          float* __restrict__ row_w, float* __restrict__ row_b) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const size_t o = (size_t)i * NF + 2 * lane;
+  const float2 g = ld2(gy + o), dg = ld2(dga + o), xh = ld2(xhat + o), dxh = ld2(dxhat + o), w = ld2(gamma + 2 * lane);
+  const float r = rstd[i], dr = drstd[i];
+  const float2 gp = make_float2(g.x * w.x, g.y * w.y), dgp = make_float2(dg.x * w.x, dg.y * w.y);
+  const float m1 = wave_sum(gp.x + gp.y) * (1.0f / NF);
+  const float c = wave_sum(fmaf(gp.x, xh.x, gp.y * xh.y)) * (1.0f / NF);
+  const float dm1 = wave_sum(dgp.x + dgp.y) * (1.0f / NF);
+  const float dc = wave_sum(fmaf(dgp.x, xh.x, dgp.y * xh.y) + fmaf(gp.x, dxh.x, gp.y * dxh.y)) * (1.0f / NF);
+  const float2 A = make_float2(gp.x - m1 - xh.x * c, gp.y - m1 - xh.y * c);
+  const float2 dA = make_float2(dgp.x - dm1 - dxh.x * c - xh.x * dc, dgp.y - dm1 - dxh.y * c - xh.y * dc);
+  st2(row_w + o, make_float2(fmaf(dg.x, xh.x, g.x * dxh.x), fmaf(dg.y, xh.y, g.y * dxh.y)));
+  st2(row_b + o, dg);
+  st2(dga + o, make_float2(fmaf(dr, A.x, r * dA.x), fmaf(dr, A.y, r * dA.y)));
+}
+int launch_layer_norm_tan_fwd(float* da, const float* xhat, const float* rstd, const float* gamma, int n_atoms, float* dxhat,
+                              float* drstd, hipStream_t s) {
+  layer_norm_tan_fwd_kernel<<<cdiv(n_atoms, 4), 256, 0, s>>>(da, xhat, rstd, gamma, n_atoms, dxhat, drstd);
+  LAUNCH_CHECK();
+  return 0;
+}
+int launch_layer_norm_tan_bwd(const float* gy, float* dga, const float* xhat, const float* rstd, const float* dxhat,
+                              const float* drstd, const float* gamma, int n_atoms, float* row_w, float* row_b, hipStream_t s) {
+  layer_norm_tan_bwd_kernel<<<cdiv(n_atoms, 4), 256, 0, s>>>(gy, dga, xhat, rstd, dxhat, drstd, gamma, n_atoms, row_w, row_b);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // =============================================================================================
 // C ABI (include/newtonnet_hip.h, "Training")
 // =============================================================================================

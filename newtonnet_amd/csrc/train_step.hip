@@ -5,6 +5,13 @@
 
 #include "common.h"
 
+int launch_layer_norm_fwd(float* a, const float* gamma, const float* beta, int n_atoms, float* xhat, float* rstd, hipStream_t s);
+int launch_layer_norm_bwd(float* g_a, const float* gamma, const float* xhat, const float* rstd, int n_atoms, hipStream_t s);
+int launch_layer_norm_tan_fwd(float* da, const float* xhat, const float* rstd, const float* gamma, int n_atoms, float* dxhat,
+                              float* drstd, hipStream_t s);
+int launch_layer_norm_tan_bwd(const float* gy, float* dga, const float* xhat, const float* rstd, const float* dxhat,
+                              const float* drstd, const float* gamma, int n_atoms, float* row_w, float* row_b, hipStream_t s);
+
 #define TS_TRY(x)          \
   do {                     \
     int _r = (x);          \
@@ -120,13 +127,23 @@ static int check(const nnhip_model* model, const nnhip_train_ws* w, const char* 
     nnhip_set_error("%s: bad arguments", who);
     return NNHIP_E_INVALID;
   }
-  for (int l = 0; l < model->n_layers; ++l)
-    if (model->layer[l].ln_w) {
-      nnhip_set_error("%s: layer_norm=True is outside the fused training path", who);
+  const bool ln = model->layer[0].ln_w != nullptr;
+  for (int l = 0; l < model->n_layers; ++l) {
+    const nnhip_layer_params& lp = model->layer[l];
+    if ((lp.ln_w != nullptr) != ln || (lp.ln_w != nullptr) != (lp.ln_b != nullptr)) {
+      nnhip_set_error("%s: layer_norm must be on for every interaction layer or for none", who);
       return NNHIP_E_UNSUPPORTED;
     }
+    if (ln && !(w->ln_xhat[l] && w->ln_rstd[l] && w->ln_dxhat[l] && w->ln_drstd[l] && w->ln_gy[l] && w->ln_row_w[l] && w->ln_row_b[l])) {
+      nnhip_set_error("%s: layer_norm=True needs the ln_* buffers of nnhip_train_ws", who);
+      return NNHIP_E_INVALID;
+    }
+  }
   return NNHIP_OK;
 }
+// layer_norm=True: the node-level stages run unfused (update | LayerNorm | next message_nodepart) -- the fused row-local
+// launches of node128s.hip have no LayerNorm stage -- with the LayerNorm value / tangent kernels between them
+static bool has_ln(const nnhip_model* model) { return model->layer[0].ln_w != nullptr; }
 
 extern "C" size_t nnhip_train_ws_bytes(void) { return sizeof(nnhip_train_ws); }
 
@@ -135,6 +152,8 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   const int N = w->n_atoms, E = w->n_edges, B = w->n_mol, L = w->n_layers, P = E / 2, act = model->activation;
   if (N == 0) return NNHIP_OK;
   const bool img_on = train_images(model, w);
+  const bool ln = has_ln(model);
+  const bool node_img = img_on && !ln;
   // parameter-only data of this step: transposed weights, radial-filter tables
   {
     const float* src[40];
@@ -221,7 +240,18 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     else
       TS_TRY(run1(d1, s));
     TS_TRY(nnhip_force_message_fwd(w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_in, w->f_out[l], N, s));
-    if (l + 1 < L) {
+    if (ln) {   // update | LayerNorm (in place; x_hat, 1/sigma kept) | next message_nodepart or head, unfused
+      const bool lastl = l + 1 == L;
+      TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nullptr, nullptr, nullptr, nullptr, nullptr,
+                            nullptr, N, act, s));
+      TS_TRY(launch_layer_norm_fwd(w->a_out[l], lp.ln_w, lp.ln_b, N, w->ln_xhat[l], w->ln_rstd[l], (hipStream_t)s));
+      nnhip_mlp_desc d = mlp_desc(MODE_FWD, w->a_out[l], NF, lastl ? model->head0_w : model->layer[l + 1].node0_w,
+                                  lastl ? model->head2_w : model->layer[l + 1].node2_w, lastl ? w->e1 : w->hn[l + 1],
+                                  lastl ? w->e2 : w->m[l + 1], N, act);
+      d.b1 = lastl ? model->head0_b : model->layer[l + 1].node0_b;
+      d.b2 = lastl ? model->head2_b : model->layer[l + 1].node2_b;
+      TS_TRY(run1(d, s));
+    } else if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
       TS_TRY(node_fwd_any(img_on, w, l, false, w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nx.node0_w, nx.node0_b,
                           nx.node2_w, nx.node2_b, w->hn[l + 1], w->m[l + 1], N, act, s));
@@ -235,13 +265,20 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   TS_TRY(nnhip_head_out(w->e2, model->head4_w, model->head4_b, model->scale, model->shift, w->z, w->mol_ptr, N, B, act,
                         w->atom_energy, w->g_e2, w->energy, s));
   // ---- sweep 2: reverse (seed 1)
-  if (img_on) {
+  // (layer_norm: the gradient at the LayerNorm OUTPUT is kept in ln_gy -- the tangent sweep differentiates the LayerNorm adjoint
+  // at it -- and GA[l] holds the gradient at the pre-norm row, which is what the update / message adjoints of layer l consume)
+  auto ln_adjoint = [&](int l) -> int {
+    HIP_TRY(hipMemcpyAsync(w->ln_gy[l], w->GA[l], sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return launch_layer_norm_bwd(w->GA[l], model->layer[l].ln_w, w->ln_xhat[l], w->ln_rstd[l], N, (hipStream_t)s);
+  };
+  if (node_img) {
     TS_TRY(node_bwd_fused(w, w->g_e2, w->e1, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T], w->t_e1, nullptr, w->GA[L - 1], L - 1,
                           nullptr, N, act, s));
   } else {
     nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->g_e2, NF, w->headT[1], w->headT[0], w->e1, w->GA[L - 1], N, act);
     d.T = w->t_e1;
     TS_TRY(run1(d, s));
+    if (ln) TS_TRY(ln_adjoint(L - 1));
     TS_TRY(node_bwd_update_any(false, w, L - 1, w->GA[L - 1], w->f_out[L - 1], w->q[L - 1], nullptr, w->wT[L - 1][6], w->gf[L - 1], N,
                                act, s));
   }
@@ -265,7 +302,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     }
     TS_TRY(nnhip_message_bwd(w->g_msg[l], w->GA[l], w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid,
                              l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0 ? 1 : 0, s));
-    if (l > 0 && img_on) {
+    if (l > 0 && node_img) {
       TS_TRY(node_bwd_fused(w, w->g_m[l], w->hn[l], w->wimg[l][IMG_NODE2_T], w->wimg[l][IMG_NODE0_T], w->t_n[l], w->GA[l],
                             w->GA[l - 1], l - 1, Gf, N, act, s));
     } else if (l > 0) {
@@ -274,6 +311,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
       d.T = w->t_n[l];
       d.accumulate = 1;
       TS_TRY(run1(d, s));
+      if (ln) TS_TRY(ln_adjoint(l - 1));
       TS_TRY(node_bwd_update_any(false, w, l - 1, w->GA[l - 1], w->f_out[l - 1], w->q[l - 1], Gf, w->wT[l - 1][6], w->gf[l - 1], N, act,
                                  s));
     }
@@ -302,6 +340,8 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
   const int N = w->n_atoms, E = w->n_edges, L = w->n_layers, P = E / 2, act = model->activation;
   if (N == 0) return NNHIP_OK;
   const bool img_on = train_images(model, w);
+  const bool ln = has_ln(model);
+  const bool node_img = img_on && !ln;
   // ---- sweep 3: tangent forward along v = -dL/dF
   TS_TRY(nnhip_edge_tangent_geom(g_forces, -1.0f, w->edge_index, w->geo, E, model->cutoff, w->tgeo, s));
   for (int l = 0; l < L; ++l) {
@@ -323,7 +363,7 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     TS_TRY(nnhip_force_message_tan_fwd(w->phi1[l], w->dphi1[l], w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr,
                                        w->col, w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1],
                                        w->df_out[l], N, s));
-    if (img_on) {   // equiv_update tangent + energy-update tangent + tangent of the next message_nodepart / head: one launch
+    if (node_img) {   // equiv_update tangent + energy-update tangent + tangent of the next message_nodepart / head: one launch
       const bool last = l + 1 == L;
       NodeTanFwdArgs a;
       memset(&a, 0, sizeof(a));
@@ -347,6 +387,9 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     }
     TS_TRY(nnhip_linear128(w->df_out[l], NF, lp.update_w, w->dq[l], NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_STORE, s));
     TS_TRY(nnhip_update_tan_fwd(w->da_mid, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], N, w->da_out[l], s));
+    if (ln)
+      TS_TRY(launch_layer_norm_tan_fwd(w->da_out[l], w->ln_xhat[l], w->ln_rstd[l], lp.ln_w, N, w->ln_dxhat[l], w->ln_drstd[l],
+                                       (hipStream_t)s));
     if (l + 1 < L) {
       const nnhip_layer_params& nx = model->layer[l + 1];
       nnhip_mlp_desc d = mlp_desc(MODE_TAN, w->da_out[l], NF, nx.node0_w, nx.node2_w, w->hn[l + 1], w->dm[l + 1], N, act);
@@ -395,7 +438,11 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
   };
   if (seed_a)
     HIP_TRY(hipMemcpyAsync(w->dGA, seed_a, sizeof(float) * (size_t)N * NF, hipMemcpyDeviceToDevice, (hipStream_t)s));
-  if (img_on) {
+  auto ln_tan_adjoint = [&](int l) -> int {   // dGA: tangent of the gradient at the LayerNorm output -> at the pre-norm row
+    return launch_layer_norm_tan_bwd(w->ln_gy[l], w->dGA, w->ln_xhat[l], w->ln_rstd[l], w->ln_dxhat[l], w->ln_drstd[l],
+                                     model->layer[l].ln_w, N, w->ln_row_w[l], w->ln_row_b[l], (hipStream_t)s);
+  };
+  if (node_img) {
     TS_TRY(tan_bwd_fused(w->dg_e2, w->e1, w->t_e1, w->de1, w->dg_e1, seed_a ? 1 : 0, w->himg[IMG_HEAD2_T], w->himg[IMG_HEAD0_T],
                          L - 1, seed_f));
   } else {
@@ -405,12 +452,13 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     d.G = w->dg_e1;
     d.accumulate = seed_a ? 1 : 0;
     TS_TRY(run1(d, s));
+    if (ln) TS_TRY(ln_tan_adjoint(L - 1));
   }
-  const float* dGf = img_on ? nullptr : seed_f;
+  const float* dGf = node_img ? nullptr : seed_f;
   int pp = 0;
   for (int l = L - 1; l >= 0; --l) {
     const bool first = l == 0;
-    if (!img_on) {
+    if (!node_img) {
       TS_TRY(nnhip_update_tan_bwd(w->GA[l], w->dGA, w->f_out[l], w->df_out[l], w->q[l], w->dq[l], dGf, N, w->gq[l], w->dgq[l],
                                   w->dgf, s));
       TS_TRY(nnhip_linear128(w->dgq[l], NF, w->wT[l][6], w->dgf, NF, nullptr, nullptr, 0, 3 * N, PRO_NONE, EPI_ACC, s));
@@ -437,7 +485,7 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     }
     TS_TRY(nnhip_message_tan_bwd(w->g_msg[l], w->dg_msg, w->GA[l], w->dGA, w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo,
                                  w->ftab[l], w->row_ptr, w->col, w->pid, w->dg_m[l], w->g_eps[l], w->dg_eps[l], N, s));
-    if (img_on) {
+    if (node_img) {
       TS_TRY(tan_bwd_fused(w->dg_m[l], w->hn[l], first ? nullptr : w->t_n[l], first ? nullptr : w->dhn[l], w->dg_hn[l], 1,
                            w->wimg[l][IMG_NODE2_T], w->wimg[l][IMG_NODE0_T], l - 1, first ? nullptr : nxt));
     } else {
@@ -447,6 +495,7 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
       d.G = w->dg_hn[l];
       d.accumulate = 1;
       TS_TRY(run1(d, s));
+      if (ln && !first) TS_TRY(ln_tan_adjoint(l - 1));
     }
     dGf = nxt;
     pp ^= 1;

@@ -134,7 +134,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None) -> Opt
 
 
 _UNSUPPORTED_FUSED = ("FusedClipAdam / the fused step serves output_properties within {'energy', 'gradient_force', 'direct_force'} "
-                      "(with 'energy') and layer_norm=False")
+                      "(with 'energy'), layer_norm on every interaction layer or on none")
 
 
 def _force_key(model):

@@ -91,7 +91,8 @@ def _train_ws_fields():
             + one('rb', 'zeros_nf')
             + one('probs', 'sums', 'slabs', 'cs_scratch', 'sp_scratch')
             + [(n, i32) for n in ('n_probs', 'chunks', 'n_sums', 'pad2_')]
-            + one('g_embedding', 'g_scale', 'g_shift', 'g_head4_b'))
+            + one('g_embedding', 'g_scale', 'g_shift', 'g_head4_b')
+            + per('ln_xhat', 'ln_rstd', 'ln_dxhat', 'ln_drstd', 'ln_gy', 'ln_row_w', 'ln_row_b'))
 
 
 class TrainWs(C.Structure):

@@ -10,10 +10,11 @@ split-K MFMA weight-gradient products.  Every kernel is an entry point of includ
 this file only owns buffers and order.  tests/tangent_ref.py states the same four sweeps in fp64 torch.
 
 Supported: every trainable head set of the reference -- ['energy'], ['energy', 'gradient_force'], ['energy', 'direct_force'],
-all three (trainer.py:299-313, loss.py:30-47) -- with layer_norm=False and every fused activation.  An energy-only loss is the
+all three (trainer.py:299-313, loss.py:30-47) -- with or without layer_norm, every fused activation.  An energy-only loss is the
 d = 0 case of the formula above; the direct_force head is an ordinary function of the final node states and back-propagates
-once (csrc/heads.hip), its adjoint seeds entering the epsilon-part of the reverse sweep.  layer_norm=True keeps the torch-graph
-path of train_ops.py.  dL/dpos is not produced (None): the reference would return it, no trainer uses it.
+once (csrc/heads.hip), its adjoint seeds entering the epsilon-part of the reverse sweep.  layer_norm=True runs the node-level
+stages unfused with LayerNorm value / tangent kernels between them (csrc/train.hip).  train_ops.py (torch graph + vendor GEMMs)
+remains only behind NNHIP_TRAIN_PATH=torch, for debugging.  dL/dpos is not produced (None): the reference would return it, no trainer uses it.
 """
 from __future__ import annotations
 
@@ -45,8 +46,9 @@ def trainable_parameters(model) -> List[torch.nn.Parameter]:
 
 def supported(model, keys) -> bool:
     keys = list(keys)
+    ln = [il.layer_norm is not None for il in model.interaction_layers]
     return ('energy' in keys and set(keys) <= {'energy', 'gradient_force', 'direct_force'} and len(set(keys)) == len(keys)
-            and all(il.layer_norm is None for il in model.interaction_layers) and model.embedding_layers.n_features == F)
+            and (all(ln) or not any(ln)) and model.embedding_layers.n_features == F)
 
 
 class TrainWorkspace:
@@ -128,6 +130,12 @@ class TrainWorkspace:
             self.grads.append(self.flat_grad[off:off + p.numel()].view(p.shape))
             off += p.numel()
         self.sp_scratch = buf(hip.lib().nnhip_species_scratch_bytes(F) // 4)
+        # ---- layer_norm=True (newtonnet.py:202-205,228-231): what the LayerNorm stages of the four sweeps keep (csrc/train.hip)
+        self.has_ln = model.interaction_layers[0].layer_norm is not None
+        if self.has_ln:
+            self.ln_xhat, self.ln_dxhat, self.ln_gy = per_layer(N, F), per_layer(N, F), per_layer(N, F)
+            self.ln_row_w, self.ln_row_b = per_layer(N, F), per_layer(N, F)
+            self.ln_rstd, self.ln_drstd = per_layer(max(N, 1)), per_layer(max(N, 1))
         # ---- direct_force head (output.py:115-132), when the model has one: forward intermediates kept for its adjoint, the
         # adjoint's rows (operands of three more weight-gradient problems / column sums) and the seeds it hands to sweep 4
         self.dfh_idx = list(model.output_properties).index('direct_force') if 'direct_force' in model.output_properties else None
@@ -197,6 +205,9 @@ class TrainWorkspace:
             colsum(G(n2.bias), self.dg_m[l], N)
             colsum(G(n0.bias), self.dg_hn[l], N)
             add(G(il.equiv_update.weight), 3 * N, self.dgq[l], B1=self.f_out[l], A2=self.gq[l], B2=self.df_out[l])
+            if self.has_ln:
+                colsum(G(il.layer_norm.weight), self.ln_row_w[l], N)
+                colsum(G(il.layer_norm.bias), self.ln_row_b[l], N)
         head = model.output_layers[list(model.output_properties).index('energy')].layers
         add(G(head[2].weight), N, self.dg_e2, A2=self.g_e2, typ=hip.WG_ACT, hB=self.e1, dhB=self.de1)
         add(G(head[0].weight), N, self.dg_e1, B1=self.a_out[L - 1], A2=self.t_e1, B2=self.da_out[L - 1], typ=hip.WG_TDACT,

@@ -564,6 +564,58 @@ def test_training_gradients_against_reference_fixture():
     assert abs(l2 - float(c['loss'])) <= 2e-5 * abs(float(c['loss']))
 
 
+@pytest.mark.parametrize('props', [['energy', 'gradient_force'], ['energy', 'gradient_force', 'direct_force']])
+def test_layer_norm_training_on_the_hand_written_kernels(props):
+    """layer_norm=True models (newtonnet.py:202-205,228-231) train on the hand-written path too: LayerNorm value / adjoint kernels
+    in the value sweeps, their tangents in sweeps 3-4 (csrc/train.hip), d gamma / d beta as column sums.  Loss, forces and every
+    parameter gradient -- including the six LayerNorm tensors -- against the fp64 oracle's double backward; the all-HIP step
+    evaluates the same objective."""
+    from newtonnet_amd.distributed import FusedClipAdam, TrainStep
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    B, N = cell.shape[0], pos.shape[0]
+    e_lab, f_lab, d_lab = torch.randn(B, generator=g), torch.randn(N, 3, generator=g), torch.randn(N, 3, generator=g)
+    torch.manual_seed(17)
+    model = NewtonNet(layer_norm=True, output_properties=list(props))
+    with torch.no_grad():      # non-trivial gamma / beta (the constructor's are ones / zeros)
+        for il in model.interaction_layers:
+            il.layer_norm.weight.add_(0.3 * torch.randn(128))
+            il.layer_norm.bias.add_(0.2 * torch.randn(128))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    model.train()
+    out = model(z.cuda(), pos.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'
+    loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(out.gradient_force, f_lab.cuda())
+    kw = {}
+    if 'direct_force' in props:
+        loss = loss + torch.nn.functional.mse_loss(out.direct_force, d_lab.cuda())
+        kw = dict(direct_head=props.index('direct_force'), direct_label=d_lab.double())
+    loss.backward()
+    want_loss, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch,
+                                              e_lab.double(), f_lab.double(), **kw)
+    assert abs(loss.item() - want_loss.item()) <= 1e-4 * abs(want_loss.item())
+    err = nrm = 0.0
+    n_ln = 0
+    for name, prm in model.named_parameters():
+        if prm.requires_grad:
+            got = prm.grad.detach().cpu().double()
+            err += (got - want[name]).norm().item() ** 2
+            nrm += want[name].norm().item() ** 2
+            if 'layer_norm' in name:
+                n_ln += 1
+                assert (got - want[name]).norm().item() <= 2e-4 * max(want[name].norm().item(), 1e-12), name
+    assert n_ln == 6
+    print(f'layer_norm training: relative gradient error {np.sqrt(err / nrm):.2e}')
+    assert np.sqrt(err) <= 1e-4 * np.sqrt(nrm), (np.sqrt(err), np.sqrt(nrm))
+    if 'direct_force' not in props:
+        step = TrainStep(model, FusedClipAdam(model, lr=0.0, max_norm=1.0), 1.0, 50.0)
+        l2 = float(step(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda(), e_lab.cuda(), f_lab.cuda()))
+        assert abs(l2 - want_loss.item()) <= 1e-4 * abs(want_loss.item())
+
+
 def test_direct_force_training_against_reference_fixture():
     """['energy', 'direct_force'] training pinned to the REFERENCE (tests/golden/case_train_direct.npz: its model in train mode,
     its loss factory {'energy': mse, 'direct_force': mse x 20}, loss.backward(); trainer.py:299-313, loss.py:41-47): the mirror's
