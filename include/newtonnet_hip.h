@@ -131,6 +131,20 @@ int nnhip_graph_count(const float* pos, const float* cell, const int64_t* batch,
 int nnhip_graph_fill(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
                      const int32_t* row_ptr, int32_t n_atoms, int32_t n_mol, int32_t n_edges, float cutoff,
                      int32_t* col, int32_t* rev, float* disp, int64_t* edge_index, void* stream);
+/* The same neighbor list with fewer launches behind the host's edge-count round trip (the path NewtonNet.forward takes):
+ * nnhip_graph_count_pairs also leaves, per row, the number of neighbors ABOVE the row's atom (the undirected pairs the row owns)
+ * in pair_cnt[0 .. N); nnhip_graph_pair_scan turns them into pair_ptr[0 .. N] (exclusive scan, in place; it can run while the
+ * host waits for the edge count); nnhip_graph_finish = nnhip_graph_fill + nnhip_graph_pairs' pid + nnhip_edge_embed in two
+ * launches (fill; then one thread per edge: reverse edge, pair id, geometry / radial basis / table position).  Bit-identical
+ * outputs to the separate entry points. */
+int nnhip_graph_count_pairs(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
+                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream);
+int nnhip_graph_pair_scan(int32_t* pair_ptr, int32_t n_atoms, int32_t* scan_scratch, void* stream);
+int nnhip_graph_finish(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                       const int32_t* row_ptr, const int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t n_edges,
+                       float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
+                       const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
+                       int32_t envelope, void* stream);
 
 /* --------------------------------------------------------------------------
  * Undirected pairs.  msg = (W_e rbf) * m[i] * m[j] (newtonnet.py:211) is symmetric under i <-> j, and so is everything

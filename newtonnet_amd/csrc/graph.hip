@@ -156,19 +156,22 @@ __global__ void __launch_bounds__(256)
 graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
                   const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cut2, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
-                  float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges) {
+                  float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges, int* __restrict__ upper = nullptr) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
   const long b = batch[i];
   if (b < 0 || b >= n_mol) {   // flagged by mol_ptr_kernel; keep every access in bounds
-    if (!FILL && lane == 0) deg[i] = 0;
+    if (!FILL && lane == 0) {
+      deg[i] = 0;
+      if (upper) upper[i] = 0;
+    }
     return;
   }
   const int s = mol_ptr[b], e = mol_ptr[b + 1];
   const CellInfo ci = load_cell(cell, b);
   const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-  int cnt = 0;
+  int cnt = 0, cnt_up = 0;   // cnt_up: neighbors above i = the undirected pairs this row owns (section "Undirected pairs")
   int w = FILL ? row_ptr[i] : 0;
   for (int j0 = s; j0 < e; j0 += 64) {
     const int j = j0 + lane;
@@ -195,9 +198,13 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
       w += __popcll(mask);
     } else {
       cnt += __popcll(mask);
+      if (upper) cnt_up += __popcll(__ballot(hit && j > i));
     }
   }
-  if (!FILL && lane == 0) deg[i] = cnt;
+  if (!FILL && lane == 0) {
+    deg[i] = cnt;
+    if (upper) upper[i] = cnt_up;
+  }
 }
 
 // exclusive scan of deg[n] -> row_ptr[n+1] in two fully parallel launches (in place is fine: deg may alias row_ptr):
@@ -306,11 +313,9 @@ __device__ __forceinline__ void envelope_eval(double x, int env, double& e, doub
 // rounded once (E x nb values; the cost is negligible next to the [E,F] tensors and it removes the
 // cancellation of the p=9 polynomial envelope near x -> 1 from the fp32 error budget).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, float cut2, int env_id, const float* __restrict__ freq, int nb,
-                  float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_edges) return;
+__device__ __forceinline__ void edge_embed_one(int e, const float* __restrict__ disp, float cutoff, float cut2, int env_id,
+                                               const float* __restrict__ freq, int nb, float* __restrict__ geo,
+                                               float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
   const double dx = disp[3 * (long)e], dy = disp[3 * (long)e + 1], dz = disp[3 * (long)e + 2];
   const double r = sqrt(dx * dx + dy * dy + dz * dz);
   const double ir = 1.0 / r;
@@ -355,12 +360,77 @@ edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, flo
   }
 }
 
+__global__ void __launch_bounds__(256)
+edge_embed_kernel(const float* __restrict__ disp, int n_edges, float cutoff, float cut2, int env_id, const float* __restrict__ freq, int nb,
+                  float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  edge_embed_one(e, disp, cutoff, cut2, env_id, freq, nb, geo, rbf, drbf, xg);
+}
+
+// Everything per-edge that follows the fill, in ONE thread-per-edge launch (the post-count part of the neighbor list sits on the
+// critical path of a step behind the host's edge-count round trip: seven tiny launches there cost more than their work):
+//   rev[e]  by binary search in row j (edge_rev_kernel);
+//   pid[e]  in closed form from pair_ptr, the scan of the per-row counts of upper edges taken by the COUNT pass
+//           (pairs_assign_kernel's formula);
+//   geo / rbf / drbf / xg of the edge embedding (edge_embed_one).
+__global__ void __launch_bounds__(256)
+edge_finish_kernel(const int* __restrict__ row_ptr, const int* __restrict__ pair_ptr, const int* __restrict__ col, const int* erow,
+                   int n_edges, int* rev, int* __restrict__ pid, const float* __restrict__ disp, float cutoff, float cut2,
+                   int env_id, const float* __restrict__ freq, int nb, float* __restrict__ geo, float* __restrict__ rbf,
+                   float* __restrict__ drbf, int2* __restrict__ xg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int i = erow[e], j = col[e];
+  int lo = row_ptr[j], hi = row_ptr[j + 1] - 1, found = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int c = col[mid];
+    if (c == i) {
+      found = mid;
+      break;
+    }
+    if (c < i) lo = mid + 1; else hi = mid - 1;
+  }
+  rev[e] = found;
+  pid[e] = (j > i) ? pair_ptr[i + 1] - (row_ptr[i + 1] - e) : pair_ptr[j + 1] - (row_ptr[j + 1] - found);
+  edge_embed_one(e, disp, cutoff, cut2, env_id, freq, nb, geo, rbf, drbf, xg);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+static int graph_count_impl(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
+                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_);
 extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms,
                                  int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
                                  void* stream_) {
+  return graph_count_impl(pos, cell, batch, n_atoms, n_mol, cutoff, mol_ptr, row_ptr, status, nullptr, stream_);
+}
+extern "C" int nnhip_graph_count_pairs(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms,
+                                       int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
+                                       int32_t* pair_cnt, void* stream_) {
+  if (!pair_cnt) {
+    nnhip_set_error("nnhip_graph_count_pairs: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  return graph_count_impl(pos, cell, batch, n_atoms, n_mol, cutoff, mol_ptr, row_ptr, status, pair_cnt, stream_);
+}
+// pair_ptr[0 .. N] = exclusive scan of the per-row upper-edge counts nnhip_graph_count_pairs left in pair_ptr[0 .. N), in place
+extern "C" int nnhip_graph_pair_scan(int32_t* pair_ptr, int32_t n_atoms, int32_t* scan_scratch, void* stream_) {
+  if (n_atoms < 0 || !pair_ptr || !scan_scratch) {
+    nnhip_set_error("nnhip_graph_pair_scan: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0) {
+    HIP_TRY(hipMemsetAsync(pair_ptr, 0, sizeof(int32_t), (hipStream_t)stream_));
+    return NNHIP_OK;
+  }
+  ScopedTimer tm(TC_GRAPH, (hipStream_t)stream_);
+  return launch_scan(pair_ptr, n_atoms, pair_ptr, scan_scratch, (hipStream_t)stream_);
+}
+static int graph_count_impl(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
+                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_atoms < 0 || n_mol < 0 || !mol_ptr || !row_ptr || !status) {
     nnhip_set_error("nnhip_graph_count: bad arguments");
@@ -377,7 +447,7 @@ extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int6
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
   graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), row_ptr,
-                                                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                                                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, pair_cnt);
   LAUNCH_CHECK();
   {
     const int rc = launch_scan(row_ptr, n_atoms, row_ptr, status + 1, stream);   // status[1..] = scan scratch
@@ -401,6 +471,30 @@ extern "C" int nnhip_graph_fill(const float* pos, const float* cell, const int64
                                                                   row_ptr, col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// fill + everything per edge, two launches (all-pairs builder; pair_ptr scanned by nnhip_graph_pair_scan)
+extern "C" int nnhip_graph_finish(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                                  const int32_t* row_ptr, const int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol,
+                                  int32_t n_edges, float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                                  int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, float* rbf,
+                                  float* drbf, int32_t* xg, int32_t envelope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms < 0 || n_edges < 0 || !pair_ptr || n_basis < 1 || n_basis > NNHIP_MAX_NB ||
+      (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_graph_finish: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0 || n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  graph_rows_kernel<true><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), nullptr,
+                                                                  row_ptr, col, rev, disp, edge_index, n_edges);
+  LAUNCH_CHECK();
+  edge_finish_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, pair_ptr, col, rev, n_edges, rev, pid, disp, cutoff,
+                                                             cut2_of(cutoff), envelope ? envelope : 9, frequencies, n_basis, geo,
+                                                             rbf, drbf, reinterpret_cast<int2*>(xg));
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

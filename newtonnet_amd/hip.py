@@ -143,6 +143,9 @@ def lib():
     L.nnhip_last_error.restype = C.c_char_p
     L.nnhip_graph_count.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.nnhip_graph_count_pairs.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.nnhip_graph_pair_scan.argtypes = [vp, i32, vp, vp]
+    L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_check_species.argtypes = [vp, i32, vp, vp]
@@ -222,7 +225,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_check_species'):
+               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -244,7 +247,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
-                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags')
+                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
+                    'nnhip_graph_pair_scan', 'nnhip_graph_finish')
 
 
 def _check(rc: int, what: str):
@@ -318,8 +322,11 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     g = Graph()
     g.n_atoms, g.n_mol, g.envelope = N, B, int(envelope)
     n_scan = (N + 1023) // 1024 + 1
-    meta = torch.empty(B + 1 + N + 1 + 1 + n_scan, dtype=torch.int32, device=dev)
-    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:]   # status[0] + scan scratch
+    # one int32 block: mol_ptr [B+1] | row_ptr [N+1] | status + scan scratch [1 + n_scan] | pair_ptr [N+1] | its scan scratch
+    meta = torch.empty(B + 1 + N + 1 + 1 + n_scan + N + 1 + n_scan, dtype=torch.int32, device=dev)
+    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:B + N + 3 + n_scan]
+    o_pp = B + N + 3 + n_scan
+    g.pair_ptr, pair_scan = meta[o_pp:o_pp + N + 1], meta[o_pp + N + 1:]
     st = _stream(dev)
     # One big orthorhombic periodic box -> O(N) cell-list kernels (bit-identical output to the all-pairs kernels).
     box = None
@@ -332,9 +339,9 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         status[:1].zero_()
         _check(L.nnhip_graph_count_cells(_ptr(pos), _ptr(cell), N, float(cutoff), box, _ptr(scratch), _ptr(g.mol_ptr),
                                          _ptr(g.row_ptr), st), 'nnhip_graph_count_cells')
-    else:
-        _check(L.nnhip_graph_count(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
-                                   _ptr(g.row_ptr), _ptr(status), st), 'nnhip_graph_count')
+    else:   # (the count pass also takes the per-row pair counts: the pair ids then need no pass of their own after the sync)
+        _check(L.nnhip_graph_count_pairs(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
+                                         _ptr(g.row_ptr), _ptr(status), _ptr(g.pair_ptr), st), 'nnhip_graph_count_pairs')
     if z is not None:
         if z.dtype != torch.int64 or not z.is_contiguous():
             z = z.long().contiguous()
@@ -345,10 +352,14 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         tail_host.copy_(tail_dev, non_blocking=True)          # queue the read-back first ...
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        while_waiting()                                        # ... then the independent work, then wait for the copy only
+        if box is None:                                        # ... then work that does not need the edge count: the pair scan,
+            _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
+        while_waiting()                                        # the caller's (parameter preparation), then wait for the copy only
         ev.synchronize()
         tail = tail_host.tolist()
     else:
+        if box is None:
+            _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
         tail = tail_dev.tolist()  # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
     if bad & 1:
@@ -356,30 +367,32 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     if bad & 2:
         raise IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
     g.n_edges = E
-    ints = torch.empty(2 * E, dtype=torch.int32, device=dev)
-    g.col, g.rev = ints[:E], ints[E:]
-    g.disp = torch.empty(E, 3, dtype=torch.float32, device=dev)
+    # Everything sized by E in three allocations (the host time between the sync and the first launch is on the step's
+    # critical path): int32 [xg 2E | col E | rev E | pid E], float32 [geo 4E | disp 3E | rbf, drbf nb E each], edge_index
+    nb = frequencies.numel()
+    ints = torch.empty(5 * E, dtype=torch.int32, device=dev)
+    g.xg, g.col, g.rev, g.pid = ints[:2 * E].view(E, 2), ints[2 * E:3 * E], ints[3 * E:4 * E], ints[4 * E:]
+    flts = torch.empty((7 + (2 * nb if want_rbf else 0)) * E, dtype=torch.float32, device=dev)
+    g.geo, g.disp = flts[:4 * E].view(E, 4), flts[4 * E:7 * E].view(E, 3)
+    g.rbf = flts[7 * E:(7 + nb) * E].view(E, nb) if want_rbf else None     # dist_edge (tests / API)
+    g.drbf = flts[(7 + nb) * E:].view(E, nb) if want_rbf else None
     g.edge_index = torch.empty(2, E, dtype=torch.int64, device=dev) if want_edge_index else None
-    if box is not None:
+    freq = _f32c(frequencies, 'frequencies')
+    if box is None:
+        _check(L.nnhip_graph_finish(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.pair_ptr), N, B, E,
+                                    float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.pid), _ptr(g.disp), _ptr(g.edge_index),
+                                    _ptr(freq), nb, _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st),
+               'nnhip_graph_finish')
+        if E == 0:
+            g.pair_ptr.zero_()
+    else:
         _check(L.nnhip_graph_fill_cells(_ptr(pos), _ptr(cell), N, E, float(cutoff), box, _ptr(scratch), _ptr(g.row_ptr),
                                         _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
                'nnhip_graph_fill_cells')
-    else:
-        _check(L.nnhip_graph_fill(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), N, B, E,
-                                  float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
-               'nnhip_graph_fill')
-    pints = torch.empty(E + N + 1 + n_scan, dtype=torch.int32, device=dev)
-    g.pid, g.pair_ptr = pints[:E], pints[E:E + N + 1]
-    _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid),
-                               _ptr(pints[E + N + 1:]), st),
-           'nnhip_graph_pairs')
-    nb = frequencies.numel()
-    g.geo = torch.empty(E, 4, dtype=torch.float32, device=dev)
-    g.rbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None     # dist_edge (tests / API)
-    g.drbf = torch.empty(E, nb, dtype=torch.float32, device=dev) if want_rbf else None
-    g.xg = torch.empty(E, 2, dtype=torch.int32, device=dev)
-    _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), nb,
-                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
+        _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid),
+                                   _ptr(pair_scan), st), 'nnhip_graph_pairs')
+        _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(freq), nb, _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf),
+                                  _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
     return g
 
 
@@ -408,6 +421,19 @@ def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:
     return out
 
 
+def alloc_outputs(N: int, B: int, dev, want_forces: bool = True, want_virial: bool = False, want_nodes: bool = True) -> dict:
+    """The output tensors of one energy_forces call (they depend on N and B only: NewtonNet.forward allocates them while the
+    host waits for the edge count)."""
+    out = dict()
+    out['energy'] = torch.empty(B, dtype=torch.float32, device=dev)
+    out['forces'] = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_forces else None
+    out['virial'] = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if (want_virial and want_forces) else None
+    out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
+    out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+    return out
+
+
 def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
                   want_virial: bool = False, want_nodes: bool = True, workspace: Optional[torch.Tensor] = None,
                   out: Optional[dict] = None, prepared: Optional[torch.Tensor] = None):
@@ -417,16 +443,10 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
     dev = z.device
     N, E, B = g.n_atoms, g.n_edges, g.n_mol
     need = L.nnhip_workspace_bytes(N, E, B, model.n_layers)
-    if workspace is None or workspace.numel() < need:
+    if workspace is None or workspace.numel() < need or workspace.device != dev:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
     if out is None:
-        out = dict()
-        out['energy'] = torch.empty(B, dtype=torch.float32, device=dev)
-        out['forces'] = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_forces else None
-        out['virial'] = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if (want_virial and want_forces) else None
-        out['atom_energy'] = torch.empty(N, dtype=torch.float32, device=dev)
-        out['atom_node'] = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
-        out['force_node'] = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev) if want_nodes else None
+        out = alloc_outputs(N, B, dev, want_forces, want_virial, want_nodes)
     out['workspace'] = workspace
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),

@@ -83,7 +83,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws'):
             state.pop(k, None)
         return state
 
@@ -184,14 +184,22 @@ class NewtonNet(nn.Module):
         with torch.no_grad():
             model = self._hip_model(energy_idx)
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
-            prep = []   # parameter-only preparation runs on the GPU while the host waits for the edge count
+            prep = []   # parameter-only preparation runs on the GPU while the host waits for the edge count ...
             overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'      # (switch for A/B timing only)
+
+            def in_the_bubble():   # ... and the host allocates what does not depend on the edge count
+                prep.append(hip.prepare(model, pos.device))
+                prep.append(hip.alloc_outputs(pos.shape[0], cell.shape[0], pos.device, want_forces, want_virial))
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies,
-                                while_waiting=(lambda: prep.append(hip.prepare(model, pos.device))) if overlap else None,
+                                while_waiting=in_the_bubble if overlap else None,
                                 z=zc, envelope=emb.edge_embedding.envelope_id)
+            # the workspace of the previous call is reused when it is large enough (the arrays in it are private to one call;
+            # everything the caller sees lives in the output tensors)
             res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
-                                    want_virial=want_virial, prepared=prep[0] if overlap else None)
+                                    want_virial=want_virial, prepared=prep[0] if overlap else None,
+                                    out=prep[1] if overlap else None, workspace=self.__dict__.get('_infer_ws'))
+            self.__dict__['_infer_ws'] = res['workspace']
 
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
                                   edge_index=g.edge_index, cell=cell, batch=batch)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Print the kernel sequence of the LAST step in a rocprofv3 rocpd (.db) kernel trace: start offset, duration and the idle
 gap before each dispatch.  A step is delimited by the first kernel name given (default mol_ptr_kernel / cells kernel).
-usage: python tools/rocpd_timeline.py results.db [first_kernel_substring]"""
+usage: python tools/rocpd_timeline.py results.db [first_kernel_substring] [steps_back]   (steps_back: 0 = the last complete
+step; bench.py's last steps are its event-instrumented pass, so pass e.g. 12 to look at a step of the timed region)"""
 import sqlite3
 import sys
 
@@ -16,7 +17,10 @@ def main():
     starts = [k for k, r in enumerate(rows) if first in r[0]]
     if len(starts) < 2:
         sys.exit('need two steps in the trace')
-    a, b = starts[-2], starts[-1]
+    back = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if len(starts) < back + 2:
+        sys.exit('not that many steps in the trace')
+    a, b = starts[-2 - back], starts[-1 - back]
     t0, prev_end = rows[a][1], rows[a][1]
     busy = 0
     for name, s, e, gx, wx in rows[a:b]:
