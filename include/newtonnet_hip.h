@@ -179,6 +179,10 @@ int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms,
  * ------------------------------------------------------------------------ */
 int nnhip_edge_disp(const float* pos, const float* cell, const int64_t* batch, const int64_t* edge_index, int32_t n_edges,
                     float* disp, void* stream);
+/* nnhip_edge_disp followed by nnhip_edge_embed, in one launch (the per-step refresh of a reused candidate list) */
+int nnhip_edge_refresh(const float* pos, const float* cell, const int64_t* batch, const int64_t* edge_index, int32_t n_edges,
+                       float cutoff, const float* frequencies, int32_t n_basis, float* disp, float* geo, float* rbf, float* drbf,
+                       int32_t* xg, int32_t envelope, void* stream);
 
 /* --------------------------------------------------------------------------
  * Species check.  The reference indexes nn.Embedding(119, F) / the scale and shift tables with z and raises

@@ -363,6 +363,53 @@ force_out_kernel(const float* __restrict__ g_d, const int* __restrict__ row_ptr,
   forces[3 * (size_t)i + 2] = fz;
 }
 
+// edge_gd + force_out in one launch when nobody needs g_d itself (no virial): 16 lanes per atom walk the row, each evaluating
+// g_d of its edge AND of the reverse edge from the per-layer g_x / g_u; the 16 partial forces are folded in a fixed order.
+__device__ __forceinline__ float4 gd_of_edge(const float* __restrict__ g_x, const float* __restrict__ g_u,
+                                             const float* __restrict__ geo, int e, int n_edges, int n_layers, float inv_rc) {
+  float gx = 0.f, gu0 = 0.f, gu1 = 0.f, gu2 = 0.f;
+  for (int l = 0; l < n_layers; ++l) {
+    gx += g_x[(size_t)l * n_edges + e];
+    const float4 v = reinterpret_cast<const float4*>(g_u)[(size_t)l * n_edges + e];
+    gu0 += v.x;
+    gu1 += v.y;
+    gu2 += v.z;
+  }
+  const float4 g = reinterpret_cast<const float4*>(geo)[e];
+  const float ir = 1.0f / g.w;
+  const float dot = gu0 * g.x + gu1 * g.y + gu2 * g.z;
+  const float a = gx * inv_rc - dot * ir;
+  return make_float4(fmaf(a, g.x, gu0 * ir), fmaf(a, g.y, gu1 * ir), fmaf(a, g.z, gu2 * ir), 0.f);
+}
+__global__ void __launch_bounds__(256)
+force_direct_kernel(const float* __restrict__ g_x, const float* __restrict__ g_u, const float* __restrict__ geo,
+                    const int* __restrict__ row_ptr, const int* __restrict__ rev, int n_atoms, int n_edges, int n_layers,
+                    float inv_rc, float* __restrict__ forces) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  if (i < n_atoms) {
+    for (int e = row_ptr[i] + sub; e < row_ptr[i + 1]; e += 16) {
+      const float4 a = gd_of_edge(g_x, g_u, geo, e, n_edges, n_layers, inv_rc);
+      const float4 b = gd_of_edge(g_x, g_u, geo, rev[e], n_edges, n_layers, inv_rc);
+      fx -= (a.x - b.x);
+      fy -= (a.y - b.y);
+      fz -= (a.z - b.z);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {   // fixed butterfly inside the 16-lane group: deterministic
+    fx += __shfl_xor(fx, o, WAVE);
+    fy += __shfl_xor(fy, o, WAVE);
+    fz += __shfl_xor(fz, o, WAVE);
+  }
+  if (i < n_atoms && sub == 0) {
+    forces[3 * (size_t)i] = fx;
+    forces[3 * (size_t)i + 1] = fy;
+    forces[3 * (size_t)i + 2] = fz;
+  }
+}
+
 // virial[b] = -dE/d(displacement_b)  (output.py:154-165), the derivative w.r.t. the symmetric strain S the reference
 // applies as pos @ S and cell @ S (newtonnet.py:153-155).  With d_e = (pos_i - pos_j) S - (cell S) n_e, exactly as
 // RadiusGraph writes the image shift (representations.py:93):
@@ -611,6 +658,12 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
                         float* virial, hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
+  if (!virial) {   // nobody reads g_d: one launch
+    force_direct_kernel<<<cdiv((long)n_atoms * 16, 256), 256, 0, s>>>(g_x, g_u, geo, row_ptr, rev, n_atoms, n_edges, n_layers,
+                                                                     1.0f / cutoff, forces);
+    LAUNCH_CHECK();
+    return 0;
+  }
   if (n_edges > 0) {
     edge_gd_kernel<<<cdiv(n_edges, 256), 256, 0, s>>>(g_x, g_u, geo, n_edges, n_layers, 1.0f / cutoff, g_d);
     LAUNCH_CHECK();

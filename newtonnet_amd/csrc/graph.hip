@@ -607,6 +607,42 @@ extern "C" int nnhip_edge_disp(const float* pos, const float* cell, const int64_
   return NNHIP_OK;
 }
 
+// nnhip_edge_disp + nnhip_edge_embed in one thread-per-edge launch (the per-step geometry refresh of a reused list: two
+// dependent launches of a few microseconds of work each cost their latency twice in the 31-launch MD step)
+__global__ void __launch_bounds__(256)
+edge_refresh_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
+                    const int64_t* __restrict__ edge_index, int n_edges, float* __restrict__ disp, float cutoff, float cut2, int env_id,
+                    const float* __restrict__ freq, int nb, float* __restrict__ geo, float* __restrict__ rbf, float* __restrict__ drbf,
+                    int2* __restrict__ xg) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const long i = edge_index[e], j = edge_index[(long)n_edges + e];
+  const CellInfo ci = load_cell(cell, batch[i]);
+  float dx, dy, dz;
+  pair_disp(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, dx, dy, dz);
+  disp[3 * (long)e] = dx;
+  disp[3 * (long)e + 1] = dy;
+  disp[3 * (long)e + 2] = dz;
+  edge_embed_one(e, disp, cutoff, cut2, env_id, freq, nb, geo, rbf, drbf, xg);
+}
+extern "C" int nnhip_edge_refresh(const float* pos, const float* cell, const int64_t* batch, const int64_t* edge_index,
+                                  int32_t n_edges, float cutoff, const float* frequencies, int32_t n_basis, float* disp, float* geo,
+                                  float* rbf, float* drbf, int32_t* xg, int32_t envelope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_edges < 0 || (n_edges && (!pos || !cell || !batch || !edge_index || !disp || !geo)) || n_basis < 1 ||
+      n_basis > NNHIP_MAX_NB || (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_edge_refresh: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  edge_refresh_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(pos, cell, batch, edge_index, n_edges, disp, cutoff, cut2_of(cutoff),
+                                                              envelope ? envelope : 9, frequencies, n_basis, geo, rbf, drbf,
+                                                              reinterpret_cast<int2*>(xg));
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
 extern "C" int nnhip_edge_embed(const float* disp, int32_t n_edges, float cutoff, const float* frequencies,
                                 int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg, int32_t envelope,
                                 void* stream_) {

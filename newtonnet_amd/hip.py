@@ -148,6 +148,7 @@ def lib():
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    L.nnhip_edge_refresh.argtypes = [vp, vp, vp, vp, i32, f32, vp, i32, vp, vp, vp, vp, vp, i32, vp]
     L.nnhip_check_species.argtypes = [vp, i32, vp, vp]
     L.nnhip_graph_cells_scratch_bytes.argtypes = [i32, _fp, f32]
     L.nnhip_graph_cells_scratch_bytes.restype = sz
@@ -225,7 +226,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish'):
+               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -248,7 +249,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
                     'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
-                    'nnhip_graph_pair_scan', 'nnhip_graph_finish')
+                    'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh')
 
 
 def _check(rc: int, what: str):
@@ -409,9 +410,9 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
     if batch.dtype != torch.int64 or not batch.is_contiguous():
         batch = batch.long().contiguous()
     E = g.n_edges
-    _check(L.nnhip_edge_disp(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.edge_index), E, _ptr(g.disp), st), 'nnhip_edge_disp')
-    _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(),
-                              _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
+    _check(L.nnhip_edge_refresh(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.edge_index), E, float(cutoff),
+                                _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(), _ptr(g.disp), _ptr(g.geo), _ptr(g.rbf),
+                                _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_refresh')
     return g
 
 
