@@ -473,7 +473,9 @@ typedef struct {
   int32_t M, lda1, lda2, ldb1, ldb2, ldh, type, b_cols32, activation, ldo, ncols, pad_;
 } nnhip_wgrad_problem;
 size_t nnhip_wgrad_slab_bytes(int32_t n_problems, int32_t chunks);
-/* bf16_operands != 0: operands rounded to bf16 after their fp32 prologue, fp32 accumulation (v_mfma_f32_32x32x16_bf16).
+/* bf16_operands: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32); 1 = operands rounded to bf16 after their fp32 prologue, fp32
+ * accumulation (v_mfma_f32_32x32x16_bf16; torch.autocast(bfloat16)); 2 = fp32-GRADE products from three bf16 pieces per operand
+ * (six MFMAs per 16 rows, 24 significant bits, no scaling: the default of fp32 training).
  * pair_rows: the row count of the problems whose M is negative (pair-level problems of a table built for a capacity: the
  * number of pairs changes from batch to batch, the table does not) */
 int nnhip_wgrad_batch(const nnhip_wgrad_problem* problems_dev, int32_t n_problems, int32_t chunks, float* slabs,

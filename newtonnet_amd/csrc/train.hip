@@ -824,6 +824,184 @@ wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32-GRADE products on the bf16 matrix pipe (the default of fp32 training since round 3).  v_mfma_f32_32x32x2_f32 made the
+// batched launch the largest kernel of a large-batch step (1.5 ms of 7.0 at 1024 aspirin conformers, 0.56 of the fp32-MFMA
+// peak); the bf16 form above is traffic-bound but carries 8 bits.  Here every fp32 operand is written as THREE bf16 pieces
+//     v = h + m + l,   h = bf16(v),  m = bf16(v - h),  l = bf16(v - h - m)          (24 significant bits, bf16's 8 exponent bits:
+// no scaling, no range problem) and a product as the six terms of order <= 2^-16:
+//     a b ~ ha hb + (ha mb + ma hb) + (ha lb + ma mb + la hb)                       (6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// The dropped terms are below 3 x 2^-24 |a b|: the class of one fp32 rounding.  Six 8-pass MFMAs replace eight 16-pass ones per
+// 16 rows (2.7x less pipe time): the kernel becomes bound by its operand traffic.  Same staging as the bf16 kernel (transposed
+// images, 40-element pitch, trips of 32 rows) with three planes per operand: 120 KiB, one buffer, one workgroup per CU -- the next
+// trip's rows are in registers while this trip's MFMAs run and are committed behind a barrier.
+// ---------------------------------------------------------------------------------------------
+struct WsLds {
+  unsigned short a1[3][4][32][WB_P], a2[3][4][32][WB_P], b1[3][4][32][WB_P], b2[3][4][32][WB_P];
+};
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&o)[3]) {   // rows r, r + 1 of one column, three planes
+  const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+  const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+  const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+  const __bf16 l0 = (__bf16)(r0 - (float)m0), l1 = (__bf16)(r1 - (float)m1);
+  bf16x2 v;
+  v[0] = h0; v[1] = h1; o[0] = __builtin_bit_cast(unsigned, v);
+  v[0] = m0; v[1] = m1; o[1] = __builtin_bit_cast(unsigned, v);
+  v[0] = l0; v[1] = l1; o[2] = __builtin_bit_cast(unsigned, v);
+}
+#define WS_PUT(ARR, CLS, X0, X1)                                                      \
+  {                                                                                   \
+    unsigned o_[3];                                                                   \
+    split3_pair(X0, X1, o_);                                                          \
+    *reinterpret_cast<unsigned*>(&L.ARR[0][CLS][c][row]) = o_[0];                     \
+    *reinterpret_cast<unsigned*>(&L.ARR[1][CLS][c][row]) = o_[1];                     \
+    *reinterpret_cast<unsigned*>(&L.ARR[2][CLS][c][row]) = o_[2];                     \
+  }
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void ws_finish_commit(const WgProb& P, WsLds& L, WbStage& g) {
+  const int act = P.activation;
+  const int c = threadIdx.x & 31;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (!NB32 && TYPE == WG_ACT) {
+      const float4 hv = g.b1[q], dh = g.b2[q];
+      g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
+      if (TWO)
+        g.b2[q] = make_float4(dact_any(hv.x, act) * dh.x, dact_any(hv.y, act) * dh.y, dact_any(hv.z, act) * dh.z,
+                              dact_any(hv.w, act) * dh.w);
+    }
+    if (TWO && TYPE == WG_TDACT) {
+      const float4 hv = g.ha[q];
+      g.a2[q] = make_float4(g.a2[q].x * dact_any(hv.x, act), g.a2[q].y * dact_any(hv.y, act), g.a2[q].z * dact_any(hv.z, act),
+                            g.a2[q].w * dact_any(hv.w, act));
+    }
+    if (!g.live[q]) {
+      g.a1[q] = zero;
+      if (TWO) g.a2[q] = zero;
+    }
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const int row = 2 * (threadIdx.x >> 5) + 16 * pr;
+    const float4 x0 = g.a1[2 * pr], x1 = g.a1[2 * pr + 1];
+    WS_PUT(a1, 0, x0.x, x1.x) WS_PUT(a1, 1, x0.y, x1.y) WS_PUT(a1, 2, x0.z, x1.z) WS_PUT(a1, 3, x0.w, x1.w)
+    const float4 y0 = g.b1[2 * pr], y1 = g.b1[2 * pr + 1];
+    WS_PUT(b1, 0, y0.x, y1.x)
+    if (!NB32) {
+      WS_PUT(b1, 1, y0.y, y1.y) WS_PUT(b1, 2, y0.z, y1.z) WS_PUT(b1, 3, y0.w, y1.w)
+    }
+    if (TWO) {
+      const float4 u0 = g.a2[2 * pr], u1 = g.a2[2 * pr + 1];
+      WS_PUT(a2, 0, u0.x, u1.x) WS_PUT(a2, 1, u0.y, u1.y) WS_PUT(a2, 2, u0.z, u1.z) WS_PUT(a2, 3, u0.w, u1.w)
+      const float4 z0 = g.b2[2 * pr], z1 = g.b2[2 * pr + 1];
+      WS_PUT(b2, 0, z0.x, z1.x)
+      if (!NB32) {
+        WS_PUT(b2, 1, z0.y, z1.y) WS_PUT(b2, 2, z0.z, z1.z) WS_PUT(b2, 3, z0.w, z1.w)
+      }
+    }
+  }
+}
+// six MFMAs: the product terms of order <= 2^-16
+#define WS_MMA(ACC, AH, AM, AL, BARR, Q)                                                                          \
+  {                                                                                                               \
+    const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(&L.BARR[0][Q][c][k0]);                                    \
+    const bf16x8 bm_ = *reinterpret_cast<const bf16x8*>(&L.BARR[1][Q][c][k0]);                                    \
+    const bf16x8 bl_ = *reinterpret_cast<const bf16x8*>(&L.BARR[2][Q][c][k0]);                                    \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL, bh_, ACC, 0, 0, 0);                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, bm_, ACC, 0, 0, 0);                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bl_, ACC, 0, 0, 0);                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AM, bh_, ACC, 0, 0, 0);                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bm_, ACC, 0, 0, 0);                                         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH, bh_, ACC, 0, 0, 0);                                         \
+  }
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void ws_run(const WgProb& P, WsLds& L, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[4]) {
+  WbStage g;
+  wb_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
+  ws_finish_commit<TYPE, TWO, NB32>(P, L, g);
+  __syncthreads();
+  for (int r0 = r_beg; r0 < r_end; r0 += WB_R) {
+    const bool more = r0 + WB_R < r_end;
+    if (more) wb_fetch<TYPE, TWO, NB32>(P, r0 + WB_R, r_end, r_beg, g);   // in flight under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int k0 = 16 * s + 8 * h;             // this lane's 8 rows of the 16-row step
+      const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(&L.a1[0][w][c][k0]);
+      const bf16x8 a1m = *reinterpret_cast<const bf16x8*>(&L.a1[1][w][c][k0]);
+      const bf16x8 a1l = *reinterpret_cast<const bf16x8*>(&L.a1[2][w][c][k0]);
+      bf16x8 a2h, a2m, a2l;
+      if (TWO) {
+        a2h = *reinterpret_cast<const bf16x8*>(&L.a2[0][w][c][k0]);
+        a2m = *reinterpret_cast<const bf16x8*>(&L.a2[1][w][c][k0]);
+        a2l = *reinterpret_cast<const bf16x8*>(&L.a2[2][w][c][k0]);
+      }
+#pragma unroll
+      for (int q = 0; q < (NB32 ? 1 : 4); ++q) {
+        WS_MMA(acc[q], a1h, a1m, a1l, b1, q)
+        if (TWO) WS_MMA(acc[q], a2h, a2m, a2l, b2, q)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                             // every wave is done reading this trip's images
+    if (more) {
+      ws_finish_commit<TYPE, TWO, NB32>(P, L, g);
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_split_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
+  WsLds& L = *reinterpret_cast<WsLds*>(wg_lds_raw);
+  WgProb P = probs[blockIdx.y];
+  if (P.M < 0) P.M = pair_rows;
+  if (!P.lda1) P.lda1 = NF;
+  if (!P.lda2) P.lda2 = NF;
+  if (!P.ldb1) P.ldb1 = NF;
+  if (!P.ldb2) P.ldb2 = NF;
+  if (!P.ldh) P.ldh = NF;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int M = P.M;
+  const int per = ((M + WB_R * chunks - 1) / (WB_R * chunks)) * WB_R;
+  const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
+  f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[q][k] = 0.f;
+  const bool two = P.A2 != nullptr;
+  const bool nb32 = P.b_cols32 != 0;
+  if (r_beg < r_end) {
+    if (nb32) {
+      if (two) ws_run<WG_PLAIN, true, true>(P, L, r_beg, r_end, w, c, h, acc);
+      else ws_run<WG_PLAIN, false, true>(P, L, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_ACT) {
+      if (two) ws_run<WG_ACT, true, false>(P, L, r_beg, r_end, w, c, h, acc);
+      else ws_run<WG_ACT, false, false>(P, L, r_beg, r_end, w, c, h, acc);
+    } else if (P.type == WG_TDACT && two) {
+      ws_run<WG_TDACT, true, false>(P, L, r_beg, r_end, w, c, h, acc);
+    } else {
+      if (two) ws_run<WG_PLAIN, true, false>(P, L, r_beg, r_end, w, c, h, acc);
+      else ws_run<WG_PLAIN, false, false>(P, L, r_beg, r_end, w, c, h, acc);
+    }
+  }
+  float* slab = slabs + ((size_t)blockIdx.y * chunks + blockIdx.x) * NF * NF;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int row = (k & 3) + 8 * (k >> 2) + 4 * h;
+    const int o = 4 * row + w;
+    if (nb32)
+      slab[(size_t)o * NF + c] = acc[0][k];
+    else
+      st4(slab + (size_t)o * NF + 4 * c, make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]));
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* __restrict__ slabs) {
   const WgProb& P = probs[blockIdx.y];
@@ -1366,10 +1544,15 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
   static const hipError_t attr_rc2 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel,
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * sizeof(WbLds));
   HIP_TRY(attr_rc2);
+  static const hipError_t attr_rc3 = hipFuncSetAttribute((const void*)wgrad_split_kernel,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(WsLds));
+  HIP_TRY(attr_rc3);
   {
     ScopedTimer t1(TC_WGRAD, s);
-    if (bf16_operands)
+    if (bf16_operands == 1)
       wgrad_bf16_kernel<<<dim3(chunks, n_problems), 256, 2 * sizeof(WbLds), s>>>(probs_dev, chunks, slabs, pair_rows);
+    else if (bf16_operands == 2)
+      wgrad_split_kernel<<<dim3(chunks, n_problems), 256, sizeof(WsLds), s>>>(probs_dev, chunks, slabs, pair_rows);
     else
       wgrad_kernel<<<dim3(chunks, n_problems), WG_THREADS, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   }

@@ -313,7 +313,9 @@ class Runner:
         if ws.model_key != key:           # (parameters re-allocated, e.g. by model.to(): rebuild the pointer table)
             ws.model_c, ws.model_key = self.model._hip_model(self.energy_idx), key
         c.n_edges = g.n_edges
-        c.bf16_wgrad = 1 if self.bf16 else 0
+        # weight-gradient products: bf16 operands under autocast(bfloat16); otherwise fp32-grade products from three bf16 pieces
+        # per operand (csrc/train.hip:wgrad_split_kernel); NNHIP_WGRAD_FORM=fp32 keeps v_mfma_f32_32x32x2_f32 (A/B, tests)
+        c.bf16_wgrad = 1 if self.bf16 else (0 if os.environ.get('NNHIP_WGRAD_FORM', 'split') == 'fp32' else 2)
         for name, t in (('z', self.z), ('pos', self.pos), ('cell', self.cell), ('batch', self.batch), ('mol_ptr', g.mol_ptr),
                         ('row_ptr', g.row_ptr), ('col', g.col), ('rev', g.rev), ('pid', g.pid), ('edge_index', g.edge_index),
                         ('geo', g.geo), ('disp', g.disp), ('rbf', g.rbf), ('drbf', g.drbf), ('xg', g.xg)):

@@ -616,6 +616,49 @@ def test_layer_norm_training_on_the_hand_written_kernels(props):
         assert abs(l2 - want_loss.item()) <= 1e-4 * abs(want_loss.item())
 
 
+def test_weight_gradient_product_forms_agree():
+    """The batched weight-gradient launch in its three product forms on the same step: fp32 MFMA (NNHIP_WGRAD_FORM=fp32), the
+    default fp32-grade form from three bf16 pieces per operand (six v_mfma_f32_32x32x16_bf16 per 16 rows), and plain bf16 operands
+    (autocast).  Against the fp64 oracle: both fp32-grade forms within 1e-4 (they measure ~5e-7), and within 2e-6 of each other
+    tensor by tensor; bf16 within 2e-2."""
+    import os
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    z, pos, cell, batch, _ = util.case_inputs('mixed_rand', torch.float32)
+    sd = util.load_state('rand', torch.float32)
+    g = torch.Generator().manual_seed(3)
+    e_lab, f_lab = torch.randn(cell.shape[0], generator=g), torch.randn(pos.shape[0], 3, generator=g)
+    _, want = ref.training_loss_grads({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch, e_lab.double(),
+                                      f_lab.double())
+
+    def grads(form, autocast=False):
+        os.environ['NNHIP_WGRAD_FORM'] = form
+        try:
+            model = NewtonNet(output_properties=['energy', 'gradient_force'])
+            model.load_state_dict(sd)
+            model = model.cuda()
+            model.train()
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                out = model(z.cuda(), pos.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+                loss = torch.nn.functional.mse_loss(out.energy.float(), e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(
+                    out.gradient_force.float(), f_lab.cuda())
+                loss.backward()
+            return {n: q.grad.detach().cpu().double() for n, q in model.named_parameters() if q.requires_grad}
+        finally:
+            os.environ.pop('NNHIP_WGRAD_FORM', None)
+
+    def rel(a):
+        err = sum((a[n] - want[n]).norm().item() ** 2 for n in a)
+        return (err / sum(want[n].norm().item() ** 2 for n in a)) ** 0.5
+    g32, gsp, gbf = grads('fp32'), grads('split'), grads('split', autocast=True)
+    print(f'weight gradients vs the fp64 oracle: fp32 MFMA {rel(g32):.2e}, bf16x3 split {rel(gsp):.2e}, bf16 {rel(gbf):.2e}')
+    assert rel(g32) <= 1e-4 and rel(gsp) <= 1e-4 and rel(gbf) <= 2e-2
+    assert rel(gsp) <= 3 * rel(g32) + 1e-7                                   # fp32-grade, not merely inside the tolerance
+    for n in g32:
+        assert (g32[n] - gsp[n]).norm().item() <= 2e-6 * max(g32[n].norm().item(), 1e-12) + 1e-9, n
+    assert any(not torch.equal(g32[n], gsp[n]) for n in g32)                  # (two forms really ran)
+
+
 def test_direct_force_training_against_reference_fixture():
     """['energy', 'direct_force'] training pinned to the REFERENCE (tests/golden/case_train_direct.npz: its model in train mode,
     its loss factory {'energy': mse, 'direct_force': mse x 20}, loss.backward(); trainer.py:299-313, loss.py:41-47): the mirror's
