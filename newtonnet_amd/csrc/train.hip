@@ -833,12 +833,44 @@ wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restric
 //     a b ~ ha hb + (ha mb + ma hb) + (ha lb + ma mb + la hb)                       (6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)
 // The dropped terms are below 3 x 2^-24 |a b|: the class of one fp32 rounding.  Six 8-pass MFMAs replace eight 16-pass ones per
 // 16 rows (2.7x less pipe time): the kernel becomes bound by its operand traffic.  Same staging as the bf16 kernel (transposed
-// images, 40-element pitch, trips of 32 rows) with three planes per operand: 120 KiB, one buffer, one workgroup per CU -- the next
-// trip's rows are in registers while this trip's MFMAs run and are committed behind a barrier.
+// images) with three planes per operand and trips of 16 rows: 72 KiB, one buffer, TWO workgroups per CU -- the next trip's rows are
+// in registers while this trip's MFMAs run and are committed behind a barrier, and the other workgroup's MFMAs cover that.
 // ---------------------------------------------------------------------------------------------
+#define WS_R 16                                  // rows per trip
+#define WS_P 24                                  // row pitch (bf16 elements) of one (class, column) line: 16 rows + 8 pad --
+                                                 // the 16 lanes of a ds_read_b128 phase then start 12 banks apart: conflict-free
 struct WsLds {
-  unsigned short a1[3][4][32][WB_P], a2[3][4][32][WB_P], b1[3][4][32][WB_P], b2[3][4][32][WB_P];
+  unsigned short a1[3][4][32][WS_P], a2[3][4][32][WS_P], b1[3][4][32][WS_P], b2[3][4][32][WS_P];   // 72 KiB: two workgroups per CU
 };
+struct WsStage {   // rows 2g, 2g+1 of the trip (g = t >> 5), lane column c = t & 31
+  float4 a1[2], a2[2], b1[2], b2[2], ha[2];
+  bool live[2];
+};
+template <int TYPE, bool TWO, bool NB32>
+__device__ __forceinline__ void ws_fetch(const WgProb& P, int r0, int r_end, int r_safe, WsStage& g) {
+  const int c = threadIdx.x & 31;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = r0 + 2 * (threadIdx.x >> 5) + q;
+    g.live[q] = r < r_end;
+    const int rr = g.live[q] ? r : r_safe;
+    g.a1[q] = ld4(P.A1 + (size_t)rr * P.lda1 + 4 * c);
+    if (NB32) {
+      g.b1[q].x = P.B1[(size_t)rr * P.ldb1 + c];
+      if (TWO) g.b2[q].x = P.B2[(size_t)rr * P.ldb2 + c];
+    } else if (TYPE == WG_ACT) {
+      g.b1[q] = ld4(P.hB + (size_t)rr * P.ldh + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.dhB + (size_t)rr * P.ldh + 4 * c);
+    } else {
+      g.b1[q] = ld4(P.B1 + (size_t)rr * P.ldb1 + 4 * c);
+      if (TWO) g.b2[q] = ld4(P.B2 + (size_t)rr * P.ldb2 + 4 * c);
+    }
+    if (TWO) {
+      g.a2[q] = ld4(P.A2 + (size_t)rr * P.lda2 + 4 * c);
+      if (TYPE == WG_TDACT) g.ha[q] = ld4(P.hA + (size_t)rr * P.ldh + 4 * c);
+    }
+  }
+}
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&o)[3]) {   // rows r, r + 1 of one column, three planes
   const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
   const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
@@ -858,12 +890,12 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned (&o)[3]
     *reinterpret_cast<unsigned*>(&L.ARR[2][CLS][c][row]) = o_[2];                     \
   }
 template <int TYPE, bool TWO, bool NB32>
-__device__ __forceinline__ void ws_finish_commit(const WgProb& P, WsLds& L, WbStage& g) {
+__device__ __forceinline__ void ws_finish_commit(const WgProb& P, WsLds& L, WsStage& g) {
   const int act = P.activation;
   const int c = threadIdx.x & 31;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 2; ++q) {
     if (!NB32 && TYPE == WG_ACT) {
       const float4 hv = g.b1[q], dh = g.b2[q];
       g.b1[q] = make_float4(act_any(hv.x, act), act_any(hv.y, act), act_any(hv.z, act), act_any(hv.w, act));
@@ -881,28 +913,25 @@ __device__ __forceinline__ void ws_finish_commit(const WgProb& P, WsLds& L, WbSt
       if (TWO) g.a2[q] = zero;
     }
   }
-#pragma unroll
-  for (int pr = 0; pr < 2; ++pr) {
-    const int row = 2 * (threadIdx.x >> 5) + 16 * pr;
-    const float4 x0 = g.a1[2 * pr], x1 = g.a1[2 * pr + 1];
-    WS_PUT(a1, 0, x0.x, x1.x) WS_PUT(a1, 1, x0.y, x1.y) WS_PUT(a1, 2, x0.z, x1.z) WS_PUT(a1, 3, x0.w, x1.w)
-    const float4 y0 = g.b1[2 * pr], y1 = g.b1[2 * pr + 1];
-    WS_PUT(b1, 0, y0.x, y1.x)
+  const int row = 2 * (threadIdx.x >> 5);
+  const float4 x0 = g.a1[0], x1 = g.a1[1];
+  WS_PUT(a1, 0, x0.x, x1.x) WS_PUT(a1, 1, x0.y, x1.y) WS_PUT(a1, 2, x0.z, x1.z) WS_PUT(a1, 3, x0.w, x1.w)
+  const float4 y0 = g.b1[0], y1 = g.b1[1];
+  WS_PUT(b1, 0, y0.x, y1.x)
+  if (!NB32) {
+    WS_PUT(b1, 1, y0.y, y1.y) WS_PUT(b1, 2, y0.z, y1.z) WS_PUT(b1, 3, y0.w, y1.w)
+  }
+  if (TWO) {
+    const float4 u0 = g.a2[0], u1 = g.a2[1];
+    WS_PUT(a2, 0, u0.x, u1.x) WS_PUT(a2, 1, u0.y, u1.y) WS_PUT(a2, 2, u0.z, u1.z) WS_PUT(a2, 3, u0.w, u1.w)
+    const float4 z0 = g.b2[0], z1 = g.b2[1];
+    WS_PUT(b2, 0, z0.x, z1.x)
     if (!NB32) {
-      WS_PUT(b1, 1, y0.y, y1.y) WS_PUT(b1, 2, y0.z, y1.z) WS_PUT(b1, 3, y0.w, y1.w)
-    }
-    if (TWO) {
-      const float4 u0 = g.a2[2 * pr], u1 = g.a2[2 * pr + 1];
-      WS_PUT(a2, 0, u0.x, u1.x) WS_PUT(a2, 1, u0.y, u1.y) WS_PUT(a2, 2, u0.z, u1.z) WS_PUT(a2, 3, u0.w, u1.w)
-      const float4 z0 = g.b2[2 * pr], z1 = g.b2[2 * pr + 1];
-      WS_PUT(b2, 0, z0.x, z1.x)
-      if (!NB32) {
-        WS_PUT(b2, 1, z0.y, z1.y) WS_PUT(b2, 2, z0.z, z1.z) WS_PUT(b2, 3, z0.w, z1.w)
-      }
+      WS_PUT(b2, 1, z0.y, z1.y) WS_PUT(b2, 2, z0.z, z1.z) WS_PUT(b2, 3, z0.w, z1.w)
     }
   }
 }
-// six MFMAs: the product terms of order <= 2^-16
+// six MFMAs: the product terms of order <= 2^-16, smallest first
 #define WS_MMA(ACC, AH, AM, AL, BARR, Q)                                                                          \
   {                                                                                                               \
     const bf16x8 bh_ = *reinterpret_cast<const bf16x8*>(&L.BARR[0][Q][c][k0]);                                    \
@@ -917,31 +946,28 @@ __device__ __forceinline__ void ws_finish_commit(const WgProb& P, WsLds& L, WbSt
   }
 template <int TYPE, bool TWO, bool NB32>
 __device__ __forceinline__ void ws_run(const WgProb& P, WsLds& L, int r_beg, int r_end, int w, int c, int h, f32x16 (&acc)[4]) {
-  WbStage g;
-  wb_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
+  WsStage g;
+  ws_fetch<TYPE, TWO, NB32>(P, r_beg, r_end, r_beg, g);
   ws_finish_commit<TYPE, TWO, NB32>(P, L, g);
   __syncthreads();
-  for (int r0 = r_beg; r0 < r_end; r0 += WB_R) {
-    const bool more = r0 + WB_R < r_end;
-    if (more) wb_fetch<TYPE, TWO, NB32>(P, r0 + WB_R, r_end, r_beg, g);   // in flight under the MFMAs below
+  const int k0 = 8 * h;                          // this lane's 8 rows of the 16-row trip
+  for (int r0 = r_beg; r0 < r_end; r0 += WS_R) {
+    const bool more = r0 + WS_R < r_end;
+    if (more) ws_fetch<TYPE, TWO, NB32>(P, r0 + WS_R, r_end, r_beg, g);   // in flight under the MFMAs below
     __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(&L.a1[0][w][c][k0]);
+    const bf16x8 a1m = *reinterpret_cast<const bf16x8*>(&L.a1[1][w][c][k0]);
+    const bf16x8 a1l = *reinterpret_cast<const bf16x8*>(&L.a1[2][w][c][k0]);
+    bf16x8 a2h, a2m, a2l;
+    if (TWO) {
+      a2h = *reinterpret_cast<const bf16x8*>(&L.a2[0][w][c][k0]);
+      a2m = *reinterpret_cast<const bf16x8*>(&L.a2[1][w][c][k0]);
+      a2l = *reinterpret_cast<const bf16x8*>(&L.a2[2][w][c][k0]);
+    }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int k0 = 16 * s + 8 * h;             // this lane's 8 rows of the 16-row step
-      const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(&L.a1[0][w][c][k0]);
-      const bf16x8 a1m = *reinterpret_cast<const bf16x8*>(&L.a1[1][w][c][k0]);
-      const bf16x8 a1l = *reinterpret_cast<const bf16x8*>(&L.a1[2][w][c][k0]);
-      bf16x8 a2h, a2m, a2l;
-      if (TWO) {
-        a2h = *reinterpret_cast<const bf16x8*>(&L.a2[0][w][c][k0]);
-        a2m = *reinterpret_cast<const bf16x8*>(&L.a2[1][w][c][k0]);
-        a2l = *reinterpret_cast<const bf16x8*>(&L.a2[2][w][c][k0]);
-      }
-#pragma unroll
-      for (int q = 0; q < (NB32 ? 1 : 4); ++q) {
-        WS_MMA(acc[q], a1h, a1m, a1l, b1, q)
-        if (TWO) WS_MMA(acc[q], a2h, a2m, a2l, b2, q)
-      }
+    for (int q = 0; q < (NB32 ? 1 : 4); ++q) {
+      WS_MMA(acc[q], a1h, a1m, a1l, b1, q)
+      if (TWO) WS_MMA(acc[q], a2h, a2m, a2l, b2, q)
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                             // every wave is done reading this trip's images
@@ -952,7 +978,7 @@ __device__ __forceinline__ void ws_run(const WgProb& P, WsLds& L, int r_beg, int
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 wgrad_split_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
   WsLds& L = *reinterpret_cast<WsLds*>(wg_lds_raw);
@@ -967,7 +993,7 @@ wgrad_split_kernel(const WgProb* __restrict__ probs, int chunks, float* __restri
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int M = P.M;
-  const int per = ((M + WB_R * chunks - 1) / (WB_R * chunks)) * WB_R;
+  const int per = ((M + WS_R * chunks - 1) / (WS_R * chunks)) * WS_R;
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
   f32x16 acc[4];
 #pragma unroll
