@@ -162,8 +162,8 @@ def train_roofline(device, conformers=1024, reps=5):
     """Roofline of the dominant kernel of a LARGE-batch training step (the 32-molecule data-parallel leg is launch-latency bound:
     no kernel of it is near any roofline).  One rank, no collective: value sweeps + MSE loss + tangent sweeps + weight gradients of
     `conformers` aspirin conformers through the same C entry points the step uses (nnhip_train_values / nnhip_loss_grad /
-    nnhip_train_grads), timed with the library's HIP-event hook.  Dominant = wgrad_kernel, ALL weight gradients of the step in one
-    batched split-K launch on v_mfma_f32_32x32x2_f32: FLOPs and operand bytes from the problem table (TrainWorkspace.wgrad_cost)."""
+    nnhip_train_grads), timed with the library's HIP-event hook.  Dominant = the batched weight-gradient launch (ALL weight
+    gradients of the step, split-K): FLOPs and operand bytes from the problem table (TrainWorkspace.wgrad_cost)."""
     from newtonnet_amd import hip, train_fused
     from newtonnet_amd.models import NewtonNet
     z, pos, cell, batch = synthetic_aspirin(conformers, seed=0, device=device)
@@ -203,17 +203,29 @@ def train_roofline(device, conformers=1024, reps=5):
     wg_ms, wg_n = tm['wgrad'][0] / max(tm['wgrad'][1], 1), tm['wgrad'][1] / reps
     flops, by = ws.wgrad_cost(gr.n_edges // 2)
     tf = flops / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
+    gbs = by / (wg_ms * 1e-3) / 1e9 if wg_ms > 0 else 0.0
     model.__dict__.pop('_train_ws', None)
-    return {'bound': 'mfma', 'kernel': 'wgrad_kernel (all 24 weight-gradient problems of a step in one batched split-K launch, '
-                                       'fp32 MFMA; operands through LDS with their activation prologue)',
-            'workload': f'{conformers} aspirin conformers (N = {N}, pairs = {gr.n_edges // 2}), value + tangent sweeps + weight '
-                        'gradients, fp32, one rank, no collective',
-            'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-            'flops_per_launch': flops, 'operand_bytes_per_launch': by, 'avg_launch_us': round(1e3 * wg_ms, 1),
-            'launches_per_step': wg_n, 'operand_gbs': round(by / (wg_ms * 1e-3) / 1e9, 1) if wg_ms > 0 else None,
-            'traffic': None, 'traffic_note': 'PMC passes: profiles/r03_train_aspirin1024_pmc_{fetch,write}_size.txt',
-            'step_ms_without_optimizer': round(ms_step, 3),
-            'share_of_step': round(wg_ms * wg_n / ms_step, 3) if ms_step > 0 else None}
+    split = os.environ.get('NNHIP_WGRAD_FORM', 'split') != 'fp32'
+    common = {'workload': f'{conformers} aspirin conformers (N = {N}, pairs = {gr.n_edges // 2}), value + tangent sweeps + weight '
+                          'gradients, fp32, one rank, no collective',
+              'flops_per_launch': flops, 'operand_bytes_per_launch': by, 'avg_launch_us': round(1e3 * wg_ms, 1),
+              'launches_per_step': wg_n, 'traffic': None,
+              'traffic_note': 'PMC passes: profiles/r03_*train_aspirin1024_pmc_{fetch,write}_size.txt',
+              'step_ms_without_optimizer': round(ms_step, 3),
+              'share_of_step': round(wg_ms * wg_n / ms_step, 3) if ms_step > 0 else None}
+    if split:   # fp32-grade products from three bf16 pieces per operand: 6 bf16 MFMAs per 16 rows -- bound by the operand rows
+        r = {'bound': 'hbm', 'kernel': 'wgrad_split_kernel (all weight-gradient problems of a step in one batched split-K launch; '
+                                       'fp32-grade products from three bf16 pieces per operand, fp32 accumulate)',
+             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+             'matrix_pipe': {'useful_fp32_tflops': round(tf, 2), 'executed_bf16_tflops': round(6 * tf, 2),
+                             'peak_bf16_tflops': MFMA_F16_PEAK_TFLOPS, 'frac': round(6 * tf / MFMA_F16_PEAK_TFLOPS, 4)}}
+    else:
+        r = {'bound': 'mfma', 'kernel': 'wgrad_kernel (all weight-gradient problems of a step in one batched split-K launch, '
+                                        'fp32 MFMA; operands through LDS with their activation prologue)',
+             'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+             'operand_gbs': round(gbs, 1)}
+    r.update(common)
+    return r
 
 
 def algorithmic_counts(N, E, L=3, F=128):
