@@ -182,7 +182,8 @@ class TrainStep:
         e_lab = hip._f32c(energy_label.detach(), 'energy_label')
         f_lab = hip._f32c(force_label.detach(), 'force_label') if force_key else None
         if e_lab.numel() != B or (f_lab is not None and f_lab.numel() != 3 * N):
-            raise ValueError(f'labels of shape {tuple(energy_label.shape)}, {tuple(force_label.shape)} for {B} molecules, {N} atoms')
+            raise ValueError(f'labels of shape {tuple(energy_label.shape)}, {tuple(getattr(force_label, "shape", ()))} for {B} molecules, '
+                             f'{N} atoms')
         with torch.no_grad():
             g = hip.build_graph(pd, cd, bc, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=zc, envelope=emb.envelope_id)
             ws = train_fused.acquire_workspace(model, g, dev)
@@ -211,7 +212,8 @@ class TrainStep:
         if self.fused:
             return self._call_fused(z, pos, cell, batch, energy_label, force_label)
         self.optimizer.zero_grad(set_to_none=True)
-        n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel(), pos.device, self.group)
+        n_e, n_f = allreduce_counts(energy_label.numel(), force_label.numel() if force_label is not None else 0, pos.device,
+                                    self.group)
         pos = pos.detach().clone().requires_grad_(True)
         out = self.model(z, pos, cell, batch)
         force_key = _force_key(self.model)
@@ -383,7 +385,8 @@ class GraphedTrainStep:
         flatten_parameters(model)
         st = dict(z=z.long().contiguous().clone(), cell=cell.float().contiguous().clone(),
                   batch=batch.long().contiguous().clone(), pos=pos.detach().float().contiguous().clone(),
-                  e=energy_label.detach().float().contiguous().clone(), f=force_label.detach().float().contiguous().clone())
+                  e=energy_label.detach().float().contiguous().clone(),
+                  f=(force_label.detach().float().contiguous().clone() if force_key else torch.zeros(1, device=dev)))
         N, B = st['pos'].shape[0], st['cell'].shape[0]
         st['graph'] = hip.build_graph(st['pos'], st['cell'], st['batch'], 1.0e6, emb.embedding.frequencies, want_rbf=True,
                                       z=st['z'], envelope=emb.envelope_id)                      # static candidate list: all pairs of every molecule
@@ -459,7 +462,8 @@ class GraphedTrainStep:
             st['norm'].copy_(norm)
         st['pos'].copy_(pos.detach(), non_blocking=True)
         st['e'].copy_(energy_label.detach(), non_blocking=True)
-        st['f'].copy_(force_label.detach(), non_blocking=True)
+        if force_label is not None and st['f'].numel() == force_label.numel():      # (energy-only models carry no force label)
+            st['f'].copy_(force_label.detach(), non_blocking=True)
         st['g1'].replay()
         if distributed:
             dist.all_reduce(st['ws'].flat_grad, op=dist.ReduceOp.SUM, group=self.group)
@@ -494,10 +498,11 @@ class GraphedTrainStep:
         """(w_E / n_E, w_F / n_F) with the GLOBAL element counts as a device tensor, and whether ANY rank's batch structure
         changed -- one small all-reduce per step under torch.distributed (every rank must take the same re-capture decision,
         or the collectives inside the capture's warm-up would be unmatched)."""
+        n_f = force_label.numel() if (force_label is not None and _force_key(self.model)) else 0
         if not (dist.is_available() and dist.is_initialized()):       # nothing to agree on: no device work
-            return torch.tensor([self.w_energy / max(energy_label.numel(), 1), self.w_force / max(force_label.numel(), 1)],
+            return torch.tensor([self.w_energy / max(energy_label.numel(), 1), self.w_force / max(n_f, 1)],
                                 dtype=torch.float32), changed
-        counts = torch.tensor([float(energy_label.numel()), float(force_label.numel()), 1.0 if changed else 0.0],
+        counts = torch.tensor([float(energy_label.numel()), float(max(n_f, 1) if n_f == 0 else n_f), 1.0 if changed else 0.0],
                               dtype=torch.float32, device=dev)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
         if not (self.assume_static and self._st is not None):

@@ -616,6 +616,29 @@ def test_layer_norm_training_on_the_hand_written_kernels(props):
         assert abs(l2 - want_loss.item()) <= 1e-4 * abs(want_loss.item())
 
 
+def test_all_hip_step_for_an_energy_only_model():
+    """['energy'] models (no force head at all, trainer.py:299-313 with an energy-only loss) through the all-HIP step, eager and
+    graphed, with no force label: the loss and the flat gradient equal autograd through the model's fused node."""
+    from newtonnet_amd.distributed import FusedClipAdam, GraphedTrainStep, TrainStep
+    from newtonnet_amd.models import NewtonNet
+    z, pos, cell, batch, e_lab, _ = _ethanol_batch(6, 5)
+    torch.manual_seed(2)
+    model = NewtonNet(output_properties=['energy']).cuda()
+    model.train()
+    out = model(z, pos, cell, batch)
+    assert type(out.energy.grad_fn).__name__ == 'FusedEnergyForcesBackward'
+    loss = 3.0 * torch.nn.functional.mse_loss(out.energy, e_lab)
+    loss.backward()
+    want = torch.cat([q.grad.reshape(-1) for n, q in model.named_parameters() if 'frequencies' not in n])
+    for cls in (TrainStep, GraphedTrainStep):
+        step = cls(model, FusedClipAdam(model, lr=0.0, max_norm=1.0), 3.0, 50.0)
+        for _ in range(2):
+            got = float(step(z, pos, cell, batch, e_lab, None))
+        assert abs(got - loss.item()) <= 2e-5 * abs(loss.item()), (cls.__name__, got, loss.item())
+        flat = (model._train_ws[-1] if cls is TrainStep else step._st['ws']).flat_grad
+        assert float((flat - want).norm() / want.norm()) <= 1e-4, cls.__name__
+
+
 def test_weight_gradient_product_forms_agree():
     """The batched weight-gradient launch in its three product forms on the same step: fp32 MFMA (NNHIP_WGRAD_FORM=fp32), the
     default fp32-grade form from three bf16 pieces per operand (six v_mfma_f32_32x32x16_bf16 per 16 rows), and plain bf16 operands
