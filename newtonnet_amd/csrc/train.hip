@@ -574,6 +574,16 @@ __device__ __forceinline__ void wg_run(const WgProb& P, WgLds* lds, int r_beg, i
   }
 }
 
+// Rows of a problem per split-K workgroup, and how many workgroups of the (chunks x problems) grid the problem uses: `chunks` is
+// sized for the LARGEST problem of the table; P.pad_ (set by the caller, 0 = off) is that problem's rows per chunk, a floor for
+// every other one -- a node-level problem of N rows next to pair-level ones of 7 N rows then writes (and wgrad_reduce_kernel
+// reads) a seventh of the slabs instead of all of them.
+__device__ __forceinline__ void wg_partition(const WgProb& P, int M, int chunks, int trip, int& per, int& nch) {
+  per = ((M + trip * chunks - 1) / (trip * chunks)) * trip;
+  if (P.pad_ > 0) per = max(per, ((P.pad_ + trip - 1) / trip) * trip);
+  nch = per > 0 ? (M + per - 1) / per : 0;
+}
+
 __global__ void __launch_bounds__(WG_THREADS)
 wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ slabs, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds_raw[];
@@ -590,7 +600,9 @@ wgrad_kernel(const WgProb* __restrict__ probs, int chunks, float* __restrict__ s
   const int c = lane & 31, h = lane >> 5;
   const int M = P.M;
   // rows of this workgroup: contiguous, a multiple of the trip size
-  const int per = ((M + WG_R * chunks - 1) / (WG_R * chunks)) * WG_R;
+  int per, nch;
+  wg_partition(P, M, chunks, WG_R, per, nch);
+  if ((int)blockIdx.x >= nch) return;            // (uniform: this problem uses fewer workgroups than the grid has)
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
   f32x16 acc[WG_NACC];
 #pragma unroll
@@ -789,7 +801,9 @@ wgrad_bf16_kernel(const WgProb* __restrict__ probs, int chunks, float* __restric
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int M = P.M;
-  const int per = ((M + WB_R * chunks - 1) / (WB_R * chunks)) * WB_R;
+  int per, nch;
+  wg_partition(P, M, chunks, WB_R, per, nch);
+  if ((int)blockIdx.x >= nch) return;            // (uniform: this problem uses fewer workgroups than the grid has)
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
   f32x16 acc[4];
 #pragma unroll
@@ -993,7 +1007,9 @@ wgrad_split_kernel(const WgProb* __restrict__ probs, int chunks, float* __restri
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int M = P.M;
-  const int per = ((M + WS_R * chunks - 1) / (WS_R * chunks)) * WS_R;
+  int per, nch;
+  wg_partition(P, M, chunks, WS_R, per, nch);
+  if ((int)blockIdx.x >= nch) return;            // (uniform: this problem uses fewer workgroups than the grid has)
   const int r_beg = blockIdx.x * per, r_end = min(M, r_beg + per);
   f32x16 acc[4];
 #pragma unroll
@@ -1029,7 +1045,7 @@ wgrad_split_kernel(const WgProb* __restrict__ probs, int chunks, float* __restri
 }
 
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* __restrict__ slabs) {
+wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* __restrict__ slabs, int pair_rows, int trip) {
   const WgProb& P = probs[blockIdx.y];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;   // one output element
   if (t >= NF * NF) return;
@@ -1038,7 +1054,9 @@ wgrad_reduce_kernel(const WgProb* __restrict__ probs, int chunks, const float* _
   if (i >= ncols) return;
   const float* slab = slabs + (size_t)blockIdx.y * chunks * NF * NF + t;
   float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += slab[(size_t)k * NF * NF];
+  int per, nch;
+  wg_partition(P, P.M < 0 ? pair_rows : P.M, chunks, trip, per, nch);
+  for (int k = 0; k < nch; ++k) s += slab[(size_t)k * NF * NF];
   P.out[(size_t)o * (P.ldo ? P.ldo : ncols) + i] = s;
 }
 
@@ -1583,7 +1601,8 @@ extern "C" int nnhip_wgrad_batch(const nnhip_wgrad_problem* probs_dev, int32_t n
       wgrad_kernel<<<dim3(chunks, n_problems), WG_THREADS, 2 * sizeof(WgLds), s>>>(probs_dev, chunks, slabs, pair_rows);
   }
   LAUNCH_CHECK();
-  wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs);
+  wgrad_reduce_kernel<<<dim3(NF * NF / 256, n_problems), 256, 0, s>>>(probs_dev, chunks, slabs, pair_rows,
+                                                                         bf16_operands == 1 ? WB_R : (bf16_operands == 2 ? WS_R : WG_R));
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

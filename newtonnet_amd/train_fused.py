@@ -229,17 +229,21 @@ class TrainWorkspace:
             sc = model.scalers[self.dfh_idx]
             self.dfh_g_scale = G(sc.scale.weight) if sc.scale is not None else None
         self.n_probs, self.n_sums = len(probs), len(sums)
+        # split-K chunks of the weight-gradient launch: ~256 rows each (every chunk costs a 64 KiB slab written and read back),
+        # but at least 32 of them while 32 rows remain per chunk (24 problems x 32 chunks fill the chip), at most 256
+        # (tools/sweep_train_chunks.sh: mixed-32 step 1.15 -> 1.05 ms, aspirin-128 2.05 -> 1.93 ms against one chunk per 32 rows)
+        M = max(P, N)
+        self.chunks = max(1, min(256, max((M + 255) // 256, min(32, (M + 31) // 32))))
+        # rows per chunk of the largest problem (3N-row ones included): the floor for all others (csrc/train.hip:wg_partition)
+        rpc = -(-max(P, 3 * N, 1) // self.chunks)
+        for q in probs:
+            q.pad_ = rpc
         arr = (hip.WgradProblem * len(probs))(*probs)
         self.prob_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         arr = (hip.ColsumProblem * len(sums))(*sums)
         self.sum_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         self.cs_scratch = torch.empty(max(hip.lib().nnhip_colsum_scratch_bytes(self.n_sums) // 4, 1), dtype=torch.float32,
                                       device=device)
-        # split-K chunks of the weight-gradient launch: ~256 rows each (every chunk costs a 64 KiB slab written and read back),
-        # but at least 32 of them while 32 rows remain per chunk (24 problems x 32 chunks fill the chip), at most 256
-        # (tools/sweep_train_chunks.sh: mixed-32 step 1.15 -> 1.05 ms, aspirin-128 2.05 -> 1.93 ms against one chunk per 32 rows)
-        M = max(P, N)
-        self.chunks = max(1, min(256, max((M + 255) // 256, min(32, (M + 31) // 32))))
         self.slabs = torch.empty(hip.lib().nnhip_wgrad_slab_bytes(self.n_probs, self.chunks) // 4, dtype=torch.float32,
                                  device=device)
         self._c_view(model, G)
