@@ -234,10 +234,13 @@ class TrainWorkspace:
         # (tools/sweep_train_chunks.sh: mixed-32 step 1.15 -> 1.05 ms, aspirin-128 2.05 -> 1.93 ms against one chunk per 32 rows)
         M = max(P, N)
         self.chunks = max(1, min(256, max((M + 255) // 256, min(32, (M + 31) // 32))))
-        # rows per chunk of the largest problem (3N-row ones included): the floor for all others (csrc/train.hip:wg_partition)
-        rpc = -(-max(P, 3 * N, 1) // self.chunks)
-        for q in probs:
-            q.pad_ = rpc
+        # (csrc/train.hip:wg_partition can give the smaller problems fewer, equally long chunks -- pad_ = rows per chunk of the
+        # largest problem.  Measured at 1024 aspirin conformers: the reduction 128 -> 116 us, the main launch 1190 -> 1280 us (the
+        # node-level problems' long chunks become its tail), step unchanged: off.  NNHIP_WGRAD_RPC=1 turns it on for A/B.)
+        if os.environ.get('NNHIP_WGRAD_RPC') == '1':
+            rpc = -(-max(P, 3 * N, 1) // self.chunks)
+            for q in probs:
+                q.pad_ = rpc
         arr = (hip.WgradProblem * len(probs))(*probs)
         self.prob_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
         arr = (hip.ColsumProblem * len(sums))(*sums)
