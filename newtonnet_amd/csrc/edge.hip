@@ -562,12 +562,33 @@ head_out_kernel(const float* __restrict__ e2, const float* __restrict__ w4, cons
 // E_b = sum of atom energies of molecule b  (output.py:246).  One wave per molecule, fp64 partial sums in a fixed
 // lane-strided order + butterfly: deterministic, one rounding at the end; a 100k-atom box no longer serialises on one
 // thread.
+// A molecule of many thousand atoms (the 100k-atom box is ONE molecule) would serialise on one wave (380 us there): molecules
+// longer than MOL_SPLIT atoms are summed by mol_energy_big_kernel, one 1024-thread workgroup per molecule, fp64 partial sums in a
+// fixed thread-strided order + a fixed tree: deterministic, one rounding at the end.
+#define MOL_SPLIT 4096
+__global__ void __launch_bounds__(1024)
+mol_energy_big_kernel(const float* __restrict__ atom_energy, const int* __restrict__ mol_ptr, int n_mol, float* __restrict__ energy) {
+  __shared__ double sh[1024];
+  const int b = blockIdx.x;
+  const int beg = mol_ptr[b], end = mol_ptr[b + 1];
+  if (end - beg <= MOL_SPLIT) return;     // (short molecules: mol_energy_kernel)
+  double s = 0.0;
+  for (int i = beg + threadIdx.x; i < end; i += 1024) s += (double)atom_energy[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) energy[b] = (float)sh[0];
+}
 __global__ void __launch_bounds__(256)
 mol_energy_kernel(const float* __restrict__ atom_energy, const int* __restrict__ mol_ptr, int n_mol,
-                  float* __restrict__ energy) {
+                  float* __restrict__ energy, int long_from) {
   const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (b >= n_mol) return;
   const int lane = threadIdx.x & 63;
+  if (mol_ptr[b + 1] - mol_ptr[b] > long_from) return;   // (left to mol_energy_big_kernel)
   double s = 0.0;
   for (int i = mol_ptr[b] + lane; i < mol_ptr[b + 1]; i += 64) s += (double)atom_energy[i];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
@@ -658,7 +679,9 @@ int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, co
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
                         float* virial, hipStream_t s) {
   ScopedTimer t0(TC_OTHER, s);
-  if (!virial) {   // nobody reads g_d: one launch
+  // (the one-launch form evaluates g_d twice per directed edge, once from each side: cheaper than a launch for molecular batches,
+  // 1.6x dearer than the two launches on the 100k-atom box with its 54 neighbours per atom -- measured 441 vs ~280 us)
+  if (!virial && n_edges <= (1 << 20)) {   // nobody reads g_d: one launch
     force_direct_kernel<<<cdiv((long)n_atoms * 16, 256), 256, 0, s>>>(g_x, g_u, geo, row_ptr, rev, n_atoms, n_edges, n_layers,
                                                                      1.0f / cutoff, forces);
     LAUNCH_CHECK();
@@ -706,8 +729,13 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
   ScopedTimer t0(TC_OTHER, s);
   head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, act, atom_energy, g_e2);
   LAUNCH_CHECK();
-  mol_energy_kernel<<<cdiv(n_mol, ROWS_PER_BLOCK), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
+  const bool big = n_atoms > MOL_SPLIT && n_mol <= 4096;   // some molecule MAY be long (the host knows only the totals); few molecules: cheap
+  mol_energy_kernel<<<cdiv(n_mol, ROWS_PER_BLOCK), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy, big ? MOL_SPLIT : 0x7fffffff);
   LAUNCH_CHECK();
+  if (big) {
+    mol_energy_big_kernel<<<n_mol, 1024, 0, s>>>(atom_energy, mol_ptr, n_mol, energy);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 
