@@ -169,6 +169,14 @@ int nnhip_graph_count_cells(const float* pos, const float* cell, int32_t n_atoms
 int nnhip_graph_fill_cells(const float* pos, const float* cell, int32_t n_atoms, int32_t n_edges, float cutoff,
                            const float* box_len_host, void* scratch, const int32_t* row_ptr, int32_t* col, int32_t* rev,
                            float* disp, int64_t* edge_index, void* stream);
+/* The cell-list counterparts of nnhip_graph_count_pairs / nnhip_graph_finish (same outputs as the separate entry points) */
+int nnhip_graph_count_cells_pairs(const float* pos, const float* cell, int32_t n_atoms, float cutoff, const float* box_len_host,
+                                  void* scratch, int32_t* mol_ptr, int32_t* row_ptr, int32_t* pair_cnt, void* stream);
+int nnhip_graph_finish_cells(const float* pos, const float* cell, int32_t n_atoms, int32_t n_edges, float cutoff,
+                             const float* box_len_host, void* scratch, const int32_t* row_ptr, const int32_t* pair_ptr,
+                             int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
+                             const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
+                             int32_t envelope, void* stream);
 
 /* --------------------------------------------------------------------------
  * Verlet-skin reuse of a neighbor list in an MD loop (caller: MLAseCalculator.calculate,

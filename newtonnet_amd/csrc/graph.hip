@@ -763,6 +763,42 @@ cells_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
   }
 }
 
+// Count pass, one wave per receiver atom: degree and the number of neighbors above the atom (the pairs the row owns)
+__global__ void __launch_bounds__(256)
+cells_count_wave_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int* __restrict__ bin_of,
+                        const int* __restrict__ bin_ptr, const int* __restrict__ bin_atoms, CellGrid g, int n_atoms, float cut2,
+                        int* __restrict__ deg, int* __restrict__ upper) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  const CellInfo ci = load_cell(cell, 0);
+  const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+  const int b = bin_of[i];
+  const int bz = b % g.nb[2], by = (b / g.nb[2]) % g.nb[1], bx = b / (g.nb[2] * g.nb[1]);
+  int cnt = 0, cnt_up = 0;
+  for (int dx = -1; dx <= 1; ++dx)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int cb = (((bx + dx + g.nb[0]) % g.nb[0]) * g.nb[1] + (by + dy + g.nb[1]) % g.nb[1]) * g.nb[2] + (bz + dz + g.nb[2]) % g.nb[2];
+        const int kend = bin_ptr[cb + 1];
+        for (int k0 = bin_ptr[cb]; k0 < kend; k0 += 64) {
+          const int k = k0 + lane;
+          const int j = k < kend ? bin_atoms[k] : -1;
+          bool hit = false;
+          if (j >= 0 && j != i) {
+            float ddx, ddy, ddz;
+            hit = pair_disp(xi, yi, zi, pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], ci, ddx, ddy, ddz) < cut2;
+          }
+          cnt += __popcll(__ballot(hit));
+          cnt_up += __popcll(__ballot(hit && j > i));
+        }
+      }
+  if (lane == 0) {
+    deg[i] = cnt;
+    if (upper) upper[i] = cnt_up;
+  }
+}
+
 // Fill pass, one WAVE per receiver atom (the thread-per-atom insertion sort above is kept for the count pass and for rows of
 // more than CW_CAP neighbors): the lanes test the atoms of the 27 surrounding cells 64 at a time, ballot-compact the hits into a
 // per-wave LDS list, rank-sort it (keys are distinct: rank = number of smaller keys) and write the row in ascending j with its
@@ -919,9 +955,24 @@ static int cells_common(const float* pos, int n_atoms, const float* box_len_host
   return NNHIP_OK;
 }
 
+static int count_cells_impl(const float* pos, const float* cell, int32_t n_atoms, float cutoff, const float* box_len_host,
+                            void* scratch, int32_t* mol_ptr, int32_t* row_ptr, int32_t* pair_cnt, void* stream_);
 extern "C" int nnhip_graph_count_cells(const float* pos, const float* cell, int32_t n_atoms, float cutoff,
                                        const float* box_len_host, void* scratch, int32_t* mol_ptr, int32_t* row_ptr,
                                        void* stream_) {
+  return count_cells_impl(pos, cell, n_atoms, cutoff, box_len_host, scratch, mol_ptr, row_ptr, nullptr, stream_);
+}
+extern "C" int nnhip_graph_count_cells_pairs(const float* pos, const float* cell, int32_t n_atoms, float cutoff,
+                                             const float* box_len_host, void* scratch, int32_t* mol_ptr, int32_t* row_ptr,
+                                             int32_t* pair_cnt, void* stream_) {
+  if (!pair_cnt) {
+    nnhip_set_error("nnhip_graph_count_cells_pairs: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  return count_cells_impl(pos, cell, n_atoms, cutoff, box_len_host, scratch, mol_ptr, row_ptr, pair_cnt, stream_);
+}
+static int count_cells_impl(const float* pos, const float* cell, int32_t n_atoms, float cutoff, const float* box_len_host,
+                            void* scratch, int32_t* mol_ptr, int32_t* row_ptr, int32_t* pair_cnt, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_atoms <= 0 || !scratch || !row_ptr || !mol_ptr) {
     nnhip_set_error("nnhip_graph_count_cells: bad arguments");
@@ -934,8 +985,8 @@ extern "C" int nnhip_graph_count_cells(const float* pos, const float* cell, int3
   if (rc) return rc;
   const int32_t mp[2] = {0, n_atoms};
   HIP_TRY(hipMemcpyAsync(mol_ptr, mp, sizeof(mp), hipMemcpyHostToDevice, stream));
-  cells_rows_kernel<false><<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cut2_of(cutoff),
-                                                                   row_ptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  cells_count_wave_kernel<<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cut2_of(cutoff), row_ptr,
+                                                                pair_cnt);
   LAUNCH_CHECK();
   {
     const int rc2 = launch_scan(row_ptr, n_atoms, row_ptr, scan_tmp_of(scratch, n_atoms, box_len_host, cutoff), stream);
@@ -962,6 +1013,35 @@ extern "C" int nnhip_graph_fill_cells(const float* pos, const float* cell, int32
                                                                col, rev, disp, edge_index, n_edges);
   LAUNCH_CHECK();
   edge_rev_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, col, rev, n_edges, rev);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// nnhip_graph_fill_cells + pair ids + edge embedding in two launches (pair_ptr from nnhip_graph_count_cells_pairs, scanned by
+// nnhip_graph_pair_scan): the cell-list counterpart of nnhip_graph_finish
+extern "C" int nnhip_graph_finish_cells(const float* pos, const float* cell, int32_t n_atoms, int32_t n_edges, float cutoff,
+                                        const float* box_len_host, void* scratch, const int32_t* row_ptr, const int32_t* pair_ptr,
+                                        int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
+                                        const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
+                                        int32_t envelope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms <= 0 || n_edges < 0 || !scratch || !pair_ptr || n_basis < 1 || n_basis > NNHIP_MAX_NB ||
+      (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_graph_finish_cells: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  CellGrid g;
+  int *bin_of, *bin_ptr, *cursor, *bin_atoms;
+  const int rc = cells_common(pos, n_atoms, box_len_host, cutoff, scratch, g, bin_of, bin_ptr, cursor, bin_atoms, false, stream);
+  if (rc) return rc;
+  cells_fill_wave_kernel<<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, bin_of, bin_ptr, bin_atoms, g, n_atoms, cut2_of(cutoff), row_ptr,
+                                                               col, rev, disp, edge_index, n_edges);
+  LAUNCH_CHECK();
+  edge_finish_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, pair_ptr, col, rev, n_edges, rev, pid, disp, cutoff,
+                                                             cut2_of(cutoff), envelope ? envelope : 9, frequencies, n_basis, geo,
+                                                             rbf, drbf, reinterpret_cast<int2*>(xg));
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

@@ -145,6 +145,8 @@ def lib():
     L.nnhip_graph_fill.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp]
     L.nnhip_graph_count_pairs.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     L.nnhip_graph_pair_scan.argtypes = [vp, i32, vp, vp]
+    L.nnhip_graph_count_cells_pairs.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp, vp]
+    L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
@@ -226,7 +228,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh'):
+               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -249,7 +251,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
                     'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
-                    'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh')
+                    'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
+                    'nnhip_graph_finish_cells')
 
 
 def _check(rc: int, what: str):
@@ -338,8 +341,8 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     if box is not None:
         scratch = torch.empty(L.nnhip_graph_cells_scratch_bytes(N, box, float(cutoff)), dtype=torch.uint8, device=dev)
         status[:1].zero_()
-        _check(L.nnhip_graph_count_cells(_ptr(pos), _ptr(cell), N, float(cutoff), box, _ptr(scratch), _ptr(g.mol_ptr),
-                                         _ptr(g.row_ptr), st), 'nnhip_graph_count_cells')
+        _check(L.nnhip_graph_count_cells_pairs(_ptr(pos), _ptr(cell), N, float(cutoff), box, _ptr(scratch), _ptr(g.mol_ptr),
+                                               _ptr(g.row_ptr), _ptr(g.pair_ptr), st), 'nnhip_graph_count_cells_pairs')
     else:   # (the count pass also takes the per-row pair counts: the pair ids then need no pass of their own after the sync)
         _check(L.nnhip_graph_count_pairs(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
                                          _ptr(g.row_ptr), _ptr(status), _ptr(g.pair_ptr), st), 'nnhip_graph_count_pairs')
@@ -353,14 +356,13 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         tail_host.copy_(tail_dev, non_blocking=True)          # queue the read-back first ...
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        if box is None:                                        # ... then work that does not need the edge count: the pair scan,
-            _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
+        # ... then work that does not need the edge count: the pair scan,
+        _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
         while_waiting()                                        # the caller's (parameter preparation), then wait for the copy only
         ev.synchronize()
         tail = tail_host.tolist()
     else:
-        if box is None:
-            _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
+        _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
         tail = tail_dev.tolist()  # (E, status): the one device->host sync of the path
     E, bad = int(tail[0]), int(tail[1])
     if bad & 1:
@@ -387,13 +389,10 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         if E == 0:
             g.pair_ptr.zero_()
     else:
-        _check(L.nnhip_graph_fill_cells(_ptr(pos), _ptr(cell), N, E, float(cutoff), box, _ptr(scratch), _ptr(g.row_ptr),
-                                        _ptr(g.col), _ptr(g.rev), _ptr(g.disp), _ptr(g.edge_index), st),
-               'nnhip_graph_fill_cells')
-        _check(L.nnhip_graph_pairs(_ptr(g.row_ptr), _ptr(g.col), _ptr(g.rev), N, E, _ptr(g.pair_ptr), _ptr(g.pid),
-                                   _ptr(pair_scan), st), 'nnhip_graph_pairs')
-        _check(L.nnhip_edge_embed(_ptr(g.disp), E, float(cutoff), _ptr(freq), nb, _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf),
-                                  _ptr(g.xg), g.envelope, st), 'nnhip_edge_embed')
+        _check(L.nnhip_graph_finish_cells(_ptr(pos), _ptr(cell), N, E, float(cutoff), box, _ptr(scratch), _ptr(g.row_ptr),
+                                          _ptr(g.pair_ptr), _ptr(g.col), _ptr(g.rev), _ptr(g.pid), _ptr(g.disp), _ptr(g.edge_index),
+                                          _ptr(freq), nb, _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st),
+               'nnhip_graph_finish_cells')
     return g
 
 
