@@ -138,16 +138,13 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
 //   g_phi1[p]   = sum_k (gf[i][k] - gf[j][k]) u_e[k]                      -> g_h12[p][0:F]   (feeds the MLP adjoint)
 //   g_phi2[p]   = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]     -> g_h12[p][F:2F]
 // ---------------------------------------------------------------------------------------------
-// OWNER_GU (rev != NULL; the inference sweep): the row that owns a pair also forms the OTHER direction's g_u -- it holds gf[j] and
-// phi1[p] anyway -- and writes it to g_u[rev e]; the other endpoint then never reads phi1 (one of its two pair-row reads; none at
-// all in the first layer, whose non-owned half disappears).  Same operands, same reduction: bit-identical g_u.
-template <bool HAS_F, bool OWNER_GU>
+template <bool HAS_F>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
                  float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms,
-                 const int2* __restrict__ xg, const int* __restrict__ rev) {
+                 const int2* __restrict__ xg) {
   const int i = wave_row(gridDim.x);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
@@ -162,17 +159,18 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   }
   const int beg = row_ptr[i], end = row_ptr[i + 1];
   const int mid = row_mid(col, beg, end, i, lane);
-  // [beg, mid): pairs owned by the other endpoint -- g_u (unless the owner forms it) and the phi2 gather only
-  for (int e = beg; e < ((OWNER_GU && !HAS_F) ? beg : mid); e += 2) {
+  // [beg, mid): pairs owned by the other endpoint -- g_u and the phi2 gather only
+  for (int e = beg; e < mid; e += 2) {
     const int e1 = min(e + 1, mid - 1);
     const int p0 = pid[e], p1 = pid[e1];
     const int eh = hi ? e1 : e;
     const size_t p = (size_t)(hi ? p1 : p0);
     const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;   // (see force_fwd_kernel: candidates outside the cutoff contribute nothing)
-    if (!OWNER_GU && (!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
+    if ((!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
       reinterpret_cast<float4*>(g_u)[eh] = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((!hi || e + 1 < mid) && inside) {
+      const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
       float4 gfj[3];
       if (HAS_F) {
         const int j0 = col[e], j1 = col[e1];
@@ -184,13 +182,10 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
           acc[k] = fma4(v2, gfj[k], acc[k]);
         }
       }
-      if (!OWNER_GU) {
-        const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
-        const float s0 = half_sum_top(dot4(gfi[0], v1));
-        const float s1 = half_sum_top(dot4(gfi[1], v1));
-        const float s2 = half_sum_top(dot4(gfi[2], v1));
-        if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
-      }
+      const float s0 = half_sum_top(dot4(gfi[0], v1));
+      const float s1 = half_sum_top(dot4(gfi[1], v1));
+      const float s2 = half_sum_top(dot4(gfi[2], v1));
+      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
     }
   }
   // [mid, end): pairs this row owns -- additionally the adjoints of the shared phi rows
@@ -206,19 +201,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const float4 g = hi ? g1 : g0;
     const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;
-    int er = 0;                          // the reverse edge (the other direction's g_u slot)
-    if (OWNER_GU) {
-      const int r0 = rev[e], r1 = rev[e1];
-      er = hi ? r1 : r0;
-    }
     if ((!hi || e + 1 < end) && !inside) {   // outside the cutoff: zero adjoints for the pair rows this row owns
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
       st4(g_h12 + p * 2 * NF + c4, zero);
       if (HAS_F) st4(g_h12 + p * 2 * NF + NF + c4, zero);
-      if ((lane & 31) == 31) {
-        reinterpret_cast<float4*>(g_u)[eh] = zero;
-        if (OWNER_GU) reinterpret_cast<float4*>(g_u)[er] = zero;
-      }
+      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = zero;
     }
     if ((!hi || e + 1 < end) && inside) {
       const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
@@ -244,12 +231,6 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
       const float s1 = half_sum_top(dot4(gfi[1], v1));
       const float s2 = half_sum_top(dot4(gfi[2], v1));
       if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
-      if (OWNER_GU) {   // the other direction's g_u = < gf[j][k], phi1[p] >
-        const float t0 = half_sum_top(dot4(gfj[0], v1));
-        const float t1 = half_sum_top(dot4(gfj[1], v1));
-        const float t2 = half_sum_top(dot4(gfj[2], v1));
-        if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[er] = make_float4(t0, t1, t2, 0.f);
-      }
     }
   }
   if (HAS_F) {
@@ -663,22 +644,17 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   return 0;
 }
 
-// rev (optional): the reverse-edge index; given, the owner of a pair writes both directions' g_u (OWNER_GU)
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* rev) {
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
-  const int2* x2 = reinterpret_cast<const int2*>(xg);
-  const dim3 grid(row_blocks(n_atoms)), block(64 * EDGE_ROWS);
-  if (has_f && rev)
-    force_bwd_kernel<true, true><<<grid, block, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, x2, rev);
-  else if (has_f)
-    force_bwd_kernel<true, false><<<grid, block, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, x2, nullptr);
-  else if (rev)
-    force_bwd_kernel<false, true><<<grid, block, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, x2, rev);
+  if (has_f)
+    force_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+                                                               g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_bwd_kernel<false, false><<<grid, block, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, x2, nullptr);
+    force_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+                                                                g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }
