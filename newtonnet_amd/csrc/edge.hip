@@ -51,7 +51,11 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
     const int2 gx = hi ? gx1 : gx0;
     if (!hi || e + 1 < end) {
       const FilterW fw = filter_weights(__int_as_float(gx.y));
+#ifdef EDGE_ABL_HALF_TABLE   // tooling (wrong results): what a pair-centric evaluation of eps could save at most
+      const float4 eps = jj > i ? filter_value(table, ABL_G(gx.x), c4, fw) : mi;
+#else
       const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
+#endif
       const float4 mj = ld4(m + (size_t)ABL_J(jj, i) * NF + c4);
       const float4 v = mul4(mul4(eps, mi), mj);
       if (ABL_ST(jj > i)) {   // the lower endpoint writes the shared pair row
@@ -285,7 +289,11 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
         const float4 gaj = ld4(g_a + (size_t)j * NF + c4);
         const float4 G = add4(add4(ld4p<EDGE_NT_GMSG != 0>(g_msg + p * NF + c4), gai), gaj);
         const FilterW fw = filter_weights(__int_as_float(gx.y));
+#ifdef EDGE_ABL_HALF_TABLE
+        const float4 eps = mi;
+#else
         const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
+#endif
         acc = fma4(mul4(G, eps), mj, acc);
       }
     }

@@ -38,6 +38,7 @@ __device__ __forceinline__ float4 ld4p(const float* p) {
 //   EDGE_ABL_PAIR   read the pair rows (phi / g_msg) from row i & 1023 instead of pid[e]
 //   EDGE_ABL_TABLE  read the filter table at row 0
 //   EDGE_ABL_STORE  drop the pair-row stores
+//   EDGE_ABL_HALF_TABLE  (edge.hip) no filter-table reads for the pairs the other endpoint owns
 #ifdef EDGE_ABL_SELF
 #define ABL_J(j, i) (i)
 #else
