@@ -258,7 +258,11 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] *= inv1;
         if (MODE == MODE_FWD) {
+#ifdef MLPS_ABL_NO_H   // tooling (wrong results downstream): the forward without its hidden-tile stores -- what recomputing h in the adjoint could save
+          if (false) {
+#else
           if (live || h_frag) {
+#endif
             float4* hp = h_frag ? reinterpret_cast<float4*>(p.H) + ((size_t)tile * 4 + nb) * 256 + lane
                                 : reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
             const int hs4 = h_frag ? 64 : 2;
