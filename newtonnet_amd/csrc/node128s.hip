@@ -30,10 +30,17 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                       // 0.298 ms per step for the six launches): the kernels are bound by their HBM streams, not the stage count
 #endif
 #define WIMG_PLANE (NF * NF * 2)             // one f16 plane of a weight image
+#ifndef NS_EARLY_MAX_TILES
+#define NS_EARLY_MAX_TILES 256               // up to one 32-row tile per CU the node kernels run their latency-oriented form
+#endif
 
 // ---- weight images ----------------------------------------------------------------------------------------------
-// src: fp32 [128][128] row-major (rows = output features of D^T = W . X^T).  dst: hi plane, lo plane ([out][k-slot] f16, slot
-// 16 T + 8 h + 4 j + c <-> input feature 16 T + 8 j + 4 h + c), then the inverse scale as one float.
+// src: fp32 [128][128] row-major (rows = output features of D^T = W . X^T).  dst: hi plane, lo plane, then the inverse scale as one
+// float.  A plane is stored in FRAGMENT order: 32 blocks (output block nb, MFMA step T) of 1 KiB, lane 32 h + r of a block
+// holding the 8 f16 that lane feeds to MFMA T as the A operand of output row 32 nb + r (k-slots 16 T + 8 h .. + 7; slot
+// 16 T + 8 h + 4 j + c <-> input feature 16 T + 8 j + 4 h + c).  One fragment load of a wave is then 1 KiB contiguous -- 8 cache
+// lines; with the rows of a [out][k-slot] matrix it was 32 lines of which 32 bytes each were used, and the node kernels spent
+// ~1.1 us of address-unit time per matrix on it (5 matrices per launch; 8x the requests of the activations they stream).
 __device__ __forceinline__ void ns_pow2_scale(float m, float& S, float& inv) {
   const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
   const bool ok = e >= 40 && e < 255;
@@ -62,7 +69,8 @@ __global__ void __launch_bounds__(1024) weight_image_kernel(WeightImageJobs jobs
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = threadIdx.x + 1024 * q, o = idx >> 5, c = idx & 31;
-    const int off = 2 * (o * NF + (c >> 2) * 16 + (c & 1) * 8 + ((c >> 1) & 1) * 4);
+    // fragment (nb = o >> 5, T = c >> 2), lane 32 h + r (h = c & 1, r = o & 31), second half of the lane's 16 bytes when c & 2
+    const int off = ((((o >> 5) * 8 + (c >> 2)) * 64 + (c & 1) * 32 + (o & 31)) << 4) + ((c >> 1) & 1) * 8;
     const float s[4] = {v[q].x * S, v[q].y * S, v[q].z * S, v[q].w * S};
     h4 hi, lo;
 #pragma unroll
@@ -103,11 +111,11 @@ struct WFrag {
 
 // A fragments of output block nb (rows nb*32 + r of the image), fetched one GEMM ahead like node128.hip:load_w
 __device__ __forceinline__ void load_wimg(WFrag& w, const STile& t, const char* __restrict__ img) {
-  const char* p = img + ((size_t)(t.nb * 32 + t.r) * NF + 8 * t.h) * 2;
+  const char* p = img + ((size_t)(t.nb * 8 * 64 + t.h * 32 + t.r) << 4);
 #pragma unroll
   for (int T = 0; T < 8; ++T) {
-    w.hi[T] = *reinterpret_cast<const h8*>(p + 32 * T);
-    w.lo[T] = *reinterpret_cast<const h8*>(p + WIMG_PLANE + 32 * T);
+    w.hi[T] = *reinterpret_cast<const h8*>(p + 1024 * T);
+    w.lo[T] = *reinterpret_cast<const h8*>(p + WIMG_PLANE + 1024 * T);
   }
   w.inv = *reinterpret_cast<const float*>(img + 2 * WIMG_PLANE);
   __builtin_amdgcn_sched_barrier(0);
@@ -199,6 +207,23 @@ __device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restri
   for (int q = 0; q < 4; ++q) p[2 * q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+#ifdef NS_CLOCK_DEBUG   // tooling: wall-clock (100 MHz) and shader-clock stamps around every GEMM of one workgroup
+#define NS_DBG_INIT() long long dbg_w[16], dbg_c[16]; int dbg_n = 0; dbg_w[0] = wall_clock64(); dbg_c[0] = clock64(); dbg_n = 1;
+#define NS_DBG_STAMP() if (dbg_n < 16) { dbg_w[dbg_n] = wall_clock64(); dbg_c[dbg_n] = clock64(); ++dbg_n; }
+#define NS_DBG_PRINT(tag)                                                                                      \
+  NS_DBG_STAMP()                                                                                               \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                                                   \
+    printf(tag " start %lld:", dbg_w[0]);                                                                      \
+    for (int k_ = 1; k_ < dbg_n; ++k_)                                                                         \
+      printf(" +%.2fus(%.2fGHz)", (dbg_w[k_] - dbg_w[k_ - 1]) / 100.0,                                         \
+             (dbg_c[k_] - dbg_c[k_ - 1]) / ((dbg_w[k_] - dbg_w[k_ - 1]) * 10.0 + 1e-9));                        \
+    printf("  end %lld\n", dbg_w[dbg_n - 1]);                                                                  \
+  }
+#else
+#define NS_DBG_INIT()
+#define NS_DBG_STAMP()
+#define NS_DBG_PRINT(tag)
+#endif
 #define NS_TILE_SETUP()                                                      \
   __shared__ __attribute__((aligned(16))) char lds[(NS_MERGE3 ? 3 : 1) * NS_LDS_BYTES]; \
   STile t;                                                                   \
@@ -212,10 +237,17 @@ __device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restri
   const bool live = row < p.N;
 
 // equiv_update + energy update + the next layer's message_nodepart (or the first two linears of the energy head)
-__global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
+// EARLY (grids of at most one workgroup per CU: single molecules, MD steps, small training batches -- a launch is then a chain
+// of dependent L2 round trips, not a bandwidth problem): a second fragment set, so that every weight matrix is requested at
+// least one whole stage before its GEMM instead of right behind the previous one.
+template <bool EARLY_>
+__global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
+  constexpr bool EARLY = EARLY_ && !NS_MERGE3;
+  NS_DBG_INIT()
   NS_TILE_SETUP()
-  WFrag wf;
+  WFrag wf, wfb;
   load_wimg(wf, t, im.Wu);
+  if (EARLY && p.W0) load_wimg(wfb, t, im.W0);
   float upd[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) upd[k] = 0.f;
@@ -253,8 +285,15 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(x2[k], qv[k], upd[k]);
   }
 #else
-  float xa[16], xb[16];
+  float xa[16], xb[16], b0v[16], b2v[16];
   sblk_load(xa, p.f, ((size_t)rc * 3 + 0) * NF, t);
+  if (EARLY) {   // every input that does not depend on this launch's own results is requested now: a first touch costs ~2 us here
+    sblk_load(a, p.a_mid, (size_t)rc * NF, t);
+    if (p.W0) {
+      sblk_load(b0v, p.b0, 0, t);
+      sblk_load(b2v, p.b2, 0, t);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float (&cur)[16] = (c & 1) ? xb : xa;
@@ -266,11 +305,15 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
     __syncthreads();
     if (c < 2)
       sblk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
-    else
+    else if (!EARLY)
       sblk_load(a, p.a_mid, (size_t)rc * NF, t);
+    NS_DBG_STAMP()
     tile_gemm_s(qv, t, wf, inv);
-    if (c == 2 && p.W0) load_wimg(wf, t, im.W0);
+    NS_DBG_STAMP()
+    if (c == 2 && p.W0) load_wimg(wf, t, EARLY ? im.W2 : im.W0);
+    if (c == 2) { NS_DBG_STAMP() }
     if (live) sblk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
+    if (c == 2) { NS_DBG_STAMP() }
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
@@ -279,16 +322,27 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
   for (int k = 0; k < 16; ++k) a[k] += upd[k];
   if (live) sblk_store(a, p.a_out, (size_t)row * NF, t);
   if (!p.W0) return;
+  NS_DBG_STAMP()
 
   // message_nodepart of the next layer
   tile_publish(a, t);
   __syncthreads();
+  NS_DBG_STAMP()
   float inv = tile_commit(a, t);
   __syncthreads();
-  float hn[16], b0v[16], b2v[16];
-  sblk_load(b0v, p.b0, 0, t);
-  tile_gemm_s(hn, t, wf, inv);
-  load_wimg(wf, t, im.W2);
+  float hn[16];
+#if NS_MERGE3
+  float b0v[16], b2v[16];
+#endif
+  if (!EARLY) sblk_load(b0v, p.b0, 0, t);
+  NS_DBG_STAMP()
+  if (EARLY) {
+    tile_gemm_s(hn, t, wfb, inv);
+    NS_DBG_STAMP()
+  } else {
+    tile_gemm_s(hn, t, wf, inv);
+    load_wimg(wf, t, im.W2);
+  }
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
   if (live) sblk_store(hn, p.hn, (size_t)row * NF, t);
@@ -298,24 +352,49 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
   __syncthreads();
   inv = tile_commit(hn, t);
   __syncthreads();
-  sblk_load(b2v, p.b2, 0, t);
+  if (!EARLY) sblk_load(b2v, p.b2, 0, t);
   float m[16];
+  NS_DBG_STAMP()
   tile_gemm_s(m, t, wf, inv);
+  NS_DBG_STAMP()
 #pragma unroll
   for (int k = 0; k < 16; ++k) m[k] += b2v[k];
   if (live) sblk_store(m, p.m, (size_t)row * NF, t);
+  NS_DBG_PRINT("node_fwd")
 }
 
 // adjoint of the upper node MLP / head, then of the lower layer's update (see node128.hip:node_bwd_kernel)
 #ifndef NS_WG_PER_CU_BWD
 #define NS_WG_PER_CU_BWD NS_WG_PER_CU
 #endif
-__global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
+template <bool EARLY_>
+__global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU_BWD) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
+  constexpr bool EARLY = EARLY_ && !NS_MERGE3;
   NS_TILE_SETUP()
   float ga[16];
-  WFrag wf;
+  WFrag wf, wfb;
+  // EARLY: every input of the launch is requested before the first stage (the GEMM chain below then never waits for a first
+  // touch: ~2 us each on a grid this small)
+  float fe[3][16], qe[3][16], ge[3][16], olde[16];
+  if (EARLY) {
+    if (p.W2T) {
+      load_wimg(wf, t, im.W2T);
+      load_wimg(wfb, t, im.W0T);
+      if (p.acc_ga) sblk_load(olde, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
+    } else {
+      if (p.WuT) load_wimg(wf, t, im.WuT);
+    }
+    if (p.WuT) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        sblk_load(fe[c], p.f, ((size_t)rc * 3 + c) * NF, t);
+        sblk_load(qe[c], p.q, ((size_t)rc * 3 + c) * NF, t);
+        if (p.G_f) sblk_load(ge[c], p.G_f, ((size_t)rc * 3 + c) * NF, t);
+      }
+    }
+  }
   if (p.W2T) {
-    load_wimg(wf, t, im.W2T);
+    if (!EARLY) load_wimg(wf, t, im.W2T);
     float x[16], hpre[16], g[16];
     sblk_load(x, p.g_top, (size_t)rc * NF, t);
     sblk_load(hpre, p.h_top, (size_t)rc * NF, t);
@@ -324,7 +403,10 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
     float inv = tile_commit(x, t);
     __syncthreads();
     tile_gemm_s(g, t, wf, inv);
-    load_wimg(wf, t, im.W0T);
+    if (!EARLY)
+      load_wimg(wf, t, im.W0T);
+    else if (p.WuT)
+      load_wimg(wf, t, im.WuT);   // (the W2T fragments are consumed)
     if (p.T && live) sblk_store(g, p.T, (size_t)row * NF, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
@@ -332,18 +414,27 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
     __syncthreads();
     inv = tile_commit(g, t);
     __syncthreads();
-    tile_gemm_s(ga, t, wf, inv);
-    if (p.WuT) load_wimg(wf, t, im.WuT);
+    if (EARLY) {
+      tile_gemm_s(ga, t, wfb, inv);
+    } else {
+      tile_gemm_s(ga, t, wf, inv);
+      if (p.WuT) load_wimg(wf, t, im.WuT);
+    }
     if (p.acc_ga) {
-      float old[16];
-      sblk_load(old, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
+      if (EARLY) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) ga[k] += old[k];
+        for (int k = 0; k < 16; ++k) ga[k] += olde[k];
+      } else {
+        float old[16];
+        sblk_load(old, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ga[k] += old[k];
+      }
     }
     if (live) sblk_store(ga, p.g_a, (size_t)row * NF, t);
   } else {
     sblk_load(ga, p.g_a, (size_t)rc * NF, t);
-    if (p.WuT) load_wimg(wf, t, im.WuT);
+    if (!EARLY && p.WuT) load_wimg(wf, t, im.WuT);
   }
   if (!p.WuT) return;
 
@@ -387,6 +478,27 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
     }
   }
 #else
+  if (EARLY) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float out[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) fe[c][k] *= ga[k];
+      tile_publish(fe[c], t);
+      __syncthreads();
+      const float inv = tile_commit(fe[c], t);
+      __syncthreads();
+      tile_gemm_s(out, t, wf, inv);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qe[c][k], out[k]);
+      if (p.G_f) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] += ge[c][k];
+      }
+      if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
+    }
+    return;
+  }
   float fa[16], fb[16];
   sblk_load(fa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
@@ -572,7 +684,10 @@ int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_
   if (a.N <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1(TC_LIN1, s);
-  node_fwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  if (cdiv(a.N, 32) <= NS_EARLY_MAX_TILES)
+    node_fwd_split_kernel<true><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  else
+    node_fwd_split_kernel<false><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
   LAUNCH_CHECK();
   return 0;
 }
@@ -580,7 +695,10 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
   if (a.N <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1(TC_LIN1, s);
-  node_bwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  if (cdiv(a.N, 32) <= NS_EARLY_MAX_TILES)
+    node_bwd_split_kernel<true><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  else
+    node_bwd_split_kernel<false><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
   LAUNCH_CHECK();
   return 0;
 }
@@ -590,23 +708,33 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
 // products: the weights come as prepared images (MlpArgs::W1_img / W2_img).  The single-molecule / MD-loop and small-batch
 // training regimes are chains of these launches; a GEMM stage is 24 MFMAs of 32 cycles instead of 64 of 64.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t) {
+// EARLY (grids of at most one tile per CU, NS_EARLY_MAX_TILES): wf / wf2 arrive loaded with the fragments of W1 / W2, both
+// requested before anything else -- a launch of this form is a chain of dependent L2 round trips, and the weights are the part of
+// it that does not depend on the previous launch; when `next` is given, each is refilled with the next MLP's matrix as soon as
+// its GEMM has consumed it.  Otherwise one fragment set (wf arrives with W1, W2 follows behind the first GEMM): 60 registers
+// less, three workgroups per CU.
+template <int MODE, bool EARLY>
+__device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t, WFrag& wf, WFrag& wf2,
+                                                    const MlpArgs* next, float (&x)[16], float (&hin)[16], const bool preloaded) {
   const int row = blockIdx.x * 32 + t.r;
   const int rc = min(row, p.M - 1);
   const bool live = row < p.M;
 
-  WFrag wf;
-  load_wimg(wf, t, p.W1_img);
-  float x[16], hv[16], hin[16];
-  sblk_load(x, p.X, (size_t)rc * p.ldx, t);
-  if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
+  float hv[16];
+  if (!preloaded) {   // (EARLY with `next`: the previous body requested this one's rows as soon as its own were consumed)
+    sblk_load(x, p.X, (size_t)rc * p.ldx, t);
+    if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
+  }
   tile_publish(x, t);
   __syncthreads();
   float inv = tile_commit(x, t);
   __syncthreads();
+  if (EARLY && next) sblk_load(x, next->X, (size_t)min(row, next->M - 1) * next->ldx, t);
   tile_gemm_s(hv, t, wf, inv);
-  load_wimg(wf, t, p.W2_img);
+  if (!EARLY)
+    load_wimg(wf, t, p.W2_img);
+  else if (next)
+    load_wimg(wf, t, next->W1_img);
   if (MODE == MODE_FWD) {
     if (p.b1) {
       float b[16];
@@ -629,12 +757,19 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
 #pragma unroll
     for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
   }
+  if (EARLY && next && MODE != MODE_FWD) sblk_load(hin, next->H, (size_t)min(row, next->M - 1) * next->ldh, t);
   tile_publish(hv, t);
   __syncthreads();
   inv = tile_commit(hv, t);
   __syncthreads();
   float y[16];
-  tile_gemm_s(y, t, wf, inv);
+  if (EARLY) {
+    tile_gemm_s(y, t, wf2, inv);
+    if (next) load_wimg(wf2, t, next->W2_img);
+  } else {
+    tile_gemm_s(y, t, wf, inv);
+    if (next) load_wimg(wf, t, next->W1_img);
+  }
   if (MODE == MODE_FWD && p.b2) {
     float b[16];
     sblk_load(b, p.b2, 0, t);
@@ -659,32 +794,49 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
   t.h = (threadIdx.x >> 5) & 1;                                              \
   t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-template <int MODE, bool ACCUM>
+template <int MODE, bool ACCUM, bool EARLY>
 __global__ void __launch_bounds__(256) mlp128_wide_split_kernel(const MlpArgs p) {
   NS_STILE_SETUP()
-  mlp_wide_split_body<MODE>(p, ACCUM, t);
+  WFrag wf, wf2;
+  load_wimg(wf, t, p.W1_img);
+  if (EARLY) load_wimg(wf2, t, p.W2_img);
+  float x[16], hin[16];
+  mlp_wide_split_body<MODE, EARLY>(p, ACCUM, t, wf, wf2, nullptr, x, hin, false);
 }
 // two MLPs over the same rows in one launch (node128.hip:mlp128_wide_pair_kernel)
-template <int MODE, bool PAR>
+template <int MODE, bool PAR, bool EARLY>
 __global__ void __launch_bounds__(256) mlp128_wide_pair_split_kernel(const MlpPair P) {
   NS_STILE_SETUP()
+  WFrag wf, wf2;
+  float x[16], hin[16];
   if (PAR) {
-    if (blockIdx.y == 0)
-      mlp_wide_split_body<MODE>(P.a[0], false, t);
-    else
-      mlp_wide_split_body<MODE>(P.a[1], false, t);
+    if (blockIdx.y == 0) {
+      load_wimg(wf, t, P.a[0].W1_img);
+      if (EARLY) load_wimg(wf2, t, P.a[0].W2_img);
+      mlp_wide_split_body<MODE, EARLY>(P.a[0], false, t, wf, wf2, nullptr, x, hin, false);
+    } else {
+      load_wimg(wf, t, P.a[1].W1_img);
+      if (EARLY) load_wimg(wf2, t, P.a[1].W2_img);
+      mlp_wide_split_body<MODE, EARLY>(P.a[1], false, t, wf, wf2, nullptr, x, hin, false);
+    }
   } else {
-    mlp_wide_split_body<MODE>(P.a[0], false, t);
+    load_wimg(wf, t, P.a[0].W1_img);
+    if (EARLY) load_wimg(wf2, t, P.a[0].W2_img);
+    mlp_wide_split_body<MODE, EARLY>(P.a[0], false, t, wf, wf2, &P.a[1], x, hin, false);
     __syncthreads();
-    mlp_wide_split_body<MODE>(P.a[1], P.accum[1] != 0, t);
+    mlp_wide_split_body<MODE, EARLY>(P.a[1], P.accum[1] != 0, t, wf, wf2, nullptr, x, hin, EARLY);
   }
 }
 
 int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   const int n_tiles = cdiv(a.M, 32);
+  const bool early = n_tiles <= NS_EARLY_MAX_TILES;
 #define WIDE_S(M_, A_)                                                       \
   if (mode == M_ && accum == A_) {                                           \
-    mlp128_wide_split_kernel<M_, A_><<<n_tiles, 256, 0, s>>>(a);             \
+    if (early)                                                               \
+      mlp128_wide_split_kernel<M_, A_, true><<<n_tiles, 256, 0, s>>>(a);     \
+    else                                                                     \
+      mlp128_wide_split_kernel<M_, A_, false><<<n_tiles, 256, 0, s>>>(a);    \
     LAUNCH_CHECK();                                                          \
     return 0;                                                                \
   }
@@ -701,14 +853,19 @@ int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s)
 int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s) {
   const int n_tiles = cdiv(P.a[0].M, 32);
   const bool par = !P.accum[1];
-#define WIDE_PAIR_S(M_)                                                                  \
-  if (mode == M_) {                                                                      \
-    if (par)                                                                             \
-      mlp128_wide_pair_split_kernel<M_, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);       \
-    else                                                                                 \
-      mlp128_wide_pair_split_kernel<M_, false><<<n_tiles, 256, 0, s>>>(P);               \
-    LAUNCH_CHECK();                                                                      \
-    return 0;                                                                            \
+  const bool early = n_tiles * (par ? 2 : 1) <= NS_EARLY_MAX_TILES;
+#define WIDE_PAIR_S(M_)                                                                           \
+  if (mode == M_) {                                                                               \
+    if (par && early)                                                                             \
+      mlp128_wide_pair_split_kernel<M_, true, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);          \
+    else if (par)                                                                                 \
+      mlp128_wide_pair_split_kernel<M_, true, false><<<dim3(n_tiles, 2), 256, 0, s>>>(P);         \
+    else if (early)                                                                               \
+      mlp128_wide_pair_split_kernel<M_, false, true><<<n_tiles, 256, 0, s>>>(P);                  \
+    else                                                                                          \
+      mlp128_wide_pair_split_kernel<M_, false, false><<<n_tiles, 256, 0, s>>>(P);                 \
+    LAUNCH_CHECK();                                                                               \
+    return 0;                                                                                     \
   }
   WIDE_PAIR_S(MODE_FWD)
   WIDE_PAIR_S(MODE_BWD)

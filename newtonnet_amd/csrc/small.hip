@@ -80,11 +80,11 @@ __device__ __forceinline__ void wg_gemm(const float* X, int ldx, const char* img
     f32x16 acc;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-    const char* wp = img + ((size_t)(nb * 32 + r) * NF + 8 * h) * 2;
+    const char* wp = img + ((size_t)(nb * 8 * 64 + h * 32 + r) << 4);   // fragment order (node128s.hip:weight_image_kernel)
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
-      const h8 ah = *reinterpret_cast<const h8*>(wp + 32 * T);
-      const h8 al = *reinterpret_cast<const h8*>(wp + SM_WIMG_PLANE + 32 * T);
+      const h8 ah = *reinterpret_cast<const h8*>(wp + 1024 * T);
+      const h8 al = *reinterpret_cast<const h8*>(wp + SM_WIMG_PLANE + 1024 * T);
       float4 x0 = xp[4 * T], x1 = xp[4 * T + 2];
       if (PRO == SPRO_ACT) {
         x0 = make_float4(silu_f(x0.x), silu_f(x0.y), silu_f(x0.z), silu_f(x0.w));
