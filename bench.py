@@ -282,6 +282,13 @@ def _profile_table(path):
     return rows, notes
 
 
+def _profile_order(path):
+    """profiles are named r<round>_v<pass>_...: order by the two numbers (r03_v14 after r03_v9)"""
+    import re
+    m = re.match(r'r(\d+)_v(\d+)', os.path.basename(path))
+    return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+
 def _largest_grid(grids):
     """the config-2 batch's launches of a kernel: the row with the most workgroups (summaries that also hold the small
     training-leg launches of the same kernels list them under their own, smaller grids)"""
@@ -301,9 +308,9 @@ def pmc_traffic(kernels):
     kernel (the config-2 batch) counts.  Returns ({kernel row name: (launches, bytes per launch)}, source) or (None, None)."""
     import glob
     def keep(f):      # the config-2 inference passes only
-        return not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved'))
-    fetch = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')) if keep(f))
-    write = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')) if keep(f))
+        return not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_'))
+    fetch = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')) if keep(f)), key=_profile_order)
+    write = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')) if keep(f)), key=_profile_order)
     if not fetch or not write:
         return None, None
     (tf, notes), (tw, _) = _profile_table(fetch[-1]), _profile_table(write[-1])
@@ -332,8 +339,8 @@ def rocprof_classes():
     un-instrumented durations of the same kernels.  `other` and the total are only formed for summaries taken with
     --no-train-leg (header note), where every row belongs to the inference step."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.txt')))
-    files = [f for f in files if not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved'))]   # the config-2 inference passes only
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.txt')), key=_profile_order)
+    files = [f for f in files if not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_'))]   # the config-2 inference passes only
     if not files:
         return None
     rows, notes = _profile_table(files[-1])

@@ -5,8 +5,8 @@
 // as two scaled f16 pieces, hi_a hi_b + hi_a lo_b + lo_a hi_b on v_mfma_f32_32x32x16_f16 with fp32 accumulation (5.3x less
 // matrix-pipe time than the v_mfma_f32_32x32x2_f32 chain, and closer to fp64).
 //   weights : f16 (hi, lo) images prepared once per parameter set (weight_image_kernel; pipeline.hip keeps them in the
-//             prepared block), scaled per matrix, k-slots permuted to the fragment order -- a wave's A fragments of one GEMM are 16
-//             16-byte loads per lane, as before;
+//             prepared block), scaled per matrix, stored in MFMA fragment order -- a wave's A fragments of one GEMM are 16
+//             16-byte loads per lane, each a contiguous 1 KiB of the image;
 //   rows    : scaled per row by the largest magnitude of the row.  A row's 128 values live in 8 lanes of 4 waves: each lane
 //             publishes the maximum of its 16 values in LDS BEFORE the barrier that already separates two uses of the tile, so the
 //             exchange costs no extra barrier; the (hi, lo) pieces are written to the LDS tile in fragment order.
@@ -30,9 +30,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                       // 0.298 ms per step for the six launches): the kernels are bound by their HBM streams, not the stage count
 #endif
 #define WIMG_PLANE (NF * NF * 2)             // one f16 plane of a weight image
-#ifndef NS_EARLY_MAX_TILES
-#define NS_EARLY_MAX_TILES 256               // up to one 32-row tile per CU the node kernels run their latency-oriented form
-#endif
 
 // ---- weight images ----------------------------------------------------------------------------------------------
 // src: fp32 [128][128] row-major (rows = output features of D^T = W . X^T).  dst: hi plane, lo plane, then the inverse scale as one
@@ -237,17 +234,11 @@ __device__ __forceinline__ void sblk_store(const float (&v)[16], float* __restri
   const bool live = row < p.N;
 
 // equiv_update + energy update + the next layer's message_nodepart (or the first two linears of the energy head)
-// EARLY (grids of at most one workgroup per CU: single molecules, MD steps, small training batches -- a launch is then a chain
-// of dependent L2 round trips, not a bandwidth problem): a second fragment set, so that every weight matrix is requested at
-// least one whole stage before its GEMM instead of right behind the previous one.
-template <bool EARLY_>
-__global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
-  constexpr bool EARLY = EARLY_ && !NS_MERGE3;
+__global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const NodeFwdArgs p, const NodeImages im) {
   NS_DBG_INIT()
   NS_TILE_SETUP()
-  WFrag wf, wfb;
+  WFrag wf;
   load_wimg(wf, t, im.Wu);
-  if (EARLY && p.W0) load_wimg(wfb, t, im.W0);
   float upd[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) upd[k] = 0.f;
@@ -285,15 +276,8 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(x2[k], qv[k], upd[k]);
   }
 #else
-  float xa[16], xb[16], b0v[16], b2v[16];
+  float xa[16], xb[16];
   sblk_load(xa, p.f, ((size_t)rc * 3 + 0) * NF, t);
-  if (EARLY) {   // every input that does not depend on this launch's own results is requested now: a first touch costs ~2 us here
-    sblk_load(a, p.a_mid, (size_t)rc * NF, t);
-    if (p.W0) {
-      sblk_load(b0v, p.b0, 0, t);
-      sblk_load(b2v, p.b2, 0, t);
-    }
-  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     float (&cur)[16] = (c & 1) ? xb : xa;
@@ -305,15 +289,13 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split
     __syncthreads();
     if (c < 2)
       sblk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
-    else if (!EARLY)
+    else
       sblk_load(a, p.a_mid, (size_t)rc * NF, t);
     NS_DBG_STAMP()
     tile_gemm_s(qv, t, wf, inv);
     NS_DBG_STAMP()
-    if (c == 2 && p.W0) load_wimg(wf, t, EARLY ? im.W2 : im.W0);
-    if (c == 2) { NS_DBG_STAMP() }
+    if (c == 2 && p.W0) load_wimg(wf, t, im.W0);
     if (live) sblk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
-    if (c == 2) { NS_DBG_STAMP() }
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
@@ -322,27 +304,18 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split
   for (int k = 0; k < 16; ++k) a[k] += upd[k];
   if (live) sblk_store(a, p.a_out, (size_t)row * NF, t);
   if (!p.W0) return;
-  NS_DBG_STAMP()
 
   // message_nodepart of the next layer
   tile_publish(a, t);
   __syncthreads();
-  NS_DBG_STAMP()
   float inv = tile_commit(a, t);
   __syncthreads();
-  float hn[16];
-#if NS_MERGE3
-  float b0v[16], b2v[16];
-#endif
-  if (!EARLY) sblk_load(b0v, p.b0, 0, t);
+  float hn[16], b0v[16], b2v[16];
+  sblk_load(b0v, p.b0, 0, t);
   NS_DBG_STAMP()
-  if (EARLY) {
-    tile_gemm_s(hn, t, wfb, inv);
-    NS_DBG_STAMP()
-  } else {
-    tile_gemm_s(hn, t, wf, inv);
-    load_wimg(wf, t, im.W2);
-  }
+  tile_gemm_s(hn, t, wf, inv);
+  NS_DBG_STAMP()
+  load_wimg(wf, t, im.W2);
 #pragma unroll
   for (int k = 0; k < 16; ++k) hn[k] += b0v[k];
   if (live) sblk_store(hn, p.hn, (size_t)row * NF, t);
@@ -352,7 +325,7 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split
   __syncthreads();
   inv = tile_commit(hn, t);
   __syncthreads();
-  if (!EARLY) sblk_load(b2v, p.b2, 0, t);
+  sblk_load(b2v, p.b2, 0, t);
   float m[16];
   NS_DBG_STAMP()
   tile_gemm_s(m, t, wf, inv);
@@ -367,34 +340,12 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU) node_fwd_split
 #ifndef NS_WG_PER_CU_BWD
 #define NS_WG_PER_CU_BWD NS_WG_PER_CU
 #endif
-template <bool EARLY_>
-__global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU_BWD) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
-  constexpr bool EARLY = EARLY_ && !NS_MERGE3;
+__global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(const NodeBwdArgs p, const NodeImages im) {
   NS_TILE_SETUP()
   float ga[16];
-  WFrag wf, wfb;
-  // EARLY: every input of the launch is requested before the first stage (the GEMM chain below then never waits for a first
-  // touch: ~2 us each on a grid this small)
-  float fe[3][16], qe[3][16], ge[3][16], olde[16];
-  if (EARLY) {
-    if (p.W2T) {
-      load_wimg(wf, t, im.W2T);
-      load_wimg(wfb, t, im.W0T);
-      if (p.acc_ga) sblk_load(olde, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
-    } else {
-      if (p.WuT) load_wimg(wf, t, im.WuT);
-    }
-    if (p.WuT) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        sblk_load(fe[c], p.f, ((size_t)rc * 3 + c) * NF, t);
-        sblk_load(qe[c], p.q, ((size_t)rc * 3 + c) * NF, t);
-        if (p.G_f) sblk_load(ge[c], p.G_f, ((size_t)rc * 3 + c) * NF, t);
-      }
-    }
-  }
+  WFrag wf;
   if (p.W2T) {
-    if (!EARLY) load_wimg(wf, t, im.W2T);
+    load_wimg(wf, t, im.W2T);
     float x[16], hpre[16], g[16];
     sblk_load(x, p.g_top, (size_t)rc * NF, t);
     sblk_load(hpre, p.h_top, (size_t)rc * NF, t);
@@ -403,10 +354,7 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU_BWD) node_bwd_s
     float inv = tile_commit(x, t);
     __syncthreads();
     tile_gemm_s(g, t, wf, inv);
-    if (!EARLY)
-      load_wimg(wf, t, im.W0T);
-    else if (p.WuT)
-      load_wimg(wf, t, im.WuT);   // (the W2T fragments are consumed)
+    load_wimg(wf, t, im.W0T);
     if (p.T && live) sblk_store(g, p.T, (size_t)row * NF, t);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g[k] *= dsilu_f(hpre[k]);
@@ -414,27 +362,18 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU_BWD) node_bwd_s
     __syncthreads();
     inv = tile_commit(g, t);
     __syncthreads();
-    if (EARLY) {
-      tile_gemm_s(ga, t, wfb, inv);
-    } else {
-      tile_gemm_s(ga, t, wf, inv);
-      if (p.WuT) load_wimg(wf, t, im.WuT);
-    }
+    tile_gemm_s(ga, t, wf, inv);
+    if (p.WuT) load_wimg(wf, t, im.WuT);
     if (p.acc_ga) {
-      if (EARLY) {
+      float old[16];
+      sblk_load(old, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ga[k] += olde[k];
-      } else {
-        float old[16];
-        sblk_load(old, p.g_a_in ? p.g_a_in : p.g_a, (size_t)rc * NF, t);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) ga[k] += old[k];
-      }
+      for (int k = 0; k < 16; ++k) ga[k] += old[k];
     }
     if (live) sblk_store(ga, p.g_a, (size_t)row * NF, t);
   } else {
     sblk_load(ga, p.g_a, (size_t)rc * NF, t);
-    if (!EARLY && p.WuT) load_wimg(wf, t, im.WuT);
+    if (p.WuT) load_wimg(wf, t, im.WuT);
   }
   if (!p.WuT) return;
 
@@ -478,27 +417,6 @@ __global__ void __launch_bounds__(256, EARLY_ ? 1 : NS_WG_PER_CU_BWD) node_bwd_s
     }
   }
 #else
-  if (EARLY) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float out[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) fe[c][k] *= ga[k];
-      tile_publish(fe[c], t);
-      __syncthreads();
-      const float inv = tile_commit(fe[c], t);
-      __syncthreads();
-      tile_gemm_s(out, t, wf, inv);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) out[k] = fmaf(ga[k], qe[c][k], out[k]);
-      if (p.G_f) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) out[k] += ge[c][k];
-      }
-      if (live) sblk_store(out, p.gf, ((size_t)row * 3 + c) * NF, t);
-    }
-    return;
-  }
   float fa[16], fb[16];
   sblk_load(fa, p.f, ((size_t)rc * 3 + 0) * NF, t);
 #pragma unroll
@@ -684,10 +602,7 @@ int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_
   if (a.N <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1(TC_LIN1, s);
-  if (cdiv(a.N, 32) <= NS_EARLY_MAX_TILES)
-    node_fwd_split_kernel<true><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
-  else
-    node_fwd_split_kernel<false><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  node_fwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
   LAUNCH_CHECK();
   return 0;
 }
@@ -695,10 +610,7 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
   if (a.N <= 0) return 0;
   ScopedTimer t0(TC_LIN, s);
   ScopedTimer t1(TC_LIN1, s);
-  if (cdiv(a.N, 32) <= NS_EARLY_MAX_TILES)
-    node_bwd_split_kernel<true><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
-  else
-    node_bwd_split_kernel<false><<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
+  node_bwd_split_kernel<<<cdiv(a.N, 32), 256, 0, s>>>(a, im);
   LAUNCH_CHECK();
   return 0;
 }
@@ -708,33 +620,23 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
 // products: the weights come as prepared images (MlpArgs::W1_img / W2_img).  The single-molecule / MD-loop and small-batch
 // training regimes are chains of these launches; a GEMM stage is 24 MFMAs of 32 cycles instead of 64 of 64.
 // ---------------------------------------------------------------------------------------------------------------
-// EARLY (grids of at most one tile per CU, NS_EARLY_MAX_TILES): wf / wf2 arrive loaded with the fragments of W1 / W2, both
-// requested before anything else -- a launch of this form is a chain of dependent L2 round trips, and the weights are the part of
-// it that does not depend on the previous launch; when `next` is given, each is refilled with the next MLP's matrix as soon as
-// its GEMM has consumed it.  Otherwise one fragment set (wf arrives with W1, W2 follows behind the first GEMM): 60 registers
-// less, three workgroups per CU.
-template <int MODE, bool EARLY>
-__device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t, WFrag& wf, WFrag& wf2,
-                                                    const MlpArgs* next, float (&x)[16], float (&hin)[16], const bool preloaded) {
+template <int MODE>
+__device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t) {
   const int row = blockIdx.x * 32 + t.r;
   const int rc = min(row, p.M - 1);
   const bool live = row < p.M;
 
-  float hv[16];
-  if (!preloaded) {   // (EARLY with `next`: the previous body requested this one's rows as soon as its own were consumed)
-    sblk_load(x, p.X, (size_t)rc * p.ldx, t);
-    if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
-  }
+  WFrag wf;
+  load_wimg(wf, t, p.W1_img);
+  float x[16], hv[16], hin[16];
+  sblk_load(x, p.X, (size_t)rc * p.ldx, t);
+  if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
   tile_publish(x, t);
   __syncthreads();
   float inv = tile_commit(x, t);
   __syncthreads();
-  if (EARLY && next) sblk_load(x, next->X, (size_t)min(row, next->M - 1) * next->ldx, t);
   tile_gemm_s(hv, t, wf, inv);
-  if (!EARLY)
-    load_wimg(wf, t, p.W2_img);
-  else if (next)
-    load_wimg(wf, t, next->W1_img);
+  load_wimg(wf, t, p.W2_img);
   if (MODE == MODE_FWD) {
     if (p.b1) {
       float b[16];
@@ -757,19 +659,12 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
 #pragma unroll
     for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
   }
-  if (EARLY && next && MODE != MODE_FWD) sblk_load(hin, next->H, (size_t)min(row, next->M - 1) * next->ldh, t);
   tile_publish(hv, t);
   __syncthreads();
   inv = tile_commit(hv, t);
   __syncthreads();
   float y[16];
-  if (EARLY) {
-    tile_gemm_s(y, t, wf2, inv);
-    if (next) load_wimg(wf2, t, next->W2_img);
-  } else {
-    tile_gemm_s(y, t, wf, inv);
-    if (next) load_wimg(wf, t, next->W1_img);
-  }
+  tile_gemm_s(y, t, wf, inv);
   if (MODE == MODE_FWD && p.b2) {
     float b[16];
     sblk_load(b, p.b2, 0, t);
@@ -794,49 +689,32 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
   t.h = (threadIdx.x >> 5) & 1;                                              \
   t.nb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-template <int MODE, bool ACCUM, bool EARLY>
+template <int MODE, bool ACCUM>
 __global__ void __launch_bounds__(256) mlp128_wide_split_kernel(const MlpArgs p) {
   NS_STILE_SETUP()
-  WFrag wf, wf2;
-  load_wimg(wf, t, p.W1_img);
-  if (EARLY) load_wimg(wf2, t, p.W2_img);
-  float x[16], hin[16];
-  mlp_wide_split_body<MODE, EARLY>(p, ACCUM, t, wf, wf2, nullptr, x, hin, false);
+  mlp_wide_split_body<MODE>(p, ACCUM, t);
 }
 // two MLPs over the same rows in one launch (node128.hip:mlp128_wide_pair_kernel)
-template <int MODE, bool PAR, bool EARLY>
+template <int MODE, bool PAR>
 __global__ void __launch_bounds__(256) mlp128_wide_pair_split_kernel(const MlpPair P) {
   NS_STILE_SETUP()
-  WFrag wf, wf2;
-  float x[16], hin[16];
   if (PAR) {
-    if (blockIdx.y == 0) {
-      load_wimg(wf, t, P.a[0].W1_img);
-      if (EARLY) load_wimg(wf2, t, P.a[0].W2_img);
-      mlp_wide_split_body<MODE, EARLY>(P.a[0], false, t, wf, wf2, nullptr, x, hin, false);
-    } else {
-      load_wimg(wf, t, P.a[1].W1_img);
-      if (EARLY) load_wimg(wf2, t, P.a[1].W2_img);
-      mlp_wide_split_body<MODE, EARLY>(P.a[1], false, t, wf, wf2, nullptr, x, hin, false);
-    }
+    if (blockIdx.y == 0)
+      mlp_wide_split_body<MODE>(P.a[0], false, t);
+    else
+      mlp_wide_split_body<MODE>(P.a[1], false, t);
   } else {
-    load_wimg(wf, t, P.a[0].W1_img);
-    if (EARLY) load_wimg(wf2, t, P.a[0].W2_img);
-    mlp_wide_split_body<MODE, EARLY>(P.a[0], false, t, wf, wf2, &P.a[1], x, hin, false);
+    mlp_wide_split_body<MODE>(P.a[0], false, t);
     __syncthreads();
-    mlp_wide_split_body<MODE, EARLY>(P.a[1], P.accum[1] != 0, t, wf, wf2, nullptr, x, hin, EARLY);
+    mlp_wide_split_body<MODE>(P.a[1], P.accum[1] != 0, t);
   }
 }
 
 int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   const int n_tiles = cdiv(a.M, 32);
-  const bool early = n_tiles <= NS_EARLY_MAX_TILES;
 #define WIDE_S(M_, A_)                                                       \
   if (mode == M_ && accum == A_) {                                           \
-    if (early)                                                               \
-      mlp128_wide_split_kernel<M_, A_, true><<<n_tiles, 256, 0, s>>>(a);     \
-    else                                                                     \
-      mlp128_wide_split_kernel<M_, A_, false><<<n_tiles, 256, 0, s>>>(a);    \
+    mlp128_wide_split_kernel<M_, A_><<<n_tiles, 256, 0, s>>>(a);             \
     LAUNCH_CHECK();                                                          \
     return 0;                                                                \
   }
@@ -853,19 +731,14 @@ int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s)
 int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s) {
   const int n_tiles = cdiv(P.a[0].M, 32);
   const bool par = !P.accum[1];
-  const bool early = n_tiles * (par ? 2 : 1) <= NS_EARLY_MAX_TILES;
-#define WIDE_PAIR_S(M_)                                                                           \
-  if (mode == M_) {                                                                               \
-    if (par && early)                                                                             \
-      mlp128_wide_pair_split_kernel<M_, true, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);          \
-    else if (par)                                                                                 \
-      mlp128_wide_pair_split_kernel<M_, true, false><<<dim3(n_tiles, 2), 256, 0, s>>>(P);         \
-    else if (early)                                                                               \
-      mlp128_wide_pair_split_kernel<M_, false, true><<<n_tiles, 256, 0, s>>>(P);                  \
-    else                                                                                          \
-      mlp128_wide_pair_split_kernel<M_, false, false><<<n_tiles, 256, 0, s>>>(P);                 \
-    LAUNCH_CHECK();                                                                               \
-    return 0;                                                                                     \
+#define WIDE_PAIR_S(M_)                                                                  \
+  if (mode == M_) {                                                                      \
+    if (par)                                                                             \
+      mlp128_wide_pair_split_kernel<M_, true><<<dim3(n_tiles, 2), 256, 0, s>>>(P);       \
+    else                                                                                 \
+      mlp128_wide_pair_split_kernel<M_, false><<<n_tiles, 256, 0, s>>>(P);               \
+    LAUNCH_CHECK();                                                                      \
+    return 0;                                                                            \
   }
   WIDE_PAIR_S(MODE_FWD)
   WIDE_PAIR_S(MODE_BWD)
