@@ -295,7 +295,9 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU) node_fwd_split_kernel(const
     tile_gemm_s(qv, t, wf, inv);
     NS_DBG_STAMP()
     if (c == 2 && p.W0) load_wimg(wf, t, im.W0);
+#ifndef NS_ABL_NO_Q   // tooling (wrong forces): the update without its q = f W_u^T round trip -- what recomputing q in the adjoint could save at most
     if (live) sblk_store(qv, p.q, ((size_t)row * 3 + c) * NF, t);
+#endif
 #pragma unroll
     for (int k = 0; k < 16; ++k) upd[k] = fmaf(cur[k], qv[k], upd[k]);
   }
@@ -431,7 +433,12 @@ __global__ void __launch_bounds__(256, NS_WG_PER_CU_BWD) node_bwd_split_kernel(c
     const float inv = tile_commit(cur, t);
     __syncthreads();
     if (c < 2) sblk_load(nxt, p.f, ((size_t)rc * 3 + c + 1) * NF, t);
+#ifdef NS_ABL_NO_Q
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qv[k] = cur[k];
+#else
     sblk_load(qv, p.q, ((size_t)rc * 3 + c) * NF, t);
+#endif
     if (p.G_f) sblk_load(gin, p.G_f, ((size_t)rc * 3 + c) * NF, t);
     tile_gemm_s(out, t, wf, inv);
 #pragma unroll
