@@ -111,8 +111,13 @@ __device__ __forceinline__ void load_wimg(WFrag& w, const STile& t, const char* 
   const char* p = img + ((size_t)(t.nb * 8 * 64 + t.h * 32 + t.r) << 4);
 #pragma unroll
   for (int T = 0; T < 8; ++T) {
+#ifdef NS_ABL_HOT_W   // tooling (wrong results): every fragment from the first KiB of the image -- the price of streaming the weights from L2
+    w.hi[T] = *reinterpret_cast<const h8*>(img + ((t.h * 32 + t.r) << 4));
+    w.lo[T] = *reinterpret_cast<const h8*>(img + ((t.h * 32 + t.r) << 4));
+#else
     w.hi[T] = *reinterpret_cast<const h8*>(p + 1024 * T);
     w.lo[T] = *reinterpret_cast<const h8*>(p + WIMG_PLANE + 1024 * T);
+#endif
   }
   w.inv = *reinterpret_cast<const float*>(img + 2 * WIMG_PLANE);
   __builtin_amdgcn_sched_barrier(0);
