@@ -416,7 +416,8 @@ typedef struct {
 } nnhip_mlp_desc;
 int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
 /* Split-f16 image of a [128][128] fp32 matrix (rows = output features): two f16 planes (hi, lo) of the matrix scaled by a power
- * of two into the f16 range, k-slots in MFMA fragment order, then the inverse scale (csrc/node128s.hip).  `count` matrices in
+ * of two into the f16 range and stored fragment by fragment (1 KiB per (output block, MFMA step), lane-linear: the image is opaque to
+ * the caller), then the inverse scale (csrc/node128s.hip).  `count` matrices in
  * one launch; each image takes nnhip_weight_image_bytes() bytes, 256-byte aligned. */
 size_t nnhip_weight_image_bytes(void);
 int nnhip_weight_images(const float* const* src, void* const* images, int32_t count, void* stream);
