@@ -328,7 +328,7 @@ def pmc_traffic(kernels):
 EDGE_KERNELS = ('msg_fwd_kernel', 'force_fwd_kernel', 'force_bwd_kernel', 'msg_bwd_kernel')
 ROCPROF_CLASSES = {'edge_msg_fwd': ('msg_fwd_kernel',), 'edge_force_fwd': ('force_fwd_kernel',),
                    'edge_force_bwd': ('force_bwd_kernel',), 'edge_msg_bwd': ('msg_bwd_kernel',),
-                   'mlp128': ('mlp128s_kernel', 'mlp128_kernel'),
+                   'mlp128': ('mlp128s_kernel', 'mlp128_kernel', 'mlp_regw_kernel'),
                    'node': ('node_fwd_split_kernel', 'node_bwd_split_kernel', 'node_fwd_kernel', 'node_bwd_kernel')}
 
 
@@ -528,10 +528,15 @@ def main():
         # fp32 product from split-f16 pieces (3 f16 MFMAs per 16 k-values) and is bound by its HBM traffic; NNHIP_MLP_SPLIT=0:
         # mlp128_kernel on v_mfma_f32_32x32x2_f32, bound by the fp32 matrix pipe.
         split = hip.split_products()
-        # algorithmic HBM bytes of one MLP phase over P pair rows, in units of 512 P: forward X in + hidden, output out = 3;
-        # adjoint g_phi, hidden in + g_msg out = 3, + g_msg in when accumulating = 4.  Per step (3 layers, phi2 skipped in
-        # layer 0): 5 forward phases, 3 plain + 2 accumulating adjoint phases
-        mlp_bytes = (E // 2) * 512.0 * (5 * 3 + 3 * 3 + 2 * 4)
+        # algorithmic HBM bytes of the MLP launches over P pair rows, in units of 512 P.  Two-phase form (mlp128s_kernel): a forward
+        # phase moves X in + hidden, output out = 3; an adjoint phase g_phi, hidden in + g_msg out = 3, + g_msg in when
+        # accumulating = 4.  One-pass form (mlp_regw_kernel, csrc/mlp128r.hip: both MLPs of a layer per tile): forward msg in +
+        # h1, h2, phi1, phi2 out = 5 (instead of 6); adjoint g_phi1, g_phi2, h1, h2 in + g_msg out = 5 (instead of 7).
+        # Per step (3 layers, phi2 skipped in layer 0): layer 0 is one phase each way (3 + 3), layers 1-2 two MLPs each way.
+        regw = int(os.environ.get('NNHIP_MLP_REGW', '1')) if split else 0   # 1 (default): adjoint launches; 2: forward too
+        fwd_units = 3 + 2 * (5 if regw >= 2 else 6)
+        bwd_units = 3 + 2 * (5 if regw >= 1 else 7)
+        mlp_bytes = (E // 2) * 512.0 * (fwd_units + bwd_units)
         mlp_gbs = mlp_bytes / (mlp_ms * 1e-3) / 1e9 if mlp_ms > 0 else 0.0
         common = {'traffic': None, 'traffic_note': 'PMC passes are separate runs: profiles/*_pmc_{fetch,write}_size.txt',
                   'launches_per_step': mlp_n, 'avg_launch_us': round(1e3 * mlp_ms / mlp_n, 2),
@@ -540,8 +545,10 @@ def main():
                   'all_dense_kernels': {'achieved': round(lin_tf, 2), 'unit': 'useful fp32 TFLOP/s', 'ms_per_step': round(lin_ms, 4),
                                         'flops_per_step': lin_flops}}
         if split:
-            mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel (fused Linear-SiLU-Linear over pair rows, fwd + adjoint; split-f16 '
-                                              'products, fp32 accumulate)',
+            mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel' + (' / mlp_regw_kernel' if regw else '') +
+                                              ' (fused Linear-SiLU-Linear over pair rows, fwd + adjoint; split-f16 products, fp32 '
+                                              'accumulate' + ('; the two-MLP adjoint launches in the one-pass register-weights form' if regw == 1 else
+                                                              '; the two-MLP launches in the one-pass register-weights form' if regw >= 2 else '') + ')',
                     'achieved': round(mlp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(mlp_gbs / HBM_PEAK_GBS, 4),
                     'matrix_pipe': {'useful_fp32_tflops': round(mlp_tf, 2), 'executed_f16_tflops': round(3 * mlp_tf, 2),
                                     'peak_f16_tflops': MFMA_F16_PEAK_TFLOPS, 'frac': round(3 * mlp_tf / MFMA_F16_PEAK_TFLOPS, 4),
@@ -569,7 +576,7 @@ def main():
                                'frac_pair_bytes': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
         hbm['per_kernel'] = per_kernel
         if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
-            t, src = pmc_traffic(['mlp128s_kernel'] if split else ['mlp128_kernel'])
+            t, src = pmc_traffic(['mlp128s_kernel', 'mlp_regw_kernel'] if split else ['mlp128_kernel'])
             if t is not None:
                 n_l = sum(n for n, _ in t.values())
                 mfma['traffic'] = round(sum(n * b for n, b in t.values()) / n_l)

@@ -298,6 +298,9 @@ struct MlpPair {      // up to two MLPs over the same M rows, run back to back b
 };
 int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s);
 int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1, bool accum1, hipStream_t s);
+// mlp128r.hip: both MLPs of a layer in one pass over the rows, weights resident in registers (large batches, FWD / BWD, images given)
+bool mlp_regw_serves(int mode, const MlpPair& P);
+int launch_mlp_regw(int mode, const MlpPair& P, hipStream_t s);
 
 // ---- row-local fused node kernels (node128.hip) -------------------------------------
 struct NodeFwdArgs {

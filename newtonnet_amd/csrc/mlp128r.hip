@@ -1,0 +1,380 @@
+// The two edge MLPs of a layer (equiv_message1 / equiv_message2, newtonnet/models/newtonnet.py:188-197,218,222) and their adjoint
+// over the pair rows of a large batch, with the weights RESIDENT IN REGISTERS (gfx950, split-f16 products as in mlp128s.hip).
+//
+// Why another form of the same arithmetic.  mlp128s.hip keeps the two matrices of ONE MLP in LDS (2 x 68 KiB), so a launch runs the
+// two MLPs as two phases: the forward reads the message rows twice, and the adjoint writes g_msg, reads it back and writes it again.
+// These launches are bound by HBM, the store side in particular (plain streaming kernels on this pool: read 6.2, write 4.5-5.1
+// TB/s, tools/ubench/hbm_stream.hip), so the second pass is paid in full.  Here an 8-wave workgroup holds ALL FOUR matrices of the
+// layer as MFMA A fragments in registers -- wave (g, nb) keeps output block nb of both matrices of MLP g, 2 x 64 VGPRs, loaded once
+// per launch from the prepared fragment-order images (node128s.hip:weight_image_kernel) -- and a 32-row tile passes through both
+// MLPs at once:
+//   forward : msg tile read ONCE -> h1 | h2 (kept for the adjoint, fragment order) -> phi1 | phi2          5 row passes instead of 6
+//   adjoint : g_phi1 | g_phi2, h1 | h2 -> both terms of g_msg summed on chip -> g_msg written ONCE        5 row passes instead of 7
+// Activations travel between the stages through LDS tiles in split-f16 fragment layout (17 KiB each); LDS holds no weights.
+//
+// Tile flow (three workgroup barriers per tile; group g = waves 4g .. 4g+3):
+//   1. every wave brings its share of the tile's input rows (requested one tile ahead, whole 512-byte rows per half-wave), scales
+//      each row by its largest magnitude (a half-wave reduction: the row lives in 32 lanes), splits it and writes the X tile
+//   2. stage 1: wave (g, nb) forms block nb of W1_g . X^T from its register fragments; the forward stores the pre-activations and
+//      applies SiLU, the adjoint multiplies by SiLU'(h); the row maxima of the result go through LDS (node128s.hip:tile_publish)
+//   3. stage 2: the same wave forms block nb of W2_g . A_g^T; forward: phi_g rows; adjoint: group 1 hands its block to group 0
+//      through LDS, group 0 adds and stores g_msg
+// Products, scales and the order of accumulation are those of mlp128s.hip (hi hi + hi lo + lo hi per 16 k-values, rows scaled per
+// row, matrices per matrix): the two forms agree to the last bit or two; tests/test_hip_parity.py holds both against float64.
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define RW_WAVES 8
+#define RW_THREADS (64 * RW_WAVES)
+#define RW_PITCH 272                       // bytes per row of one plane of an LDS tile (128 f16 + 16 pad: conflict-free b128 reads)
+#define RW_PLANE (32 * RW_PITCH)
+#define RW_TILE (2 * RW_PLANE)             // hi plane, lo plane
+#define RW_WIMG_PLANE (NF * NF * 2)
+
+struct RwLds {
+  char xt[2][RW_TILE];          // stage-1 operand tiles, one per group (forward: both hold the msg tile; adjoint: g_phi1 / g_phi2)
+  char at[2][RW_TILE];          // stage-2 operand tiles, one per MLP
+  float pmax[2][8 * 32];        // per (wave of the group, lane half) maxima of each row of the stage-1 result
+  float invx[2][32];            // inverse row scales of the X tiles
+  float4 part[2][4][4 * 64];    // adjoint: group 1's stage-2 blocks on their way to group 0, double-buffered
+  unsigned bar[2];              // arrival counters of the two 4-wave groups (rw_group_sync)
+  unsigned ready[4], taken[4];  // hand-over counters per block: tiles published by wave (1, nb) / consumed by wave (0, nb)
+};
+
+struct RwFrag {
+  h8 hi[8], lo[8];
+  float inv;
+};
+
+__device__ __forceinline__ void rw_pow2_scale(float m, float& S, float& inv) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  const bool ok = e >= 40 && e < 255;
+  S = ok ? __uint_as_float((unsigned)(268 - e) << 23) : 1.0f;
+  inv = ok ? __uint_as_float((unsigned)(e - 14) << 23) : 1.0f;
+}
+// largest value of each 32-lane half (inputs >= 0), in every lane of the half: DPP folds + two v_readlane (common.h:half_sum_top)
+#define RW_DPP_MAX(v, ctrl, row_mask) \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xF, false)))
+__device__ __forceinline__ float rw_half_max(float v, int h) {
+  RW_DPP_MAX(v, 0xB1, 0xF);
+  RW_DPP_MAX(v, 0x4E, 0xF);
+  RW_DPP_MAX(v, 0x141, 0xF);
+  RW_DPP_MAX(v, 0x140, 0xF);
+  RW_DPP_MAX(v, 0x142, 0xA);
+  const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  return h ? hi : lo;
+}
+// Barrier of ONE 4-wave group (gfx950 has no named barriers; s_barrier would hold both groups in lockstep, and then the MFMA
+// phase of one never overlaps the VALU phase of the other on the SIMD they share).  A counter in LDS: LDS operations of a wave
+// execute in order, so the arrival (ds_add after this wave's tile writes) publishes them; the spin is bounded so that a lost
+// arrival shows up as a wrong result in the tests instead of a hung GPU.  Only LDS traffic is ordered here -- no vmcnt wait, the
+// prefetched rows and the streaming stores stay in flight across it.
+__device__ __forceinline__ void rw_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void rw_spin_until(const unsigned* cnt, unsigned target) {
+  unsigned spins = 0;
+  while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0 && ++spins < (1u << 22))
+    __builtin_amdgcn_s_sleep(1);
+  rw_wait_lds();
+}
+__device__ __forceinline__ void rw_signal(unsigned* cnt, int lane) {
+  rw_wait_lds();
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rw_group_sync(unsigned* cnt, unsigned& target, int lane) {
+  target += 4;
+  rw_signal(cnt, lane);
+  rw_spin_until(cnt, target);
+}
+// A fragments of output block nb from a fragment-order image (node128s.hip:load_wimg)
+__device__ __forceinline__ void rw_load_frag(RwFrag& w, const char* __restrict__ img, int nb, int r, int h) {
+  const char* p = img + ((size_t)(nb * 8 * 64 + h * 32 + r) << 4);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    w.hi[T] = *reinterpret_cast<const h8*>(p + 1024 * T);
+    w.lo[T] = *reinterpret_cast<const h8*>(p + RW_WIMG_PLANE + 1024 * T);
+  }
+  w.inv = *reinterpret_cast<const float*>(img + 2 * RW_WIMG_PLANE);
+}
+// block of D^T = W . X^T for the 32 rows of an LDS tile (node128s.hip:tile_gemm_s)
+__device__ __forceinline__ f32x16 rw_gemm(const char* tile, const RwFrag& w, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const char* xr = tile + r * RW_PITCH + 16 * h;
+  h8 bh0 = *reinterpret_cast<const h8*>(xr), bl0 = *reinterpret_cast<const h8*>(xr + RW_PLANE);
+  h8 bh1 = *reinterpret_cast<const h8*>(xr + 32), bl1 = *reinterpret_cast<const h8*>(xr + RW_PLANE + 32);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    h8 bh2, bl2;
+    if (T < 6) {
+      bh2 = *reinterpret_cast<const h8*>(xr + 32 * (T + 2));
+      bl2 = *reinterpret_cast<const h8*>(xr + RW_PLANE + 32 * (T + 2));
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bh0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bl0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[T], bh0, acc, 0, 0, 0);
+    bh0 = bh1;
+    bl0 = bl1;
+    if (T < 6) {
+      bh1 = bh2;
+      bl1 = bl2;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  return acc;
+}
+// one 512-byte input row per half-wave: scale by the row maximum, split, write into an X tile (k-slot 16 T + 8 h' + 4 j + c <->
+// feature 16 T + 8 j + 4 h' + c, the permutation of the images); lane & 31 == 0 keeps the inverse scale
+__device__ __forceinline__ void rw_commit_row(const float4& v, char* tile, float* invx, int row, int c, int h) {
+  const float m = rw_half_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), h);
+  float S, inv;
+  rw_pow2_scale(m, S, inv);
+  const float s[4] = {v.x * S, v.y * S, v.z * S, v.w * S};
+  h4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const _Float16 a = (_Float16)s[j];
+    hi[j] = a;
+    lo[j] = (_Float16)(s[j] - (float)a);
+  }
+  char* p = tile + row * RW_PITCH + 2 * ((c >> 2) * 16 + (c & 1) * 8 + ((c >> 1) & 1) * 4);
+  *reinterpret_cast<h4*>(p) = hi;
+  *reinterpret_cast<h4*>(p + RW_PLANE) = lo;
+  if (c == 0) invx[row] = inv;
+}
+// stage-1 result of this lane (16 values of block nb) -> the group's stage-2 tile, scaled by the row maximum (node128s.hip:tile_commit)
+__device__ __forceinline__ float rw_commit_block(const float (&v)[16], char* tile, const float* pmax, int nb, int r, int h) {
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, pmax[j * 32 + r]);
+  float S, inv;
+  rw_pow2_scale(m, S, inv);
+  char* row = tile + r * RW_PITCH + 2 * (nb * 32 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = v[4 * q + c] * S;
+      const _Float16 a = (_Float16)s;
+      hi[c] = a;
+      lo[c] = (_Float16)(s - (float)a);
+    }
+    const int off = 2 * ((q >> 1) * 16 + (q & 1) * 4);
+    *reinterpret_cast<h4*>(row + off) = hi;
+    *reinterpret_cast<h4*>(row + RW_PLANE + off) = lo;
+  }
+  return inv;
+}
+
+// MODE_FWD: a[0] / a[1] = the two MLPs over the same X (msg);  MODE_BWD: a[g].X = g_phi_g, a[g].H = h_g, both Y = g_msg.
+// H is always in fragment order (h_frag); W1_img / W2_img are the stage-1 / stage-2 images of each MLP.
+#ifdef RW_CLOCK_DEBUG   // tooling: wall-clock (100 MHz) time of every phase of the tile loop, summed over the tiles of one wave
+#define RW_DBG_DECL() long long dbg_t[12]; long long dbg_s[12]; int dbg_k = 0; int dbg_tiles = 0; for (int k_ = 0; k_ < 12; ++k_) dbg_s[k_] = 0;
+#define RW_DBG_TOP() dbg_k = 0; dbg_t[0] = wall_clock64(); ++dbg_tiles;
+#define RW_DBG() { ++dbg_k; dbg_t[dbg_k] = wall_clock64(); dbg_s[dbg_k] += dbg_t[dbg_k] - dbg_t[dbg_k - 1]; }
+#define RW_DBG_PRINT()                                                                                                        \
+  if (blockIdx.x == 3 && lane == 0 && (wave == 0 || wave == 5)) {                                                              \
+    const double d_ = 100.0 * dbg_tiles;                                                                                      \
+    printf("regw mode %d wave %d: %d tiles, us per tile: waitX %.2f commitX %.2f req+bar %.2f gemm1 %.2f epi1 %.2f bar %.2f commit+bar %.2f gemm2 %.2f epi2 %.2f\n", \
+           MODE, wave, dbg_tiles, dbg_s[1] / d_, dbg_s[2] / d_, dbg_s[3] / d_, dbg_s[4] / d_, dbg_s[5] / d_, dbg_s[6] / d_, dbg_s[7] / d_,        \
+           dbg_s[8] / d_, dbg_s[9] / d_);                                                                                                    \
+  }
+#else
+#define RW_DBG_DECL()
+#define RW_DBG_TOP()
+#define RW_DBG()
+#define RW_DBG_PRINT()
+#endif
+
+template <int MODE>
+__global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  RwLds& L = *reinterpret_cast<RwLds*>(lds_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = wave >> 2, nb = wave & 3;
+  const int r = lane & 31, h = lane >> 5;
+  const int M = P.a[0].M;
+  const int n_tiles = (M + 31) >> 5;
+
+  // this wave's weights: block nb of both matrices of MLP g, for the whole launch
+  RwFrag w1, w2;
+  rw_load_frag(w1, g ? P.a[1].W1_img : P.a[0].W1_img, nb, r, h);
+  rw_load_frag(w2, g ? P.a[1].W2_img : P.a[0].W2_img, nb, r, h);
+
+  // input rows this wave brings per tile: 8 of the 32 rows of its group's X (forward: both groups bring the msg tile, the second
+  // read comes from L2; adjoint: g_phi_g)
+  constexpr int NX = 4;
+  const float* Xg = g ? P.a[1].X : P.a[0].X;
+  const int ldx = g ? P.a[1].ldx : P.a[0].ldx;
+  const int xrow0 = 8 * nb;
+  const float* Hg = g ? P.a[1].H : P.a[0].H;
+  float* Yg = g ? P.a[1].Y : P.a[0].Y;
+  const int ldy = g ? P.a[1].ldy : P.a[0].ldy;
+  char* xtile = L.xt[g];
+  float* invx = L.invx[g];
+  unsigned* bar = &L.bar[g];
+  unsigned bar_target = 0;
+
+  if (threadIdx.x < 2) L.bar[threadIdx.x] = 0;
+  if (threadIdx.x < 4) L.ready[threadIdx.x] = L.taken[threadIdx.x] = 0;
+  __syncthreads();                  // (the only workgroup-wide barrier of the launch)
+
+  float4 xq[NX], hq[4];
+  auto request = [&](int tile) {
+    const int tc = min(tile, n_tiles - 1);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int row = min((tc << 5) + xrow0 + 2 * i + h, M - 1);
+      // (adjoint: g_phi is streamed once -- keep it from displacing the g_msg rows this launch writes for the next kernel)
+      xq[i] = MODE == MODE_BWD ? ld4_nt(Xg + (size_t)row * ldx + 4 * r) : ld4(Xg + (size_t)row * ldx + 4 * r);
+    }
+    if (MODE == MODE_BWD) {
+      const float4* hp = reinterpret_cast<const float4*>(Hg) + ((size_t)tc * 4 + nb) * 256 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hq[q] = ld4_nt(reinterpret_cast<const float*>(hp + 64 * q));
+    }
+  };
+  request(blockIdx.x);
+  RW_DBG_DECL()
+
+  int k = 0;                        // tiles done by this workgroup
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++k) {
+    RW_DBG_TOP()
+    const int e = (tile << 5) + r;
+    const bool live = e < M;
+    // ---------------- 1. the group's X tile
+#ifdef RW_CLOCK_DEBUG
+    asm volatile("" ::"v"(xq[NX - 1].w));   // (the rows have arrived: phase 1 is the wait, phase 2 the commit)
+    RW_DBG()
+#endif
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rw_commit_row(xq[i], xtile, invx, xrow0 + 2 * i + h, r, h);
+    float4 hin[4];
+    if (MODE == MODE_BWD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hin[q] = hq[q];
+    }
+    RW_DBG()   // 1: X commit (waits for the prefetched rows)
+    request(tile + gridDim.x);      // the next tile's rows travel while this one is computed
+    rw_group_sync(bar, bar_target, lane);
+    RW_DBG()   // 2: request + barrier
+    // ---------------- 2. stage 1
+    float a[16];
+    {
+      const f32x16 acc = rw_gemm(xtile, w1, r, h);
+      RW_DBG()   // 3: GEMM 1
+      const float sc = invx[r] * w1.inv;
+      if (MODE == MODE_FWD) {
+        float4* hp = reinterpret_cast<float4*>(g ? P.a[1].H : P.a[0].H) + ((size_t)tile * 4 + nb) * 256 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 hv = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
+          st4_nt(reinterpret_cast<float*>(hp + 64 * q), hv);   // (the region is padded to whole tiles)
+          a[4 * q] = silu_f(hv.x);
+          a[4 * q + 1] = silu_f(hv.y);
+          a[4 * q + 2] = silu_f(hv.z);
+          a[4 * q + 3] = silu_f(hv.w);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a[4 * q] = acc[4 * q] * sc * dsilu_f(hin[q].x);
+          a[4 * q + 1] = acc[4 * q + 1] * sc * dsilu_f(hin[q].y);
+          a[4 * q + 2] = acc[4 * q + 2] * sc * dsilu_f(hin[q].z);
+          a[4 * q + 3] = acc[4 * q + 3] * sc * dsilu_f(hin[q].w);
+        }
+      }
+    }
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(a[q]));
+      L.pmax[g][(nb * 2 + h) * 32 + r] = m;
+    }
+    RW_DBG()   // 4: stage-1 epilogue (H stores / loads, activation, publish)
+    rw_group_sync(bar, bar_target, lane);   // the row maxima are visible; every wave of the group is done with the X tile
+    RW_DBG()   // 5: barrier
+    const float inv2 = rw_commit_block(a, L.at[g], L.pmax[g], nb, r, h);
+    rw_group_sync(bar, bar_target, lane);
+    RW_DBG()   // 6: commit + barrier
+    // ---------------- 3. stage 2
+    {
+      const f32x16 acc = rw_gemm(L.at[g], w2, r, h);
+      RW_DBG()   // 7: GEMM 2
+      const float sc = inv2 * w2.inv;
+      if (MODE == MODE_FWD) {
+        if (live) {
+          float4* yp = reinterpret_cast<float4*>(Yg + (size_t)e * ldy + nb * 32 + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            yp[2 * q] = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
+        }
+      } else if (g == 1) {
+        // wave (1, nb) -> wave (0, nb): buffer k & 1 is free once tile k - 2 has been taken
+        rw_spin_until(&L.taken[nb], (unsigned)(k - 1));
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          L.part[k & 1][nb][q * 64 + lane] = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
+        rw_signal(&L.ready[nb], lane);
+      } else {
+        rw_spin_until(&L.ready[nb], (unsigned)(k + 1));
+        float4 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = L.part[k & 1][nb][q * 64 + lane];
+        rw_signal(&L.taken[nb], lane);
+        if (live) {
+          float4* yp = reinterpret_cast<float4*>(Yg + (size_t)e * ldy + nb * 32 + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            yp[2 * q] = make_float4(acc[4 * q] * sc + o[q].x, acc[4 * q + 1] * sc + o[q].y, acc[4 * q + 2] * sc + o[q].z,
+                                    acc[4 * q + 3] * sc + o[q].w);
+        }
+      }
+    }
+    RW_DBG()   // 8: stage-2 epilogue (stores; adjoint: the hand-over)
+  }
+  RW_DBG_PRINT()
+}
+
+// NNHIP_MLP_REGW: 1 (default) = the adjoint launches take this form (measured 106 us against 121 us per launch on the config-2
+// batch: g_msg is written once); 2 = the forward launches too (108 us against 106 us: the message rows are read once, but the
+// per-tile cost of passing activations through LDS eats the gain -- mlp128s.hip hands them over in registers); 0 = off
+static int mlp_regw_level() {
+  static const int level = [] {
+    const char* v = getenv("NNHIP_MLP_REGW");
+    return v ? atoi(v) : 1;
+  }();
+  return level;
+}
+bool mlp_regw_serves(int mode, const MlpPair& P) {
+  const int level = mlp_regw_level();
+  if (level <= 0 || P.n != 2 || !((mode == MODE_BWD) || (mode == MODE_FWD && level >= 2))) return false;
+  for (int k = 0; k < 2; ++k)
+    if (!P.a[k].W1_img || !P.a[k].W2_img || !P.a[k].h_frag || P.a[k].act != NNHIP_ACT_SILU || P.a[k].b1 || P.a[k].b2) return false;
+  if (mode == MODE_FWD) return P.a[0].X == P.a[1].X && P.a[0].ldx == P.a[1].ldx && !P.accum[0] && !P.accum[1];
+  return P.a[0].Y == P.a[1].Y && P.a[0].ldy == P.a[1].ldy && !P.accum[0] && P.accum[1];
+}
+template <int MODE>
+static int launch_regw_t(const MlpPair& P, hipStream_t s) {
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute((const void*)mlp_regw_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RwLds));
+  HIP_TRY(attr_rc);
+  const int n_tiles = (P.a[0].M + 31) / 32;
+  const int blocks = n_tiles < 256 ? n_tiles : 256;   // one persistent workgroup per CU
+  mlp_regw_kernel<MODE><<<blocks, RW_THREADS, sizeof(RwLds), s>>>(P);
+  LAUNCH_CHECK();
+  return 0;
+}
+int launch_mlp_regw(int mode, const MlpPair& P, hipStream_t s) {
+  return mode == MODE_FWD ? launch_regw_t<MODE_FWD>(P, s) : launch_regw_t<MODE_BWD>(P, s);
+}

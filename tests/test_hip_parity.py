@@ -921,6 +921,66 @@ def test_fp32_mfma_form_still_serves(tmp_path):
     assert np.abs(res['0']['forces'] - res['1']['forces']).max() <= 5e-6
 
 
+def test_one_pass_edge_mlp_form_agrees_with_the_two_phase_form(tmp_path):
+    """csrc/mlp128r.hip runs both edge MLPs of a layer (and both terms of g_msg) in one pass over the pair rows, weights in
+    registers; NNHIP_MLP_REGW selects 0 = the two-phase LDS-resident form (mlp128s.hip) everywhere, 1 = the adjoint launches
+    (default), 2 = forward launches too (read once per process: own processes).  Same arithmetic, so the three must agree to
+    rounding -- 512 aspirin conformers + one 13-atom molecule (78 k pair rows, not a multiple of 32: the ragged last tile) -- and
+    each holds the float64 oracle on the first 64 conformers."""
+    import os
+    import subprocess
+    import sys
+    from oracle import newtonnet_ref as ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'run_case.py'
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np, torch\n"
+        "from tests import util\n"
+        "from tests.test_hip_parity import make_model\n"
+        "from newtonnet_amd import hip\n"
+        "assert hip.split_products()\n"
+        "a = util.load_npz('aspirin_frames.npz')\n"
+        "B, n = 512, 21\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "pos = torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=g)\n"
+        "z = torch.from_numpy(a['z']).long().repeat(B)\n"
+        "batch = torch.repeat_interleave(torch.arange(B), n)\n"
+        "pos = torch.cat([pos, pos[:13] + 0.01])\n"
+        "z = torch.cat([z, z[:13]])\n"
+        "batch = torch.cat([batch, torch.full((13,), B)])\n"
+        "model, _ = make_model('ckpt')\n"
+        "out = model(z.cuda(), pos.cuda(), torch.zeros(B + 1, 3, 3, device='cuda'), batch.cuda())\n"
+        "assert out.edge_index.shape[1] // 2 > 26624 and (out.edge_index.shape[1] // 2) % 32 != 0\n"
+        "np.savez(sys.argv[1], energy=out.energy.cpu().numpy(), forces=out.gradient_force.cpu().numpy(), pos=pos.numpy(),\n"
+        "         z=z.numpy())\n")
+    res = {}
+    for level in ('0', '1', '2'):
+        out = tmp_path / f'out{level}.npz'
+        env = dict(os.environ, NNHIP_MLP_REGW=level)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[level] = dict(np.load(out))
+    n_ref = 64 * 21
+    pos = torch.from_numpy(res['0']['pos'][:n_ref]).double()
+    z = torch.from_numpy(res['0']['z'][:n_ref])
+    batch = torch.repeat_interleave(torch.arange(64), 21)
+    sd = util.load_state('ckpt', torch.float64)
+    o = ref.energy_forces(sd, z, pos, torch.zeros(64, 3, 3, dtype=torch.float64), batch)
+    e_ref, f_ref = o['energy'].numpy(), o['forces'].numpy()
+    for level in ('0', '1', '2'):
+        mae = np.abs(res[level]['forces'][:n_ref] - f_ref).mean()
+        print(f"NNHIP_MLP_REGW={level}: force MAE vs float64 oracle {mae:.2e} eV/A, max |dE| {np.abs(res[level]['energy'][:64] - e_ref).max():.2e} eV")
+        assert mae <= util.FORCE_MAE_TOL and np.all(np.abs(res[level]['energy'][:64] - e_ref) <= util.energy_tol(e_ref))
+    # the forward arithmetic is the same in levels 0 and 1 (only the adjoint differs), and the forms agree to fp32 rounding
+    assert np.array_equal(res['0']['energy'], res['1']['energy'])
+    fmax = np.abs(res['0']['forces']).max()
+    for level in ('1', '2'):
+        assert np.abs(res[level]['forces'] - res['0']['forces']).max() <= 2e-6 * max(fmax, 1.0)
+        assert np.abs(res[level]['energy'] - res['0']['energy']).max() <= 2 * np.spacing(np.float32(np.abs(res['0']['energy']).max()))
+
+
 def test_split_products_properties_at_full_size():
     """Size-independent properties of the persistent edge-MLP kernel at the config-2 row count (156 503 pair rows), no oracle
     needed: (1) the per-row power-of-two scales are exact -- multiplying input rows by powers of two multiplies the linear
