@@ -42,6 +42,7 @@ struct RwLds {
   float invx[2][32];            // inverse row scales of the X tiles
   float4 part[2][4][4 * 64];    // adjoint: group 1's stage-2 blocks on their way to group 0, double-buffered
   unsigned bar[2];              // arrival counters of the two 4-wave groups (rw_group_sync)
+  unsigned xbar;                // forward: arrivals of all 8 waves at the shared X tile
   unsigned ready[4], taken[4];  // hand-over counters per block: tiles published by wave (1, nb) / consumed by wave (0, nb)
 };
 
@@ -85,8 +86,8 @@ __device__ __forceinline__ void rw_signal(unsigned* cnt, int lane) {
   rw_wait_lds();
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void rw_group_sync(unsigned* cnt, unsigned& target, int lane) {
-  target += 4;
+__device__ __forceinline__ void rw_group_sync(unsigned* cnt, unsigned& target, int lane, unsigned waves = 4) {
+  target += waves;
   rw_signal(cnt, lane);
   rw_spin_until(cnt, target);
 }
@@ -211,20 +212,20 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
   rw_load_frag(w1, g ? P.a[1].W1_img : P.a[0].W1_img, nb, r, h);
   rw_load_frag(w2, g ? P.a[1].W2_img : P.a[0].W2_img, nb, r, h);
 
-  // input rows this wave brings per tile: 8 of the 32 rows of its group's X (forward: both groups bring the msg tile, the second
-  // read comes from L2; adjoint: g_phi_g)
-  constexpr int NX = 4;
-  const float* Xg = g ? P.a[1].X : P.a[0].X;
-  const int ldx = g ? P.a[1].ldx : P.a[0].ldx;
-  const int xrow0 = 8 * nb;
+  // input rows this wave brings per tile.  Forward: 4 of the 32 msg rows -- ONE X tile serves both groups, double-buffered by tile
+  // parity (a wave writes tile k + 1 only after its own tile k, and nobody passes the 8-wave arrival of tile k before every wave
+  // has left tile k - 1, so the buffer of tile k - 1 is free by then).  Adjoint: 8 of the 32 rows of the group's own g_phi_g.
+  constexpr int NX = MODE == MODE_FWD ? 2 : 4;
+  const float* Xg = (MODE == MODE_FWD || g == 0) ? P.a[0].X : P.a[1].X;
+  const int ldx = (MODE == MODE_FWD || g == 0) ? P.a[0].ldx : P.a[1].ldx;
+  const int xrow0 = MODE == MODE_FWD ? 4 * wave : 8 * nb;
   const float* Hg = g ? P.a[1].H : P.a[0].H;
   float* Yg = g ? P.a[1].Y : P.a[0].Y;
   const int ldy = g ? P.a[1].ldy : P.a[0].ldy;
-  char* xtile = L.xt[g];
-  float* invx = L.invx[g];
   unsigned* bar = &L.bar[g];
-  unsigned bar_target = 0;
+  unsigned bar_target = 0, xbar_target = 0;
 
+  if (threadIdx.x == 0) L.xbar = 0;
   if (threadIdx.x < 2) L.bar[threadIdx.x] = 0;
   if (threadIdx.x < 4) L.ready[threadIdx.x] = L.taken[threadIdx.x] = 0;
   __syncthreads();                  // (the only workgroup-wide barrier of the launch)
@@ -252,7 +253,9 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
     RW_DBG_TOP()
     const int e = (tile << 5) + r;
     const bool live = e < M;
-    // ---------------- 1. the group's X tile
+    char* xtile = L.xt[MODE == MODE_FWD ? (k & 1) : g];
+    float* invx = L.invx[MODE == MODE_FWD ? (k & 1) : g];
+    // ---------------- 1. the X tile (forward: shared; adjoint: the group's own)
 #ifdef RW_CLOCK_DEBUG
     asm volatile("" ::"v"(xq[NX - 1].w));   // (the rows have arrived: phase 1 is the wait, phase 2 the commit)
     RW_DBG()
@@ -266,7 +269,10 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
     }
     RW_DBG()   // 1: X commit (waits for the prefetched rows)
     request(tile + gridDim.x);      // the next tile's rows travel while this one is computed
-    rw_group_sync(bar, bar_target, lane);
+    if (MODE == MODE_FWD)
+      rw_group_sync(&L.xbar, xbar_target, lane, 8);
+    else
+      rw_group_sync(bar, bar_target, lane);
     RW_DBG()   // 2: request + barrier
     // ---------------- 2. stage 1
     float a[16];
