@@ -73,13 +73,15 @@ __device__ __forceinline__ float rw_half_max(float v, int h) {
 // Barrier of ONE 4-wave group (gfx950 has no named barriers; s_barrier would hold both groups in lockstep, and then the MFMA
 // phase of one never overlaps the VALU phase of the other on the SIMD they share).  A counter in LDS: LDS operations of a wave
 // execute in order, so the arrival (ds_add after this wave's tile writes) publishes them; the spin is bounded so that a lost
-// arrival shows up as a wrong result in the tests instead of a hung GPU.  Only LDS traffic is ordered here -- no vmcnt wait, the
+// arrival aborts the launch instead of hanging the GPU.  Only LDS traffic is ordered here -- no vmcnt wait, the
 // prefetched rows and the streaming stores stay in flight across it.
 __device__ __forceinline__ void rw_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void rw_spin_until(const unsigned* cnt, unsigned target) {
   unsigned spins = 0;
-  while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0 && ++spins < (1u << 22))
+  while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
+    if (++spins > (1u << 22)) __builtin_trap();   // ~0.1 s without the partner: abort the launch (a HIP error), never a silent result
     __builtin_amdgcn_s_sleep(1);
+  }
   rw_wait_lds();
 }
 __device__ __forceinline__ void rw_signal(unsigned* cnt, int lane) {
