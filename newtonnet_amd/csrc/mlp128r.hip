@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 hv = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
-          st4_nt(reinterpret_cast<float*>(hp + 64 * q), hv);   // (the region is padded to whole tiles)
+          // (the scratch keeps silu'(h), mlp128s.hip; the region is padded to whole tiles)
+          st4_nt(reinterpret_cast<float*>(hp + 64 * q), make_float4(dsilu_f(hv.x), dsilu_f(hv.y), dsilu_f(hv.z), dsilu_f(hv.w)));
           a[4 * q] = silu_f(hv.x);
           a[4 * q + 1] = silu_f(hv.y);
           a[4 * q + 2] = silu_f(hv.z);
@@ -296,10 +297,10 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          a[4 * q] = acc[4 * q] * sc * dsilu_f(hin[q].x);
-          a[4 * q + 1] = acc[4 * q + 1] * sc * dsilu_f(hin[q].y);
-          a[4 * q + 2] = acc[4 * q + 2] * sc * dsilu_f(hin[q].z);
-          a[4 * q + 3] = acc[4 * q + 3] * sc * dsilu_f(hin[q].w);
+          a[4 * q] = acc[4 * q] * sc * hin[q].x;      // (hin = silu'(h), left by the forward)
+          a[4 * q + 1] = acc[4 * q + 1] * sc * hin[q].y;
+          a[4 * q + 2] = acc[4 * q + 2] * sc * hin[q].z;
+          a[4 * q + 3] = acc[4 * q + 3] * sc * hin[q].w;
         }
       }
     }

@@ -266,9 +266,15 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
             float4* hp = h_frag ? reinterpret_cast<float4*>(p.H) + ((size_t)tile * 4 + nb) * 256 + lane
                                 : reinterpret_cast<float4*>(p.H + (size_t)e * p.ldh + nb * 32 + 4 * h);
             const int hs4 = h_frag ? 64 : 2;
+            // fragment order = private scratch of this forward and its adjoint (inference): keep silu'(h), which shares the
+            // sigmoid with the activation here and is all the adjoint wants of h (an exp, a reciprocal and four products per
+            // element less in a kernel that is bound by its VALU issue, mlp128r.hip); row-major H is the pre-activation itself
+            float keep[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) keep[k] = h_frag ? dsilu_f(acc[k]) : acc[k];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float4 hv = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+              const float4 hv = make_float4(keep[4 * q], keep[4 * q + 1], keep[4 * q + 2], keep[4 * q + 3]);
               if (MLP_NT_H)
                 st4_nt(reinterpret_cast<float*>(hp + hs4 * q), hv);
               else
@@ -302,12 +308,13 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
 #pragma unroll
             for (int q = 0; q < 4; ++q) st4(tp + 8 * q, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
           }
+          const bool kept = MODE == MODE_BWD && h_frag;   // (the forward left silu'(h) in the fragment-order scratch)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            hs[nb][4 * q] = acc[4 * q] * dsilu_f(hin[q].x);
-            hs[nb][4 * q + 1] = acc[4 * q + 1] * dsilu_f(hin[q].y);
-            hs[nb][4 * q + 2] = acc[4 * q + 2] * dsilu_f(hin[q].z);
-            hs[nb][4 * q + 3] = acc[4 * q + 3] * dsilu_f(hin[q].w);
+            hs[nb][4 * q] = acc[4 * q] * (kept ? hin[q].x : dsilu_f(hin[q].x));
+            hs[nb][4 * q + 1] = acc[4 * q + 1] * (kept ? hin[q].y : dsilu_f(hin[q].y));
+            hs[nb][4 * q + 2] = acc[4 * q + 2] * (kept ? hin[q].z : dsilu_f(hin[q].z));
+            hs[nb][4 * q + 3] = acc[4 * q + 3] * (kept ? hin[q].w : dsilu_f(hin[q].w));
           }
         }
       }
