@@ -241,8 +241,9 @@ typedef struct {
   size_t m[NNHIP_MAX_LAYERS];      /* [N][F]   message_nodepart output */
   size_t hn[NNHIP_MAX_LAYERS];     /* [N][F]   message_nodepart hidden pre-activation */
   size_t msg[NNHIP_MAX_LAYERS];    /* [P][F]   message, one row per undirected pair (P = E/2, row pid[e]) */
-  size_t h12[NNHIP_MAX_LAYERS];    /* 2 x [pad32(P)][F] equiv_message{1,2} hidden pre-activations, private to the MLP kernels
-                                      (MFMA-fragment order when P > 49152, row-major below) */
+  size_t h12[NNHIP_MAX_LAYERS];    /* 2 x [pad32(P)][F] scratch between the equiv_message{1,2} forward and its adjoint, private to
+                                      the MLP kernels: the hidden pre-activations h, row-major, up to 26 624 pair rows; above that
+                                      silu'(h) in MFMA-fragment order (all the adjoint needs of h) */
   size_t phi1[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t phi2[NNHIP_MAX_LAYERS];   /* [P][F] */
   size_t a_mid[NNHIP_MAX_LAYERS];  /* [N][F]   atom_node after the invariant update */
