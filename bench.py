@@ -503,7 +503,7 @@ def main():
     value = world * N * args.steps / dt
 
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream --------------------
-    roofline = edge_roofline = None
+    roofline = edge_roofline = onepass = None
     classes = {}
     if rank == 0:
         n_inst = max(3, min(10, args.steps))
@@ -534,10 +534,20 @@ def main():
         # h1, h2, phi1, phi2 out = 5 (instead of 6); adjoint g_phi1, g_phi2, h1, h2 in + g_msg out = 5 (instead of 7).
         # Per step (3 layers, phi2 skipped in layer 0): layer 0 is one phase each way (3 + 3), layers 1-2 two MLPs each way.
         regw = int(os.environ.get('NNHIP_MLP_REGW', '1')) if split else 0   # 1 (default): adjoint launches; 2: forward too
-        fwd_units = 3 + 2 * (5 if regw >= 2 else 6)
-        bwd_units = 3 + 2 * (5 if regw >= 1 else 7)
-        mlp_bytes = (E // 2) * 512.0 * (fwd_units + bwd_units)
+        one_ms = classes['mlp_onepass']['ms_per_step']
+        one_n = classes['mlp_onepass']['launches_per_step']
+        if one_n == 0:
+            regw = 0                                   # (batch below the persistent regime, or no weight images)
+        row_unit = (E // 2) * 512.0
+        one_bytes = row_unit * 5 * one_n               # every one-pass launch moves five row passes
+        # the launches mlp128s_kernel keeps: layer 0 (3 + 3 units) and whatever of layers 1-2 the one-pass form does not serve
+        mlp_bytes = row_unit * (3 + 3 + (0 if regw >= 2 else 2 * 6) + (0 if regw >= 1 else 2 * 7))
+        # FLOPs: ten equal MLP phases per step (5 forward, 5 adjoint); a one-pass launch is two of them
+        one_flops = mlp_flops * 2.0 * one_n / 10.0
+        all_mlp_ms = mlp_ms
+        mlp_ms, mlp_n, mlp_flops = max(mlp_ms - one_ms, 0.0), max(mlp_n - one_n, 1), mlp_flops - one_flops
         mlp_gbs = mlp_bytes / (mlp_ms * 1e-3) / 1e9 if mlp_ms > 0 else 0.0
+        mlp_tf = mlp_flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         common = {'traffic': None, 'traffic_note': 'PMC passes are separate runs: profiles/*_pmc_{fetch,write}_size.txt',
                   'launches_per_step': mlp_n, 'avg_launch_us': round(1e3 * mlp_ms / mlp_n, 2),
                   'flops_per_launch': mlp_flops / mlp_n, 'algorithmic_bytes_per_launch': round(mlp_bytes / mlp_n),
@@ -545,10 +555,10 @@ def main():
                   'all_dense_kernels': {'achieved': round(lin_tf, 2), 'unit': 'useful fp32 TFLOP/s', 'ms_per_step': round(lin_ms, 4),
                                         'flops_per_step': lin_flops}}
         if split:
-            mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel' + (' / mlp_regw_kernel' if regw else '') +
-                                              ' (fused Linear-SiLU-Linear over pair rows, fwd + adjoint; split-f16 products, fp32 '
-                                              'accumulate' + ('; the two-MLP adjoint launches in the one-pass register-weights form' if regw == 1 else
-                                                              '; the two-MLP launches in the one-pass register-weights form' if regw >= 2 else '') + ')',
+            mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel (fused Linear-SiLU-Linear over pair rows: ' +
+                                              ('the forward launches and the layer-0 adjoint' if regw == 1 else
+                                               'the layer-0 launches' if regw >= 2 else 'forward + adjoint') +
+                                              '; split-f16 products, fp32 accumulate)',
                     'achieved': round(mlp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(mlp_gbs / HBM_PEAK_GBS, 4),
                     'matrix_pipe': {'useful_fp32_tflops': round(mlp_tf, 2), 'executed_f16_tflops': round(3 * mlp_tf, 2),
                                     'peak_f16_tflops': MFMA_F16_PEAK_TFLOPS, 'frac': round(3 * mlp_tf / MFMA_F16_PEAK_TFLOPS, 4),
@@ -576,7 +586,7 @@ def main():
                                'frac_pair_bytes': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
         hbm['per_kernel'] = per_kernel
         if args.workload == 'aspirin' and args.conformers == 1024:   # the stored PMC passes are of this workload
-            t, src = pmc_traffic(['mlp128s_kernel', 'mlp_regw_kernel'] if split else ['mlp128_kernel'])
+            t, src = pmc_traffic(['mlp128s_kernel'] if split else ['mlp128_kernel'])
             if t is not None:
                 n_l = sum(n for n, _ in t.values())
                 mfma['traffic'] = round(sum(n * b for n, b in t.values()) / n_l)
@@ -596,6 +606,25 @@ def main():
                 cnt_gbs = step_bytes / (edge_ms * 1e-3) / 1e9
                 hbm['achieved_counter_bytes'] = round(cnt_gbs, 1)
                 hbm['frac_vs_counter_bytes'] = round(cnt_gbs / HBM_PEAK_GBS, 4)
+        # the one-pass register-weights form of the two edge MLPs (csrc/mlp128r.hip): its own object -- it left the HBM roof for
+        # the VALU-issue one by moving 29 % fewer bytes, so its fraction of the HBM peak is lower than the two-phase form's
+        onepass = None
+        if one_n > 0:
+            one_gbs = one_bytes / (one_ms * 1e-3) / 1e9 if one_ms > 0 else 0.0
+            onepass = {'bound': 'hbm', 'kernel': 'mlp_regw_kernel (both edge MLPs of a layer in one pass over the pair rows, weights '
+                                                 'resident in registers: ' + ('the adjoint launches' if regw == 1 else 'forward and adjoint launches') +
+                                                 ' of layers 1-2; bound by VALU issue, priced here against the HBM peak)',
+                       'achieved': round(one_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(one_gbs / HBM_PEAK_GBS, 4),
+                       'traffic': None, 'launches_per_step': one_n, 'avg_launch_us': round(1e3 * one_ms / one_n, 2),
+                       'algorithmic_bytes_per_launch': round(one_bytes / one_n), 'ms_per_step': round(one_ms, 4),
+                       'two_phase_form_bytes_per_launch': round(row_unit * 7), 'flops_per_launch': one_flops / one_n,
+                       'all_edge_mlp_launches_ms_per_step': round(all_mlp_ms, 4)}
+            if args.workload == 'aspirin' and args.conformers == 1024:
+                t, src = pmc_traffic(['mlp_regw_kernel'])
+                if t is not None:
+                    n_l = sum(n for n, _ in t.values())
+                    onepass['traffic'] = round(sum(n * b for n, b in t.values()) / n_l)
+                    onepass['traffic_source'] = src
         # `roofline` = the single kernel with the largest share of the step (the edge MLP kernel unless one of the four edge
         # kernels outweighs it); the other object is reported as `roofline_secondary`
         top_edge = max(classes[k]['ms_per_step'] for k in ('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd'))
@@ -691,7 +720,7 @@ def main():
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
-            'roofline': roofline, 'roofline_secondary': edge_roofline, 'kernel_classes': classes,
+            'roofline': roofline, 'roofline_secondary': edge_roofline, 'roofline_onepass_mlp': onepass, 'kernel_classes': classes,
             'kernel_classes_note': ('event-timed in a separate instrumented pass: every launch is bracketed by HIP events, which '
                                     f'inflates the classes (their sum {sum(classes[k]["ms_per_step"] for k in ("edge_all", "linear_mfma", "other", "graph")) if classes else 0:.3f} ms vs '
                                     f'ms_per_step {1e3 * dt / args.steps:.3f}); kernel_classes_rocprof holds the un-instrumented '

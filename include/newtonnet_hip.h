@@ -608,9 +608,10 @@ int nnhip_split_products(void);
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,
  *          3-6 = msg_fwd / force_fwd / force_bwd / msg_bwd, 7 = graph build, 8 = fused edge-MLP kernel (mlp128),
  *          9 = single linears (lin128), 10 = the batched weight-gradient kernel of training (wgrad_kernel, without its
- *          slab reduction).  Disabled (0) by default.
+ *          slab reduction), 11 = the one-pass register-weights form of the two edge MLPs (mlp_regw_kernel; its launches are
+ *          counted in class 8 as well).  Disabled (0) by default.
  * ------------------------------------------------------------------------ */
-#define NNHIP_N_TIMER_CLASSES 11
+#define NNHIP_N_TIMER_CLASSES 12
 int nnhip_timers_enable(int32_t on);
 int nnhip_timers_read(double* ms_per_class, int64_t* launches_per_class, int32_t reset);
 

@@ -430,7 +430,10 @@ int launch_mlp_pair(int mode, const MlpArgs& a0, bool accum0, const MlpArgs& a1,
   P.n = 2;
   P.accum[0] = accum0 ? 1 : 0;
   P.accum[1] = accum1 ? 1 : 0;
-  if (split_products_enabled() && mlp_regw_serves(mode, P)) return launch_mlp_regw(mode, P, s);   // both MLPs in one pass (mlp128r.hip)
+  if (split_products_enabled() && mlp_regw_serves(mode, P)) {   // both MLPs in one pass (mlp128r.hip); timed inside 'mlp128' too
+    ScopedTimer t2(TC_MLP_ONEPASS, s);
+    return launch_mlp_regw(mode, P, s);
+  }
   return launch_mlp_dispatch(mode, accum1, P, s);
 }
 
