@@ -12,15 +12,22 @@
 //   adjoint : g_phi1 | g_phi2, h1 | h2 -> both terms of g_msg summed on chip -> g_msg written ONCE        5 row passes instead of 7
 // Activations travel between the stages through LDS tiles in split-f16 fragment layout (17 KiB each); LDS holds no weights.
 //
-// Tile flow (three workgroup barriers per tile; group g = waves 4g .. 4g+3):
+// Tile flow (group g = waves 4g .. 4g+3 = MLP g; one wave of each group per SIMD).  The groups are synchronised among their own
+// four waves only, by arrival counters in LDS (rw_group_sync) -- s_barrier would hold both groups in lockstep, and then the MFMA
+// phase of one never overlaps the VALU phase of the other on the SIMD they share (measured: 116 us in lockstep, 104 us apart):
 //   1. every wave brings its share of the tile's input rows (requested one tile ahead, whole 512-byte rows per half-wave), scales
-//      each row by its largest magnitude (a half-wave reduction: the row lives in 32 lanes), splits it and writes the X tile
-//   2. stage 1: wave (g, nb) forms block nb of W1_g . X^T from its register fragments; the forward stores the pre-activations and
-//      applies SiLU, the adjoint multiplies by SiLU'(h); the row maxima of the result go through LDS (node128s.hip:tile_publish)
-//   3. stage 2: the same wave forms block nb of W2_g . A_g^T; forward: phi_g rows; adjoint: group 1 hands its block to group 0
-//      through LDS, group 0 adds and stores g_msg
+//      each row by its largest magnitude (a DPP reduction: the row lives in 32 lanes), splits it and writes the X tile
+//      (adjoint: the group's own g_phi_g tile; forward: ONE msg tile for both groups, double-buffered, behind an 8-wave arrival)
+//   2. stage 1: wave (g, nb) forms block nb of W1_g . X^T from its register fragments; the forward leaves silu'(h) in the scratch
+//      the adjoint reads (mlp128s.hip) and applies SiLU, the adjoint multiplies by that silu'(h); the row maxima of the result go
+//      through LDS (node128s.hip:tile_publish)
+//   3. stage 2: the same wave forms block nb of W2_g . A_g^T; forward: phi_g rows; adjoint: wave (1, nb) hands its block to wave
+//      (0, nb) through a double-buffered LDS slot (ready / taken counters), which adds and stores g_msg
 // Products, scales and the order of accumulation are those of mlp128s.hip (hi hi + hi lo + lo hi per 16 k-values, rows scaled per
-// row, matrices per matrix): the two forms agree to the last bit or two; tests/test_hip_parity.py holds both against float64.
+// row, matrices per matrix): the two forms agree to the last bit or two
+// (tests/test_hip_parity.py::test_one_pass_edge_mlp_form_agrees_with_the_two_phase_form holds both against float64).
+// The kernel is bound by VALU issue (~760 wave-instructions per wave and tile, 1.5x mlp128s.hip -- the price of passing
+// activations through LDS instead of handing them over in registers), which is why only the adjoint launches take it by default.
 #include <stdlib.h>
 
 #include "common.h"
