@@ -9,7 +9,7 @@
 // (build.sh adds -DNNHIP_TOOLING to any build with extra flags; nnhip_build_flags() bit 0 reports it and newtonnet_amd.hip
 // refuses to load such a library unless NNHIP_ALLOW_TOOLING_LIB=1).
 #if (defined(EDGE_ABL_SELF) || defined(EDGE_ABL_PAIR) || defined(EDGE_ABL_TABLE) || defined(EDGE_ABL_STORE) ||              \
-     defined(EDGE_ABL_NO_TABLE) || defined(EDGE_ABL_HALF_TABLE) || defined(MLPS_ABL_NO_H) || defined(NS_ABL_NO_Q) || defined(NS_ABL_HOT_W) || defined(MLPS_ABL_X) || defined(ABL_NO_SILU) || defined(ABL_NO_STORE) ||                  \
+     defined(EDGE_ABL_NO_TABLE) || defined(EDGE_ABL_HALF_TABLE) || defined(EDGE_ABL_NOTAB) || defined(EDGE_ABL_NOMJ) || defined(MLPS_ABL_NO_H) || defined(NS_ABL_NO_Q) || defined(NS_ABL_HOT_W) || defined(MLPS_ABL_X) || defined(ABL_NO_SILU) || defined(ABL_NO_STORE) ||                  \
      (defined(LIN_ABLATE_NO_LOAD) && LIN_ABLATE_NO_LOAD) || (defined(LIN_ABLATE_NO_STORE) && LIN_ABLATE_NO_STORE) ||         \
      (defined(LIN_ABLATE_NO_MFMA) && LIN_ABLATE_NO_MFMA) || (defined(LIN_ABLATE_NO_LDS) && LIN_ABLATE_NO_LDS)) &&            \
     !defined(NNHIP_TOOLING)

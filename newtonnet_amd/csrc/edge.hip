@@ -53,10 +53,16 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
       const FilterW fw = filter_weights(__int_as_float(gx.y));
 #ifdef EDGE_ABL_HALF_TABLE   // tooling (wrong results): what a pair-centric evaluation of eps could save at most
       const float4 eps = jj > i ? filter_value(table, ABL_G(gx.x), c4, fw) : mi;
+#elif defined(EDGE_ABL_NOTAB)   // tooling (wrong results): no table reads at all
+      const float4 eps = mul4(mi, fw.w[0] + fw.w[1] + fw.w[2] + fw.w[3]);
 #else
       const float4 eps = filter_value(table, ABL_G(gx.x), c4, fw);
 #endif
+#ifdef EDGE_ABL_NOMJ            // tooling (wrong results): no sender-row gather
+      const float4 mj = mi;
+#else
       const float4 mj = ld4(m + (size_t)ABL_J(jj, i) * NF + c4);
+#endif
       const float4 v = mul4(mul4(eps, mi), mj);
       if (ABL_ST(jj > i)) {   // the lower endpoint writes the shared pair row
         const int p0 = pid[e], p1 = pid[e1];
