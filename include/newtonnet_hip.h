@@ -277,6 +277,13 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  * to nnhip_energy_forces.  prepared == NULL: nnhip_energy_forces rebuilds the block inside its workspace on every call. */
 size_t nnhip_prepared_bytes(int32_t n_layers);
 int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream);
+/* Has any parameter changed since `prepared` was last checked?  One launch: every parameter tensor of `model` is compared
+ * bit for bit with a snapshot kept inside the block (the snapshot is brought up to date in the same pass) and `bit` is OR-ed into
+ * *status (device int32) when something differed.  A caller that keeps one block per model runs this every call -- ahead of a
+ * read-back it does anyway -- and calls nnhip_prepare only when the bit comes back set (always after allocating the block: its
+ * snapshot is uninitialised).  Replaces nothing in the reference: torch modules keep no derived state. */
+int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
+                        void* stream);
 
 /* --------------------------------------------------------------------------
  * One dense 128 -> 128 linear on the matrix cores (fp32 MFMA, exact fp32):

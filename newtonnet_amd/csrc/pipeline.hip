@@ -51,7 +51,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 102; }   // 102: weight images in MFMA fragment order
+extern "C" int nnhip_version(void) { return 103; }   // 103: nnhip_prepare_check (102: weight images in MFMA fragment order)
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
@@ -151,9 +151,36 @@ struct PrepLayout {
   // split-f16 images (node128s.hip) of every [128][128] weight and its transpose (IMG_* of common.h), and of the head's
   size_t img[NNHIP_MAX_LAYERS][IMG_PER_LAYER];
   size_t img_head[IMG_HEAD_COUNT];
+  size_t snap;                     // the parameter values the block was last checked against (nnhip_prepare_check), fp32 words
   size_t total;
 };
 static size_t prep_bytes(int L);
+// every parameter tensor of a model, in a fixed order, with its size in floats (the snapshot layout of nnhip_prepare_check)
+#define PREP_MAX_PARAMS (2 + 12 * NNHIP_MAX_LAYERS + 8)
+static int model_params(const nnhip_model* m, const float** ptr, int* count) {
+  const int nb = m->n_basis;
+  int c = 0;
+  auto add = [&](const float* p, int n) {
+    ptr[c] = p;
+    count[c++] = p ? n : 0;
+  };
+  add(m->node_embedding, NNHIP_N_ELEMENTS * NF);
+  add(m->frequencies, nb);
+  for (int l = 0; l < m->n_layers; ++l) {
+    const nnhip_layer_params& lp = m->layer[l];
+    add(lp.node0_w, NF * NF), add(lp.node0_b, NF), add(lp.node2_w, NF * NF), add(lp.node2_b, NF);
+    add(lp.edge_w, NF * nb);
+    add(lp.eq1_0_w, NF * NF), add(lp.eq1_2_w, NF * NF), add(lp.eq2_0_w, NF * NF), add(lp.eq2_2_w, NF * NF);
+    add(lp.update_w, NF * NF), add(lp.ln_w, NF), add(lp.ln_b, NF);
+  }
+  add(m->head0_w, NF * NF), add(m->head0_b, NF), add(m->head2_w, NF * NF), add(m->head2_b, NF);
+  add(m->head4_w, NF), add(m->head4_b, 1), add(m->scale, NNHIP_N_ELEMENTS), add(m->shift, NNHIP_N_ELEMENTS);
+  return c;
+}
+static size_t snapshot_floats(int L) {   // capacity for the largest basis
+  return (size_t)NNHIP_N_ELEMENTS * NF + NNHIP_MAX_NB + (size_t)L * (7 * NF * NF + 4 * NF + NF * NNHIP_MAX_NB) + 2 * NF * NF + 3 * NF +
+         1 + 2 * NNHIP_N_ELEMENTS;
+}
 
 static size_t carve(size_t& off, size_t bytes) {
   const size_t o = off;
@@ -178,6 +205,7 @@ static void make_prep_layout(int L, PrepLayout& q) {
   for (int l = 0; l < L; ++l)
     for (int k = 0; k < IMG_PER_LAYER; ++k) q.img[l][k] = carve(off, WIMG_BYTES);
   for (int k = 0; k < IMG_HEAD_COUNT; ++k) q.img_head[k] = carve(off, WIMG_BYTES);
+  q.snap = carve(off, snapshot_floats(L) * 4);
   q.total = off;
 }
 static size_t prep_bytes(int L) {
@@ -365,6 +393,67 @@ extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t pr
     return NNHIP_E_WORKSPACE;
   }
   return run_prepare(model, pq, (char*)prepared, (hipStream_t)stream_);
+}
+
+// Did a parameter change since this block was last checked?  Exact (bitwise) comparison of every parameter tensor with the
+// snapshot kept inside the block; the snapshot is brought up to date in the same pass and `bit` is OR-ed into *status when
+// anything differed.  NewtonNet.forward runs it ahead of the edge-count read-back and reads the answer with the count: the
+// block is refilled (nnhip_prepare) only when the answer says so -- nothing is keyed on tensor identity or version counters,
+// which in-place writers outside torch (nnhip_clip_adam) and recycled allocations defeat.
+struct ParamTable {
+  int n;
+  const float* src[PREP_MAX_PARAMS];
+  int count[PREP_MAX_PARAMS];
+  int off[PREP_MAX_PARAMS];
+};
+#define PARAM_CHECK_CHUNKS 4
+__global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit) {
+  const int k = blockIdx.x;
+  const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(t.src[k]);
+  uint32_t* __restrict__ dst = snap + t.off[k];
+  const int n = t.count[k];
+  int differs = 0;
+  for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * PARAM_CHECK_CHUNKS) {
+    const uint32_t v = src[e];
+    if (v != dst[e]) {
+      dst[e] = v;
+      differs = 1;
+    }
+  }
+  if (__syncthreads_or(differs) && threadIdx.x == 0) atomicOr(status, bit);
+}
+
+extern "C" int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
+                                   void* stream_) {
+  TRY(check_model(model, "nnhip_prepare_check"));
+  PrepLayout pq;
+  make_prep_layout(model->n_layers, pq);
+  if (!prepared || !status || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
+    nnhip_set_error("nnhip_prepare_check: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  ParamTable t;
+  memset(&t, 0, sizeof(t));
+  const float* ptr[PREP_MAX_PARAMS];
+  int count[PREP_MAX_PARAMS];
+  const int n = model_params(model, ptr, count);
+  int off = 0;
+  for (int k = 0; k < n; ++k) {
+    if (count[k] == 0) continue;
+    t.src[t.n] = ptr[k];
+    t.count[t.n] = count[k];
+    t.off[t.n] = off;
+    off += count[k];
+    ++t.n;
+  }
+  if ((size_t)off > snapshot_floats(model->n_layers)) {
+    nnhip_set_error("nnhip_prepare_check: snapshot overflow");
+    return NNHIP_E_INVALID;
+  }
+  param_check_kernel<<<dim3(t.n, PARAM_CHECK_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), status, bit);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
 }
 
 // ---- the hot path --------------------------------------------------------------------------------------

@@ -165,6 +165,7 @@ def lib():
     L.nnhip_prepared_bytes.argtypes = [i32]
     L.nnhip_prepared_bytes.restype = sz
     L.nnhip_prepare.argtypes = [C.POINTER(Model), vp, sz, vp]
+    L.nnhip_prepare_check.argtypes = [C.POINTER(Model), vp, sz, vp, i32, vp]
     L.nnhip_linear128.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     L.nnhip_mlp128.argtypes = [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]
     L.nnhip_direct_force.argtypes = [vp] * 10 + [i32, i32, vp, vp, vp]
@@ -228,7 +229,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
+               'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -250,7 +251,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows',
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
-                    'nnhip_prepare', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
+                    'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells')
 
@@ -280,16 +281,26 @@ CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fa
 class Graph:
     """Neighbor list + edge embedding of one batch (device tensors)."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status')
 
 
-def prepare(model: Model, device) -> torch.Tensor:
-    """Fill a prepared block (nnhip_prepare) for `model` on the current stream and return it."""
+def prepare(model: Model, device, block: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fill a prepared block (nnhip_prepare) for `model` on the current stream and return it (a new one unless `block`)."""
     L = lib()
     n = L.nnhip_prepared_bytes(model.n_layers)
-    buf = torch.empty(max(n, 256), dtype=torch.uint8, device=device)
+    buf = block if block is not None else torch.empty(max(n, 256), dtype=torch.uint8, device=device)
     _check(L.nnhip_prepare(C.byref(model), _ptr(buf), buf.numel(), _stream(buf.device)), 'nnhip_prepare')
     return buf
+
+
+STATUS_PARAMS_CHANGED = 4   # bit of the graph status word: nnhip_prepare_check found a parameter that differs from its snapshot
+
+
+def prepare_check(model: Model, block: torch.Tensor, status: torch.Tensor):
+    """Queue the exact parameters-vs-snapshot comparison of `block` (nnhip_prepare_check); STATUS_PARAMS_CHANGED is OR-ed into
+    the device int32 `status[0]` when a parameter changed since the previous check of this block."""
+    _check(lib().nnhip_prepare_check(C.byref(model), _ptr(block), block.numel(), _ptr(status), STATUS_PARAMS_CHANGED,
+                                     _stream(block.device)), 'nnhip_prepare_check')
 
 
 def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
@@ -309,12 +320,15 @@ def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
 
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
                 frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False,
-                while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None, envelope: int = 9) -> Graph:
+                while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None, envelope: int = 9,
+                before_sync=None) -> Graph:
     """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU.
     `while_waiting`: callable run after the counting kernels are queued and before the host waits for the edge count --
     work it launches on the stream fills the GPU's idle time during that round trip (NewtonNet.forward passes
     nnhip_prepare here).  `z` (int64, optional): species, range-checked on the device in the same round trip (the
-    reference raises IndexError for z outside 0..118).  `cell_host`: the cell as a host array, when the caller has it."""
+    reference raises IndexError for z outside 0..118).  `cell_host`: the cell as a host array, when the caller has it.
+    `before_sync(status)`: callable that may queue kernels OR-ing further bits (>= 4) into the device status word before it is
+    read back with the edge count; the word comes back as `graph.status`."""
     L = lib()
     dev = pos.device
     pos = _f32c(pos, 'pos')
@@ -350,6 +364,8 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         if z.dtype != torch.int64 or not z.is_contiguous():
             z = z.long().contiguous()
         _check(L.nnhip_check_species(_ptr(z), N, _ptr(status), st), 'nnhip_check_species')
+    if before_sync is not None:
+        before_sync(status[:1])
     tail_dev = meta[B + N + 1:B + N + 3]
     if while_waiting is not None:
         tail_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
@@ -370,6 +386,7 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     if bad & 2:
         raise IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
     g.n_edges = E
+    g.status = bad
     # Everything sized by E in three allocations (the host time between the sync and the first launch is on the step's
     # critical path): int32 [xg 2E | col E | rev E | pid E], float32 [geo 4E | disp 3E | rbf, drbf nb E each], edge_index
     nb = frequencies.numel()

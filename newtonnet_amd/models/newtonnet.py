@@ -83,7 +83,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block'):
             state.pop(k, None)
         return state
 
@@ -184,21 +184,45 @@ class NewtonNet(nn.Module):
         with torch.no_grad():
             model = self._hip_model(energy_idx)
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
-            prep = []   # parameter-only preparation runs on the GPU while the host waits for the edge count ...
-            overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'      # (switch for A/B timing only)
+            # Parameter-only preparation (transposed weights, split-f16 weight images, radial-filter tables, layer 0's
+            # message_nodepart per element) lives in one block per module and is refilled only when a parameter CHANGED: every
+            # call compares the parameters bit for bit with the block's snapshot on the device (nnhip_prepare_check, one small
+            # launch ahead of the edge-count read-back) and the answer comes back with the count.  Nothing is keyed on tensor
+            # identity or version counters.  NNHIP_PREPARE_EVERY_CALL=1 refills the block on every call (inside the sync
+            # bubble, the behaviour of rounds 1-2), NNHIP_PREPARE_OVERLAP=0 rebuilds it inside the workspace: A/B timing only.
+            every_call = os.environ.get('NNHIP_PREPARE_EVERY_CALL', '0') == '1'
+            overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'
+            key = (pos.device, model.n_layers, model.n_basis, model.activation, model.envelope, hip.lib().nnhip_split_products())
+            cached = self.__dict__.get('_prep_block')
+            fresh = cached is None or cached[0] != key
+            block = None if fresh else cached[1]
+            prep = []
 
-            def in_the_bubble():   # ... and the host allocates what does not depend on the edge count
-                prep.append(hip.prepare(model, pos.device))
+            def before_sync(status):
+                if overlap and not every_call and not fresh:
+                    hip.prepare_check(model, block, status)
+
+            def in_the_bubble():   # the host allocates what does not depend on the edge count while it waits for it
+                if overlap and (every_call or fresh):
+                    prep.append(hip.prepare(model, pos.device, block))
                 prep.append(hip.alloc_outputs(pos.shape[0], cell.shape[0], pos.device, want_forces, want_virial))
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies,
-                                while_waiting=in_the_bubble if overlap else None,
+                                while_waiting=in_the_bubble, before_sync=before_sync,
                                 z=zc, envelope=emb.edge_embedding.envelope_id)
+            if overlap:
+                if len(prep) == 2:
+                    block = prep[0]
+                    if fresh and not every_call:   # (its snapshot is uninitialised: take it now, the answer is not needed)
+                        hip.prepare_check(model, block, g.row_ptr.new_zeros(1))
+                elif g.status & hip.STATUS_PARAMS_CHANGED:
+                    hip.prepare(model, pos.device, block)
+                self.__dict__['_prep_block'] = (key, block)
             # the workspace of the previous call is reused when it is large enough (the arrays in it are private to one call;
             # everything the caller sees lives in the output tensors)
             res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
-                                    want_virial=want_virial, prepared=prep[0] if overlap else None,
-                                    out=prep[1] if overlap else None, workspace=self.__dict__.get('_infer_ws'))
+                                    want_virial=want_virial, prepared=block if overlap else None,
+                                    out=prep[-1], workspace=self.__dict__.get('_infer_ws'))
             self.__dict__['_infer_ws'] = res['workspace']
 
         outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],

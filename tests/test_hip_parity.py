@@ -421,6 +421,79 @@ def test_fresh_cell_tensor_each_frame_is_read_every_call():
     assert ptr                                            # (frames really were separate tensors)
 
 
+def test_prepared_block_follows_every_parameter_change():
+    """NewtonNet.forward keeps its parameter-derived block (weight images, transposes, radial-filter tables, layer 0's
+    per-element message_nodepart) across calls and refills it only when nnhip_prepare_check finds a parameter whose BITS
+    changed.  Every route to a change must be seen -- in-place torch updates, load_state_dict, a raw-pointer writer that no
+    version counter records (nnhip_clip_adam writes parameters that way), swapped storages -- and an unchanged model must keep
+    producing bitwise the same numbers.  Reference semantics: the module's parameters ARE the state (newtonnet.py:74-104)."""
+    from newtonnet_amd import hip
+    from newtonnet_amd.models import NewtonNet
+    z, pos, cell, batch, _ = util.case_inputs('aspirin8_rand', torch.float32)
+    z, pos, cell, batch = z.cuda(), pos.cuda(), cell.cuda(), batch.cuda()
+    model, _ = make_model('rand')
+
+    def run(m):
+        o = m(z, pos, cell, batch)
+        return o.energy.clone(), o.gradient_force.clone()
+
+    def fresh_copy():
+        m = NewtonNet(output_properties=['energy', 'gradient_force'])
+        m.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        m = m.cuda()
+        m.eval()      # (returns None, as the reference's does)
+        return m
+
+    def same(a, b):
+        return torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    first = run(model)
+    block = model.__dict__['_prep_block'][1]
+    assert same(run(model), first) and model.__dict__['_prep_block'][1] is block      # unchanged: same block, same bits
+    # (a) in-place torch update of every parameter (an optimizer step)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.mul_(1.0 + 2.0 ** -6)
+    got = run(model)
+    assert not same(got, first) and same(got, run(fresh_copy()))
+    # (b) ONE element of one matrix written behind torch's back (no version bump): a raw device-to-device copy through HIP
+    w = model.interaction_layers[1].equiv_message2[2].weight
+    version = w._version
+    src = torch.full((1,), 0.37, device='cuda')
+    torch.cuda.synchronize()
+    import ctypes
+    libhip = ctypes.CDLL('libamdhip64.so')
+    rc = libhip.hipMemcpy(ctypes.c_void_p(w.data_ptr() + 4 * 777), ctypes.c_void_p(src.data_ptr()), ctypes.c_size_t(4), ctypes.c_int(3))
+    assert rc == 0 and w._version == version and float(w.detach().view(-1)[777]) == float(src[0])
+    got_b = run(model)
+    assert not same(got_b, got) and same(got_b, run(fresh_copy()))
+    # (c) only the radial-filter weights / only a bias / only the Bessel frequencies
+    for q in (model.interaction_layers[0].message_edgepart.weight, model.interaction_layers[0].message_nodepart[0].bias,
+              model.embedding_layers.edge_embedding.embedding.frequencies):
+        before = run(model)
+        with torch.no_grad():
+            q.mul_(1.0 - 2.0 ** -5)
+        after = run(model)
+        assert not same(after, before) and same(after, run(fresh_copy())), q.shape
+    # (d) load_state_dict back to the first weights: the first numbers come back bit for bit
+    model.load_state_dict({k: v.to('cuda') for k, v in util.load_state('rand', torch.float32).items()}, strict=False)
+    assert same(run(model), first)
+    # (e) storages swapped for new tensors with other values (model.to / .float() style): pointers change, values change
+    with torch.no_grad():
+        for q in model.parameters():
+            q.data = (q.data * (1.0 + 2.0 ** -7)).clone()
+    got_e = run(model)
+    assert not same(got_e, first) and same(got_e, run(fresh_copy()))
+    assert model.__dict__['_prep_block'][1] is block                                  # one block per module throughout
+    # (f) the A/B switch that refills the block on every call gives the same bits
+    import os
+    os.environ['NNHIP_PREPARE_EVERY_CALL'] = '1'
+    try:
+        assert same(run(model), got_e)
+    finally:
+        del os.environ['NNHIP_PREPARE_EVERY_CALL']
+
+
 def test_triclinic_fuzz_count_against_the_reference():
     """How often does the neighbor list disagree with the REFERENCE on general triclinic cells at the decision boundaries?
     100 000 random cells x one pair each, placed at fractional separations +-0.5 +- k ulp, at distances r (1 +- k ulp), or both
