@@ -145,6 +145,15 @@ int nnhip_graph_finish(const float* pos, const float* cell, const int64_t* batch
                        float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                        const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
                        int32_t envelope, void* stream);
+/* The same two launches BEFORE the host has read the edge count: every array holds `capacity` edges (edge_index 2 x capacity
+ * int64; its rows are written at the true stride, so the first 2 E entries are the contiguous [2][E] result), the kernels take the
+ * count from row_ptr[n_atoms] on the device and write nothing when it exceeds `capacity` -- the caller, who learns E from its
+ * read-back, then calls nnhip_graph_finish.  Fills the GPU's idle time behind the edge-count round trip. */
+int nnhip_graph_finish_early(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                             const int32_t* row_ptr, const int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
+                             float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
+                             const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
+                             int32_t envelope, void* stream);
 
 /* --------------------------------------------------------------------------
  * Undirected pairs.  msg = (W_e rbf) * m[i] * m[j] (newtonnet.py:211) is symmetric under i <-> j, and so is everything

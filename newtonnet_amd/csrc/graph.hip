@@ -156,9 +156,15 @@ __global__ void __launch_bounds__(256)
 graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell, const int64_t* __restrict__ batch,
                   const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cut2, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
-                  float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges, int* __restrict__ upper = nullptr) {
+                  float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges, int* __restrict__ upper = nullptr,
+                  const int* __restrict__ n_edges_dev = nullptr) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
+  if (FILL && n_edges_dev) {   // early launch (nnhip_graph_finish_early): n_edges is the CAPACITY of the arrays, the count is on the device
+    const int cap = n_edges;
+    n_edges = *n_edges_dev;
+    if (n_edges > cap) return;   // the arrays are too small: nothing is written, the host repeats the launch with the real count
+  }
   const int lane = threadIdx.x & 63;
   const long b = batch[i];
   if (b < 0 || b >= n_mol) {   // flagged by mol_ptr_kernel; keep every access in bounds
@@ -378,8 +384,13 @@ __global__ void __launch_bounds__(256)
 edge_finish_kernel(const int* __restrict__ row_ptr, const int* __restrict__ pair_ptr, const int* __restrict__ col, const int* erow,
                    int n_edges, int* rev, int* __restrict__ pid, const float* __restrict__ disp, float cutoff, float cut2,
                    int env_id, const float* __restrict__ freq, int nb, float* __restrict__ geo, float* __restrict__ rbf,
-                   float* __restrict__ drbf, int2* __restrict__ xg) {
+                   float* __restrict__ drbf, int2* __restrict__ xg, const int* __restrict__ n_edges_dev = nullptr) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_edges_dev) {   // early launch: the grid covers the capacity, the count is on the device
+    const int cap = n_edges;
+    n_edges = *n_edges_dev;
+    if (n_edges > cap) return;
+  }
   if (e >= n_edges) return;
   const int i = erow[e], j = col[e];
   int lo = row_ptr[j], hi = row_ptr[j + 1] - 1, found = -1;
@@ -495,6 +506,34 @@ extern "C" int nnhip_graph_finish(const float* pos, const float* cell, const int
   edge_finish_kernel<<<cdiv(n_edges, 256), 256, 0, stream>>>(row_ptr, pair_ptr, col, rev, n_edges, rev, pid, disp, cutoff,
                                                              cut2_of(cutoff), envelope ? envelope : 9, frequencies, n_basis, geo,
                                                              rbf, drbf, reinterpret_cast<int2*>(xg));
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// nnhip_graph_finish BEFORE the host knows the edge count: the arrays hold `capacity` edges (edge_index: 2 x capacity int64, its
+// two rows written at the TRUE stride, so the first 2 E entries are the contiguous [2][E] result), the kernels read the count
+// from row_ptr[n_atoms] and write nothing at all when it exceeds the capacity (the caller then calls nnhip_graph_finish).
+// NewtonNet.forward launches this while the host waits for the count: the ~24 us of GPU idle time behind that round trip.
+extern "C" int nnhip_graph_finish_early(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                                        const int32_t* row_ptr, const int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol,
+                                        int32_t capacity, float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                                        int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, float* rbf,
+                                        float* drbf, int32_t* xg, int32_t envelope, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms < 0 || capacity < 0 || !pair_ptr || !row_ptr || n_basis < 1 || n_basis > NNHIP_MAX_NB ||
+      (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_graph_finish_early: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_atoms == 0 || capacity == 0) return NNHIP_OK;
+  ScopedTimer tm(TC_GRAPH, stream);
+  graph_rows_kernel<true><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), nullptr,
+                                                                  row_ptr, col, rev, disp, edge_index, capacity, nullptr,
+                                                                  row_ptr + n_atoms);
+  LAUNCH_CHECK();
+  edge_finish_kernel<<<cdiv(capacity, 256), 256, 0, stream>>>(row_ptr, pair_ptr, col, rev, capacity, rev, pid, disp, cutoff,
+                                                              cut2_of(cutoff), envelope ? envelope : 9, frequencies, n_basis, geo,
+                                                              rbf, drbf, reinterpret_cast<int2*>(xg), row_ptr + n_atoms);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

@@ -148,6 +148,7 @@ def lib():
     L.nnhip_graph_count_cells_pairs.argtypes = [vp, vp, i32, f32, _fp, vp, vp, vp, vp, vp]
     L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
+    L.nnhip_graph_finish_early.argtypes = L.nnhip_graph_finish.argtypes
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_edge_refresh.argtypes = [vp, vp, vp, vp, i32, f32, vp, i32, vp, vp, vp, vp, vp, i32, vp]
@@ -229,7 +230,7 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
+               'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -252,7 +253,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_cells_scratch_bytes', 'nnhip_graph_count_cells', 'nnhip_graph_fill_cells',
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
                     'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
-                    'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
+                    'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells')
 
 
@@ -321,14 +322,17 @@ def _orthorhombic_box(cell: torch.Tensor, cutoff: float, cell_host=None):
 def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float,
                 frequencies: torch.Tensor, want_edge_index: bool = True, want_rbf: bool = False,
                 while_waiting=None, z: Optional[torch.Tensor] = None, cell_host=None, envelope: int = 9,
-                before_sync=None) -> Graph:
+                before_sync=None, edge_capacity: int = 0) -> Graph:
     """RadiusGraph + ScaledNorm + envelope x Bessel (representations.py:20-43) on the GPU.
     `while_waiting`: callable run after the counting kernels are queued and before the host waits for the edge count --
     work it launches on the stream fills the GPU's idle time during that round trip (NewtonNet.forward passes
     nnhip_prepare here).  `z` (int64, optional): species, range-checked on the device in the same round trip (the
     reference raises IndexError for z outside 0..118).  `cell_host`: the cell as a host array, when the caller has it.
     `before_sync(status)`: callable that may queue kernels OR-ing further bits (>= 4) into the device status word before it is
-    read back with the edge count; the word comes back as `graph.status`."""
+    read back with the edge count; the word comes back as `graph.status`.
+    `edge_capacity` > 0 (with `while_waiting`; all-pairs builder): the edge arrays are allocated for that many edges and
+    nnhip_graph_finish_early is queued BEFORE the host waits for the count -- the kernels read it on the device; when the
+    count turns out larger than the capacity they have written nothing and the ordinary path runs after the wait."""
     L = lib()
     dev = pos.device
     pos = _f32c(pos, 'pos')
@@ -367,14 +371,46 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     if before_sync is not None:
         before_sync(status[:1])
     tail_dev = meta[B + N + 1:B + N + 3]
+    nb = frequencies.numel()
+    freq = _f32c(frequencies, 'frequencies')
+
+    def edge_arrays(cap):
+        # everything sized by the edge count in three allocations (the host time between the sync and the first launch is on the
+        # step's critical path): int32 [xg 2 cap | col | rev | pid], float32 [geo 4 cap | disp 3 cap | rbf, drbf nb cap each], edge_index
+        ints = torch.empty(5 * cap, dtype=torch.int32, device=dev)
+        flts = torch.empty((7 + (2 * nb if want_rbf else 0)) * cap, dtype=torch.float32, device=dev)
+        ei = torch.empty(2 * cap, dtype=torch.int64, device=dev) if want_edge_index else None
+        return ints, flts, ei
+
+    def bind(arrays, cap, E):   # views of the first E edges (edge_index: its rows were written at stride E)
+        ints, flts, ei = arrays
+        g.xg, g.col = ints[:2 * cap].view(cap, 2)[:E], ints[2 * cap:2 * cap + E]
+        g.rev, g.pid = ints[3 * cap:3 * cap + E], ints[4 * cap:4 * cap + E]
+        g.geo, g.disp = flts[:4 * cap].view(cap, 4)[:E], flts[4 * cap:7 * cap].view(cap, 3)[:E]
+        g.rbf = flts[7 * cap:(7 + nb) * cap].view(cap, nb)[:E] if want_rbf else None     # dist_edge (tests / API)
+        g.drbf = flts[(7 + nb) * cap:].view(cap, nb)[:E] if want_rbf else None
+        g.edge_index = ei[:2 * E].view(2, E) if want_edge_index else None
+
+    def finish_args(arrays, cap):
+        ints, flts, ei = arrays
+        return (_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.pair_ptr), N, B, cap, float(cutoff),
+                C.c_void_p(ints.data_ptr() + 8 * cap), C.c_void_p(ints.data_ptr() + 12 * cap), C.c_void_p(ints.data_ptr() + 16 * cap),
+                C.c_void_p(flts.data_ptr() + 16 * cap), _ptr(ei), _ptr(freq), nb, _ptr(flts),
+                C.c_void_p(flts.data_ptr() + 28 * cap) if want_rbf else None,
+                C.c_void_p(flts.data_ptr() + (28 + 4 * nb) * cap) if want_rbf else None, _ptr(ints), g.envelope, st)
+
+    early = None
     if while_waiting is not None:
         tail_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
         tail_host.copy_(tail_dev, non_blocking=True)          # queue the read-back first ...
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        # ... then work that does not need the edge count: the pair scan,
+        # ... then work that does not need the edge count on the host: the pair scan,
         _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
-        while_waiting()                                        # the caller's (parameter preparation), then wait for the copy only
+        if edge_capacity > 0 and box is None:                  # the fill itself, into arrays of the caller's capacity,
+            early = edge_arrays(int(edge_capacity))
+            _check(L.nnhip_graph_finish_early(*finish_args(early, int(edge_capacity))), 'nnhip_graph_finish_early')
+        while_waiting()                                        # the caller's (allocations), then wait for the copy only
         ev.synchronize()
         tail = tail_host.tolist()
     else:
@@ -387,22 +423,15 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         raise IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
     g.n_edges = E
     g.status = bad
-    # Everything sized by E in three allocations (the host time between the sync and the first launch is on the step's
-    # critical path): int32 [xg 2E | col E | rev E | pid E], float32 [geo 4E | disp 3E | rbf, drbf nb E each], edge_index
-    nb = frequencies.numel()
-    ints = torch.empty(5 * E, dtype=torch.int32, device=dev)
-    g.xg, g.col, g.rev, g.pid = ints[:2 * E].view(E, 2), ints[2 * E:3 * E], ints[3 * E:4 * E], ints[4 * E:]
-    flts = torch.empty((7 + (2 * nb if want_rbf else 0)) * E, dtype=torch.float32, device=dev)
-    g.geo, g.disp = flts[:4 * E].view(E, 4), flts[4 * E:7 * E].view(E, 3)
-    g.rbf = flts[7 * E:(7 + nb) * E].view(E, nb) if want_rbf else None     # dist_edge (tests / API)
-    g.drbf = flts[(7 + nb) * E:].view(E, nb) if want_rbf else None
-    g.edge_index = torch.empty(2, E, dtype=torch.int64, device=dev) if want_edge_index else None
-    freq = _f32c(frequencies, 'frequencies')
+    if early is not None and E <= int(edge_capacity):          # the early launch has done the work
+        bind(early, int(edge_capacity), E)
+        if E == 0:
+            g.pair_ptr.zero_()
+        return g
+    arrays = edge_arrays(E)
+    bind(arrays, E, E)
     if box is None:
-        _check(L.nnhip_graph_finish(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.pair_ptr), N, B, E,
-                                    float(cutoff), _ptr(g.col), _ptr(g.rev), _ptr(g.pid), _ptr(g.disp), _ptr(g.edge_index),
-                                    _ptr(freq), nb, _ptr(g.geo), _ptr(g.rbf), _ptr(g.drbf), _ptr(g.xg), g.envelope, st),
-               'nnhip_graph_finish')
+        _check(L.nnhip_graph_finish(*finish_args(arrays, E)), 'nnhip_graph_finish')
         if E == 0:
             g.pair_ptr.zero_()
     else:

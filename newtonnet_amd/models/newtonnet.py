@@ -83,7 +83,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint'):
             state.pop(k, None)
         return state
 
@@ -206,10 +206,16 @@ class NewtonNet(nn.Module):
                 if overlap and (every_call or fresh):
                     prep.append(hip.prepare(model, pos.device, block))
                 prep.append(hip.alloc_outputs(pos.shape[0], cell.shape[0], pos.device, want_forces, want_virial))
+            # The neighbor-list fill is queued BEFORE the host has the edge count, into arrays sized from the previous call with
+            # the same atom count (+ 1/16): its kernels read the count on the device and write nothing when it does not fit (the
+            # ordinary path then runs after the wait).  NNHIP_GRAPH_EARLY=0: always the ordinary path (A/B timing).
+            hint = self.__dict__.get('_edge_hint', (None, 0))
+            cap = hint[1] if (hint[0] == pos.shape[0] and os.environ.get('NNHIP_GRAPH_EARLY', '1') != '0') else 0
             g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
                                 emb.edge_embedding.embedding.frequencies,
                                 while_waiting=in_the_bubble, before_sync=before_sync,
-                                z=zc, envelope=emb.edge_embedding.envelope_id)
+                                z=zc, envelope=emb.edge_embedding.envelope_id, edge_capacity=cap)
+            self.__dict__['_edge_hint'] = (pos.shape[0], g.n_edges + (g.n_edges >> 4) + 256 if g.n_edges > 0 else 0)
             if overlap:
                 if len(prep) == 2:
                     block = prep[0]

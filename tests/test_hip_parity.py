@@ -421,6 +421,48 @@ def test_fresh_cell_tensor_each_frame_is_read_every_call():
     assert ptr                                            # (frames really were separate tensors)
 
 
+def test_early_neighbor_list_fill_is_the_same_list():
+    """From the second call with the same atom count on, NewtonNet.forward queues the neighbor-list fill before the host has
+    read the edge count (nnhip_graph_finish_early: arrays of the previous call's size + 1/16, the count read on the device).
+    The list and everything computed from it must be what a first call returns -- when the count equals, undercuts, slightly
+    exceeds (inside the head room) and far exceeds (nothing written, ordinary path) the capacity.  RadiusGraph semantics:
+    representations.py:57-100."""
+    z, pos, cell, batch, c = util.case_inputs('aspirin8_rand', torch.float32)
+    z, pos, cell, batch = z.cuda(), pos.cuda(), cell.cuda(), batch.cuda()
+    model, _ = make_model('rand')
+    centre = pos.mean(dim=0, keepdim=True)
+
+    def first_call(p):
+        m, _ = make_model('rand')
+        return m(z, p, cell, batch)
+
+    def check(p, expect_early):
+        hint = model.__dict__.get('_edge_hint', (None, 0))
+        o, ref = model(z, p, cell, batch), first_call(p)
+        E = ref.edge_index.shape[1]
+        assert (hint[0] == p.shape[0] and 0 < hint[1] and E <= hint[1]) == expect_early, (hint, E)
+        assert o.edge_index.shape == ref.edge_index.shape and o.edge_index.is_contiguous()
+        assert torch.equal(o.edge_index, ref.edge_index)
+        assert torch.equal(o.energy, ref.energy) and torch.equal(o.gradient_force, ref.gradient_force)
+        assert torch.equal(o.atom_node, ref.atom_node) and torch.equal(o.force_node, ref.force_node)
+        return E
+
+    E0 = check(pos, False)                                   # first call: ordinary path
+    assert np.array_equal(model(z, pos, cell, batch).edge_index.cpu().numpy(), c['f32_edge_index'])   # early path vs the reference
+    assert check(pos, True) == E0                            # same count
+    # each conformer scaled about ITS centre (molecules never interact, their positions relative to each other do not matter)
+    mol_centre = torch.stack([pos[batch == b].mean(dim=0) for b in range(int(batch.max()) + 1)])[batch]
+    wide = mol_centre + 1.6 * (pos - mol_centre)
+    E_wide = check(wide, True)                               # fewer edges than the capacity
+    assert E_wide < E0
+    tight = mol_centre + 0.97 * (pos - mol_centre)
+    E_tight = check(tight, False)                            # the capacity now follows the sparse list: far too small
+    assert E_tight > E_wide + (E_wide >> 4) + 256
+    check(tight, True)
+    check(mol_centre + 0.96 * (pos - mol_centre), True)      # a few edges more: inside the head room
+    del centre
+
+
 def test_prepared_block_follows_every_parameter_change():
     """NewtonNet.forward keeps its parameter-derived block (weight images, transposes, radial-filter tables, layer 0's
     per-element message_nodepart) across calls and refills it only when nnhip_prepare_check finds a parameter whose BITS
