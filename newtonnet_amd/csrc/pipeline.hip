@@ -406,20 +406,28 @@ struct ParamTable {
   int count[PREP_MAX_PARAMS];
   int off[PREP_MAX_PARAMS];
 };
-#define PARAM_CHECK_CHUNKS 4
+// one workgroup per 1024 consecutive words of one tensor, four words per thread (all loads independent): ~400 workgroups, ~3 us
+#define PARAM_CHECK_MAX_CHUNKS ((NNHIP_N_ELEMENTS * NF + 1023) / 1024 > NF * NF / 1024 ? (NNHIP_N_ELEMENTS * NF + 1023) / 1024 : NF * NF / 1024)
 __global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit) {
   const int k = blockIdx.x;
+  const int n = t.count[k];
+  const int e0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (blockIdx.y * 1024 >= n) return;   // (block-uniform)
   const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(t.src[k]);
   uint32_t* __restrict__ dst = snap + t.off[k];
-  const int n = t.count[k];
+  uint32_t v[4], w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = e0 + q < n ? src[e0 + q] : 0u;
+    w[q] = e0 + q < n ? dst[e0 + q] : 0u;
+  }
   int differs = 0;
-  for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += 256 * PARAM_CHECK_CHUNKS) {
-    const uint32_t v = src[e];
-    if (v != dst[e]) {
-      dst[e] = v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (v[q] != w[q]) {
+      dst[e0 + q] = v[q];
       differs = 1;
     }
-  }
   if (__syncthreads_or(differs) && threadIdx.x == 0) atomicOr(status, bit);
 }
 
@@ -450,7 +458,7 @@ extern "C" int nnhip_prepare_check(const nnhip_model* model, void* prepared, siz
     nnhip_set_error("nnhip_prepare_check: snapshot overflow");
     return NNHIP_E_INVALID;
   }
-  param_check_kernel<<<dim3(t.n, PARAM_CHECK_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+  param_check_kernel<<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
       t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), status, bit);
   LAUNCH_CHECK();
   return NNHIP_OK;

@@ -279,10 +279,56 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 CELL_LIST_MIN_ATOMS = 2048   # below this the all-pairs kernel is at least as fast
 
 
+_EDGE_FIELDS = ('col', 'rev', 'disp', 'edge_index', 'geo', 'rbf', 'drbf', 'xg', 'pid')
+
+
 class Graph:
-    """Neighbor list + edge embedding of one batch (device tensors)."""
+    """Neighbor list + edge embedding of one batch (device tensors).  The per-edge arrays (`col`, `rev`, `pid`, `xg`, `geo`,
+    `disp`, `rbf`, `drbf`, `edge_index`) are views into three allocations; they are created on first access -- the host time
+    between the edge-count read-back and the first launch behind it is on the step's critical path, and a dozen view
+    constructions are ~15 us of it -- and `edge_ptr(name)` gives the raw device address without creating one."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status', '_arrays', '_cap', '_nb')
+
+    def __getattr__(self, name):   # (only reached when the slot is still empty)
+        if name in _EDGE_FIELDS and self._bind():
+            return object.__getattribute__(self, name)
+        raise AttributeError(name)
+
+    def _bind(self) -> bool:
+        try:
+            ints, flts, ei = object.__getattribute__(self, '_arrays')
+        except AttributeError:
+            return False
+        cap, E, nb = self._cap, self.n_edges, self._nb
+        self.xg, self.col = ints[:2 * cap].view(cap, 2)[:E], ints[2 * cap:2 * cap + E]
+        self.rev, self.pid = ints[3 * cap:3 * cap + E], ints[4 * cap:4 * cap + E]
+        self.geo, self.disp = flts[:4 * cap].view(cap, 4)[:E], flts[4 * cap:7 * cap].view(cap, 3)[:E]
+        want_rbf = flts.numel() > 7 * cap
+        self.rbf = flts[7 * cap:(7 + nb) * cap].view(cap, nb)[:E] if want_rbf else None     # dist_edge (tests / API)
+        self.drbf = flts[(7 + nb) * cap:].view(cap, nb)[:E] if want_rbf else None
+        self.edge_index = ei[:2 * E].view(2, E) if ei is not None else None   # (its rows were written at stride E)
+        return True
+
+    def edge_ptr(self, name: str):
+        """Device address of a per-edge array (None when absent), without materialising the view."""
+        try:
+            ints, flts, ei = object.__getattribute__(self, '_arrays')
+        except AttributeError:
+            return _ptr(getattr(self, name))
+        cap, nb = self._cap, self._nb
+        if cap == 0:
+            return None
+        off = {'xg': (ints, 0), 'col': (ints, 8 * cap), 'rev': (ints, 12 * cap), 'pid': (ints, 16 * cap), 'geo': (flts, 0),
+               'disp': (flts, 16 * cap)}
+        if name in off:
+            base, o = off[name]
+            return C.c_void_p(base.data_ptr() + o)
+        if name == 'edge_index':
+            return _ptr(ei)
+        if flts.numel() <= 7 * cap:
+            return None
+        return C.c_void_p(flts.data_ptr() + (28 * cap if name == 'rbf' else (28 + 4 * nb) * cap))
 
 
 def prepare(model: Model, device, block: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -382,14 +428,8 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         ei = torch.empty(2 * cap, dtype=torch.int64, device=dev) if want_edge_index else None
         return ints, flts, ei
 
-    def bind(arrays, cap, E):   # views of the first E edges (edge_index: its rows were written at stride E)
-        ints, flts, ei = arrays
-        g.xg, g.col = ints[:2 * cap].view(cap, 2)[:E], ints[2 * cap:2 * cap + E]
-        g.rev, g.pid = ints[3 * cap:3 * cap + E], ints[4 * cap:4 * cap + E]
-        g.geo, g.disp = flts[:4 * cap].view(cap, 4)[:E], flts[4 * cap:7 * cap].view(cap, 3)[:E]
-        g.rbf = flts[7 * cap:(7 + nb) * cap].view(cap, nb)[:E] if want_rbf else None     # dist_edge (tests / API)
-        g.drbf = flts[(7 + nb) * cap:].view(cap, nb)[:E] if want_rbf else None
-        g.edge_index = ei[:2 * E].view(2, E) if want_edge_index else None
+    def bind(arrays, cap, E):   # (views of the first E edges: made on first access, Graph._bind)
+        g._arrays, g._cap, g._nb = arrays, cap, nb
 
     def finish_args(arrays, cap):
         ints, flts, ei = arrays
@@ -495,8 +535,8 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
         out = alloc_outputs(N, B, dev, want_forces, want_virial, want_nodes)
     out['workspace'] = workspace
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
-    _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.col),
-                                 _ptr(g.rev), _ptr(g.pid), _ptr(g.geo), _ptr(g.xg), _ptr(g.disp), N, E, B,
+    _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), g.edge_ptr('col'),
+                                 g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'), g.edge_ptr('disp'), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
                                  _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
                                  _ptr(out['force_node']), _ptr(prepared), _stream(dev)), 'nnhip_energy_forces')
