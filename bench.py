@@ -423,6 +423,9 @@ def main():
                     help='inference (default): the headline metric, with the data-parallel train step reported beside it in '
                          '"train"; train: the train step (BASELINE configs[3]) is the reported value')
     ap.add_argument('--no-train-leg', action='store_true')
+    ap.add_argument('--batches', type=int, default=4,
+                    help='distinct synthetic batches (own noise, own edge count) the steps cycle through, all resident in HBM: '
+                         'no step sees the positions of the step before it')
     ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     args = ap.parse_args()
 
@@ -471,14 +474,22 @@ def main():
     model = model.to(device)
     model.eval()
 
+    # K distinct batches of the same shape (batch k of rank r: noise seed r + 7919 k), cycled through by the steps: positions --
+    # and the edge count -- change from step to step as in an MD run or a dataset sweep; nothing a step computes can be carried
+    # over from the step before it.  (Batch 0 is the one the CPU baseline runs.)
+    n_batches = max(1, args.batches) if args.workload == 'aspirin' else 1
     if args.workload == 'box100k':
-        z, pos, cell, batch = synthetic_box(100000, 47, seed=rank, device=device)
+        data = [synthetic_box(100000, 47, seed=rank, device=device)]
     else:
-        z, pos, cell, batch = synthetic_aspirin(args.conformers, seed=rank, device=device)
+        data = [synthetic_aspirin(args.conformers, seed=rank + 7919 * k, device=device) for k in range(n_batches)]
+    z, pos, cell, batch = data[0]
     N = z.shape[0]
+    n_calls = [0]
 
     def step():
-        return model(z, pos, cell, batch)
+        d = data[n_calls[0] % n_batches]
+        n_calls[0] += 1
+        return model(*d)
 
     def sync_all():
         torch.cuda.synchronize()          # this rank's queued work is done ...
@@ -499,7 +510,9 @@ def main():
         t = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    E = int(out.edge_index.shape[1])
+    edge_counts = [int(model(*d).edge_index.shape[1]) for d in data]
+    E = int(round(sum(edge_counts) / len(edge_counts)))          # (mean over the batches: what the byte / FLOP models below use)
+    out = model(*data[0])                                         # batch 0: compared with the CPU baseline below
     value = world * N * args.steps / dt
 
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream --------------------
@@ -717,6 +730,13 @@ def main():
                        if args.workload == 'aspirin' else
                        'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
+                       'distinct_batches': n_batches, 'edges_per_batch': edge_counts,
+                       'step_to_step': ('the steps cycle through distinct batches (own noise, own edge count).  Per-module state '
+                                        'that survives a step: the workspace allocation, the parameter-derived block (weight images, '
+                                        'radial-filter tables; checked against the parameters bit for bit on every step, '
+                                        'nnhip_prepare_check, refilled on change) and the CAPACITY of the neighbor-list arrays (the '
+                                        'fill is queued before the host has the edge count and redone if the count does not fit) -- '
+                                        'no result of a step is reused'),
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
