@@ -463,6 +463,49 @@ def test_early_neighbor_list_fill_is_the_same_list():
     del centre
 
 
+def test_one_module_through_a_random_sequence_of_batches():
+    """The state a module keeps between calls (workspace, prepared block, the capacity of the neighbor-list arrays) must never
+    show in its results: 40 random batches -- atom counts that repeat and change, molecules stretched and squeezed so that the
+    edge count falls below, inside and beyond the capacity the previous call left, a parameter update in the middle -- each
+    compared bit for bit with a module that sees the batch as its first call."""
+    from newtonnet_amd.models import NewtonNet
+    a = util.load_npz('aspirin_frames.npz')
+    base = torch.from_numpy(a['train_pos'][0]).float()
+    zb = torch.from_numpy(a['z']).long()
+    gen = torch.Generator().manual_seed(5)
+    model, sd = make_model('rand')
+    early = fallback = 0
+    for step in range(40):
+        n_mol = int(torch.randint(1, 4, (1,), generator=gen)) * 3          # 3, 6 or 9 molecules: atom counts repeat often
+        scale = float(0.9 + 0.9 * torch.rand(1, generator=gen))            # 0.9 .. 1.8: 420 .. ~150 edges per molecule
+        centre = base.mean(dim=0, keepdim=True)
+        pos = torch.cat([centre + scale * (base - centre) + 0.05 * torch.randn(21, 3, generator=gen) + 30.0 * k
+                         for k in range(n_mol)])
+        z = zb.repeat(n_mol)
+        batch = torch.repeat_interleave(torch.arange(n_mol), 21)
+        cell = torch.zeros(n_mol, 3, 3)
+        if step == 20:
+            with torch.no_grad():
+                for q in model.parameters():
+                    q.mul_(1.0 + 2.0 ** -8)
+        hint = model.__dict__.get('_edge_hint', (None, 0))
+        args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+        got = model(*args)
+        fresh = NewtonNet(output_properties=['energy', 'gradient_force'])
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        fresh = fresh.cuda()
+        fresh.eval()
+        want = fresh(*args)
+        E = want.edge_index.shape[1]
+        if hint[0] == z.shape[0] and hint[1] > 0:
+            early += E <= hint[1]
+            fallback += E > hint[1]
+        assert torch.equal(got.edge_index, want.edge_index) and got.edge_index.is_contiguous(), step
+        assert torch.equal(got.energy, want.energy) and torch.equal(got.gradient_force, want.gradient_force), step
+        assert torch.equal(got.atom_node, want.atom_node) and torch.equal(got.force_node, want.force_node), step
+    assert early >= 5 and fallback >= 2, (early, fallback)      # both sides of the early fill were exercised
+
+
 def test_prepared_block_follows_every_parameter_change():
     """NewtonNet.forward keeps its parameter-derived block (weight images, transposes, radial-filter tables, layer 0's
     per-element message_nodepart) across calls and refills it only when nnhip_prepare_check finds a parameter whose BITS
