@@ -288,7 +288,7 @@ class Graph:
     between the edge-count read-back and the first launch behind it is on the step's critical path, and a dozen view
     constructions are ~15 us of it -- and `edge_ptr(name)` gives the raw device address without creating one."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status', '_arrays', '_cap', '_nb')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status', '_arrays', '_cap', '_nb', '_want_rbf')
 
     def __getattr__(self, name):   # (only reached when the slot is still empty)
         if name in _EDGE_FIELDS and self._bind():
@@ -304,7 +304,7 @@ class Graph:
         self.xg, self.col = ints[:2 * cap].view(cap, 2)[:E], ints[2 * cap:2 * cap + E]
         self.rev, self.pid = ints[3 * cap:3 * cap + E], ints[4 * cap:4 * cap + E]
         self.geo, self.disp = flts[:4 * cap].view(cap, 4)[:E], flts[4 * cap:7 * cap].view(cap, 3)[:E]
-        want_rbf = flts.numel() > 7 * cap
+        want_rbf = self._want_rbf
         self.rbf = flts[7 * cap:(7 + nb) * cap].view(cap, nb)[:E] if want_rbf else None     # dist_edge (tests / API)
         self.drbf = flts[(7 + nb) * cap:].view(cap, nb)[:E] if want_rbf else None
         self.edge_index = ei[:2 * E].view(2, E) if ei is not None else None   # (its rows were written at stride E)
@@ -326,7 +326,7 @@ class Graph:
             return C.c_void_p(base.data_ptr() + o)
         if name == 'edge_index':
             return _ptr(ei)
-        if flts.numel() <= 7 * cap:
+        if not self._want_rbf:
             return None
         return C.c_void_p(flts.data_ptr() + (28 * cap if name == 'rbf' else (28 + 4 * nb) * cap))
 
@@ -429,7 +429,7 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
         return ints, flts, ei
 
     def bind(arrays, cap, E):   # (views of the first E edges: made on first access, Graph._bind)
-        g._arrays, g._cap, g._nb = arrays, cap, nb
+        g._arrays, g._cap, g._nb, g._want_rbf = arrays, cap, nb, bool(want_rbf)
 
     def finish_args(arrays, cap):
         ints, flts, ei = arrays
