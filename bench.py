@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+# What plain float4 streaming kernels sustain on this pool beyond the 256 MB memory-side cache (tools/ubench/hbm_stream.hip,
+# profiles/r03_ubench_hbm_stream.txt: 320 MB - 1.28 GB arrays).  Context for the fractions of the 8 TB/s spec, never the `peak`.
+POOL_STREAMING_GBS = {'read': (6010.0, 6240.0), 'write': (4490.0, 5150.0), 'copy_read_plus_write': (4620.0, 5020.0)}
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -573,6 +576,13 @@ def main():
                                                'the layer-0 launches' if regw >= 2 else 'forward + adjoint') +
                                               '; split-f16 products, fp32 accumulate)',
                     'achieved': round(mlp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(mlp_gbs / HBM_PEAK_GBS, 4),
+                    'pool_streaming_ceiling': {
+                        'GB/s': POOL_STREAMING_GBS, 'source': 'profiles/r03_ubench_hbm_stream.txt (plain float4 streaming kernels, arrays '
+                                                              'beyond the memory-side cache; measured once, not in this run)',
+                        'frac_of_copy_ceiling': [round(mlp_gbs / POOL_STREAMING_GBS['copy_read_plus_write'][1], 3),
+                                                 round(mlp_gbs / POOL_STREAMING_GBS['copy_read_plus_write'][0], 3)],
+                        'note': 'the forward launches write 2 of every 3 bytes they move: they sit on the write / copy ceiling of the '
+                                'pool; `frac` above stays priced against the 8 TB/s spec'},
                     'matrix_pipe': {'useful_fp32_tflops': round(mlp_tf, 2), 'executed_f16_tflops': round(3 * mlp_tf, 2),
                                     'peak_f16_tflops': MFMA_F16_PEAK_TFLOPS, 'frac': round(3 * mlp_tf / MFMA_F16_PEAK_TFLOPS, 4),
                                     'note': '3 v_mfma_f32_32x32x16_f16 per 16 k-values (hi*hi + hi*lo + lo*hi); the same FLOPs on '
