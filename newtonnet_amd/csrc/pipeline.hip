@@ -68,6 +68,7 @@ struct TimerRec {
 };
 // (host threads driving different streams may time concurrently: the switch is atomic, the lists are under one mutex)
 static std::atomic<bool> g_timers_on{false};
+static std::atomic<uint32_t> g_timer_mask{0xffffffffu};   // classes that record events (nnhip_timers_enable)
 static std::mutex g_timer_mu;
 static std::vector<TimerRec> g_pending;
 static std::vector<hipEvent_t> g_event_pool;
@@ -87,7 +88,8 @@ static hipEvent_t get_event() {
   if (hipEventCreate(&e) != hipSuccess) return nullptr;
   return e;
 }
-ScopedTimer::ScopedTimer(int c, hipStream_t st) : cls(c), s(st), e0(nullptr), on(g_timers_on.load()) {
+ScopedTimer::ScopedTimer(int c, hipStream_t st)
+    : cls(c), s(st), e0(nullptr), on(g_timers_on.load() && ((g_timer_mask.load() >> c) & 1u)) {
   if (on) {
     e0 = get_event();
     if (e0) (void)hipEventRecord(e0, s); else on = false;
@@ -101,8 +103,11 @@ ScopedTimer::~ScopedTimer() {
   std::lock_guard<std::mutex> lk(g_timer_mu);
   g_pending.push_back({cls, e0, e1});
 }
+// on: 0 = off, 1 = every class, otherwise bit (k + 1) selects class k -- only the selected classes put events into the stream, so
+// a class can be timed without the two events per launch of all the others (which delay every kernel boundary a little)
 extern "C" int nnhip_timers_enable(int32_t on) {
   g_timers_on = on != 0;
+  g_timer_mask = (on == 0 || on == 1) ? 0xffffffffu : ((uint32_t)on >> 1);
   return NNHIP_OK;
 }
 extern "C" int nnhip_timers_read(double* ms, int64_t* cnt, int32_t reset) {

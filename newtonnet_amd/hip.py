@@ -607,8 +607,15 @@ def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def timers_enable(on: bool):
-    _check(lib().nnhip_timers_enable(1 if on else 0), 'nnhip_timers_enable')
+def timers_enable(on, classes=None):
+    """Event timers of the library on / off.  `classes` (names of TIMER_CLASSES): only those classes record events."""
+    if on and classes:
+        mask = 0
+        for name in classes:
+            mask |= 1 << (TIMER_CLASSES.index(name) + 1)
+        _check(lib().nnhip_timers_enable(mask), 'nnhip_timers_enable')
+    else:
+        _check(lib().nnhip_timers_enable(1 if on else 0), 'nnhip_timers_enable')
 
 
 def split_products() -> bool:
