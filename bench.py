@@ -197,7 +197,7 @@ def train_roofline(device, conformers=1024, reps=5):
             one()
         torch.cuda.synchronize()
         ms_step = 1e3 * (time.perf_counter() - t0) / reps
-        hip.timers_enable(True)
+        hip.timers_enable(True, classes=('wgrad',))     # (only the weight-gradient launches are bracketed by events)
         for _ in range(reps):
             one()
         torch.cuda.synchronize()
