@@ -519,7 +519,7 @@ def main():
     value = world * N * args.steps / dt
 
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream --------------------
-    roofline = edge_roofline = onepass = None
+    roofline = edge_roofline = onepass = edge_all_roofline = None
     classes = {}
     if rank == 0:
         # One pass per group of classes: only the group's launches are bracketed by events.  (With every launch bracketed the
@@ -561,11 +561,16 @@ def main():
         if one_n == 0:
             regw = 0                                   # (batch below the persistent regime, or no weight images)
         row_unit = (E // 2) * 512.0
-        one_bytes = row_unit * 5 * one_n               # every one-pass launch moves five row passes
-        # the launches mlp128s_kernel keeps: layer 0 (3 + 3 units) and whatever of layers 1-2 the one-pass form does not serve
-        mlp_bytes = row_unit * (3 + 3 + (0 if regw >= 2 else 2 * 6) + (0 if regw >= 1 else 2 * 7))
-        # FLOPs: ten equal MLP phases per step (5 forward, 5 adjoint); a one-pass launch is two of them
-        one_flops = mlp_flops * 2.0 * one_n / 10.0
+        # one-pass launches: a two-MLP launch moves five row passes; the single-MLP adjoint of layer 0 (NNHIP_MLP_REGW_SINGLE,
+        # default on: g_phi1, h1 in + g_msg out) three, and with level 2 its forward (msg in + h1, phi1 out) three
+        single = int(os.environ.get('NNHIP_MLP_REGW_SINGLE', '1')) if regw >= 1 else 0
+        n_single = min(single, 2)
+        n_pair = max(one_n - n_single, 0)
+        one_bytes = row_unit * (5 * n_pair + 3 * n_single)
+        # the launches mlp128s_kernel keeps: what of layer 0 (3 + 3 units) and of layers 1-2 the one-pass forms do not serve
+        mlp_bytes = row_unit * ((3 if single < 2 else 0) + (3 if single < 1 else 0) + (0 if regw >= 2 else 2 * 6) + (0 if regw >= 1 else 2 * 7))
+        # FLOPs: ten equal MLP phases per step (5 forward, 5 adjoint); a two-MLP launch is two of them, a single-MLP launch one
+        one_flops = mlp_flops * (2.0 * n_pair + 1.0 * n_single) / 10.0
         all_mlp_ms = mlp_ms
         mlp_ms, mlp_n, mlp_flops = max(mlp_ms - one_ms, 0.0), max(mlp_n - one_n, 1), mlp_flops - one_flops
         mlp_gbs = mlp_bytes / (mlp_ms * 1e-3) / 1e9 if mlp_ms > 0 else 0.0
@@ -578,7 +583,7 @@ def main():
                                         'flops_per_step': lin_flops}}
         if split:
             mfma = {'bound': 'hbm', 'kernel': 'mlp128s_kernel (fused Linear-SiLU-Linear over pair rows: ' +
-                                              ('the forward launches and the layer-0 adjoint' if regw == 1 else
+                                              (('the forward launches' if single >= 1 else 'the forward launches and the layer-0 adjoint') if regw == 1 else
                                                'the layer-0 launches' if regw >= 2 else 'forward + adjoint') +
                                               '; split-f16 products, fp32 accumulate)',
                     'achieved': round(mlp_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(mlp_gbs / HBM_PEAK_GBS, 4),
@@ -642,7 +647,8 @@ def main():
             one_gbs = one_bytes / (one_ms * 1e-3) / 1e9 if one_ms > 0 else 0.0
             onepass = {'bound': 'hbm', 'kernel': 'mlp_regw_kernel (both edge MLPs of a layer in one pass over the pair rows, weights '
                                                  'resident in registers: ' + ('the adjoint launches' if regw == 1 else 'forward and adjoint launches') +
-                                                 ' of layers 1-2; bound by VALU issue, priced here against the HBM peak)',
+                                                 ' of layers 1-2' + (' + the single-MLP adjoint of layer 0' if n_single else '') +
+                                                 '; bound by VALU issue, priced here against the HBM peak)',
                        'achieved': round(one_gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(one_gbs / HBM_PEAK_GBS, 4),
                        'traffic': None, 'launches_per_step': one_n, 'avg_launch_us': round(1e3 * one_ms / one_n, 2),
                        'algorithmic_bytes_per_launch': round(one_bytes / one_n), 'ms_per_step': round(one_ms, 4),
@@ -654,10 +660,43 @@ def main():
                     n_l = sum(n for n, _ in t.values())
                     onepass['traffic'] = round(sum(n * b for n, b in t.values()) / n_l)
                     onepass['traffic_source'] = src
-        # `roofline` = the single kernel with the largest share of the step (the edge MLP kernel unless one of the four edge
-        # kernels outweighs it); the other object is reported as `roofline_secondary`
-        top_edge = max(classes[k]['ms_per_step'] for k in ('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd'))
-        roofline, edge_roofline = (mfma, hbm) if mlp_ms >= top_edge else (hbm, mfma)
+        # `roofline` = the single KERNEL (by name: the instantiations of a template count together) with the largest share of the
+        # step, `roofline_secondary` the next one; candidates: mlp128s_kernel, mlp_regw_kernel and each of the four edge kernels
+        # (an object of its own, built from its row of per_kernel and its counter traffic).  The aggregate over the four edge
+        # kernels stays in the line as `roofline_edge_kernels`.
+        edge_names = {'edge_msg_fwd': 'msg_fwd_kernel', 'edge_force_fwd': 'force_fwd_kernel', 'edge_force_bwd': 'force_bwd_kernel',
+                      'edge_msg_bwd': 'msg_bwd_kernel'}
+
+        def edge_object(cls):
+            pk, name = per_kernel[cls], edge_names[cls]
+            n = max(classes[cls]['launches_per_step'], 1)
+            ms = classes[cls]['ms_per_step']
+            gbs = pk['algorithmic_bytes_per_step'] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            o = {'bound': 'hbm', 'kernel': f'{name} (one wave per receiver row, two edges per instruction; every launch of a step, '
+                                           'first layer included)',
+                 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                 'launches_per_step': n, 'avg_launch_us': round(1e3 * ms / n, 2),
+                 'algorithmic_bytes_per_launch': round(pk['algorithmic_bytes_per_step'] / n), 'ms_per_step': round(ms, 4),
+                 'algorithmic_note': 'bytes the pair-once layout must move (bench.py:edge_kernel_bytes; DESIGN.md section 4)'}
+            tpi = hbm.get('traffic_per_instantiation')
+            if tpi:
+                rows = [(k, b) for k, b in tpi.items() if _kernel_match(k, name)]
+                if rows:   # (instantiation <true> runs in layers 1-2, <false> in layer 0; msg_fwd has one form, three launches)
+                    w = {k: (1.0 if '<false>' in k else 2.0 if '<true>' in k else 3.0) for k, _ in rows}
+                    o['traffic'] = round(sum(w[k] * b for k, b in rows) / sum(w.values()))
+                    o['traffic_source'] = hbm.get('traffic_source')
+                    cg = o['traffic'] * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                    o['achieved_counter_bytes'], o['frac_vs_counter_bytes'] = round(cg, 1), round(cg / HBM_PEAK_GBS, 4)
+            return o
+
+        cands = [(mlp_ms, 'mlp', mfma)]
+        if onepass is not None:
+            cands.append((one_ms, 'regw', onepass))
+        cands += [(classes[c]['ms_per_step'], c, None) for c in edge_names]
+        cands.sort(key=lambda t: -t[0])
+        picked = [(obj if obj is not None else edge_object(tag)) for _, tag, obj in cands[:2]]
+        roofline, edge_roofline = picked[0], picked[1]
+        edge_all_roofline = hbm
 
     # ---- CPU baseline (rank 0, N = 1 only): the parity oracle on the host cores ----------------------------
     cpu_baseline = None
@@ -756,7 +795,9 @@ def main():
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
-            'roofline': roofline, 'roofline_secondary': edge_roofline, 'roofline_onepass_mlp': onepass, 'kernel_classes': classes,
+            'roofline': roofline, 'roofline_secondary': edge_roofline, 'roofline_onepass_mlp': onepass,
+            'roofline_mlp128s': mfma, 'roofline_edge_kernels': edge_all_roofline,
+            'kernel_classes': classes,
             'kernel_classes_note': ('event-timed in instrumented passes after the timed region, one pass per group of classes (only that '
                                     "group's launches are bracketed by HIP events); sum of edge_all + linear_mfma + other + graph = "
                                     f'{sum(classes[k]["ms_per_step"] for k in ("edge_all", "linear_mfma", "other", "graph")) if classes else 0:.3f} ms vs '

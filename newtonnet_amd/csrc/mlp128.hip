@@ -395,6 +395,10 @@ int launch_mlp(int mode, bool accum, const MlpArgs& a, hipStream_t s) {
   P.a[0] = P.a[1] = a;
   P.n = 1;
   P.accum[0] = P.accum[1] = accum ? 1 : 0;
+  if (split_products_enabled() && mlp_regw_serves(mode, P)) {   // the single-MLP adjoint with register-resident weights (mlp128r.hip)
+    ScopedTimer t2(TC_MLP_ONEPASS, s);
+    return launch_mlp_regw(mode, P, s);
+  }
   return launch_mlp_dispatch(mode, accum, P, s);
 }
 

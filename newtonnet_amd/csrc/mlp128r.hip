@@ -205,8 +205,11 @@ __device__ __forceinline__ float rw_commit_block(const float (&v)[16], char* til
 #define RW_DBG_PRINT()
 #endif
 
-template <int MODE>
+// SINGLE (adjoint only): ONE MLP (layer 0 has no equiv_message2 term) -- both groups hold the same two matrices and take
+// alternate tiles, each storing its own g_msg rows; the groups then never meet (no hand-over, own trip counts).
+template <int MODE, bool SINGLE = false>
 __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P) {
+  constexpr bool OWN_X = MODE != MODE_FWD || SINGLE;   // every group stages its own X tile (the two-MLP forward shares one)
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   RwLds& L = *reinterpret_cast<RwLds*>(lds_raw);
   const int lane = threadIdx.x & 63;
@@ -217,20 +220,23 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
   const int n_tiles = (M + 31) >> 5;
 
   // this wave's weights: block nb of both matrices of MLP g, for the whole launch
+  const int ga = SINGLE ? 0 : g;    // whose arguments and matrices this wave works with
   RwFrag w1, w2;
-  rw_load_frag(w1, g ? P.a[1].W1_img : P.a[0].W1_img, nb, r, h);
-  rw_load_frag(w2, g ? P.a[1].W2_img : P.a[0].W2_img, nb, r, h);
+  rw_load_frag(w1, ga ? P.a[1].W1_img : P.a[0].W1_img, nb, r, h);
+  rw_load_frag(w2, ga ? P.a[1].W2_img : P.a[0].W2_img, nb, r, h);
 
   // input rows this wave brings per tile.  Forward: 4 of the 32 msg rows -- ONE X tile serves both groups, double-buffered by tile
   // parity (a wave writes tile k + 1 only after its own tile k, and nobody passes the 8-wave arrival of tile k before every wave
   // has left tile k - 1, so the buffer of tile k - 1 is free by then).  Adjoint: 8 of the 32 rows of the group's own g_phi_g.
-  constexpr int NX = MODE == MODE_FWD ? 2 : 4;
-  const float* Xg = (MODE == MODE_FWD || g == 0) ? P.a[0].X : P.a[1].X;
-  const int ldx = (MODE == MODE_FWD || g == 0) ? P.a[0].ldx : P.a[1].ldx;
-  const int xrow0 = MODE == MODE_FWD ? 4 * wave : 8 * nb;
-  const float* Hg = g ? P.a[1].H : P.a[0].H;
-  float* Yg = g ? P.a[1].Y : P.a[0].Y;
-  const int ldy = g ? P.a[1].ldy : P.a[0].ldy;
+  constexpr int NX = OWN_X ? 4 : 2;
+  const float* Xg = (MODE == MODE_FWD || ga == 0) ? P.a[0].X : P.a[1].X;
+  const int ldx = (MODE == MODE_FWD || ga == 0) ? P.a[0].ldx : P.a[1].ldx;
+  const int xrow0 = OWN_X ? 8 * nb : 4 * wave;
+  const float* Hg = ga ? P.a[1].H : P.a[0].H;
+  float* Yg = ga ? P.a[1].Y : P.a[0].Y;
+  const int ldy = ga ? P.a[1].ldy : P.a[0].ldy;
+  const int tile0 = SINGLE ? 2 * (int)blockIdx.x + g : (int)blockIdx.x;
+  const int tile_step = SINGLE ? 2 * (int)gridDim.x : (int)gridDim.x;
   unsigned* bar = &L.bar[g];
   unsigned bar_target = 0, xbar_target = 0;
 
@@ -254,16 +260,16 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       for (int q = 0; q < 4; ++q) hq[q] = ld4_nt(reinterpret_cast<const float*>(hp + 64 * q));
     }
   };
-  request(blockIdx.x);
+  request(tile0);
   RW_DBG_DECL()
 
-  int k = 0;                        // tiles done by this workgroup
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++k) {
+  int k = 0;                        // tiles done by this workgroup (SINGLE: by this group)
+  for (int tile = tile0; tile < n_tiles; tile += tile_step, ++k) {
     RW_DBG_TOP()
     const int e = (tile << 5) + r;
     const bool live = e < M;
-    char* xtile = L.xt[MODE == MODE_FWD ? (k & 1) : g];
-    float* invx = L.invx[MODE == MODE_FWD ? (k & 1) : g];
+    char* xtile = L.xt[OWN_X ? g : (k & 1)];
+    float* invx = L.invx[OWN_X ? g : (k & 1)];
     // ---------------- 1. the X tile (forward: shared; adjoint: the group's own)
 #ifdef RW_CLOCK_DEBUG
     asm volatile("" ::"v"(xq[NX - 1].w));   // (the rows have arrived: phase 1 is the wait, phase 2 the commit)
@@ -277,8 +283,8 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       for (int q = 0; q < 4; ++q) hin[q] = hq[q];
     }
     RW_DBG()   // 1: X commit (waits for the prefetched rows)
-    request(tile + gridDim.x);      // the next tile's rows travel while this one is computed
-    if (MODE == MODE_FWD)
+    request(tile + tile_step);      // the next tile's rows travel while this one is computed
+    if (!OWN_X)
       rw_group_sync(&L.xbar, xbar_target, lane, 8);
     else
       rw_group_sync(bar, bar_target, lane);
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       RW_DBG()   // 3: GEMM 1
       const float sc = invx[r] * w1.inv;
       if (MODE == MODE_FWD) {
-        float4* hp = reinterpret_cast<float4*>(g ? P.a[1].H : P.a[0].H) + ((size_t)tile * 4 + nb) * 256 + lane;
+        float4* hp = reinterpret_cast<float4*>(ga ? P.a[1].H : P.a[0].H) + ((size_t)tile * 4 + nb) * 256 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 hv = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       const f32x16 acc = rw_gemm(L.at[g], w2, r, h);
       RW_DBG()   // 7: GEMM 2
       const float sc = inv2 * w2.inv;
-      if (MODE == MODE_FWD) {
+      if (MODE == MODE_FWD || SINGLE) {
         if (live) {
           float4* yp = reinterpret_cast<float4*>(Yg + (size_t)e * ldy + nb * 32 + 4 * h);
 #pragma unroll
@@ -374,23 +380,30 @@ static int mlp_regw_level() {
 }
 bool mlp_regw_serves(int mode, const MlpPair& P) {
   const int level = mlp_regw_level();
+  // one MLP (layer 0): NNHIP_MLP_REGW_SINGLE = 0 off, 1 the adjoint, 2 the forward too (A/B timing)
+  static const int single = getenv("NNHIP_MLP_REGW_SINGLE") ? atoi(getenv("NNHIP_MLP_REGW_SINGLE")) : 1;
+  if (P.n == 1)
+    return level > 0 && ((mode == MODE_BWD && single >= 1) || (mode == MODE_FWD && single >= 2)) && P.a[0].W1_img &&
+           P.a[0].W2_img && P.a[0].h_frag && P.a[0].act == NNHIP_ACT_SILU && !P.a[0].b1 && !P.a[0].b2 && !P.accum[0];
   if (level <= 0 || P.n != 2 || !((mode == MODE_BWD) || (mode == MODE_FWD && level >= 2))) return false;
   for (int k = 0; k < 2; ++k)
     if (!P.a[k].W1_img || !P.a[k].W2_img || !P.a[k].h_frag || P.a[k].act != NNHIP_ACT_SILU || P.a[k].b1 || P.a[k].b2) return false;
   if (mode == MODE_FWD) return P.a[0].X == P.a[1].X && P.a[0].ldx == P.a[1].ldx && !P.accum[0] && !P.accum[1];
   return P.a[0].Y == P.a[1].Y && P.a[0].ldy == P.a[1].ldy && !P.accum[0] && P.accum[1];
 }
-template <int MODE>
+template <int MODE, bool SINGLE>
 static int launch_regw_t(const MlpPair& P, hipStream_t s) {
-  static const hipError_t attr_rc =
-      hipFuncSetAttribute((const void*)mlp_regw_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RwLds));
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp_regw_kernel<MODE, SINGLE>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RwLds));
   HIP_TRY(attr_rc);
   const int n_tiles = (P.a[0].M + 31) / 32;
-  const int blocks = n_tiles < 256 ? n_tiles : 256;   // one persistent workgroup per CU
-  mlp_regw_kernel<MODE><<<blocks, RW_THREADS, sizeof(RwLds), s>>>(P);
+  const int units = SINGLE ? (n_tiles + 1) / 2 : n_tiles;   // (SINGLE: a workgroup takes two tiles per trip, one per group)
+  const int blocks = units < 256 ? units : 256;              // one persistent workgroup per CU
+  mlp_regw_kernel<MODE, SINGLE><<<blocks, RW_THREADS, sizeof(RwLds), s>>>(P);
   LAUNCH_CHECK();
   return 0;
 }
 int launch_mlp_regw(int mode, const MlpPair& P, hipStream_t s) {
-  return mode == MODE_FWD ? launch_regw_t<MODE_FWD>(P, s) : launch_regw_t<MODE_BWD>(P, s);
+  if (P.n == 1) return mode == MODE_FWD ? launch_regw_t<MODE_FWD, true>(P, s) : launch_regw_t<MODE_BWD, true>(P, s);
+  return mode == MODE_FWD ? launch_regw_t<MODE_FWD, false>(P, s) : launch_regw_t<MODE_BWD, false>(P, s);
 }
