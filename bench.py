@@ -116,23 +116,27 @@ def train_leg(device, dist, backend, world, rank, steps, warmup, molecules=32):
             dist.barrier()
         torch.cuda.synchronize()
     loss0 = float(step(*data))
-    for _ in range(max(warmup, 1)):
-        loss = step(*data)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step(*data)
-    sync_all()
-    dt = time.perf_counter() - t0
+    last = [None]
+
+    def one():
+        last[0] = step(*data)
+
+    def reduce_max(t):
+        if dist is None:
+            return t
+        v = torch.tensor([t], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+    timing = timed_regions(one, steps, max(warmup, 1), sync_all, reduce_max, min_warm_s=0.5)
+    loss = last[0]
+    dt = timing['dt']
     n_atoms = data[0].shape[0]
     tot = torch.tensor([dt, float(n_atoms)], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
     flat = step._st['ws'].flat_grad
     ar_us = None
     if dist is not None:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt, n_atoms = float(mx[0]), int(tot[1])
+        n_atoms = int(tot[1])               # (dt is already the max over ranks of the median region)
         buf = flat.clone()
         for _ in range(3):
             dist.all_reduce(buf)
@@ -153,6 +157,8 @@ def train_leg(device, dist, backend, world, rank, steps, warmup, molecules=32):
     return {'workload': f'mixed MD17-shaped molecules (9 shapes), {molecules} molecules per rank, loss MSE(E) + 50 MSE(F), '
                         'Adam 1e-3, clip 1.0 (BASELINE.json configs[3]); fp32; fully fused HIP-graph step',
             'atoms_total': n_atoms, 'ms_per_step': round(1e3 * dt / steps, 4),
+            'region_ms_per_step': timing['region_ms_per_step'], 'value_rule': timing['value_rule'],
+            'step_ms_gpu_median': sorted(timing['step_ms_gpu'])[len(timing['step_ms_gpu']) // 2],
             'atom_steps_per_s': round(n_atoms * steps / dt, 1), 'molecule_steps_per_s': round(world * molecules * steps / dt, 1),
             'gradient_bytes': int(flat.numel() * 4), 'allreduce_us': None if ar_us is None else round(ar_us, 1),
             'collectives_per_step': 0 if dist is None else 1,
@@ -396,6 +402,62 @@ def edge_kernel_bytes(N, E, L=3, F=128):
     return out
 
 
+MIN_WARM_S = 1.0        # warm-up runs for at least --warmup steps AND this much wall time (clocks, allocator, code objects settle)
+N_REGIONS = 5           # timed regions of --steps steps each; the MEDIAN region is the reported value
+
+
+def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, min_warm_s=MIN_WARM_S):
+    """SURVEY 8(d) "steady state", made checkable.  Warm up for max(`warmup` steps, `min_warm_s` of wall time); then time
+    `regions` regions of EXACTLY `steps` steps, each bracketed by barrier + torch.cuda.synchronize() on both sides
+    (`sync_all`), wall-clock, max over ranks (`reduce_max`).  A host timestamp is taken after every step call.  One more region
+    (never the reported one) records a HIP event after every step on the launch stream: per-step GPU time, which is what a
+    step costs when the host queues ahead.  Returns a dict; `ms_per_step` is the MEDIAN region (never the minimum)."""
+    t_w, n_warm = time.perf_counter(), 0
+    while n_warm < warmup or time.perf_counter() - t_w < min_warm_s:
+        step()
+        n_warm += 1
+        if n_warm % 16 == 0:
+            torch.cuda.synchronize()                      # (bounds how far the host may queue ahead while warming up)
+    sync_all()
+    warm_s = time.perf_counter() - t_w
+    region_dt, region_steps = [], []
+    for _ in range(regions):
+        sync_all()
+        stamps = [time.perf_counter()]
+        for _ in range(steps):
+            step()
+            stamps.append(time.perf_counter())
+        sync_all()
+        dt = time.perf_counter() - stamps[0]
+        region_dt.append(reduce_max(dt))
+        region_steps.append([1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])])
+    # diagnostic region: per-step GPU time from events on the launch stream
+    sync_all()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    for k in range(steps):
+        step()
+        evs[k + 1].record()
+    sync_all()
+    gpu_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+    order = sorted(range(regions), key=lambda k: region_dt[k])
+    med = order[len(order) // 2]
+    all_host = sorted(v for r in region_steps for v in r)
+    return {'dt': region_dt[med], 'ms_per_step': 1e3 * region_dt[med] / steps,
+            'region_ms_per_step': [round(1e3 * d / steps, 4) for d in region_dt],
+            'value_rule': f'median of {regions} timed regions of {steps} steps each (barrier + synchronize on both sides of '
+                          'every region, wall clock, max over ranks); never the minimum',
+            'step_ms': [round(v, 4) for v in region_steps[med]],
+            'step_ms_note': 'host timestamp after every step call of the median region: the time the HOST spent in the call '
+                            '(queueing + any wait it makes), not the GPU time of the step once the host queues ahead',
+            'step_ms_min': round(all_host[0], 4), 'step_ms_median': round(all_host[len(all_host) // 2], 4),
+            'step_ms_max': round(all_host[-1], 4),
+            'step_ms_gpu': [round(v, 4) for v in gpu_steps],
+            'step_ms_gpu_note': 'one extra region (not among the timed ones): HIP event after every step on the launch stream',
+            'warmup_steps_run': n_warm, 'warmup_wall_s': round(warm_s, 3),
+            'warmup_rule': f'max(--warmup steps, {min_warm_s} s of wall time)'}
+
+
 def self_launch(n):
     """Run this script under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` as a child process (rendezvous
     on 127.0.0.1, a free port), relay its output -- rank 0's single JSON line on stdout -- and return its exit code."""
@@ -429,6 +491,7 @@ def main():
     ap.add_argument('--batches', type=int, default=4,
                     help='distinct synthetic batches (own noise, own edge count) the steps cycle through, all resident in HBM: '
                          'no step sees the positions of the step before it')
+    ap.add_argument('--regions', type=int, default=N_REGIONS, help='timed regions of --steps steps (the median is reported)')
     ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     args = ap.parse_args()
 
@@ -500,19 +563,15 @@ def main():
             dist.barrier()                # ... on every rank
         torch.cuda.synchronize()
 
-    out = None
-    for _ in range(args.warmup):
-        out = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+    def reduce_max(dt):
+        if dist is None:
+            return dt
         t = torch.tensor([dt], device=device if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    timing = timed_regions(step, args.steps, args.warmup, sync_all, reduce_max, regions=args.regions)
+    dt = timing['dt']
     edge_counts = [int(model(*d).edge_index.shape[1]) for d in data]
     E = int(round(sum(edge_counts) / len(edge_counts)))          # (mean over the batches: what the byte / FLOP models below use)
     out = model(*data[0])                                         # batch 0: compared with the CPU baseline below
@@ -555,7 +614,8 @@ def main():
         # accumulating = 4.  One-pass form (mlp_regw_kernel, csrc/mlp128r.hip: both MLPs of a layer per tile): forward msg in +
         # h1, h2, phi1, phi2 out = 5 (instead of 6); adjoint g_phi1, g_phi2, h1, h2 in + g_msg out = 5 (instead of 7).
         # Per step (3 layers, phi2 skipped in layer 0): layer 0 is one phase each way (3 + 3), layers 1-2 two MLPs each way.
-        regw = int(os.environ.get('NNHIP_MLP_REGW', '1')) if split else 0   # 1 (default): adjoint launches; 2: forward too
+        forms = hip.mlp_forms()                        # what the LIBRARY does (nnhip_mlp_forms), not a re-reading of its env switches
+        regw = (2 if forms['regw_fwd'] else 1 if forms['regw_bwd'] else 0) if split else 0   # 1 (default): adjoint launches; 2: forward too
         one_ms = classes['mlp_onepass']['ms_per_step']
         one_n = classes['mlp_onepass']['launches_per_step']
         if one_n == 0:
@@ -563,7 +623,7 @@ def main():
         row_unit = (E // 2) * 512.0
         # one-pass launches: a two-MLP launch moves five row passes; the single-MLP adjoint of layer 0 (NNHIP_MLP_REGW_SINGLE,
         # default on: g_phi1, h1 in + g_msg out) three, and with level 2 its forward (msg in + h1, phi1 out) three
-        single = int(os.environ.get('NNHIP_MLP_REGW_SINGLE', '1')) if regw >= 1 else 0
+        single = (2 if forms['regw_single_fwd'] else 1 if forms['regw_single_bwd'] else 0) if regw >= 1 else 0
         n_single = min(single, 2)
         n_pair = max(one_n - n_single, 0)
         one_bytes = row_unit * (5 * n_pair + 3 * n_single)
@@ -775,33 +835,48 @@ def main():
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'], 'roofline': train.get('roofline'), 'train': train}))
     elif rank == 0:
+        kernel_sum = sum(classes[k]['ms_per_step'] for k in ('edge_all', 'linear_mfma', 'other', 'graph')) if classes else 0.0
+        host_gap = 1e3 * dt / args.steps - kernel_sum
         line = {
             'metric': 'atom-steps/sec (energy+force) on batched MD17 aspirin',
             'value': round(value, 1), 'unit': 'atom-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'value_rule': timing['value_rule'], 'region_ms_per_step': timing['region_ms_per_step'],
+            'step_ms': timing['step_ms'], 'step_ms_note': timing['step_ms_note'], 'step_ms_min': timing['step_ms_min'],
+            'step_ms_median': timing['step_ms_median'], 'step_ms_max': timing['step_ms_max'],
+            'step_ms_gpu': timing['step_ms_gpu'], 'step_ms_gpu_note': timing['step_ms_gpu_note'],
             'config': {'workload': (f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
                                     f'fp32, energy+force, neighbor list included (BASELINE.json configs[1])')
                        if args.workload == 'aspirin' else
                        'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights,
+                       'warmup_rule': timing['warmup_rule'], 'warmup_steps_run': timing['warmup_steps_run'],
+                       'warmup_wall_s': timing['warmup_wall_s'], 'timed_regions': len(timing['region_ms_per_step']),
                        'distinct_batches': n_batches, 'edges_per_batch': edge_counts,
-                       'step_to_step': ('the steps cycle through distinct batches (own noise, own edge count).  Per-module state '
-                                        'that survives a step: the workspace allocation, the parameter-derived block (weight images, '
-                                        'radial-filter tables; checked against the parameters bit for bit on every step, '
-                                        'nnhip_prepare_check, refilled on change) and the CAPACITY of the neighbor-list arrays (the '
-                                        'fill is queued before the host has the edge count and redone if the count does not fit) -- '
-                                        'no result of a step is reused'),
+                       'step_to_step': ('the steps cycle through distinct batches (own noise, own edge count).  No device->host round trip '
+                                        'inside a step: every kernel of a step is queued into arrays whose CAPACITY comes from the edge '
+                                        'count of an earlier step (the kernels read the true count on the device; a count beyond the '
+                                        'capacity empties the graph on the device and the step is repeated); the count / status words are '
+                                        'looked at when a result is touched or when the next step starts.  Per-module state that '
+                                        'survives a step: the workspace allocation, the parameter-derived block (weight images, '
+                                        'radial-filter tables; compared with the parameters bit for bit on every step, '
+                                        'nnhip_prepare_check, refilled on change) and that capacity -- no result of a step is reused'),
+                       'deferred_checks': bool(model.__dict__.get('_last_deferred') is not None),
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'roofline_onepass_mlp': onepass,
             'roofline_mlp128s': mfma, 'roofline_edge_kernels': edge_all_roofline,
             'kernel_classes': classes,
-            'kernel_classes_note': ('event-timed in instrumented passes after the timed region, one pass per group of classes (only that '
-                                    "group's launches are bracketed by HIP events); sum of edge_all + linear_mfma + other + graph = "
-                                    f'{sum(classes[k]["ms_per_step"] for k in ("edge_all", "linear_mfma", "other", "graph")) if classes else 0:.3f} ms vs '
-                                    f'ms_per_step {1e3 * dt / args.steps:.3f}; kernel_classes_rocprof holds the durations of the same '
+            'kernel_sum_ms': round(kernel_sum, 4) if classes else None,
+            'host_gap_ms': round(host_gap, 4) if classes else None,
+            'timing_anomaly': bool(classes and host_gap > 0.15 * kernel_sum),
+            'timing_anomaly_rule': 'host_gap_ms = ms_per_step - kernel_sum_ms (event-timed classes edge_all + linear_mfma + other + '
+                                   'graph of the same process); anomaly when it exceeds 15 % of kernel_sum_ms: the timed regions then '
+                                   'held time that no kernel of the step accounts for (host stalls, clocks, other tenants)',
+            'kernel_classes_note': ('event-timed in instrumented passes after the timed regions, one pass per group of classes (only that '
+                                    "group's launches are bracketed by HIP events); kernel_classes_rocprof holds the durations of the same "
                                     'kernels from the committed rocprofv3 trace'),
             'kernel_classes_rocprof': rocprof_classes() if (args.workload == 'aspirin' and args.conformers == 1024) else None,
             'cpu_baseline': cpu_baseline,

@@ -279,6 +279,32 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
                         float* virial, float* atom_energy, float* atom_node, float* force_node,
                         const void* prepared, void* stream);
 
+/* The same step queued BEFORE the host knows the edge count: no device->host round trip inside a step, so a slow host costs
+ * nothing (the reference has no counterpart: RadiusGraph.forward, representations.py:57-100, is synchronous by construction;
+ * the caller it serves is still NewtonNet.forward, newtonnet.py:74-104).
+ *   nnhip_graph_finish_dev   = nnhip_graph_finish_early into arrays of `capacity` edges (even, > 0) + a guard: when the count
+ *       (row_ptr[n_atoms]) exceeds the capacity nothing was filled and the guard EMPTIES the graph on the device
+ *       (row_ptr = pair_ptr = 0), so that the step below runs on zero edges, inside the arrays.  count_copy: one scratch int32.
+ *   nnhip_energy_forces_dev  = nnhip_energy_forces with n_edges := capacity (array / workspace sizes,
+ *       nnhip_workspace_bytes(n_atoms, capacity, ...)) and the true number of undirected pairs read on the device from
+ *       *n_pairs_dev (= &pair_ptr[n_atoms]).
+ * The host copies (row_ptr[n_atoms], status) out asynchronously BEFORE nnhip_graph_finish_dev and looks at them whenever it
+ * likes (NewtonNet.forward: when a result of the call is first touched, or when the next call starts): count > capacity or a
+ * stale prepared block => repeat the step the ordinary way; status bits 1 / 2 => the reference's ValueError / IndexError.
+ * Species outside [0, 118] never index a table (the kernels clamp them; the status bit reports them). */
+int nnhip_graph_finish_dev(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
+                           int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
+                           float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
+                           const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
+                           int32_t envelope, int32_t* count_copy, void* stream);
+int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                            const int32_t* mol_ptr,
+                            const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
+                            const int32_t* xg, const float* disp, int32_t n_atoms, int32_t capacity,
+                            int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
+                            float* virial, float* atom_energy, float* atom_node, float* force_node,
+                            const void* prepared, const int32_t* n_pairs_dev, void* stream);
+
 /* Parameter-only preparation (transposed weights for the reverse sweep, radial-filter tables, layer 0's
  * message_nodepart per element): what the reference gets for free from nn.Module state.  `prepared` is a caller-owned
  * 256-byte-aligned block of nnhip_prepared_bytes(n_layers); fill it with nnhip_prepare whenever the parameters may have
@@ -286,11 +312,12 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  * to nnhip_energy_forces.  prepared == NULL: nnhip_energy_forces rebuilds the block inside its workspace on every call. */
 size_t nnhip_prepared_bytes(int32_t n_layers);
 int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream);
-/* Has any parameter changed since `prepared` was last checked?  One launch: every parameter tensor of `model` is compared
- * bit for bit with a snapshot kept inside the block (the snapshot is brought up to date in the same pass) and `bit` is OR-ed into
- * *status (device int32) when something differed.  A caller that keeps one block per model runs this every call -- ahead of a
- * read-back it does anyway -- and calls nnhip_prepare only when the bit comes back set (always after allocating the block: its
- * snapshot is uninitialised).  Replaces nothing in the reference: torch modules keep no derived state. */
+/* Has any parameter changed since `prepared` was last FILLED?  One launch: every parameter tensor of `model` is compared bit for
+ * bit with the snapshot nnhip_prepare took when it filled the block, and `bit` is OR-ed into *status (device int32) when
+ * something differs.  Compare only: the snapshot moves in nnhip_prepare alone, so a change stays visible until the block has
+ * really been refilled (a caller that fails between the check and the refill cannot lose it).  A caller that keeps one block
+ * per model runs this every call and calls nnhip_prepare only when the bit comes back set.  Replaces nothing in the
+ * reference: torch modules keep no derived state. */
 int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
                         void* stream);
 
@@ -617,6 +644,12 @@ int nnhip_direct_force_bwd(const float* g_out, const float* force_node, const in
  * read once per process): v_mfma_f32_32x32x2_f32 everywhere.  Inputs, outputs and accumulators are fp32 either way.
  * ------------------------------------------------------------------------ */
 int nnhip_split_products(void);
+/* Which forms the fused edge-MLP launches of a large batch take (what bench.py prices its byte model with):
+ *   bit 0  split-f16 products (nnhip_split_products)
+ *   bit 1  the two-MLP adjoint launches run in the one-pass register-weights kernel (mlp_regw_kernel)
+ *   bit 2  ... the two-MLP forward launches too
+ *   bit 3  the single-MLP adjoint (layer 0) runs in mlp_regw_kernel        bit 4  ... the single-MLP forward too */
+int nnhip_mlp_forms(void);
 
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call

@@ -246,6 +246,10 @@ __device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_fl
 __device__ __forceinline__ float2 fma2(float2 a, float2 b, float2 c) { return make_float2(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)); }
 __device__ __forceinline__ float2 fma2(float2 a, float s, float2 c) { return make_float2(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y)); }
 
+// species index into the [119]-row tables: values outside 0..118 are flagged by check_species_kernel and raised by the host (possibly
+// AFTER the step was queued: nnhip_energy_forces_dev) -- the kernels must never index with them
+__device__ __forceinline__ long clamp_species(long z) { return z < 0 ? 0 : (z >= NNHIP_N_ELEMENTS ? NNHIP_N_ELEMENTS - 1 : z); }
+
 // ---- dense 128x128 linear launcher (lin128.hip) ---------------------------------
 enum { PRO_NONE = 0, PRO_SILU = 1 };
 enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_DSILU = 2, EPI_ACC = 3 };
@@ -290,7 +294,12 @@ struct MlpArgs {
   // optional split-f16 images of W1 / W2 (node128s.hip:weight_image_kernel): the row-local kernel then takes the split-f16 form
   const char* W1_img;
   const char* W2_img;
+  // optional: the TRUE row count on the device (a step queued before the host knows its edge count: nnhip_energy_forces_dev).
+  // M then is the capacity the arrays, the layout and the grid are sized for; the kernels process min(M, *M_dev) rows.
+  const int* M_dev;
 };
+// rows a kernel works on (uniform: a scalar load)
+__device__ __forceinline__ int mlp_rows(const MlpArgs& a) { return a.M_dev ? min(a.M, *a.M_dev) : a.M; }
 struct MlpPair {      // up to two MLPs over the same M rows, run back to back by one persistent launch (mlp128.hip)
   MlpArgs a[2];
   int n;

@@ -507,7 +507,7 @@ __global__ void embed_kernel(const int64_t* __restrict__ z, const float* __restr
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 each
   if (t >= (size_t)n_atoms * (NF / 4)) return;
   const int i = (int)(t / (NF / 4)), c = (int)(t % (NF / 4));
-  const size_t zi = (size_t)z[i];
+  const size_t zi = (size_t)clamp_species(z[i]);
   reinterpret_cast<float4*>(a0)[t] = reinterpret_cast<const float4*>(table + zi * NF)[c];
   reinterpret_cast<float4*>(m0)[t] = reinterpret_cast<const float4*>(m_table + zi * NF)[c];
 }
@@ -563,7 +563,7 @@ head_out_kernel(const float* __restrict__ e2, const float* __restrict__ w4, cons
   const bool silu = act == NNHIP_ACT_SILU;   // uniform
   const float ax = silu ? silu_f(h.x) : act_f(h.x, act), ay = silu ? silu_f(h.y) : act_f(h.y, act);
   const float s = wave_sum(fmaf(ax, w.x, ay * w.y));
-  const long zi = z[i];
+  const long zi = clamp_species(z[i]);
   const float sc = scale ? scale[zi] : 1.0f;
   const float sh = shift ? shift[zi] : 0.0f;
   if (lane == 0) atom_energy[i] = fmaf(s + b4[0], sc, sh);

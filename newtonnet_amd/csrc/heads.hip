@@ -22,7 +22,7 @@ direct_force_adj_kernel(const float* __restrict__ g_out /*[N][3]*/, const float*
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   const int lane = threadIdx.x & 63;
-  const float sc = scale ? scale[z[i]] : 1.0f;
+  const float sc = scale ? scale[clamp_species(z[i])] : 1.0f;
   const float2 dv = ld2(d3 + (size_t)i * NF + 2 * lane);
   float2 acc = make_float2(0.f, 0.f);
   float raw = 0.f;

@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(MLP_THREADS, MLP_WAVES / 4) mlp128_kernel(cons
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int M = P.a[0].M;
+  const int M = mlp_rows(P.a[0]);
+  if (M <= 0) return;   // (uniform; only possible with a device-side count)
   const int n_tiles = (M + 31) >> 5;
   const float* w1row = w1s + r * MW_LD + 4 * h;
   const float* w2row = w2s + r * MW_LD + 4 * h;

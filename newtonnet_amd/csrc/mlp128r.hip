@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = wave >> 2, nb = wave & 3;
   const int r = lane & 31, h = lane >> 5;
-  const int M = P.a[0].M;
+  const int M = mlp_rows(P.a[0]);
+  if (M <= 0) return;   // (uniform; only possible with a device-side count)
   const int n_tiles = (M + 31) >> 5;
 
   // this wave's weights: block nb of both matrices of MLP g, for the whole launch
@@ -378,10 +379,20 @@ static int mlp_regw_level() {
   }();
   return level;
 }
+// one MLP (layer 0): NNHIP_MLP_REGW_SINGLE = 0 off, 1 the adjoint, 2 the forward too (A/B timing)
+static int mlp_regw_single() {
+  static const int single = getenv("NNHIP_MLP_REGW_SINGLE") ? atoi(getenv("NNHIP_MLP_REGW_SINGLE")) : 1;
+  return single;
+}
+// what the library does with the switches above, for callers that model its traffic (bench.py); include/newtonnet_hip.h
+extern "C" int nnhip_mlp_forms(void) {
+  const bool split = split_products_enabled();
+  const int level = split ? mlp_regw_level() : 0, single = level > 0 ? mlp_regw_single() : 0;
+  return (split ? 1 : 0) | (level >= 1 ? 2 : 0) | (level >= 2 ? 4 : 0) | (single >= 1 ? 8 : 0) | (single >= 2 ? 16 : 0);
+}
 bool mlp_regw_serves(int mode, const MlpPair& P) {
   const int level = mlp_regw_level();
-  // one MLP (layer 0): NNHIP_MLP_REGW_SINGLE = 0 off, 1 the adjoint, 2 the forward too (A/B timing)
-  static const int single = getenv("NNHIP_MLP_REGW_SINGLE") ? atoi(getenv("NNHIP_MLP_REGW_SINGLE")) : 1;
+  const int single = mlp_regw_single();
   if (P.n == 1)
     return level > 0 && ((mode == MODE_BWD && single >= 1) || (mode == MODE_FWD && single >= 2)) && P.a[0].W1_img &&
            P.a[0].W2_img && P.a[0].h_frag && P.a[0].act == NNHIP_ACT_SILU && !P.a[0].b1 && !P.a[0].b2 && !P.accum[0];

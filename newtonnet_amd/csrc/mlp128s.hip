@@ -185,7 +185,8 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int M = P.a[0].M;
+  const int M = mlp_rows(P.a[0]);
+  if (M <= 0) return;   // (uniform; only possible with a device-side count)
   const int n_tiles = (M + 31) >> 5;
   const char* w1row = img + r * SW_PITCH + 16 * h;             // + nb * 32 * SW_PITCH + 32 T
   const char* w2row = img + SW_MAT + r * SW_PITCH + 16 * h;

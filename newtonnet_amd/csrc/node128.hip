@@ -270,9 +270,11 @@ int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ void mlp_wide_body(const MlpArgs& p, const bool accum, Tile& t) {
+  const int M = mlp_rows(p);
+  if ((int)blockIdx.x * 32 >= M) return;   // (block-uniform: a tile beyond a device-side row count; never taken otherwise)
   const int row = blockIdx.x * 32 + t.r;
-  const int rc = min(row, p.M - 1);
-  const bool live = row < p.M;
+  const int rc = min(row, M - 1);
+  const bool live = row < M;
 
   float4 wf[16];
   load_w(wf, t, p.W1);
@@ -463,7 +465,7 @@ direct_force_tail_kernel(const float* __restrict__ d, const float* __restrict__ 
     s[k] = wave_sum(fmaf(dv.x, f.x, dv.y * f.y));
   }
   if (lane == 0) {
-    const float sc = scale ? scale[z[i]] : 1.0f;
+    const float sc = scale ? scale[clamp_species(z[i])] : 1.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = s[k] * sc;
   }

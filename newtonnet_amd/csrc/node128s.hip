@@ -634,9 +634,11 @@ int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool accum, STile& t) {
+  const int M = mlp_rows(p);
+  if ((int)blockIdx.x * 32 >= M) return;   // (block-uniform: a tile beyond a device-side row count; never taken otherwise)
   const int row = blockIdx.x * 32 + t.r;
-  const int rc = min(row, p.M - 1);
-  const bool live = row < p.M;
+  const int rc = min(row, M - 1);
+  const bool live = row < M;
 
   WFrag wf;
   load_wimg(wf, t, p.W1_img);

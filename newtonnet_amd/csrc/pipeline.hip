@@ -389,16 +389,6 @@ extern "C" size_t nnhip_prepared_bytes(int32_t L) {
   return prep_bytes(L);
 }
 
-extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream_) {
-  TRY(check_model(model, "nnhip_prepare"));
-  PrepLayout pq;
-  make_prep_layout(model->n_layers, pq);
-  if (!prepared || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
-    nnhip_set_error("nnhip_prepare: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
-    return NNHIP_E_WORKSPACE;
-  }
-  return run_prepare(model, pq, (char*)prepared, (hipStream_t)stream_);
-}
 
 // Did a parameter change since this block was last checked?  Exact (bitwise) comparison of every parameter tensor with the
 // snapshot kept inside the block; the snapshot is brought up to date in the same pass and `bit` is OR-ed into *status when
@@ -413,6 +403,10 @@ struct ParamTable {
 };
 // one workgroup per 1024 consecutive words of one tensor, four words per thread (all loads independent): ~400 workgroups, ~3 us
 #define PARAM_CHECK_MAX_CHUNKS ((NNHIP_N_ELEMENTS * NF + 1023) / 1024 > NF * NF / 1024 ? (NNHIP_N_ELEMENTS * NF + 1023) / 1024 : NF * NF / 1024)
+// UPDATE = false: compare only -- OR `bit` into *status when a word differs (the snapshot is left alone, so a change stays
+// visible until nnhip_prepare refills the block: a caller that fails between the check and the refill cannot lose it);
+// UPDATE = true: copy the parameters into the snapshot (the tail of nnhip_prepare).
+template <bool UPDATE>
 __global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit) {
   const int k = blockIdx.x;
   const int n = t.count[k];
@@ -430,22 +424,12 @@ __global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     if (v[q] != w[q]) {
-      dst[e0 + q] = v[q];
+      if (UPDATE) dst[e0 + q] = v[q];
       differs = 1;
     }
-  if (__syncthreads_or(differs) && threadIdx.x == 0) atomicOr(status, bit);
+  if (!UPDATE && __syncthreads_or(differs) && threadIdx.x == 0) atomicOr(status, bit);
 }
-
-extern "C" int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
-                                   void* stream_) {
-  TRY(check_model(model, "nnhip_prepare_check"));
-  PrepLayout pq;
-  make_prep_layout(model->n_layers, pq);
-  if (!prepared || !status || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
-    nnhip_set_error("nnhip_prepare_check: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
-    return NNHIP_E_WORKSPACE;
-  }
-  ParamTable t;
+static int make_param_table(const nnhip_model* model, ParamTable& t) {
   memset(&t, 0, sizeof(t));
   const float* ptr[PREP_MAX_PARAMS];
   int count[PREP_MAX_PARAMS];
@@ -460,23 +444,58 @@ extern "C" int nnhip_prepare_check(const nnhip_model* model, void* prepared, siz
     ++t.n;
   }
   if ((size_t)off > snapshot_floats(model->n_layers)) {
-    nnhip_set_error("nnhip_prepare_check: snapshot overflow");
+    nnhip_set_error("nnhip_prepare: snapshot overflow");
     return NNHIP_E_INVALID;
   }
-  param_check_kernel<<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
+                                   void* stream_) {
+  TRY(check_model(model, "nnhip_prepare_check"));
+  PrepLayout pq;
+  make_prep_layout(model->n_layers, pq);
+  if (!prepared || !status || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
+    nnhip_set_error("nnhip_prepare_check: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  ParamTable t;
+  TRY(make_param_table(model, t));
+  param_check_kernel<false><<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
       t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), status, bit);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
 
+// Fill a prepared block AND take the snapshot of the parameters it was filled from (what nnhip_prepare_check compares with).
+extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_bytes, void* stream_) {
+  TRY(check_model(model, "nnhip_prepare"));
+  PrepLayout pq;
+  make_prep_layout(model->n_layers, pq);
+  if (!prepared || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
+    nnhip_set_error("nnhip_prepare: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  TRY(run_prepare(model, pq, (char*)prepared, (hipStream_t)stream_));
+  ParamTable t;
+  TRY(make_param_table(model, t));
+  param_check_kernel<true><<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), nullptr, 0);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
 // ---- the hot path --------------------------------------------------------------------------------------
-extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
-                                   const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
-                                   const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
-                                   const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
-                                   size_t workspace_bytes, float* energy, float* forces, float* virial,
-                                   float* atom_energy_out, float* atom_node_out, float* force_node_out,
-                                   const void* prepared, void* stream_) {
+// n_pairs_dev == NULL: E is the edge count.  Otherwise (nnhip_energy_forces_dev) E is the CAPACITY the per-edge arrays and the
+// workspace are sized for and *n_pairs_dev the true number of undirected pairs (= pair_ptr[N]): the row kernels walk row_ptr, the
+// per-edge kernels cover the capacity (rows beyond the count hold nothing anybody reads), the pair-row kernels read the count.
+static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                              const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
+                              const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
+                              const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
+                              size_t workspace_bytes, float* energy, float* forces, float* virial,
+                              float* atom_energy_out, float* atom_node_out, float* force_node_out,
+                              const void* prepared, const int32_t* n_pairs_dev, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -540,7 +559,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
     // (two rounds of 14 dependent edge iterations per row phase, two to three rounds of GEMM units per dense phase).
     // NNHIP_SMALL_STEP=1 selects it (read per call); tests keep it parity-checked.
     const bool small_on = getenv("NNHIP_SMALL_STEP") && atoi(getenv("NNHIP_SMALL_STEP")) == 1;
-    bool plain = split_nodes && small_on && !virial && N <= SMALL_MAX_ATOMS && E <= SMALL_MAX_EDGES;
+    bool plain = split_nodes && small_on && !virial && !n_pairs_dev && N <= SMALL_MAX_ATOMS && E <= SMALL_MAX_EDGES;
     for (int l = 0; l < L; ++l) plain = plain && !model->layer[l].ln_w;
     if (plain) {
       SmallArgs a;
@@ -632,6 +651,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
       m1.act = m2.act = act;
+      m1.M_dev = m2.M_dev = n_pairs_dev;
       if (split_nodes) {   // (used by the row-local form only: small pair counts)
         m1.W1_img = pbase + pq.img[l][IMG_EQ1_0];
         m1.W2_img = pbase + pq.img[l][IMG_EQ1_2];
@@ -762,6 +782,7 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
       MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
       m1.h_frag = m2.h_frag = 1;
       m1.act = m2.act = act;
+      m1.M_dev = m2.M_dev = n_pairs_dev;
       if (split_nodes) {
         m1.W1_img = pbase + pq.img[l][IMG_EQ1_2_T];
         m1.W2_img = pbase + pq.img[l][IMG_EQ1_0_T];
@@ -815,6 +836,36 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
   TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, pos, cell, row_ptr, col, rev, mol_ptr, N, E, B, L,
                           model->cutoff, P(w.g_d), forces, virial, s));
   return NNHIP_OK;
+}
+
+extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                                   const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
+                                   const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
+                                   const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
+                                   size_t workspace_bytes, float* energy, float* forces, float* virial,
+                                   float* atom_energy_out, float* atom_node_out, float* force_node_out,
+                                   const void* prepared, void* stream_) {
+  return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, E, B, workspace, workspace_bytes,
+                            energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared, nullptr, stream_);
+}
+// The same step queued BEFORE the host knows the edge count (NewtonNet.forward's steady state: no device->host round trip inside
+// a step).  `capacity` (even, > 0) sizes the per-edge arrays (nnhip_graph_finish_dev) and the workspace
+// (nnhip_workspace_bytes(N, capacity, ...)); n_pairs_dev = &pair_ptr[N].  When the count exceeded the capacity the graph arrives
+// here emptied by nnhip_graph_finish_dev's guard: the step runs on zero edges, in bounds, and the host repeats it.
+extern "C" int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                                       const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
+                                       const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
+                                       const float* disp, int32_t N, int32_t capacity, int32_t B, void* workspace,
+                                       size_t workspace_bytes, float* energy, float* forces, float* virial,
+                                       float* atom_energy_out, float* atom_node_out, float* force_node_out,
+                                       const void* prepared, const int32_t* n_pairs_dev, void* stream_) {
+  if (!n_pairs_dev || capacity < 2 || (capacity & 1)) {
+    nnhip_set_error("nnhip_energy_forces_dev: needs n_pairs_dev and an even capacity > 0");
+    return NNHIP_E_INVALID;
+  }
+  return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, capacity, B, workspace,
+                            workspace_bytes, energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared,
+                            n_pairs_dev, stream_);
 }
 
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----

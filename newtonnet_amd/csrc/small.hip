@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(SM_THREADS, 1) small_step_kernel(const SmallAr
   // ---- embedding: atom_node = Embedding[z]; m of layer 0 from its per-element table
   for (int t = threadIdx.x; t < N * (NF / 4); t += SM_THREADS) {
     const int i = t / (NF / 4), c = t % (NF / 4);
-    const size_t zi = (size_t)A.z[i];
+    const size_t zi = (size_t)clamp_species(A.z[i]);
     reinterpret_cast<float4*>(A.a0)[t] = reinterpret_cast<const float4*>(A.emb + zi * NF)[c];
     reinterpret_cast<float4*>(A.m[0])[t] = reinterpret_cast<const float4*>(A.m_tab + zi * NF)[c];
   }
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(SM_THREADS, 1) small_step_kernel(const SmallAr
     const float2 hv = ld2(A.e2 + (size_t)i * NF + c2);
     const float2 w = ld2(A.w4 + c2);
     const float s = wave_sum(fmaf(silu_f(hv.x), w.x, silu_f(hv.y) * w.y));
-    const long zi = A.z[i];
+    const long zi = clamp_species(A.z[i]);
     const float sc = A.scale ? A.scale[zi] : 1.0f;
     const float sh = A.shift ? A.shift[zi] : 0.0f;
     if (lane == 0) A.atom_energy[i] = fmaf(s + A.b4[0], sc, sh);

@@ -149,6 +149,10 @@ def lib():
     L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish_early.argtypes = L.nnhip_graph_finish.argtypes
+    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp]
+    L.nnhip_energy_forces_dev.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
+                                          vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.nnhip_mlp_forms.restype = C.c_int
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_edge_refresh.argtypes = [vp, vp, vp, vp, i32, f32, vp, i32, vp, vp, vp, vp, vp, i32, vp]
@@ -230,7 +234,8 @@ def lib():
     for fn in ('nnhip_graph_count', 'nnhip_graph_fill', 'nnhip_edge_embed', 'nnhip_workspace_layout',
                'nnhip_energy_forces', 'nnhip_timers_enable', 'nnhip_timers_read', 'nnhip_linear128', 'nnhip_segment_sum', 'nnhip_gather_rows', 'nnhip_graph_count_cells',
                'nnhip_graph_fill_cells', 'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp',
-               'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells'):
+               'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_graph_count_pairs', 'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs', 'nnhip_graph_finish_cells',
+               'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev'):
         getattr(L, fn).restype = C.c_int
     _lib = L
     return L
@@ -254,7 +259,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
                     'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
-                    'nnhip_graph_finish_cells')
+                    'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms')
 
 
 def _check(rc: int, what: str):
@@ -288,7 +293,8 @@ class Graph:
     between the edge-count read-back and the first launch behind it is on the step's critical path, and a dozen view
     constructions are ~15 us of it -- and `edge_ptr(name)` gives the raw device address without creating one."""
     __slots__ = ('n_atoms', 'n_mol', 'n_edges', 'mol_ptr', 'row_ptr', 'col', 'rev', 'disp', 'edge_index', 'geo',
-                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status', '_arrays', '_cap', '_nb', '_want_rbf')
+                 'rbf', 'drbf', 'xg', 'pid', 'pair_ptr', '_train_eg', 'envelope', 'status', '_arrays', '_cap', '_nb', '_want_rbf',
+                 '_meta')
 
     def __getattr__(self, name):   # (only reached when the slot is still empty)
         if name in _EDGE_FIELDS and self._bind():
@@ -499,6 +505,90 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
                                 _ptr(_f32c(frequencies, 'frequencies')), frequencies.numel(), _ptr(g.disp), _ptr(g.geo), _ptr(g.rbf),
                                 _ptr(g.drbf), _ptr(g.xg), g.envelope, st), 'nnhip_edge_refresh')
     return g
+
+
+def build_graph_dev(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float, frequencies: torch.Tensor,
+                    capacity: int, tail_host: torch.Tensor, z: Optional[torch.Tensor] = None, envelope: int = 9,
+                    before_copy=None, want_edge_index: bool = True):
+    """build_graph for a step that never waits for the host (all-pairs builder only): every kernel of the neighbor list is
+    queued into arrays of `capacity` edges (even, > 0); the (edge count, status) words are copied into the pinned int32 pair
+    `tail_host` asynchronously and the returned event fires when they have arrived -- nothing here blocks.  The returned Graph
+    has `n_edges = None` until the caller has looked at the count (NewtonNet.forward's deferred checks) and sets it.  When the
+    count exceeds the capacity the device-side guard of nnhip_graph_finish_dev empties the graph (the step that follows runs on
+    zero edges, inside its arrays) and the caller repeats the call through build_graph.  `before_copy(status)`: may queue
+    kernels OR-ing bits >= 4 into the status word ahead of the copy (nnhip_prepare_check)."""
+    L = lib()
+    dev = pos.device
+    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    if batch.dtype != torch.int64 or not batch.is_contiguous():
+        batch = batch.long().contiguous()
+    N, B, cap = pos.shape[0], cell.shape[0], int(capacity)
+    if cap < 2 or cap & 1:
+        raise ValueError('build_graph_dev: capacity must be even and positive')
+    g = Graph()
+    g.n_atoms, g.n_mol, g.envelope, g.n_edges, g.status = N, B, int(envelope), None, 0
+    n_scan = (N + 1023) // 1024 + 1
+    # the int32 block of build_graph + one word: the guard's copy of the count
+    meta = torch.empty(B + 1 + N + 1 + 1 + n_scan + N + 1 + n_scan + 1, dtype=torch.int32, device=dev)
+    g._meta = meta
+    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:B + N + 3 + n_scan]
+    o_pp = B + N + 3 + n_scan
+    g.pair_ptr, pair_scan = meta[o_pp:o_pp + N + 1], meta[o_pp + N + 1:o_pp + N + 1 + n_scan]
+    count_copy = meta[-1:]
+    st = _stream(dev)
+    _check(L.nnhip_graph_count_pairs(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
+                                     _ptr(g.row_ptr), _ptr(status), _ptr(g.pair_ptr), st), 'nnhip_graph_count_pairs')
+    if z is not None:
+        _check(L.nnhip_check_species(_ptr(z), N, _ptr(status), st), 'nnhip_check_species')
+    if before_copy is not None:
+        before_copy(status[:1])
+    tail_host.copy_(meta[B + N + 1:B + N + 3], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
+    nb = frequencies.numel()
+    freq = _f32c(frequencies, 'frequencies')
+    ints = torch.empty(5 * cap, dtype=torch.int32, device=dev)
+    flts = torch.empty(7 * cap, dtype=torch.float32, device=dev)
+    ei = torch.empty(2 * cap, dtype=torch.int64, device=dev) if want_edge_index else None
+    g._arrays, g._cap, g._nb, g._want_rbf = (ints, flts, ei), cap, nb, False
+    _check(L.nnhip_graph_finish_dev(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.pair_ptr), N, B,
+                                    cap, float(cutoff), C.c_void_p(ints.data_ptr() + 8 * cap),
+                                    C.c_void_p(ints.data_ptr() + 12 * cap), C.c_void_p(ints.data_ptr() + 16 * cap),
+                                    C.c_void_p(flts.data_ptr() + 16 * cap), _ptr(ei), _ptr(freq), nb, _ptr(flts), None, None,
+                                    _ptr(ints), g.envelope, _ptr(count_copy), st), 'nnhip_graph_finish_dev')
+    return g, ev
+
+
+def energy_forces_dev(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
+                      want_virial: bool = False, workspace: Optional[torch.Tensor] = None, out: Optional[dict] = None,
+                      prepared: Optional[torch.Tensor] = None):
+    """energy_forces on a graph of build_graph_dev: sizes from the capacity, the pair count read on the device."""
+    L = lib()
+    dev = z.device
+    N, cap, B = g.n_atoms, g._cap, g.n_mol
+    need = L.nnhip_workspace_bytes(N, cap, B, model.n_layers)
+    if workspace is None or workspace.numel() < need or workspace.device != dev:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+    if out is None:
+        out = alloc_outputs(N, B, dev, want_forces, want_virial, True)
+    out['workspace'] = workspace
+    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    n_pairs_dev = C.c_void_p(g.pair_ptr.data_ptr() + 4 * N)
+    _check(L.nnhip_energy_forces_dev(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr),
+                                     g.edge_ptr('col'), g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'),
+                                     g.edge_ptr('disp'), N, cap, B, _ptr(workspace), workspace.numel(), _ptr(out['energy']),
+                                     _ptr(out['forces']), _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
+                                     _ptr(out['force_node']), _ptr(prepared), n_pairs_dev, _stream(dev)),
+           'nnhip_energy_forces_dev')
+    return out
+
+
+def mlp_forms() -> dict:
+    """Which forms the fused edge-MLP launches of a large batch take (nnhip_mlp_forms): what bench.py's byte model asks."""
+    v = lib().nnhip_mlp_forms()
+    return {'split': bool(v & 1), 'regw_bwd': bool(v & 2), 'regw_fwd': bool(v & 4), 'regw_single_bwd': bool(v & 8),
+            'regw_single_fwd': bool(v & 16)}
 
 
 def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:

@@ -26,6 +26,82 @@ from newtonnet_amd.models.output import (CustomOutputSet, DerivativeProperty, En
                                          StressOutput, VirialOutput, get_aggregator_by_string, get_output_by_string)
 
 
+# A/B and debugging switches, read once (never per call)
+_DEFERRED = os.environ.get('NNHIP_DEFERRED', '1') != '0'                 # 0: every eval-mode call waits for its edge count
+_GRAPH_EARLY = os.environ.get('NNHIP_GRAPH_EARLY', '1') != '0'           # (synchronous path) fill queued ahead of the wait
+_PREPARE_EVERY_CALL = os.environ.get('NNHIP_PREPARE_EVERY_CALL', '0') == '1'
+
+
+class _Deferred:
+    """One eval-mode forward call whose host-side checks are deferred (NewtonNet._forward_deferred).
+
+    The reference's forward is synchronous (RadiusGraph.forward, representations.py:57-100, sizes its tensors from the edge
+    count) and raises IndexError / ValueError on the spot.  Here the steady-state call queues everything and returns; the
+    two words the host needs -- the edge count and the status bits -- are read when a result is first touched (`settle`) or
+    when the module's next call starts (`NewtonNet._settle_last`):
+      status bit 1 / 2   -> the ValueError (batch order) / IndexError (species) the synchronous call raises;
+      count > capacity   -> the device emptied the graph (nnhip_graph_finish_dev): the call is repeated synchronously;
+      status bit 4       -> a parameter changed since the prepared block was filled: refill and repeat likewise.
+    A repeat reads the caller's input tensors again: if one of them was modified in place in the meantime the record raises
+    instead of returning numbers for the wrong inputs."""
+    QUEUED, WORDS, DONE = 0, 1, 2
+    __slots__ = ('owner', 'inputs', 'zc', 'energy_idx', 'want_forces', 'want_virial', 'res', 'graph', 'tail', 'event', 'cap',
+                 'versions', 'state', 'error', 'reported', 'count', 'bad')
+
+    def __init__(self, owner, inputs, zc, energy_idx, want_forces, want_virial):
+        self.owner, self.inputs, self.zc, self.energy_idx = owner, inputs, zc, energy_idx
+        self.want_forces, self.want_virial = want_forces, want_virial
+        self.res = self.graph = self.tail = self.event = self.versions = self.error = None
+        self.cap = self.count = self.bad = 0
+        self.state, self.reported = _Deferred.QUEUED, False
+
+    def read_words(self):
+        """Wait for the (count, status) words of this call -- they leave the GPU right behind its counting kernels -- and take
+        them off the pinned slot.  No kernel is launched, nothing is repeated here."""
+        if self.state != _Deferred.QUEUED:
+            return
+        self.event.synchronize()
+        self.count, self.bad = (int(v) for v in self.tail.tolist())
+        self.tail = self.event = None
+        self.state = _Deferred.WORDS
+        if self.bad & 1:
+            self.error = ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
+        elif self.bad & 2:
+            self.error = IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
+        else:
+            self.owner._note_count(self.inputs[1].shape[0], self.count)
+
+    def settle(self):
+        if self.state == _Deferred.DONE:
+            if self.error is not None:
+                raise self.error
+            return self
+        self.read_words()
+        if self.error is not None:
+            self.state, self.reported = _Deferred.DONE, True
+            raise self.error
+        if self.count > self.cap or (self.bad & hip.STATUS_PARAMS_CHANGED):
+            if tuple(t._version for t in self.inputs) != self.versions:
+                self.error = RuntimeError(
+                    'this forward call has to be repeated (its edge count exceeded the capacity taken from the previous call, or a '
+                    'parameter had changed), but one of its input tensors was modified in place before its outputs were read: '
+                    'read the outputs before modifying the inputs, or call model.synchronize_checks() right after forward')
+                self.state = _Deferred.DONE
+                raise self.error
+            owner = self.owner
+            z, pos, cell, batch = self.inputs
+            with torch.no_grad():
+                model = owner._hip_model(self.energy_idx)
+                self.res, self.graph = owner._forward_sync(model, self.zc, pos, cell, batch, self.want_forces, self.want_virial)
+        else:
+            self.graph.n_edges, self.graph.status = self.count, self.bad
+        self.state = _Deferred.DONE
+        return self
+
+    def result(self, name):
+        return self.settle().res[name]
+
+
 class EmbeddingNet(nn.Module):
     """Node embedding table + edge-embedding hyper-parameters (newtonnet.py:116-137)."""
     def __init__(self, cutoff, n_features, n_basis):
@@ -83,7 +159,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync'):
             state.pop(k, None)
         return state
 
@@ -182,80 +258,164 @@ class NewtonNet(nn.Module):
             return self._forward_train(z, pos, cell, batch, keys, energy_idx, make_displacement())
 
         with torch.no_grad():
+            # bookkeeping of the previous deferred call (edge-count hint, stale prepared block); raises ITS deferred error when
+            # nobody has looked at its outputs yet
+            self._settle_last()
             model = self._hip_model(energy_idx)
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
-            # Parameter-only preparation (transposed weights, split-f16 weight images, radial-filter tables, layer 0's
-            # message_nodepart per element) lives in one block per module and is refilled only when a parameter CHANGED: every
-            # call compares the parameters bit for bit with the block's snapshot on the device (nnhip_prepare_check, one small
-            # launch ahead of the edge-count read-back) and the answer comes back with the count.  Nothing is keyed on tensor
-            # identity or version counters.  NNHIP_PREPARE_EVERY_CALL=1 refills the block on every call (inside the sync
-            # bubble, the behaviour of rounds 1-2), NNHIP_PREPARE_OVERLAP=0 rebuilds it inside the workspace: A/B timing only.
-            every_call = os.environ.get('NNHIP_PREPARE_EVERY_CALL', '0') == '1'
-            overlap = os.environ.get('NNHIP_PREPARE_OVERLAP', '1') != '0'
-            key = (pos.device, model.n_layers, model.n_basis, model.activation, model.envelope, hip.lib().nnhip_split_products())
-            cached = self.__dict__.get('_prep_block')
-            fresh = cached is None or cached[0] != key
-            block = None if fresh else cached[1]
-            prep = []
+            rec = _Deferred(self, (z, pos, cell, batch), zc, energy_idx, want_forces, want_virial)
+            if not self._forward_deferred(rec, model):
+                rec.res, rec.graph = self._forward_sync(model, zc, pos, cell, batch, want_forces, want_virial)
+                rec.state = _Deferred.DONE
 
-            def before_sync(status):
-                if overlap and not every_call and not fresh:
-                    hip.prepare_check(model, block, status)
-
-            def in_the_bubble():   # the host allocates what does not depend on the edge count while it waits for it
-                if overlap and (every_call or fresh):
-                    prep.append(hip.prepare(model, pos.device, block))
-                prep.append(hip.alloc_outputs(pos.shape[0], cell.shape[0], pos.device, want_forces, want_virial))
-            # The neighbor-list fill is queued BEFORE the host has the edge count, into arrays sized from the previous call with
-            # the same atom count (+ 1/16): its kernels read the count on the device and write nothing when it does not fit (the
-            # ordinary path then runs after the wait).  NNHIP_GRAPH_EARLY=0: always the ordinary path (A/B timing).
-            hint = self.__dict__.get('_edge_hint', (None, 0))
-            cap = hint[1] if (hint[0] == pos.shape[0] and os.environ.get('NNHIP_GRAPH_EARLY', '1') != '0') else 0
-            g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
-                                emb.edge_embedding.embedding.frequencies,
-                                while_waiting=in_the_bubble, before_sync=before_sync,
-                                z=zc, envelope=emb.edge_embedding.envelope_id, edge_capacity=cap)
-            self.__dict__['_edge_hint'] = (pos.shape[0], g.n_edges + (g.n_edges >> 4) + 256 if g.n_edges > 0 else 0)
-            if overlap:
-                if len(prep) == 2:
-                    block = prep[0]
-                    if fresh and not every_call:   # (its snapshot is uninitialised: take it now, the answer is not needed)
-                        hip.prepare_check(model, block, g.row_ptr.new_zeros(1))
-                elif g.status & hip.STATUS_PARAMS_CHANGED:
-                    hip.prepare(model, pos.device, block)
-                self.__dict__['_prep_block'] = (key, block)
-            # the workspace of the previous call is reused when it is large enough (the arrays in it are private to one call;
-            # everything the caller sees lives in the output tensors)
-            res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
-                                    want_virial=want_virial, prepared=block if overlap else None,
-                                    out=prep[-1], workspace=self.__dict__.get('_infer_ws'))
-            self.__dict__['_infer_ws'] = res['workspace']
-
-        outputs = CustomOutputSet(z=z, pos=pos, atom_node=res['atom_node'], force_node=res['force_node'],
-                                  edge_index=g.edge_index, cell=cell, batch=batch)
+        # Every result of the call sits behind the record: touching one settles the deferred host-side checks first (a few
+        # microseconds when the words have arrived, which they have unless the host is a whole step ahead of the GPU).
+        outputs = CustomOutputSet(z=z, pos=pos, cell=cell, batch=batch)
         outputs.lazy('displacement', make_displacement)
+        outputs.lazy('atom_node', lambda: rec.result('atom_node'))
+        outputs.lazy('force_node', lambda: rec.result('force_node'))
+        outputs.lazy('edge_index', lambda: rec.settle().graph.edge_index)
         if want_forces:
-            outputs.lazy('pos_grad', lambda: -res['forces'])
+            outputs.lazy('pos_grad', lambda: -rec.result('forces'))
             if want_virial:
-                outputs.lazy('displacement_grad', lambda: -res['virial'])
+                outputs.lazy('displacement_grad', lambda: -rec.result('virial'))
         for key in keys:
             if key == 'energy':
-                outputs.energy = res['energy']
+                outputs.lazy('energy', lambda: rec.result('energy'))
             elif key == 'gradient_force':
-                outputs.gradient_force = res['forces']
+                outputs.lazy('gradient_force', lambda: rec.result('forces'))
             elif key == 'virial':
-                outputs.virial = res['virial']
+                outputs.lazy('virial', lambda: rec.result('virial'))
             elif key == 'stress':
-                outputs.stress = -res['virial'] / cell.det().view(-1, 1, 1)
+                outputs.lazy('stress', lambda: -rec.result('virial') / cell.det().view(-1, 1, 1))
             elif key == 'direct_force':
-                k = keys.index('direct_force')
-                sc = self.scalers[k].scale
-                with torch.no_grad():
-                    outputs.direct_force = hip.direct_force(res['atom_node'], res['force_node'], zc,
-                                                            self.output_layers[k].layers,
-                                                            sc.weight if sc is not None else None,
-                                                            hip.ACTIVATION_IDS[self.activation_name])
+                def direct(k=keys.index('direct_force')):
+                    sc = self.scalers[k].scale
+                    with torch.no_grad():
+                        return hip.direct_force(rec.result('atom_node'), rec.result('force_node'), zc, self.output_layers[k].layers,
+                                                sc.weight if sc is not None else None, hip.ACTIVATION_IDS[self.activation_name])
+                outputs.lazy('direct_force', direct)
+        if rec.state == _Deferred.DONE:      # (synchronous call: nothing is pending, hand the tensors over as plain attributes)
+            for name in ('atom_node', 'force_node', 'edge_index', 'energy', 'gradient_force', 'virial'):
+                if name in outputs.__dict__.get('_lazy', {}):
+                    getattr(outputs, name)
         return outputs
+
+    # ------------------------------------------------------------------------------------------
+    def _prep_key(self, model, device):
+        return (device, model.n_layers, model.n_basis, model.activation, model.envelope, hip.lib().nnhip_split_products())
+
+    def _forward_sync(self, model, zc, pos, cell, batch, want_forces, want_virial):
+        """One eval-mode call with the host in the loop: the edge count (and the status word) are read back before the
+        per-edge arrays are sized -- the first call of a module, the first call with a new atom count, periodic boxes on the
+        cell-list builder, and the repeat of a deferred call whose capacity did not fit or whose prepared block was stale.
+        Returns (result dict, Graph)."""
+        emb = self.embedding_layers
+        # Parameter-only preparation (transposed weights, split-f16 weight images, radial-filter tables, layer 0's
+        # message_nodepart per element) lives in one block per module and is refilled only when a parameter CHANGED: every
+        # call compares the parameters bit for bit with the snapshot nnhip_prepare took (nnhip_prepare_check, one small launch
+        # ahead of the edge-count read-back; compare only -- a change stays visible until the block HAS been refilled, so a
+        # call that fails in between cannot lose it) and the answer comes back with the count.  Nothing is keyed on tensor
+        # identity or version counters.  NNHIP_PREPARE_EVERY_CALL=1 refills the block on every call (A/B timing).
+        key = self._prep_key(model, pos.device)
+        cached = self.__dict__.get('_prep_block')
+        fresh = cached is None or cached[0] != key
+        block = None if fresh else cached[1]
+        refill = fresh or _PREPARE_EVERY_CALL
+        prep = []
+
+        def before_sync(status):
+            if not refill:
+                hip.prepare_check(model, block, status)
+
+        def in_the_bubble():   # the host allocates what does not depend on the edge count while it waits for it
+            if refill:
+                prep.append(hip.prepare(model, pos.device, block))
+            prep.append(hip.alloc_outputs(pos.shape[0], cell.shape[0], pos.device, want_forces, want_virial))
+        # The neighbor-list fill is queued BEFORE the host has the edge count, into arrays sized from the previous call with
+        # the same atom count: its kernels read the count on the device and write nothing when it does not fit (the ordinary
+        # path then runs after the wait).  NNHIP_GRAPH_EARLY=0: always the ordinary path (A/B timing).
+        hint = self.__dict__.get('_edge_hint', (None, 0))
+        cap = hint[1] if (hint[0] == pos.shape[0] and _GRAPH_EARLY) else 0
+        g = hip.build_graph(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
+                            emb.edge_embedding.embedding.frequencies,
+                            while_waiting=in_the_bubble, before_sync=before_sync,
+                            z=zc, envelope=emb.edge_embedding.envelope_id, edge_capacity=cap)
+        self._note_count(pos.shape[0], g.n_edges)
+        if refill:
+            block = prep[0]
+            self.__dict__['_prep_block'] = (key, block)
+        elif g.status & hip.STATUS_PARAMS_CHANGED:
+            hip.prepare(model, pos.device, block)
+        # the workspace of the previous call is reused when it is large enough (the arrays in it are private to one call;
+        # everything the caller sees lives in the output tensors)
+        res = hip.energy_forces(model, zc, pos.detach(), cell.detach(), g, want_forces=want_forces,
+                                want_virial=want_virial, prepared=block, out=prep[-1], workspace=self.__dict__.get('_infer_ws'))
+        self.__dict__['_infer_ws'] = res['workspace']
+        return res, g
+
+    def _note_count(self, n_atoms, n_edges):
+        """Capacity of the per-edge arrays for the next call with this atom count: the last count + 1/16 (+ 256), kept while
+        the counts stay inside it with some room to spare (a stable capacity = stable allocation sizes)."""
+        hint = self.__dict__.get('_edge_hint', (None, 0))
+        if n_edges <= 0:
+            cap = 0
+        elif hint[0] == n_atoms and n_edges + (n_edges >> 5) <= hint[1] <= n_edges + (n_edges >> 3) + 512:
+            cap = hint[1]
+        else:
+            cap = (n_edges + (n_edges >> 4) + 256 + 1) & ~1
+        self.__dict__['_edge_hint'] = (n_atoms, cap)
+
+    def _forward_deferred(self, rec, model):
+        """The steady-state call: NOTHING waits for the device.  The neighbor list, the edge embedding and the whole
+        energy / force pipeline are queued into arrays sized from the previous call's edge count (the kernels read the true
+        count on the device); the (count, status) words travel to pinned host memory on the side and are looked at when a result
+        of the call is first touched or when the next call starts (`_Deferred.settle`).  Returns False when the call has to
+        take the synchronous path (no capacity yet for this atom count, no prepared block yet, a box the cell-list builder
+        serves, NNHIP_DEFERRED=0)."""
+        z, pos, cell, batch = rec.inputs
+        N, B = pos.shape[0], cell.shape[0]
+        hint = self.__dict__.get('_edge_hint', (None, 0))
+        cached = self.__dict__.get('_prep_block')
+        if (not _DEFERRED or _PREPARE_EVERY_CALL or hint[0] != N or hint[1] < 2 or cached is None
+                or cached[0] != self._prep_key(model, pos.device) or (B == 1 and N >= hip.CELL_LIST_MIN_ATOMS)
+                or self.__dict__.pop('_force_sync', False)):
+            return False
+        emb = self.embedding_layers
+        block, cap = cached[1], hint[1]
+        ring = self.__dict__.get('_tail_ring')
+        if ring is None:
+            ring = self.__dict__['_tail_ring'] = [torch.empty(4, 2, dtype=torch.int32, pin_memory=True), 0]
+        tail = ring[0][ring[1] & 3]      # (a slot is read by the next call at the latest: _settle_last)
+        ring[1] += 1
+        g, ev = hip.build_graph_dev(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
+                                    emb.edge_embedding.embedding.frequencies, cap, tail, z=rec.zc,
+                                    envelope=emb.edge_embedding.envelope_id,
+                                    before_copy=lambda status: hip.prepare_check(model, block, status))
+        res = hip.energy_forces_dev(model, rec.zc, pos.detach(), cell.detach(), g, want_forces=rec.want_forces,
+                                    want_virial=rec.want_virial, prepared=block, workspace=self.__dict__.get('_infer_ws'))
+        self.__dict__['_infer_ws'] = res['workspace']
+        rec.res, rec.graph, rec.tail, rec.event, rec.cap = res, g, tail, ev, cap
+        rec.versions = tuple(t._version for t in rec.inputs)
+        rec.state = _Deferred.QUEUED
+        self.__dict__['_last_deferred'] = rec
+        return True
+
+    def _settle_last(self):
+        rec = self.__dict__.pop('_last_deferred', None)
+        if rec is not None and rec.state == _Deferred.QUEUED:
+            rec.read_words()
+            if rec.bad & hip.STATUS_PARAMS_CHANGED:      # the block is stale: this call takes the synchronous path, which refills it
+                self.__dict__['_force_sync'] = True
+            if rec.error is not None and not rec.reported:
+                rec.reported = True
+                raise type(rec.error)(f'(raised by the PREVIOUS forward call, whose checks were deferred) {rec.error}')
+
+    def synchronize_checks(self):
+        """Settle the deferred host-side checks of the last eval-mode call now (raises what it would have raised)."""
+        rec = self.__dict__.get('_last_deferred')
+        if rec is not None:
+            rec.settle()
 
     # ------------------------------------------------------------------------------------------
     def _forward_train(self, z, pos, cell, batch, keys, energy_idx, displacement):

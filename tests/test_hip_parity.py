@@ -50,6 +50,135 @@ def test_golden_case(case):
         f = out.force_node.cpu().numpy()
         np.testing.assert_allclose(a, c['f64_atom_node_2'], rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(f, c['f64_force_node_2'], rtol=2e-4, atol=2e-5)
+    # the same module called again takes the steady-state path (queued without waiting for the edge count, checks deferred:
+    # NewtonNet._forward_deferred) -- same list, same bits
+    again = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    assert torch.equal(again.edge_index, out.edge_index) and again.edge_index.is_contiguous()
+    assert torch.equal(again.energy, out.energy) and torch.equal(again.gradient_force, out.gradient_force)
+    assert torch.equal(again.atom_node, out.atom_node) and torch.equal(again.force_node, out.force_node)
+
+
+def test_deferred_checks_errors_and_repeats():
+    """The steady-state eval call returns before the host has seen the edge count or the status word
+    (NewtonNet._forward_deferred; the reference's forward, newtonnet.py:74-104, is synchronous).  Whatever the synchronous call
+    does must still happen -- at the first touch of a result, or when the next call starts: the IndexError for species outside
+    the tables (newtonnet.py:142) and the ValueError for an unsorted batch vector; a repeat when the capacity taken from the
+    previous call does not fit or a parameter changed; and never numbers for inputs that were modified behind the record's
+    back.  Also ADVICE r03: a parameter change followed by a failing call must not leave a stale prepared block."""
+    from newtonnet_amd.models import NewtonNet
+    from newtonnet_amd.models import newtonnet as nn_mod
+    z, pos, cell, batch, _ = util.case_inputs('aspirin8_rand', torch.float32)
+    z, pos, cell, batch = z.cuda(), pos.cuda(), cell.cuda(), batch.cuda()
+    model, _ = make_model('rand')
+
+    def fresh_copy():
+        m = NewtonNet(output_properties=['energy', 'gradient_force'])
+        m.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        m = m.cuda()
+        m.eval()
+        return m
+
+    def same(a, b):
+        return (torch.equal(a.energy, b.energy) and torch.equal(a.gradient_force, b.gradient_force)
+                and torch.equal(a.edge_index, b.edge_index))
+
+    first = model(z, pos, cell, batch)                       # synchronous (no capacity yet)
+    assert model.__dict__.get('_last_deferred') is None
+    second = model(z, pos, cell, batch)                      # deferred
+    rec = model.__dict__['_last_deferred']
+    assert rec.state == rec.QUEUED and same(second, first) and rec.state == rec.DONE
+    # (a) species outside the tables: raised at the first touch, every touch, and never indexed with on the device
+    zbad = z.clone()
+    zbad[5] = 200
+    bad = model(zbad, pos, cell, batch)
+    with pytest.raises(IndexError):
+        bad.energy
+    with pytest.raises(IndexError):
+        bad.gradient_force
+    assert same(model(z, pos, cell, batch), first)           # the module is fine afterwards
+    # ... or when the next call starts, if nobody touched the outputs
+    model(zbad, pos, cell, batch)
+    with pytest.raises(IndexError, match='PREVIOUS'):
+        model(z, pos, cell, batch)
+    assert same(model(z, pos, cell, batch), first)
+    model(z, pos, cell, torch.flip(batch, [0]))              # unsorted batch vector
+    with pytest.raises(ValueError):
+        model.synchronize_checks()
+    assert same(model(z, pos, cell, batch), first)
+    # (b) ADVICE r03: parameters change, the next call fails, the call after it must use the NEW parameters
+    with torch.no_grad():
+        for q in model.parameters():
+            q.mul_(1.0 + 2.0 ** -7)
+    with pytest.raises(IndexError):
+        model(zbad, pos, cell, batch).energy
+    got = model(z, pos, cell, batch)
+    assert not torch.equal(got.energy, first.energy) and same(got, fresh_copy()(z, pos, cell, batch))
+    # ... the same through the synchronous path
+    with torch.no_grad():
+        for q in model.parameters():
+            q.mul_(1.0 - 2.0 ** -7)
+    nn_mod._DEFERRED = False
+    try:
+        with pytest.raises(IndexError):
+            model(zbad, pos, cell, batch)
+        got = model(z, pos, cell, batch)
+        assert same(got, fresh_copy()(z, pos, cell, batch))
+    finally:
+        nn_mod._DEFERRED = True
+    # (c) a repeat (capacity overflow) after the inputs were modified in place: an error, never numbers for other inputs
+    ref_first = fresh_copy()(z, pos, cell, batch)
+    mol_centre = torch.stack([pos[batch == b].mean(dim=0) for b in range(int(batch.max()) + 1)])[batch]
+    wide = mol_centre + 1.6 * (pos - mol_centre)
+    model(z, wide, cell, batch).energy                       # the capacity follows the sparse list
+    model(z, wide, cell, batch).energy
+    p2 = pos.clone()
+    late = model(z, p2, cell, batch)                         # far more edges than the capacity: emptied on the device
+    p2.add_(1.0)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        late.energy
+    p3 = pos.clone()
+    model(z, wide, cell, batch).energy
+    model(z, wide, cell, batch).energy
+    late = model(z, p3, cell, batch)                         # untouched inputs: repeated, the right numbers
+    assert same(late, ref_first)
+
+
+def test_host_delay_between_steps_costs_nothing():
+    """No device->host round trip inside a steady-state step: the host queues a step ahead, so a host that dawdles for a
+    millisecond between calls (1.6 ms of GPU work per step at BASELINE configs[1] size) must not lengthen the run -- VERDICT
+    r03 item 2: wall time grows by < 5 %."""
+    import time
+    import bench
+    from newtonnet_amd.models import newtonnet as nn_mod
+    data = [bench.synthetic_aspirin(1024, seed=7919 * k, device='cuda') for k in range(4)]
+    model, _ = make_model('rand')
+
+    def run(n, delay):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            model(*data[k % 4])
+            if delay:
+                time.sleep(delay)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for _ in range(3):
+        run(20, 0.0)
+    plain = min(run(20, 0.0) for _ in range(5))
+    slept = min(run(20, 1e-3) for _ in range(5))
+    nn_mod._DEFERRED = False
+    try:
+        run(20, 0.0)
+        sync_plain = min(run(20, 0.0) for _ in range(3))
+        sync_slept = min(run(20, 1e-3) for _ in range(3))
+    finally:
+        nn_mod._DEFERRED = True
+    print(f'20 steps: deferred {1e3 * plain:.2f} ms, with 1 ms host sleeps {1e3 * slept:.2f} ms; '
+          f'synchronous {1e3 * sync_plain:.2f} ms, with sleeps {1e3 * sync_slept:.2f} ms')
+    assert slept <= 1.05 * plain, (plain, slept)
+    # (the synchronous path waits early in a step and queues the rest behind the wait, so it hides such sleeps as well as long as
+    # they are shorter than the rest of the step; what it cannot hide is a delay of the read-back itself -- printed, not asserted)
 
 
 def test_intermediates_against_trace():
@@ -571,12 +700,12 @@ def test_prepared_block_follows_every_parameter_change():
     assert not same(got_e, first) and same(got_e, run(fresh_copy()))
     assert model.__dict__['_prep_block'][1] is block                                  # one block per module throughout
     # (f) the A/B switch that refills the block on every call gives the same bits
-    import os
-    os.environ['NNHIP_PREPARE_EVERY_CALL'] = '1'
+    from newtonnet_amd.models import newtonnet as nn_mod      # (the switch is read once, at import: NNHIP_PREPARE_EVERY_CALL)
+    nn_mod._PREPARE_EVERY_CALL = True
     try:
         assert same(run(model), got_e)
     finally:
-        del os.environ['NNHIP_PREPARE_EVERY_CALL']
+        nn_mod._PREPARE_EVERY_CALL = False
 
 
 def test_triclinic_fuzz_count_against_the_reference():
