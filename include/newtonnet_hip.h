@@ -284,7 +284,9 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  * the caller it serves is still NewtonNet.forward, newtonnet.py:74-104).
  *   nnhip_graph_finish_dev   = nnhip_graph_finish_early into arrays of `capacity` edges (even, > 0) + a guard: when the count
  *       (row_ptr[n_atoms]) exceeds the capacity nothing was filled and the guard EMPTIES the graph on the device
- *       (row_ptr = pair_ptr = 0), so that the step below runs on zero edges, inside the arrays.  count_copy: one scratch int32.
+ *       (row_ptr = pair_ptr = 0), so that the step below runs on zero edges, inside the arrays; likewise when the status word
+ *       of nnhip_graph_count_pairs / nnhip_check_species carries bit 1 or 2 (the synchronous path raises on those BEFORE it
+ *       runs the step: a broken batch vector can give an edge set without reverse edges).  count_copy: one scratch int32.
  *   nnhip_energy_forces_dev  = nnhip_energy_forces with n_edges := capacity (array / workspace sizes,
  *       nnhip_workspace_bytes(n_atoms, capacity, ...)) and the true number of undirected pairs read on the device from
  *       *n_pairs_dev (= &pair_ptr[n_atoms]).
@@ -296,7 +298,7 @@ int nnhip_graph_finish_dev(const float* pos, const float* cell, const int64_t* b
                            int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                            float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                            const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                           int32_t envelope, int32_t* count_copy, void* stream);
+                           int32_t envelope, const int32_t* status, int32_t* count_copy, void* stream);
 int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                             const int32_t* mol_ptr,
                             const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,

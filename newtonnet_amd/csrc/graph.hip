@@ -543,12 +543,15 @@ extern "C" int nnhip_graph_finish_early(const float* pos, const float* cell, con
 // 0: every kernel of the step that follows sees zero edges and stays inside the arrays) -- the host finds count > capacity in the
 // (count, status) words it copied out BEFORE this call and repeats the step with the real count.  `count_copy` is a scratch word
 // (the guard must not read row_ptr[n_atoms] while other workgroups clear it).
-__global__ void graph_count_copy_kernel(const int* __restrict__ row_ptr, int n_atoms, int* __restrict__ count_copy) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count_copy = row_ptr[n_atoms];
+// (an invalid batch vector or species -- status bits 1 / 2, which the synchronous path raises on BEFORE it runs the step -- empties
+// the graph too: with a broken batch vector the edge set need not be symmetric and pid would index out of the pair arrays)
+__global__ void graph_count_copy_kernel(const int* __restrict__ row_ptr, int n_atoms, int capacity, const int* __restrict__ status,
+                                        int* __restrict__ count_copy) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_copy = ((status[0] & 3) || row_ptr[n_atoms] > capacity) ? -1 : row_ptr[n_atoms];
 }
 __global__ void __launch_bounds__(256)
-graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, int capacity, const int* __restrict__ count_copy) {
-  if (*count_copy <= capacity) return;
+graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, const int* __restrict__ count_copy) {
+  if (*count_copy >= 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n_atoms) {
     row_ptr[i] = 0;
@@ -559,20 +562,20 @@ extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const
                                       int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                                       float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                                       const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                                      int32_t envelope, int32_t* count_copy, void* stream_) {
+                                      int32_t envelope, const int32_t* status, int32_t* count_copy, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!count_copy || capacity < 1) {
+  if (!count_copy || !status || capacity < 1) {
     nnhip_set_error("nnhip_graph_finish_dev: bad arguments");
     return NNHIP_E_INVALID;
   }
   if (n_atoms == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
-  graph_count_copy_kernel<<<1, 64, 0, stream>>>(row_ptr, n_atoms, count_copy);
+  graph_count_copy_kernel<<<1, 64, 0, stream>>>(row_ptr, n_atoms, capacity, status, count_copy);
   LAUNCH_CHECK();
   const int rc = nnhip_graph_finish_early(pos, cell, batch, mol_ptr, row_ptr, pair_ptr, n_atoms, n_mol, capacity, cutoff, col, rev,
                                           pid, disp, edge_index, frequencies, n_basis, geo, rbf, drbf, xg, envelope, stream_);
   if (rc) return rc;
-  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, capacity, count_copy);
+  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, count_copy);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

@@ -149,7 +149,7 @@ def lib():
     L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish_early.argtypes = L.nnhip_graph_finish.argtypes
-    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp]
+    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp, vp]
     L.nnhip_energy_forces_dev.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_mlp_forms.restype = C.c_int
@@ -556,7 +556,7 @@ def build_graph_dev(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, 
                                     cap, float(cutoff), C.c_void_p(ints.data_ptr() + 8 * cap),
                                     C.c_void_p(ints.data_ptr() + 12 * cap), C.c_void_p(ints.data_ptr() + 16 * cap),
                                     C.c_void_p(flts.data_ptr() + 16 * cap), _ptr(ei), _ptr(freq), nb, _ptr(flts), None, None,
-                                    _ptr(ints), g.envelope, _ptr(count_copy), st), 'nnhip_graph_finish_dev')
+                                    _ptr(ints), g.envelope, _ptr(status), _ptr(count_copy), st), 'nnhip_graph_finish_dev')
     return g, ev
 
 
