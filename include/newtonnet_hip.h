@@ -307,6 +307,39 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
                             float* virial, float* atom_energy, float* atom_node, float* force_node,
                             const void* prepared, const int32_t* n_pairs_dev, void* stream);
 
+/* The whole deferred step in ONE call (what NewtonNet.forward issues in its steady state: the ~8 host calls of the pieces above
+ * cost a small molecule more than its kernels): nnhip_graph_count_pairs, nnhip_check_species, nnhip_prepare_check (status bit
+ * 4), the asynchronous copy of (edge count, status) into tail_host[2] (pinned host memory) followed by a record of `event` (a
+ * hipEvent_t the caller waits on before reading the two words), nnhip_graph_pair_scan, nnhip_graph_finish_dev,
+ * nnhip_energy_forces_dev.  Everything per-step lives in caller-allocated arenas laid out by nnhip_step_layout. */
+typedef struct {
+  size_t i32_count, f32_count;   /* elements of the two arenas (int32 / float32, both 256-byte aligned by the caller) */
+  /* int32 arena */
+  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, count_copy, xg, col, rev, pid;
+  /* float32 arena: edge geometry, then the small outputs */
+  size_t geo, disp, energy, forces, virial, atom_energy;
+} nnhip_step_layout;
+int nnhip_step_layout_of(int32_t n_atoms, int32_t n_mol, int32_t capacity, nnhip_step_layout* out);
+typedef struct {
+  const int64_t* z;        /* [N] */
+  const float* pos;        /* [N][3] */
+  const float* cell;       /* [B][3][3] */
+  const int64_t* batch;    /* [N] */
+  int32_t n_atoms, n_mol, capacity /* even, > 0 */, want_forces, want_virial, pad_;
+  int32_t* i32;            /* arena of nnhip_step_layout.i32_count ints */
+  float* f32;              /* arena of nnhip_step_layout.f32_count floats */
+  int64_t* edge_index;     /* [2 * capacity] or NULL */
+  float* atom_node;        /* [N][F] */
+  float* force_node;       /* [N][3][F] */
+  void* workspace;         /* nnhip_workspace_bytes(N, capacity, B, L) */
+  size_t workspace_bytes;
+  void* prepared;          /* nnhip_prepared_bytes(L), filled by nnhip_prepare */
+  size_t prepared_bytes;
+  int32_t* tail_host;      /* pinned host memory, 2 ints: (edge count, status) */
+  void* event;             /* hipEvent_t recorded right behind the copy into tail_host */
+} nnhip_step_dev;
+int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* step, void* stream);
+
 /* Parameter-only preparation (transposed weights for the reverse sweep, radial-filter tables, layer 0's
  * message_nodepart per element): what the reference gets for free from nn.Module state.  `prepared` is a caller-owned
  * 256-byte-aligned block of nnhip_prepared_bytes(n_layers); fill it with nnhip_prepare whenever the parameters may have

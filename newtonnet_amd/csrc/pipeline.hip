@@ -868,6 +868,71 @@ extern "C" int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* 
                             n_pairs_dev, stream_);
 }
 
+// ---- the deferred step as one call -----------------------------------------------------------------------------
+extern "C" int nnhip_step_layout_of(int32_t N, int32_t B, int32_t cap, nnhip_step_layout* out) {
+  if (!out || N < 0 || B < 0 || cap < 2 || (cap & 1)) {
+    nnhip_set_error("nnhip_step_layout_of: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  memset(out, 0, sizeof(*out));
+  const size_t n_scan = (size_t)(N + 1023) / 1024 + 1;
+  size_t o = 0;
+  auto take = [&](size_t n) {   // 16-byte granules: the per-edge arrays are read as int2 / float4
+    const size_t at = o;
+    o += (n + 3) & ~(size_t)3;
+    return at;
+  };
+  out->mol_ptr = take((size_t)B + 1);
+  out->row_ptr = take((size_t)N + 1 + 1 + n_scan);   // row_ptr [N + 1] | status word | the scan scratch behind it
+  out->status = out->row_ptr + N + 1;                  // (adjacent to row_ptr[N]: ONE 8-byte copy brings count and status)
+  out->pair_ptr = take((size_t)N + 1);
+  out->pair_scan = take(n_scan);
+  out->count_copy = take(1);
+  out->xg = take(2 * (size_t)cap);
+  out->col = take(cap);
+  out->rev = take(cap);
+  out->pid = take(cap);
+  out->i32_count = o;
+  o = 0;
+  out->geo = take(4 * (size_t)cap);
+  out->disp = take(3 * (size_t)cap);
+  out->energy = take(B);
+  out->forces = take(3 * (size_t)N);
+  out->virial = take(9 * (size_t)B);
+  out->atom_energy = take(N);
+  out->f32_count = o;
+  return NNHIP_OK;
+}
+
+extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* st, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  TRY(check_model(model, "nnhip_forward_dev"));
+  if (!st || !st->i32 || !st->f32 || !st->tail_host || !st->event || !st->prepared || !st->atom_node || !st->force_node) {
+    nnhip_set_error("nnhip_forward_dev: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  const int N = st->n_atoms, B = st->n_mol, cap = st->capacity;
+  nnhip_step_layout lay;
+  TRY(nnhip_step_layout_of(N, B, cap, &lay));
+  int32_t* I = st->i32;
+  float* F = st->f32;
+  int32_t *mol_ptr = I + lay.mol_ptr, *row_ptr = I + lay.row_ptr, *status = I + lay.status, *pair_ptr = I + lay.pair_ptr;
+  TRY(nnhip_graph_count_pairs(st->pos, st->cell, st->batch, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr, stream_));
+  TRY(nnhip_check_species(st->z, N, status, stream_));
+  TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, status, 4, stream_));
+  // (count, status) -> pinned host memory, on the side
+  HIP_TRY(hipMemcpyAsync(st->tail_host, row_ptr + N, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
+  TRY(nnhip_graph_pair_scan(pair_ptr, N, I + lay.pair_scan, stream_));
+  TRY(nnhip_graph_finish_dev(st->pos, st->cell, st->batch, mol_ptr, row_ptr, pair_ptr, N, B, cap, model->cutoff, I + lay.col,
+                             I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies, model->n_basis,
+                             F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, I + lay.count_copy, stream_));
+  return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
+                            I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
+                            st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
+                            F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, stream_);
+}
+
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----
 extern "C" size_t nnhip_filter_table_bytes(void) { return 3 * FT_PLANE * sizeof(float); }
 extern "C" int nnhip_filter_tables(const float* const* edge_w, float* const* tables, int32_t n_layers, const float* freq,

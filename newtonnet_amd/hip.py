@@ -153,6 +153,10 @@ def lib():
     L.nnhip_energy_forces_dev.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_mlp_forms.restype = C.c_int
+    L.nnhip_step_layout_of.argtypes = [i32, i32, i32, vp]
+    L.nnhip_step_layout_of.restype = C.c_int
+    L.nnhip_forward_dev.argtypes = [C.POINTER(Model), vp, vp]
+    L.nnhip_forward_dev.restype = C.c_int
     L.nnhip_edge_embed.argtypes = [vp, i32, f32, vp, i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_edge_disp.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     L.nnhip_edge_refresh.argtypes = [vp, vp, vp, vp, i32, f32, vp, i32, vp, vp, vp, vp, vp, i32, vp]
@@ -259,7 +263,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_mlp128', 'nnhip_graph_pairs', 'nnhip_direct_force', 'nnhip_edge_disp', 'nnhip_prepared_bytes',
                     'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
-                    'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms')
+                    'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
+                    'nnhip_step_layout_of', 'nnhip_forward_dev')
 
 
 def _check(rc: int, what: str):
@@ -507,81 +512,104 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
     return g
 
 
-def build_graph_dev(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cutoff: float, frequencies: torch.Tensor,
-                    capacity: int, tail_host: torch.Tensor, z: Optional[torch.Tensor] = None, envelope: int = 9,
-                    before_copy=None, want_edge_index: bool = True):
-    """build_graph for a step that never waits for the host (all-pairs builder only): every kernel of the neighbor list is
-    queued into arrays of `capacity` edges (even, > 0); the (edge count, status) words are copied into the pinned int32 pair
-    `tail_host` asynchronously and the returned event fires when they have arrived -- nothing here blocks.  The returned Graph
-    has `n_edges = None` until the caller has looked at the count (NewtonNet.forward's deferred checks) and sets it.  When the
-    count exceeds the capacity the device-side guard of nnhip_graph_finish_dev empties the graph (the step that follows runs on
-    zero edges, inside its arrays) and the caller repeats the call through build_graph.  `before_copy(status)`: may queue
-    kernels OR-ing bits >= 4 into the status word ahead of the copy (nnhip_prepare_check)."""
+class StepLayout(C.Structure):
+    """nnhip_step_layout."""
+    _fields_ = [(n, C.c_size_t) for n in ('i32_count', 'f32_count', 'mol_ptr', 'row_ptr', 'status', 'pair_ptr', 'pair_scan',
+                                          'count_copy', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
+                                          'atom_energy')]
+
+
+class StepDev(C.Structure):
+    """nnhip_step_dev."""
+    _fields_ = ([(n, C.c_void_p) for n in ('z', 'pos', 'cell', 'batch')]
+                + [(n, C.c_int32) for n in ('n_atoms', 'n_mol', 'capacity', 'want_forces', 'want_virial', 'pad_')]
+                + [(n, C.c_void_p) for n in ('i32', 'f32', 'edge_index', 'atom_node', 'force_node', 'workspace')]
+                + [('workspace_bytes', C.c_size_t), ('prepared', C.c_void_p), ('prepared_bytes', C.c_size_t),
+                   ('tail_host', C.c_void_p), ('event', C.c_void_p)])
+
+
+_step_layouts = {}
+
+
+def step_layout(N: int, B: int, cap: int) -> StepLayout:
+    key = (N, B, cap)
+    lay = _step_layouts.get(key)
+    if lay is None:
+        lay = StepLayout()
+        _check(lib().nnhip_step_layout_of(N, B, cap, C.byref(lay)), 'nnhip_step_layout_of')
+        if len(_step_layouts) > 256:
+            _step_layouts.clear()
+        _step_layouts[key] = lay
+    return lay
+
+
+class DevStep:
+    """Arenas of one deferred step (nnhip_forward_dev) and lazily made views of what a caller may look at.  Quacks like the
+    result dict of energy_forces (`step[name]`) and like a Graph as far as NewtonNet.forward needs one (`edge_index`,
+    `n_edges`, `status`).  `n_edges` is None until the caller has read the count."""
+    __slots__ = ('N', 'B', 'cap', 'lay', 'i32', 'f32', 'ei', 'atom_node', 'force_node', 'workspace', 'n_edges', 'status',
+                 'want_forces', 'want_virial', '_views')
+
+    def __getitem__(self, name):
+        v = self._views.get(name)
+        if v is None:
+            lay, N, B = self.lay, self.N, self.B
+            if name == 'energy':
+                v = self.f32[lay.energy:lay.energy + B]
+            elif name == 'forces':
+                v = self.f32[lay.forces:lay.forces + 3 * N].view(N, 3) if self.want_forces else None
+            elif name == 'virial':
+                v = self.f32[lay.virial:lay.virial + 9 * B].view(B, 3, 3) if (self.want_forces and self.want_virial) else None
+            elif name == 'atom_energy':
+                v = self.f32[lay.atom_energy:lay.atom_energy + N]
+            elif name == 'atom_node':
+                v = self.atom_node
+            elif name == 'force_node':
+                v = self.force_node
+            elif name == 'workspace':
+                v = self.workspace
+            else:
+                raise KeyError(name)
+            self._views[name] = v
+        return v
+
+    @property
+    def edge_index(self):
+        E = self.n_edges
+        return self.ei[:2 * E].view(2, E)
+
+
+def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Tensor, tail_host_ptr: int, event_handle: int,
+                want_forces: bool, want_virial: bool, workspace: Optional[torch.Tensor]) -> DevStep:
+    """The whole deferred step in one C call (nnhip_forward_dev): neighbor list into arrays of `cap` edges, the (count, status)
+    words on their way to the pinned slot `tail_host_ptr` with `event_handle` recorded behind them, energy / forces pipeline.
+    Four allocations per step (two arenas, edge_index, the node states)."""
     L = lib()
     dev = pos.device
-    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
-    if batch.dtype != torch.int64 or not batch.is_contiguous():
-        batch = batch.long().contiguous()
-    N, B, cap = pos.shape[0], cell.shape[0], int(capacity)
-    if cap < 2 or cap & 1:
-        raise ValueError('build_graph_dev: capacity must be even and positive')
-    g = Graph()
-    g.n_atoms, g.n_mol, g.envelope, g.n_edges, g.status = N, B, int(envelope), None, 0
-    n_scan = (N + 1023) // 1024 + 1
-    # the int32 block of build_graph + one word: the guard's copy of the count
-    meta = torch.empty(B + 1 + N + 1 + 1 + n_scan + N + 1 + n_scan + 1, dtype=torch.int32, device=dev)
-    g._meta = meta
-    g.mol_ptr, g.row_ptr, status = meta[:B + 1], meta[B + 1:B + N + 2], meta[B + N + 2:B + N + 3 + n_scan]
-    o_pp = B + N + 3 + n_scan
-    g.pair_ptr, pair_scan = meta[o_pp:o_pp + N + 1], meta[o_pp + N + 1:o_pp + N + 1 + n_scan]
-    count_copy = meta[-1:]
-    st = _stream(dev)
-    _check(L.nnhip_graph_count_pairs(_ptr(pos), _ptr(cell), _ptr(batch), N, B, float(cutoff), _ptr(g.mol_ptr),
-                                     _ptr(g.row_ptr), _ptr(status), _ptr(g.pair_ptr), st), 'nnhip_graph_count_pairs')
-    if z is not None:
-        _check(L.nnhip_check_species(_ptr(z), N, _ptr(status), st), 'nnhip_check_species')
-    if before_copy is not None:
-        before_copy(status[:1])
-    tail_host.copy_(meta[B + N + 1:B + N + 3], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    _check(L.nnhip_graph_pair_scan(_ptr(g.pair_ptr), N, _ptr(pair_scan), st), 'nnhip_graph_pair_scan')
-    nb = frequencies.numel()
-    freq = _f32c(frequencies, 'frequencies')
-    ints = torch.empty(5 * cap, dtype=torch.int32, device=dev)
-    flts = torch.empty(7 * cap, dtype=torch.float32, device=dev)
-    ei = torch.empty(2 * cap, dtype=torch.int64, device=dev) if want_edge_index else None
-    g._arrays, g._cap, g._nb, g._want_rbf = (ints, flts, ei), cap, nb, False
-    _check(L.nnhip_graph_finish_dev(_ptr(pos), _ptr(cell), _ptr(batch), _ptr(g.mol_ptr), _ptr(g.row_ptr), _ptr(g.pair_ptr), N, B,
-                                    cap, float(cutoff), C.c_void_p(ints.data_ptr() + 8 * cap),
-                                    C.c_void_p(ints.data_ptr() + 12 * cap), C.c_void_p(ints.data_ptr() + 16 * cap),
-                                    C.c_void_p(flts.data_ptr() + 16 * cap), _ptr(ei), _ptr(freq), nb, _ptr(flts), None, None,
-                                    _ptr(ints), g.envelope, _ptr(status), _ptr(count_copy), st), 'nnhip_graph_finish_dev')
-    return g, ev
-
-
-def energy_forces_dev(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.Tensor, g: Graph, want_forces: bool = True,
-                      want_virial: bool = False, workspace: Optional[torch.Tensor] = None, out: Optional[dict] = None,
-                      prepared: Optional[torch.Tensor] = None):
-    """energy_forces on a graph of build_graph_dev: sizes from the capacity, the pair count read on the device."""
-    L = lib()
-    dev = z.device
-    N, cap, B = g.n_atoms, g._cap, g.n_mol
+    N, B = pos.shape[0], cell.shape[0]
+    lay = step_layout(N, B, cap)
+    st = DevStep()
+    st.N, st.B, st.cap, st.lay, st.n_edges, st.status, st._views = N, B, cap, lay, None, 0, {}
+    st.want_forces, st.want_virial = want_forces, want_virial
+    st.i32 = torch.empty(lay.i32_count, dtype=torch.int32, device=dev)
+    st.f32 = torch.empty(lay.f32_count, dtype=torch.float32, device=dev)
+    st.ei = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+    st.atom_node = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev)
+    st.force_node = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev)
     need = L.nnhip_workspace_bytes(N, cap, B, model.n_layers)
     if workspace is None or workspace.numel() < need or workspace.device != dev:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
-    if out is None:
-        out = alloc_outputs(N, B, dev, want_forces, want_virial, True)
-    out['workspace'] = workspace
-    pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
-    n_pairs_dev = C.c_void_p(g.pair_ptr.data_ptr() + 4 * N)
-    _check(L.nnhip_energy_forces_dev(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr),
-                                     g.edge_ptr('col'), g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'),
-                                     g.edge_ptr('disp'), N, cap, B, _ptr(workspace), workspace.numel(), _ptr(out['energy']),
-                                     _ptr(out['forces']), _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
-                                     _ptr(out['force_node']), _ptr(prepared), n_pairs_dev, _stream(dev)),
-           'nnhip_energy_forces_dev')
-    return out
+    st.workspace = workspace
+    a = StepDev()
+    a.z, a.pos, a.cell, a.batch = z.data_ptr(), pos.data_ptr(), cell.data_ptr(), batch.data_ptr()
+    a.n_atoms, a.n_mol, a.capacity, a.want_forces, a.want_virial = N, B, cap, int(want_forces), int(want_virial)
+    a.i32, a.f32, a.edge_index = st.i32.data_ptr(), st.f32.data_ptr(), st.ei.data_ptr()
+    a.atom_node, a.force_node = st.atom_node.data_ptr(), st.force_node.data_ptr()
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    a.prepared, a.prepared_bytes = prepared.data_ptr(), prepared.numel()
+    a.tail_host, a.event = tail_host_ptr, event_handle
+    _check(L.nnhip_forward_dev(C.byref(model), C.byref(a), _stream(dev)), 'nnhip_forward_dev')
+    return st
 
 
 def mlp_forms() -> dict:

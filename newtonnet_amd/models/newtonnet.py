@@ -159,7 +159,8 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache',
+                  '_step_cache'):
             state.pop(k, None)
         return state
 
@@ -173,6 +174,78 @@ class NewtonNet(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _hip_model(self, energy_idx: int) -> hip.Model:
+        """The nnhip_model struct of this module (device addresses of every parameter).  Built by a full walk with all checks
+        (`_hip_model_build`) and kept with what is needed to see, in a few microseconds, that it still describes the module:
+        the identity of every submodule on the way to a parameter (`module._modules[name] is child`), and address / dtype /
+        contiguity of every parameter tensor read straight from the `_parameters` dicts.  Anything else -- a replaced
+        submodule or Parameter, `.to()` / `.data =` swaps, head surgery on output_layers / scalers -- rebuilds it.  Only
+        ADDRESSES are cached; parameter VALUES are compared on the device every call (nnhip_prepare_check)."""
+        c = self.__dict__.get('_model_cache')
+        if c is not None and c[0] == energy_idx:
+            ee = self.embedding_layers.edge_embedding
+            if c[1] == (self.activation_name, ee.cutoff, ee.n_basis, ee.envelope_id, len(self.interaction_layers._modules)):
+                ok = True
+                for d, k, child in c[2]:
+                    if d.get(k) is not child:
+                        ok = False
+                        break
+                if ok:
+                    f32 = torch.float32
+                    for (d, k), ptr in zip(c[3], c[4]):
+                        t = d[k]
+                        if t.data_ptr() != ptr or t.dtype is not f32 or not t.is_contiguous():
+                            ok = False
+                            break
+                    if ok:
+                        return c[5]
+        m = self._hip_model_build(energy_idx)
+        try:
+            self.__dict__['_model_cache'] = self._model_cache_entry(energy_idx, m)
+        except (KeyError, AttributeError):      # an unexpected module layout: no cache, the full walk serves every call
+            self.__dict__.pop('_model_cache', None)
+        return m
+
+    def _model_cache_entry(self, energy_idx, m):
+        guards, seen, params, ptrs = [], set(), [], []
+
+        def add(*path):
+            mod = self
+            for name in path[:-1]:
+                # (an absent optional submodule -- layer_norm / scale / shift = None -- is a plain None attribute, not an
+                # entry of _modules; assigning a Module later creates the entry, which the guard below then sees)
+                child = mod._modules.get(name)
+                if child is None and getattr(mod, name) is not None:
+                    raise KeyError(name)
+                if (id(mod), name) not in seen:
+                    seen.add((id(mod), name))
+                    guards.append((mod._modules, name, child))
+                if child is None:
+                    return
+                mod = child
+            t = mod._parameters[path[-1]]
+            params.append((mod._parameters, path[-1]))
+            ptrs.append(t.data_ptr())
+
+        add('embedding_layers', 'node_embedding', 'weight')
+        add('embedding_layers', 'edge_embedding', 'embedding', 'frequencies')
+        ee = self.embedding_layers.edge_embedding
+        guards.append((ee._modules, 'envelope', ee._modules.get('envelope')))
+        for l in range(len(self.interaction_layers)):
+            il = ('interaction_layers', str(l))
+            for sub in (('message_nodepart', '0', 'weight'), ('message_nodepart', '0', 'bias'), ('message_nodepart', '2', 'weight'),
+                        ('message_nodepart', '2', 'bias'), ('message_edgepart', 'weight'), ('equiv_message1', '0', 'weight'),
+                        ('equiv_message1', '2', 'weight'), ('equiv_message2', '0', 'weight'), ('equiv_message2', '2', 'weight'),
+                        ('equiv_update', 'weight'), ('layer_norm', 'weight'), ('layer_norm', 'bias')):
+                add(*il, *sub)
+        k = str(energy_idx)
+        for sub in (('0', 'weight'), ('0', 'bias'), ('2', 'weight'), ('2', 'bias'), ('4', 'weight'), ('4', 'bias')):
+            add('output_layers', k, 'layers', *sub)
+        add('scalers', k, 'scale', 'weight')
+        add('scalers', k, 'shift', 'weight')
+        key = (self.activation_name, ee.cutoff, ee.n_basis, ee.envelope_id, len(self.interaction_layers._modules))
+        return (energy_idx, key, guards, params, ptrs, m)
+
+    def _hip_model_build(self, energy_idx: int) -> hip.Model:
         emb = self.embedding_layers
         F, nb, L = emb.n_features, emb.edge_embedding.n_basis, len(self.interaction_layers)
         if F != hip.NNHIP_F or not (1 <= nb <= hip.NNHIP_MAX_NB) or not (1 <= L <= hip.NNHIP_MAX_LAYERS):
@@ -381,21 +454,29 @@ class NewtonNet(nn.Module):
                 or cached[0] != self._prep_key(model, pos.device) or (B == 1 and N >= hip.CELL_LIST_MIN_ATOMS)
                 or self.__dict__.pop('_force_sync', False)):
             return False
-        emb = self.embedding_layers
         block, cap = cached[1], hint[1]
+        # pinned (count, status) slots and the events behind them: a ring of four per module (a slot is read by the next call at
+        # the latest, _settle_last)
         ring = self.__dict__.get('_tail_ring')
-        if ring is None:
-            ring = self.__dict__['_tail_ring'] = [torch.empty(4, 2, dtype=torch.int32, pin_memory=True), 0]
-        tail = ring[0][ring[1] & 3]      # (a slot is read by the next call at the latest: _settle_last)
-        ring[1] += 1
-        g, ev = hip.build_graph_dev(pos.detach(), cell.detach(), batch, emb.edge_embedding.cutoff,
-                                    emb.edge_embedding.embedding.frequencies, cap, tail, z=rec.zc,
-                                    envelope=emb.edge_embedding.envelope_id,
-                                    before_copy=lambda status: hip.prepare_check(model, block, status))
-        res = hip.energy_forces_dev(model, rec.zc, pos.detach(), cell.detach(), g, want_forces=rec.want_forces,
-                                    want_virial=rec.want_virial, prepared=block, workspace=self.__dict__.get('_infer_ws'))
-        self.__dict__['_infer_ws'] = res['workspace']
-        rec.res, rec.graph, rec.tail, rec.event, rec.cap = res, g, tail, ev, cap
+        if ring is None or ring[5] != pos.device:
+            tails = torch.empty(4, 2, dtype=torch.int32, pin_memory=True)
+            events = [torch.cuda.Event() for _ in range(4)]
+            handles = []
+            for ev in events:
+                ev.record(torch.cuda.current_stream(pos.device))      # (creates the hipEvent_t behind ev.cuda_event)
+                h = ev.cuda_event
+                handles.append(int(h.value if hasattr(h, 'value') else h))
+            ring = self.__dict__['_tail_ring'] = [tails, events, handles, 0, tails.data_ptr(), pos.device]
+        k = ring[3] & 3
+        ring[3] += 1
+        pd, cd = pos.detach(), cell.detach()
+        if pd.dtype != torch.float32 or cd.dtype != torch.float32:
+            raise NotImplementedError(f'the HIP path computes in float32 (got pos {pd.dtype}, cell {cd.dtype})')
+        bt = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else batch.long().contiguous()
+        st = hip.forward_dev(model, rec.zc, pd.contiguous(), cd.contiguous(), bt, cap, block, ring[4] + 8 * k, ring[2][k],
+                             rec.want_forces, rec.want_virial, self.__dict__.get('_infer_ws'))
+        self.__dict__['_infer_ws'] = st.workspace
+        rec.res, rec.graph, rec.tail, rec.event, rec.cap = st, st, ring[0][k], ring[1][k], cap
         rec.versions = tuple(t._version for t in rec.inputs)
         rec.state = _Deferred.QUEUED
         self.__dict__['_last_deferred'] = rec
