@@ -420,7 +420,7 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
             torch.cuda.synchronize()                      # (bounds how far the host may queue ahead while warming up)
     sync_all()
     warm_s = time.perf_counter() - t_w
-    region_dt, region_steps = [], []
+    region_dt, region_steps, local_dt = [], [], []
     for _ in range(regions):
         sync_all()
         stamps = [time.perf_counter()]
@@ -429,6 +429,7 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
             stamps.append(time.perf_counter())
         sync_all()
         dt = time.perf_counter() - stamps[0]
+        local_dt.append(dt)
         region_dt.append(reduce_max(dt))
         region_steps.append([1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])])
     # diagnostic region: per-step GPU time from events on the launch stream
@@ -444,6 +445,7 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
     med = order[len(order) // 2]
     all_host = sorted(v for r in region_steps for v in r)
     return {'dt': region_dt[med], 'ms_per_step': 1e3 * region_dt[med] / steps,
+            'local_ms_per_step': 1e3 * local_dt[med] / steps,          # this rank's own time of the same region
             'region_ms_per_step': [round(1e3 * d / steps, 4) for d in region_dt],
             'value_rule': f'median of {regions} timed regions of {steps} steps each (barrier + synchronize on both sides of '
                           'every region, wall clock, max over ranks); never the minimum',
@@ -456,6 +458,23 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
             'step_ms_gpu_note': 'one extra region (not among the timed ones): HIP event after every step on the launch stream',
             'warmup_steps_run': n_warm, 'warmup_wall_s': round(warm_s, 3),
             'warmup_rule': f'max(--warmup steps, {min_warm_s} s of wall time)'}
+
+
+def pin_rank_cores(local_rank, local_world):
+    """One process per GPU: give every rank its own contiguous block of the host cores this process may run on (before anything
+    touches the GPU), so that N launch threads never share a core and a rank's helper threads stay near it.  Returns the core
+    list as a compact string for the bench line, or None where the platform has no affinity call.  Only used with N > 1: the
+    single-GPU run is left exactly as the OS schedules it."""
+    if not hasattr(os, 'sched_getaffinity'):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // max(1, local_world))
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores[-per:]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return f'{mine[0]}-{mine[-1]}' if len(mine) > 1 else str(mine[0])
 
 
 def self_launch(n):
@@ -504,6 +523,7 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    core_set = pin_rank_cores(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None
     # One process per GPU.  (BENCH_SHARE_GPU=1 + BENCH_DIST_BACKEND=gloo lets several ranks share one device: used only to
     # exercise this launch path on a 1-GPU box.)
     n_dev = torch.cuda.device_count()
@@ -572,6 +592,13 @@ def main():
 
     timing = timed_regions(step, args.steps, args.warmup, sync_all, reduce_max, regions=args.regions)
     dt = timing['dt']
+    # every rank's own view of the run (a straggler shows here; `value` stays the max-over-ranks time of the median region)
+    per_rank = {'ms_per_step': [round(timing['local_ms_per_step'], 4)], 'cores': [core_set]}
+    if dist is not None:
+        got = [None] * world
+        dist.all_gather_object(got, (timing['local_ms_per_step'], core_set))
+        per_rank = {'ms_per_step': [round(v[0], 4) for v in got], 'cores': [v[1] for v in got]}
+    per_rank['min'], per_rank['max'] = min(per_rank['ms_per_step']), max(per_rank['ms_per_step'])
     edge_counts = [int(model(*d).edge_index.shape[1]) for d in data]
     E = int(round(sum(edge_counts) / len(edge_counts)))          # (mean over the batches: what the byte / FLOP models below use)
     out = model(*data[0])                                         # batch 0: compared with the CPU baseline below
@@ -865,6 +892,7 @@ def main():
                        'deferred_checks': bool(model.__dict__.get('_last_deferred') is not None),
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
+            'per_rank': per_rank,
             'allreduce_us': train['allreduce_us'] if train else None, 'train': train,
             'roofline': roofline, 'roofline_secondary': edge_roofline, 'roofline_onepass_mlp': onepass,
             'roofline_mlp128s': mfma, 'roofline_edge_kernels': edge_all_roofline,

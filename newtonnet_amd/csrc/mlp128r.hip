@@ -78,21 +78,26 @@ __device__ __forceinline__ float rw_half_max(float v, int h) {
   return h ? hi : lo;
 }
 // Barrier of ONE 4-wave group (gfx950 has no named barriers; s_barrier would hold both groups in lockstep, and then the MFMA
-// phase of one never overlaps the VALU phase of the other on the SIMD they share).  A counter in LDS: LDS operations of a wave
-// execute in order, so the arrival (ds_add after this wave's tile writes) publishes them; the spin is bounded so that a lost
-// arrival aborts the launch instead of hanging the GPU.  Only LDS traffic is ordered here -- no vmcnt wait, the
-// prefetched rows and the streaming stores stay in flight across it.
-__device__ __forceinline__ void rw_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// phase of one never overlaps the VALU phase of the other on the SIMD they share).  A counter in LDS with workgroup-scope
+// release / acquire fences restricted to the LDS address space (`__builtin_amdgcn_fence(order, "workgroup", "local")`: the
+// compiler orders this wave's tile accesses against the counter and emits s_waitcnt lgkmcnt(0) only) -- no vmcnt wait, the
+// prefetched rows and the streaming stores stay in flight across it.  The spin is bounded (RW_SPIN_LIMIT polls, several seconds:
+// far beyond anything a profiler's serialisation can add) so that a lost arrival aborts the launch instead of hanging the GPU.
+#ifndef RW_SPIN_LIMIT
+#define RW_SPIN_LIMIT (1u << 26)
+#endif
+__device__ __forceinline__ void rw_release_lds() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }
+__device__ __forceinline__ void rw_acquire_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); }
 __device__ __forceinline__ void rw_spin_until(const unsigned* cnt, unsigned target) {
   unsigned spins = 0;
   while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
-    if (++spins > (1u << 22)) __builtin_trap();   // ~0.1 s without the partner: abort the launch (a HIP error), never a silent result
+    if (++spins > RW_SPIN_LIMIT) __builtin_trap();   // seconds without the partner: abort the launch (a HIP error), never a silent result
     __builtin_amdgcn_s_sleep(1);
   }
-  rw_wait_lds();
+  rw_acquire_lds();
 }
 __device__ __forceinline__ void rw_signal(unsigned* cnt, int lane) {
-  rw_wait_lds();
+  rw_release_lds();
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void rw_group_sync(unsigned* cnt, unsigned& target, int lane, unsigned waves = 4) {

@@ -139,9 +139,15 @@ _UNSUPPORTED_FUSED = ("FusedClipAdam / the fused step serves output_properties w
 
 def _force_key(model):
     """The force the step's loss is on: 'gradient_force' when the model has that head, else 'direct_force', else None (an
-    energy-only model, loss.py:30-47).  (A model with BOTH force heads trains the gradient force here; any other combination of
-    terms goes through the model's train-mode forward and a torch loss -- the same kernels behind one autograd node.)"""
+    energy-only model, loss.py:30-47).  A model with BOTH force heads is refused: its two loss terms go through the model's
+    train-mode forward and a torch loss -- the same kernels behind one autograd node."""
     keys = list(getattr(model, 'output_properties', ('energy', 'gradient_force')))
+    if 'gradient_force' in keys and 'direct_force' in keys:
+        # The reference's loss factory sums a term per configured head (loss.py:30-47).  The fused step carries ONE force term:
+        # with both heads it would train the direct-force head with a zero gradient -- refuse rather than do that silently.
+        raise NotImplementedError(
+            "the fused training step carries one force term; a model with both 'gradient_force' and 'direct_force' trains "
+            "through its train-mode forward (one autograd node on the same kernels) and a torch loss over both heads")
     return 'gradient_force' if 'gradient_force' in keys else ('direct_force' if 'direct_force' in keys else None)
 
 
@@ -429,13 +435,14 @@ class GraphedTrainStep:
         """Eager (exact list) or replay (static candidate list)?  Decided ONCE, on the first call, from the LARGEST per-rank atom
         count (one MAX all-reduce): every rank takes the same path -- the two paths issue different collectives, so a rank-local
         decision with uneven shards around the threshold would leave them unmatched."""
+        if not (dist.is_available() and dist.is_initialized()):
+            # one process: nothing to agree on -- decide per call (a small first batch must not pin later large ones, or one
+            # large molecule, onto the static all-pairs candidate list, which grows with sum n_i^2)
+            return n_atoms >= self.EAGER_ABOVE_ATOMS
         if self._use_eager is None:
-            n = n_atoms
-            if dist.is_available() and dist.is_initialized():
-                t = torch.tensor([float(n_atoms)], dtype=torch.float32, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                n = int(t.item())
-            self._use_eager = n >= self.EAGER_ABOVE_ATOMS
+            t = torch.tensor([float(n_atoms)], dtype=torch.float32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self._use_eager = int(t.item()) >= self.EAGER_ABOVE_ATOMS
         return self._use_eager
 
     def _call_fused(self, z, pos, cell, batch, energy_label, force_label):

@@ -885,3 +885,37 @@ def test_bench_self_launches_its_ranks():
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['ranks_joined'] == 2 and line['scaling'] == 'weak'
     assert line['value'] > 0 and line['train']['replicas_in_sync'] is True and line['train']['allreduce_us'] > 0
+
+
+def test_bench_eight_ranks_on_one_box():
+    """The SCALE run's widest point, `python bench.py --gpus 8`, as far as a 1-GPU box can take it: eight ranks started by
+    bench.py itself, sharing the device over gloo (BENCH_SHARE_GPU / BENCH_DIST_BACKEND), every rank pinned to its own block
+    of host cores, one JSON line with all eight joined and every rank's own step time in it (reported at 1, 2, 4
+    and 8 GPUs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_SHARE_GPU='1', BENCH_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE'):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--conformers', '64', '--no-train-roofline'], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, start_new_session=True, env=env, cwd=root)
+    try:
+        out, err = p.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, 9)
+        out, err = p.communicate()
+        raise AssertionError('bench.py --gpus 8 timed out\n' + err[-3000:])
+    assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out[-3000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['ranks_joined'] == 8 and line['scaling'] == 'weak'
+    pr = line['per_rank']
+    assert len(pr['ms_per_step']) == 8 and pr['min'] > 0 and pr['max'] >= pr['min']
+    assert len(set(pr['cores'])) == 8 and None not in pr['cores']        # eight disjoint core blocks
+    assert abs(line['ms_per_step'] - pr['max']) <= 0.25 * pr['max']      # the line is the slowest rank's region (max over ranks)
+    assert line['train']['replicas_in_sync'] is True and line['value'] > 0

@@ -198,3 +198,15 @@ def test_tooling_builds_are_marked_and_refused(tmp_path):
     finally:
         if os.path.exists(so):
             os.remove(so)
+
+
+def test_fused_step_refuses_a_model_with_both_force_heads():
+    """the fused training step carries ONE force term (loss.py:30-47 sums a term per configured head); with both
+    'gradient_force' and 'direct_force' it must refuse instead of training the direct-force head with a zero gradient."""
+    from newtonnet_amd.distributed import _force_key
+    from newtonnet_amd.models import NewtonNet
+    assert _force_key(NewtonNet(output_properties=['energy', 'gradient_force'])) == 'gradient_force'
+    assert _force_key(NewtonNet(output_properties=['energy', 'direct_force'])) == 'direct_force'
+    assert _force_key(NewtonNet(output_properties=['energy'])) is None
+    with pytest.raises(NotImplementedError):
+        _force_key(NewtonNet(output_properties=['energy', 'gradient_force', 'direct_force']))
