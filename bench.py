@@ -411,13 +411,19 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
     `regions` regions of EXACTLY `steps` steps, each bracketed by barrier + torch.cuda.synchronize() on both sides
     (`sync_all`), wall-clock, max over ranks (`reduce_max`).  A host timestamp is taken after every step call.  One more region
     (never the reported one) records a HIP event after every step on the launch stream: per-step GPU time, which is what a
-    step costs when the host queues ahead.  Returns a dict; `ms_per_step` is the MEDIAN region (never the minimum)."""
+    step costs when the host queues ahead.  Every rank runs the same number of warm-up steps (batches of 8 beyond `warmup`,
+    agreed through `reduce_max`).  Returns a dict; `ms_per_step` is the MEDIAN region (never the minimum)."""
     t_w, n_warm = time.perf_counter(), 0
-    while n_warm < warmup or time.perf_counter() - t_w < min_warm_s:
-        step()
-        n_warm += 1
-        if n_warm % 16 == 0:
-            torch.cuda.synchronize()                      # (bounds how far the host may queue ahead while warming up)
+    while True:
+        for _ in range(max(warmup, 1) if n_warm == 0 else 8):
+            step()
+            n_warm += 1
+        torch.cuda.synchronize()                          # (also bounds how far the host may queue ahead while warming up)
+        more = time.perf_counter() - t_w < min_warm_s
+        # every rank runs the SAME number of warm-up steps (a step may hold a collective: the training leg's all-reduce):
+        # all go on while any rank wants more time
+        if not reduce_max(1.0 if more else 0.0):
+            break
     sync_all()
     warm_s = time.perf_counter() - t_w
     region_dt, region_steps, local_dt = [], [], []
@@ -511,6 +517,8 @@ def main():
                     help='distinct synthetic batches (own noise, own edge count) the steps cycle through, all resident in HBM: '
                          'no step sees the positions of the step before it')
     ap.add_argument('--regions', type=int, default=N_REGIONS, help='timed regions of --steps steps (the median is reported)')
+    ap.add_argument('--warm-seconds', type=float, default=MIN_WARM_S,
+                    help='warm-up lasts at least this long AND at least --warmup steps (profiler passes shorten it: fewer dispatches)')
     ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     args = ap.parse_args()
 
@@ -590,7 +598,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    timing = timed_regions(step, args.steps, args.warmup, sync_all, reduce_max, regions=args.regions)
+    timing = timed_regions(step, args.steps, args.warmup, sync_all, reduce_max, regions=args.regions, min_warm_s=args.warm_seconds)
     dt = timing['dt']
     # every rank's own view of the run (a straggler shows here; `value` stays the max-over-ranks time of the median region)
     per_rank = {'ms_per_step': [round(timing['local_ms_per_step'], 4)], 'cores': [core_set]}
@@ -769,7 +777,7 @@ def main():
             if tpi:
                 rows = [(k, b) for k, b in tpi.items() if _kernel_match(k, name)]
                 if rows:   # (instantiation <true> runs in layers 1-2, <false> in layer 0; msg_fwd has one form, three launches)
-                    w = {k: (1.0 if '<false>' in k else 2.0 if '<true>' in k else 3.0) for k, _ in rows}
+                    w = {k: (1.0 if '<false' in k else 2.0 if '<true' in k else 3.0) for k, _ in rows}
                     o['traffic'] = round(sum(w[k] * b for k, b in rows) / sum(w.values()))
                     o['traffic_source'] = hbm.get('traffic_source')
                     cg = o['traffic'] * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

@@ -30,20 +30,25 @@
 // forward: message + invariant aggregation
 //   msg[pid e] = eps_e * m[i] * m[j] (written by the row with i < j);  a_mid[i] = a_in[i] + sum_{e in row i} msg_e
 // ---------------------------------------------------------------------------------------------
+template <int WPR>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                const float* __restrict__ a_in, float* __restrict__ msg /*[P][F]*/, float* __restrict__ a_mid,
                int n_atoms) {
-  const int i = wave_row(gridDim.x);
-  if (i >= n_atoms) return;
+  __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 1)];
+  int part;
+  const int i_ = wave_row_split<WPR>(gridDim.x, part);
+  const bool active = i_ < n_atoms;
+  if (WPR == 1 && !active) return;
+  const int i = active ? i_ : 0;            // (split rows: an idle wave still meets the others at the barrier of row_combine)
   const int lane = threadIdx.x & 63;
   const int c4 = 4 * (lane & 31);
   const bool hi = lane >= 32;
   const float4 mi = ld4(m + (size_t)i * NF + c4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int beg = row_ptr[i], end = row_ptr[i + 1];
-  for (int e = beg; e < end; e += 2) {
+  const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
+  for (int e = beg + 2 * part; e < end; e += 2 * WPR) {
     const int e1 = min(e + 1, end - 1);
     const int j0 = col[e], j1 = col[e1];
     const int2 gx0 = xg[e], gx1 = xg[e1];   // wave-uniform
@@ -75,7 +80,12 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
     }
   }
   acc = add4(acc, upper_half(acc));
-  if (!hi) st4(a_mid + (size_t)i * NF + c4, add4(ld4(a_in + (size_t)i * NF + c4), acc));
+  {
+    float4 a1[1] = {acc};
+    row_combine<WPR, 1>(a1, comb, part, lane);
+    acc = a1[0];
+  }
+  if (active && part == 0 && !hi) st4(a_mid + (size_t)i * NF + c4, add4(ld4(a_in + (size_t)i * NF + c4), acc));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -83,24 +93,28 @@ msg_fwd_kernel(const float* __restrict__ m, const int2* __restrict__ xg, const f
 //   f_out[i][k] = f_in[i][k] + sum_e ( phi1[pid e] * u_e[k] + phi2[pid e] * f_in[j][k] )
 // HAS_F = false for the first layer, where force_node == 0 (newtonnet.py:143): the phi2 term vanishes.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_F>
+template <bool HAS_F, int WPR>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restrict__ phi2, const float* __restrict__ geo,
                  const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                  const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms, const int2* __restrict__ xg) {
-  const int i = wave_row(gridDim.x);
-  if (i >= n_atoms) return;
+  __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 3)];
+  int part;
+  const int i_ = wave_row_split<WPR>(gridDim.x, part);
+  const bool active = i_ < n_atoms;
+  if (WPR == 1 && !active) return;
+  const int i = active ? i_ : 0;
   const int lane = threadIdx.x & 63;
   const int c4 = 4 * (lane & 31);          // this lane's four features
   const bool hi = lane >= 32;              // upper half-wave: the odd edge of each pair of edges
   float4 acc[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    acc[k] = (HAS_F && !hi) ? ld4(f_in + ((size_t)i * 3 + k) * NF + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int beg = row_ptr[i], end = row_ptr[i + 1];
+    acc[k] = (HAS_F && !hi && part == 0) ? ld4(f_in + ((size_t)i * 3 + k) * NF + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
   const int mid = row_mid(col, beg, end, i, lane);
   auto run = [&](const int rb, const int re, auto nt) {   // nt: stream the pair rows (the other endpoint owns them)
-    for (int e = rb; e < re; e += 2) {
+    for (int e = rb + 2 * part; e < re; e += 2 * WPR) {
       const int e1 = min(e + 1, re - 1);    // (clamped; the odd half is masked off when the range has no edge e + 1)
       const float4 g0 = reinterpret_cast<const float4*>(geo)[e];   // (ux,uy,uz,r), wave-uniform
       const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
@@ -131,10 +145,11 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
   run(beg, mid, std::integral_constant<bool, EDGE_NT_PHI_FWD != 0>());
   run(mid, end, std::false_type());
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float4 o = add4(acc[k], upper_half(acc[k]));
-    if (!hi) st4(f_out + ((size_t)i * 3 + k) * NF + c4, o);
-  }
+  for (int k = 0; k < 3; ++k) acc[k] = add4(acc[k], upper_half(acc[k]));
+  row_combine<WPR, 3>(acc, comb, part, lane);
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (active && part == 0 && !hi) st4(f_out + ((size_t)i * 3 + k) * NF + c4, acc[k]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -148,15 +163,19 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
 //   g_phi1[p]   = sum_k (gf[i][k] - gf[j][k]) u_e[k]                      -> g_h12[p][0:F]   (feeds the MLP adjoint)
 //   g_phi2[p]   = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]     -> g_h12[p][F:2F]
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_F>
+template <bool HAS_F, int WPR>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
                  float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms,
                  const int2* __restrict__ xg) {
-  const int i = wave_row(gridDim.x);
-  if (i >= n_atoms) return;
+  __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 3)];
+  int part;
+  const int i_ = wave_row_split<WPR>(gridDim.x, part);
+  const bool active = i_ < n_atoms;
+  if (WPR == 1 && !active) return;
+  const int i = active ? i_ : 0;
   const int lane = threadIdx.x & 63;
   const int c4 = 4 * (lane & 31);
   const bool hi = lane >= 32;
@@ -164,13 +183,13 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     gfi[k] = ld4(gf + ((size_t)i * 3 + k) * NF + c4);
-    acc[k] = hi ? make_float4(0.f, 0.f, 0.f, 0.f) : gfi[k];
+    acc[k] = (hi || part != 0) ? make_float4(0.f, 0.f, 0.f, 0.f) : gfi[k];
     if (HAS_F) fi[k] = ld4(f_in + ((size_t)i * 3 + k) * NF + c4);
   }
-  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
   const int mid = row_mid(col, beg, end, i, lane);
   // [beg, mid): pairs owned by the other endpoint -- g_u and the phi2 gather only
-  for (int e = beg; e < mid; e += 2) {
+  for (int e = beg + 2 * part; e < mid; e += 2 * WPR) {
     const int e1 = min(e + 1, mid - 1);
     const int p0 = pid[e], p1 = pid[e1];
     const int eh = hi ? e1 : e;
@@ -199,7 +218,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     }
   }
   // [mid, end): pairs this row owns -- additionally the adjoints of the shared phi rows
-  for (int e = mid; e < end; e += 2) {
+  for (int e = mid + 2 * part; e < end; e += 2 * WPR) {
     const int e1 = min(e + 1, end - 1);
     const int p0 = pid[e], p1 = pid[e1];
     const int j0 = col[e], j1 = col[e1];
@@ -245,10 +264,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   }
   if (HAS_F) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float4 o = add4(acc[k], upper_half(acc[k]));
-      if (!hi) st4(g_fin + ((size_t)i * 3 + k) * NF + c4, o);
-    }
+    for (int k = 0; k < 3; ++k) acc[k] = add4(acc[k], upper_half(acc[k]));
+    row_combine<WPR, 3>(acc, comb, part, lane);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (active && part == 0 && !hi) st4(g_fin + ((size_t)i * 3 + k) * NF + c4, acc[k]);
   }
 }
 
@@ -263,26 +283,31 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
 // ---------------------------------------------------------------------------------------------
 // NEED_GM = false for the first layer: its m = message_nodepart(Embedding[z]) does not depend on the positions, so g_m is
 // never used and the rows only visit the pairs they own (for g_x).
-template <bool NEED_GM>
+template <bool NEED_GM, int WPR>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
                const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
                float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms) {
-  const int i = wave_row(gridDim.x);
-  if (i >= n_atoms) return;
+  __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 1)];
+  int part;
+  const int i_ = wave_row_split<WPR>(gridDim.x, part);
+  const bool active = i_ < n_atoms;
+  if (WPR == 1 && !active) return;
+  const int i = active ? i_ : 0;
   const int lane = threadIdx.x & 63;
   const int c4 = 4 * (lane & 31);
   const bool hi = lane >= 32;
   const float4 mi = ld4(m + (size_t)i * NF + c4);
   const float4 gai = ld4(g_a + (size_t)i * NF + c4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int beg = row_ptr[i], end = row_ptr[i + 1];
+  const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
   const int mid = row_mid(col, beg, end, i, lane);
-  for (int e = beg + lane; e < mid; e += 64) g_x[e] = 0.f;   // the pair's owner carries all of g_x
+  if (part == 0)
+    for (int e = beg + lane; e < mid; e += 64) g_x[e] = 0.f;   // the pair's owner carries all of g_x
   if (NEED_GM) {
     // [beg, mid): pairs owned by the other endpoint -- value table only
-    for (int e = beg; e < mid; e += 2) {
+    for (int e = beg + 2 * part; e < mid; e += 2 * WPR) {
       const int e1 = min(e + 1, mid - 1);
       const int j0 = col[e], j1 = col[e1];
       const int p0 = pid[e], p1 = pid[e1];
@@ -305,7 +330,7 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
     }
   }
   // [mid, end): pairs this row owns -- value and derivative, g_x
-  for (int e = mid; e < end; e += 2) {
+  for (int e = mid + 2 * part; e < end; e += 2 * WPR) {
     const int e1 = min(e + 1, end - 1);
     const int j0 = col[e], j1 = col[e1];
     const int p0 = pid[e], p1 = pid[e1];
@@ -328,7 +353,9 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   }
   if (NEED_GM) {
     acc = add4(acc, upper_half(acc));
-    if (!hi) st4(g_m + (size_t)i * NF + c4, acc);
+    float4 a1[1] = {acc};
+    row_combine<WPR, 1>(a1, comb, part, lane);
+    if (active && part == 0 && !hi) st4(g_m + (size_t)i * NF + c4, a1[0]);
   }
 }
 
@@ -628,7 +655,7 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (used by pipeline.hip)
 // ---------------------------------------------------------------------------------------------
-static inline int row_blocks(int n_atoms) { return cdiv(n_atoms, EDGE_ROWS); }
+static inline int row_blocks(int n_atoms, int wpr) { return cdiv(n_atoms, EDGE_ROWS / wpr); }
 // tooling: NNHIP_EDGE_LDS=<bytes> attaches unused dynamic LDS to the edge kernels to cap their occupancy
 static inline size_t edge_lds() {
   static const size_t v = getenv("NNHIP_EDGE_LDS") ? (size_t)atol(getenv("NNHIP_EDGE_LDS")) : 0;
@@ -639,7 +666,7 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
+  msg_fwd_kernel<EDGE_WPR_MSG_FWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
                                                      msg, a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
@@ -651,9 +678,9 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    force_fwd_kernel<true, EDGE_WPR_FORCE_FWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_fwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    force_fwd_kernel<false, EDGE_WPR_FORCE_FWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }
@@ -664,10 +691,10 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    force_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<true, EDGE_WPR_FORCE_BWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
+    force_bwd_kernel<false, EDGE_WPR_FORCE_BWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
                                                                 g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
@@ -679,10 +706,10 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   if (need_gm)
-    msg_bwd_kernel<true><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<true, EDGE_WPR_MSG_BWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                             row_ptr, col, pid, g_m, g_x, n_atoms);
   else
-    msg_bwd_kernel<false><<<row_blocks(n_atoms), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
+    msg_bwd_kernel<false, EDGE_WPR_MSG_BWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
                                                              row_ptr, col, pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;

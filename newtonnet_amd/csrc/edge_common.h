@@ -70,6 +70,58 @@ __device__ __forceinline__ int wave_row(int n_rows_padded_blocks) {
   return tile * EDGE_ROWS + wave;
 }
 
+// Split rows (the four inference kernels of edge.hip): a receiver row's edges are shared by WPR consecutive waves of the
+// workgroup (wave w of a row takes the edge pairs 2 w, 2 w + 2 WPR, ... of each of the row's two ranges), so a row lives 1 / WPR as
+// long and WPR times fewer rows are in flight at the same occupancy: the second read of a pair row by its other endpoint then
+// finds the line still in the XCD's 4 MB L2.  The partial row sums meet in LDS and are added in wave order by
+// the row's first wave: a fixed order, deterministic, independent of the order of the molecules.
+// WPR (waves per row: 1, 2 or 4) is a template parameter of each kernel; the shipped settings are below (measured on config 2,
+// profiles/r04_split_rows_*: two waves per row take 20-30 % of the fabric reads out of force_fwd / msg_bwd and 3-5 % of the time out
+// of the message kernels; force_bwd reads six rows of its own per WAVE and is faster unsplit).
+#ifndef EDGE_WPR_MSG_FWD
+#define EDGE_WPR_MSG_FWD 2
+#endif
+#ifndef EDGE_WPR_FORCE_FWD
+#define EDGE_WPR_FORCE_FWD 2
+#endif
+#ifndef EDGE_WPR_FORCE_BWD
+#define EDGE_WPR_FORCE_BWD 1
+#endif
+#ifndef EDGE_WPR_MSG_BWD
+#define EDGE_WPR_MSG_BWD 2
+#endif
+template <int WPR>
+__device__ __forceinline__ int wave_row_split(int n_blocks, int& part) {
+#ifdef EDGE_NO_XCD_MAP
+  const int tile = blockIdx.x;
+#else
+  const int tile = xcd_tile(blockIdx.x, n_blocks);
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  part = wave % WPR;
+  return tile * (EDGE_ROWS / WPR) + wave / WPR;
+}
+// K float4 row sums per lane, valid in lanes 0-31 (halves already folded): parts 1 .. WPR-1 publish, part 0 adds them in order.
+// EVERY wave of the workgroup must call this (a workgroup barrier inside); `comb` = (EDGE_ROWS / WPR) * (WPR - 1) * K * 32 float4.
+template <int WPR, int K>
+__device__ __forceinline__ void row_combine(float4 (&acc)[K], float4* comb, int part, int lane) {
+  if (WPR == 1) return;
+  const int row_local = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / WPR;
+  float4* mine = comb + (size_t)row_local * (WPR - 1) * K * 32;
+  if (part > 0 && lane < 32) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) mine[((part - 1) * K + k) * 32 + lane] = acc[k];
+  }
+  __syncthreads();
+  if (part == 0 && lane < 32) {
+#pragma unroll
+    for (int q = 1; q < WPR; ++q)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] = add4(acc[k], mine[((q - 1) * K + k) * 32 + lane]);
+  }
+}
+#define EDGE_COMB_SIZE(WPR, K) ((WPR) > 1 ? (EDGE_ROWS / (WPR)) * ((WPR) - 1) * (K) * 32 : 1)
+
 // Radial filter eps_e = W_e rbf(x_e) (message_edgepart, newtonnet.py:186,210) and d eps_e/dx from per-layer tables
 // (graph.hip:filter_table_kernel, FT_G intervals, built in fp64 on every call).  Evaluating the 20-term contraction per
 // (edge, feature) on the VALU was the bottleneck of both message kernels (80 FMA + 40 scalar loads per edge in the adjoint); the
