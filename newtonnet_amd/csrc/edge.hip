@@ -656,6 +656,29 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // host-side launchers (used by pipeline.hip)
 // ---------------------------------------------------------------------------------------------
 static inline int row_blocks(int n_atoms, int wpr) { return cdiv(n_atoms, EDGE_ROWS / wpr); }
+// Small systems (the one-molecule MD step, small training batches) are bound by the latency chain of a row, not by traffic or
+// occupancy: below EDGE_SMALL_ATOMS rows every kernel gives a row four waves (NNHIP_EDGE_SMALL_ATOMS overrides, 0 = never).
+#ifndef EDGE_SMALL_ATOMS
+#define EDGE_SMALL_ATOMS 4096
+#endif
+static inline bool edge_small(int n_atoms) {
+  static const int lim = getenv("NNHIP_EDGE_SMALL_ATOMS") ? atoi(getenv("NNHIP_EDGE_SMALL_ATOMS")) : EDGE_SMALL_ATOMS;
+  return n_atoms <= lim;
+}
+#define EDGE_LAUNCH(KERNEL, WPR_, ...)                                                                          \
+  do {                                                                                                          \
+    if (edge_small(n_atoms))                                                                                    \
+      KERNEL<4><<<row_blocks(n_atoms, 4), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                        \
+    else                                                                                                        \
+      KERNEL<WPR_><<<row_blocks(n_atoms, WPR_), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                  \
+  } while (0)
+#define EDGE_LAUNCH_B(KERNEL, FLAG, WPR_, ...)                                                                  \
+  do {                                                                                                          \
+    if (edge_small(n_atoms))                                                                                    \
+      KERNEL<FLAG, 4><<<row_blocks(n_atoms, 4), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                  \
+    else                                                                                                        \
+      KERNEL<FLAG, WPR_><<<row_blocks(n_atoms, WPR_), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);            \
+  } while (0)
 // tooling: NNHIP_EDGE_LDS=<bytes> attaches unused dynamic LDS to the edge kernels to cap their occupancy
 static inline size_t edge_lds() {
   static const size_t v = getenv("NNHIP_EDGE_LDS") ? (size_t)atol(getenv("NNHIP_EDGE_LDS")) : 0;
@@ -666,8 +689,7 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_MSG, s);
-  msg_fwd_kernel<EDGE_WPR_MSG_FWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in,
-                                                     msg, a_mid, n_atoms);
+  EDGE_LAUNCH(msg_fwd_kernel, EDGE_WPR_MSG_FWD, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, a_in, msg, a_mid, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }
@@ -678,9 +700,9 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    force_fwd_kernel<true, EDGE_WPR_FORCE_FWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_fwd_kernel, true, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_fwd_kernel<false, EDGE_WPR_FORCE_FWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_FWD), 64 * EDGE_ROWS, edge_lds(), s>>>(phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_fwd_kernel, false, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }
@@ -691,11 +713,9 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    force_bwd_kernel<true, EDGE_WPR_FORCE_BWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
-                                                               g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_bwd_kernel, true, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   else
-    force_bwd_kernel<false, EDGE_WPR_FORCE_BWD><<<row_blocks(n_atoms, EDGE_WPR_FORCE_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u,
-                                                                g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_bwd_kernel, false, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
   LAUNCH_CHECK();
   return 0;
 }
@@ -706,11 +726,9 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   if (need_gm)
-    msg_bwd_kernel<true, EDGE_WPR_MSG_BWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
-                                                            row_ptr, col, pid, g_m, g_x, n_atoms);
+    EDGE_LAUNCH_B(msg_bwd_kernel, true, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms);
   else
-    msg_bwd_kernel<false, EDGE_WPR_MSG_BWD><<<row_blocks(n_atoms, EDGE_WPR_MSG_BWD), 64 * EDGE_ROWS, edge_lds(), s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table,
-                                                             row_ptr, col, pid, g_m, g_x, n_atoms);
+    EDGE_LAUNCH_B(msg_bwd_kernel, false, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms);
   LAUNCH_CHECK();
   return 0;
 }

@@ -147,6 +147,12 @@ def test_skin_list_equals_exact_list_for_every_activation(activation):
     def make(skin):
         torch.manual_seed(13)
         m = NewtonNet(activation=activation, output_properties=['energy', 'gradient_force'])
+        # A seeded default-initialised model with an activation that never vanishes (softplus) blows its energy up to 3e8 eV and
+        # its forces to 5e9 eV/A through cancelling terms: any reordering of a row's fp32 sum then shows at several 1e-6 relative.
+        # Quarter-size interaction weights keep every activation's model at a physical scale (fix the model, not the bound).
+        with torch.no_grad():
+            for q in m.interaction_layers.parameters():
+                q.mul_(0.25)
         return MLAseCalculator(m, properties=['energy', 'forces'], device='cuda', skin=skin)
     fast, exact = make(0.5), make(0.0)
     for t in (0, 1, 2):
@@ -157,10 +163,9 @@ def test_skin_list_equals_exact_list_for_every_activation(activation):
             exact.calculate(a)
             n_cand = fast._md['g'].n_edges
             fs = max(1.0, float(np.abs(exact.results['forces']).max()))
-            assert np.abs(fast.results['forces'] - exact.results['forces']).max() < 5e-6 * fs, (activation, t, sub)
-            # (the skin list sums a row's pairs in a different order than the exact list; softplus never vanishes and blows the
-            # seeded model's energy up to 3e8 eV, where that fp32 reordering alone shows at a few 1e-6 relative)
-            assert abs(float(fast.results['energy']) - float(exact.results['energy'])) <= 5e-6 * max(
+            assert np.abs(fast.results['forces'] - exact.results['forces']).max() < 2e-6 * fs, (activation, t, sub)
+            # (the skin list sums a row's pairs in a different order than the exact list: fp32 reordering only)
+            assert abs(float(fast.results['energy']) - float(exact.results['energy'])) <= 2e-6 * max(
                 1.0, abs(float(exact.results['energy'])))
     assert n_cand > 306           # the skin list really holds candidates beyond the cutoff (exact list of frame 0: 306)
 
