@@ -307,6 +307,17 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
                             float* virial, float* atom_energy, float* atom_node, float* force_node,
                             const void* prepared, const int32_t* n_pairs_dev, void* stream);
 
+/* The neighbor list of a small system (1 .. nnhip_graph_small_max_atoms() atoms) in ONE launch: everything nnhip_graph_count_pairs,
+ * nnhip_check_species, nnhip_graph_pair_scan and nnhip_graph_finish_dev do, as the phases of one workgroup (same list, bit for
+ * bit).  tail[0] = the true edge count, tail[1] = the status bits; when the count exceeds `capacity` or a status bit 1 / 2 is
+ * set, row_ptr / pair_ptr come back all-zero (the emptied graph of nnhip_graph_finish_dev).  Used by nnhip_forward_dev. */
+int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                          int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
+                          int32_t* pair_ptr, int32_t* tail, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                          int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, int32_t* xg,
+                          int32_t envelope, void* stream);
+int nnhip_graph_small_max_atoms(void);
+
 /* The whole deferred step in ONE call (what NewtonNet.forward issues in its steady state: the ~8 host calls of the pieces above
  * cost a small molecule more than its kernels): nnhip_graph_count_pairs, nnhip_check_species, nnhip_prepare_check (status bit
  * 4), the asynchronous copy of (edge count, status) into tail_host[2] (pinned host memory) followed by a record of `event` (a
@@ -315,7 +326,7 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
 typedef struct {
   size_t i32_count, f32_count;   /* elements of the two arenas (int32 / float32, both 256-byte aligned by the caller) */
   /* int32 arena */
-  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, count_copy, xg, col, rev, pid;
+  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, count_copy, tail /* 2 ints */, xg, col, rev, pid;
   /* float32 arena: edge geometry, then the small outputs */
   size_t geo, disp, energy, forces, virial, atom_energy;
 } nnhip_step_layout;

@@ -580,6 +580,186 @@ extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const
   return NNHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole neighbor list of a SMALL system in ONE launch (at most SG_MAX_ATOMS atoms; the deferred step of NewtonNet.forward):
+// what nnhip_graph_count_pairs + nnhip_check_species + nnhip_graph_pair_scan + nnhip_graph_finish_dev do in fourteen launches of
+// 3-4 us each, as the phases of one 1024-thread workgroup -- molecule extents and species check, per-row degree and upper-edge
+// counts (one wave per row, the same ballot scan as graph_rows_kernel), both prefix scans in LDS, the capacity / status decision
+// (an emptied graph when the count does not fit or the status word carries an error bit), fill, reverse edges, pair ids and edge
+// embedding.  Same device functions, same order: the list is bit-identical to the multi-launch path (tested).
+// tail[0] = the TRUE edge count, tail[1] = the status bits (nnhip_prepare_check ORs its bit in behind this kernel).
+// ---------------------------------------------------------------------------------------------
+#define SG_MAX_ATOMS 1024
+#define SG_THREADS 1024
+struct SmallGraphArgs {
+  const float* pos; const float* cell; const int64_t* batch; const int64_t* z;
+  int n_atoms, n_mol, capacity; float cutoff, cut2;
+  int *mol_ptr, *row_ptr, *pair_ptr, *tail, *col, *rev, *pid;
+  float* disp; int64_t* edge_index; const float* freq; int nb, env; float* geo; int2* xg;
+};
+__device__ __forceinline__ int sg_block_excl_scan(int v, int* wave_tot, int& total) {   // 1024 threads, one value each
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int n = __shfl_up(inc, o, WAVE);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) wave_tot[w] = inc;
+  __syncthreads();
+  int before = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < SG_THREADS / 64; ++k) {
+    const int t = wave_tot[k];
+    before += k < w ? t : 0;
+    tot += t;
+  }
+  __syncthreads();            // (wave_tot is reused by the next scan)
+  total = tot;
+  return before + inc - v;
+}
+__global__ void __launch_bounds__(SG_THREADS) graph_small_kernel(const SmallGraphArgs a) {
+  __shared__ int s_status, s_ok, s_edges;
+  __shared__ int rp[SG_MAX_ATOMS + 1], pp[SG_MAX_ATOMS + 1], wave_tot[SG_THREADS / 64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int N = a.n_atoms, B = a.n_mol;
+  if (t == 0) s_status = 0;
+  for (int k = t; k <= B; k += SG_THREADS) a.mol_ptr[k] = 0;
+  __syncthreads();
+  // ---- molecule extents (mol_ptr_kernel) + species check (check_species_kernel)
+  if (t < N) {
+    const long b = a.batch[t];
+    const long bp = (t == 0) ? -1 : a.batch[t - 1];
+    if (b < bp || b < 0 || b >= B) {
+      atomicOr(&s_status, 1);
+    } else {
+      for (long k = bp + 1; k <= b; ++k) a.mol_ptr[k] = t;
+      if (t == N - 1)
+        for (long k = b + 1; k <= B; ++k) a.mol_ptr[k] = N;
+    }
+    if (a.z) {
+      const long zi = a.z[t];
+      if (zi < 0 || zi >= NNHIP_N_ELEMENTS) atomicOr(&s_status, 2);
+    }
+  }
+  __syncthreads();
+  // ---- degrees and upper-edge counts, one wave per row (graph_rows_kernel<false>)
+  for (int i = wave; i < N; i += SG_THREADS / 64) {
+    const long b = a.batch[i];
+    int cnt = 0, cnt_up = 0;
+    if (b >= 0 && b < B) {
+      const int s = a.mol_ptr[b], e = a.mol_ptr[b + 1];
+      const CellInfo ci = load_cell(a.cell, b);
+      const float xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
+      for (int j0 = s; j0 < e; j0 += 64) {
+        const int j = j0 + lane;
+        bool hit = false;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (j < e && j != i) hit = pair_disp(xi, yi, zi, a.pos[3 * j], a.pos[3 * j + 1], a.pos[3 * j + 2], ci, dx, dy, dz) < a.cut2;
+        cnt += __popcll(__ballot(hit));
+        cnt_up += __popcll(__ballot(hit && j > i));
+      }
+    }
+    if (lane == 0) {
+      rp[i] = cnt;
+      pp[i] = cnt_up;
+    }
+  }
+  __syncthreads();
+  // ---- both exclusive scans
+  {
+    int total, total_up;
+    const int d = t < N ? rp[t] : 0, u = t < N ? pp[t] : 0;
+    const int ex = sg_block_excl_scan(d, wave_tot, total);
+    const int exu = sg_block_excl_scan(u, wave_tot, total_up);
+    if (t < N) {
+      rp[t] = ex;
+      pp[t] = exu;
+    }
+    if (t == 0) {
+      rp[N] = total;
+      pp[N] = total_up;
+      const int st = s_status;
+      s_edges = total;
+      s_ok = (!(st & 3) && total <= a.capacity) ? 1 : 0;
+      a.tail[0] = total;
+      a.tail[1] = st;
+    }
+  }
+  __syncthreads();
+  const int E = s_edges;
+  const bool ok = s_ok != 0;
+  for (int k = t; k <= N; k += SG_THREADS) {     // (an emptied graph when the step must not run on this list: graph_guard_kernel)
+    a.row_ptr[k] = ok ? rp[k] : 0;
+    a.pair_ptr[k] = ok ? pp[k] : 0;
+  }
+  if (!ok) return;
+  // ---- fill (graph_rows_kernel<true>; `rev` doubles as the receiver-of-edge scratch)
+  for (int i = wave; i < N; i += SG_THREADS / 64) {
+    const long b = a.batch[i];
+    const int s = a.mol_ptr[b], e = a.mol_ptr[b + 1];
+    const CellInfo ci = load_cell(a.cell, b);
+    const float xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
+    int w = rp[i];
+    for (int j0 = s; j0 < e; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (j < e && j != i) hit = pair_disp(xi, yi, zi, a.pos[3 * j], a.pos[3 * j + 1], a.pos[3 * j + 2], ci, dx, dy, dz) < a.cut2;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int o = w + __popcll(mask & ((1ull << lane) - 1ull));
+        a.col[o] = j;
+        a.rev[o] = i;
+        a.disp[3 * (long)o] = dx;
+        a.disp[3 * (long)o + 1] = dy;
+        a.disp[3 * (long)o + 2] = dz;
+        if (a.edge_index) {
+          a.edge_index[o] = i;
+          a.edge_index[(long)E + o] = j;
+        }
+      }
+      w += __popcll(mask);
+    }
+  }
+  __syncthreads();
+  // ---- reverse edge, pair id, edge embedding (edge_finish_kernel)
+  for (int e = t; e < E; e += SG_THREADS) {
+    const int i = a.rev[e], j = a.col[e];
+    int lo = rp[j], hi = rp[j + 1] - 1, found = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const int c = a.col[mid];
+      if (c == i) {
+        found = mid;
+        break;
+      }
+      if (c < i) lo = mid + 1; else hi = mid - 1;
+    }
+    a.rev[e] = found;
+    a.pid[e] = (j > i) ? pp[i + 1] - (rp[i + 1] - e) : pp[j + 1] - (rp[j + 1] - found);
+    edge_embed_one(e, a.disp, a.cutoff, a.cut2, a.env, a.freq, a.nb, a.geo, nullptr, nullptr, a.xg);
+  }
+}
+extern "C" int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                                     int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
+                                     int32_t* pair_ptr, int32_t* tail, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                                     int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, int32_t* xg,
+                                     int32_t envelope, void* stream_) {
+  if (n_atoms < 1 || n_atoms > SG_MAX_ATOMS || n_mol < 0 || capacity < 2 || !tail || !mol_ptr || !row_ptr || !pair_ptr || n_basis < 1 ||
+      n_basis > NNHIP_MAX_NB || (envelope < 0 && envelope != NNHIP_ENVELOPE_COSINE) || envelope > 64) {
+    nnhip_set_error("nnhip_graph_small_dev: bad arguments (1..%d atoms)", SG_MAX_ATOMS);
+    return NNHIP_E_INVALID;
+  }
+  ScopedTimer tm(TC_GRAPH, (hipStream_t)stream_);
+  SmallGraphArgs a = {pos, cell, batch, z, n_atoms, n_mol, capacity, cutoff, cut2_of(cutoff), mol_ptr, row_ptr, pair_ptr, tail,
+                      col, rev, pid, disp, edge_index, frequencies, n_basis, envelope ? envelope : 9, geo, reinterpret_cast<int2*>(xg)};
+  graph_small_kernel<<<1, SG_THREADS, 0, (hipStream_t)stream_>>>(a);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+extern "C" int nnhip_graph_small_max_atoms(void) { return SG_MAX_ATOMS; }
+
 // Radial-filter tables of one layer, nodes x_g = g / FT_G (row = g + 1; fp64 evaluation, one rounding per entry):
 //   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)                         (values; node -1 = the analytic continuation to x < 0)
 //   S[g][f] = (eps_f(x_g+1) - eps_f(x_g)) FT_G                   (secant slopes, differenced in fp64)

@@ -888,6 +888,7 @@ extern "C" int nnhip_step_layout_of(int32_t N, int32_t B, int32_t cap, nnhip_ste
   out->pair_ptr = take((size_t)N + 1);
   out->pair_scan = take(n_scan);
   out->count_copy = take(1);
+  out->tail = take(2);
   out->xg = take(2 * (size_t)cap);
   out->col = take(cap);
   out->rev = take(cap);
@@ -917,6 +918,22 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   int32_t* I = st->i32;
   float* F = st->f32;
   int32_t *mol_ptr = I + lay.mol_ptr, *row_ptr = I + lay.row_ptr, *status = I + lay.status, *pair_ptr = I + lay.pair_ptr;
+  static const bool small_off = getenv("NNHIP_GRAPH_SMALL") && atoi(getenv("NNHIP_GRAPH_SMALL")) == 0;   // (A/B, tests)
+  if (N >= 1 && N <= nnhip_graph_small_max_atoms() && !small_off) {
+    // a small system: the whole neighbor list in one launch (graph.hip:graph_small_kernel), then the parameter check ORs its bit
+    // into the status word behind the count, then the two words leave for the host
+    int32_t* tail = I + lay.tail;
+    TRY(nnhip_graph_small_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, tail,
+                              I + lay.col, I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies,
+                              model->n_basis, F + lay.geo, I + lay.xg, model->envelope, stream_));
+    TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, tail + 1, 4, stream_));
+    HIP_TRY(hipMemcpyAsync(st->tail_host, tail, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
+    return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
+                              I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
+                              st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
+                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, stream_);
+  }
   TRY(nnhip_graph_count_pairs(st->pos, st->cell, st->batch, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr, stream_));
   TRY(nnhip_check_species(st->z, N, status, stream_));
   TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, status, 4, stream_));

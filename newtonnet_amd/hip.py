@@ -264,7 +264,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
-                    'nnhip_step_layout_of', 'nnhip_forward_dev')
+                    'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms')
 
 
 def _check(rc: int, what: str):
@@ -515,7 +515,7 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
 class StepLayout(C.Structure):
     """nnhip_step_layout."""
     _fields_ = [(n, C.c_size_t) for n in ('i32_count', 'f32_count', 'mol_ptr', 'row_ptr', 'status', 'pair_ptr', 'pair_scan',
-                                          'count_copy', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
+                                          'count_copy', 'tail', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
                                           'atom_energy')]
 
 
