@@ -51,7 +51,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 103; }   // 103: nnhip_prepare_check (102: weight images in MFMA fragment order)
+extern "C" int nnhip_version(void) { return 104; }   // 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
