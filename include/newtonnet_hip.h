@@ -351,6 +351,17 @@ typedef struct {
 } nnhip_step_dev;
 int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* step, void* stream);
 
+/* nnhip_energy_forces for a caller that kept pair_ptr[n_atoms + 1] (the scan of the per-row pair counts): the row kernels then
+ * find the split of a row into "pairs the other endpoint owns | pairs this row owns" with two scalar loads instead of a ballot
+ * over its cols.  Same results. */
+int nnhip_energy_forces_pp(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                           const int32_t* mol_ptr,
+                           const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
+                           const int32_t* xg, const float* disp, int32_t n_atoms, int32_t n_edges,
+                           int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
+                           float* virial, float* atom_energy, float* atom_node, float* force_node,
+                           const void* prepared, const int32_t* pair_ptr, void* stream);
+
 /* Parameter-only preparation (transposed weights for the reverse sweep, radial-filter tables, layer 0's
  * message_nodepart per element): what the reference gets for free from nn.Module state.  `prepared` is a caller-owned
  * 256-byte-aligned block of nnhip_prepared_bytes(n_layers); fill it with nnhip_prepare whenever the parameters may have

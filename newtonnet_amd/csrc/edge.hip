@@ -97,7 +97,8 @@ template <bool HAS_F, int WPR>
 __global__ void __launch_bounds__(64 * EDGE_ROWS)
 force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restrict__ phi2, const float* __restrict__ geo,
                  const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
-                 const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms, const int2* __restrict__ xg) {
+                 const float* __restrict__ f_in, float* __restrict__ f_out, int n_atoms, const int2* __restrict__ xg,
+                 const int* __restrict__ pair_ptr) {
   __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 3)];
   int part;
   const int i_ = wave_row_split<WPR>(gridDim.x, part);
@@ -112,7 +113,7 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
   for (int k = 0; k < 3; ++k)
     acc[k] = (HAS_F && !hi && part == 0) ? ld4(f_in + ((size_t)i * 3 + k) * NF + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
-  const int mid = row_mid(col, beg, end, i, lane);
+  const int mid = row_mid_of(pair_ptr, col, beg, end, i, lane, active);
   auto run = [&](const int rb, const int re, auto nt) {   // nt: stream the pair rows (the other endpoint owns them)
     for (int e = rb + 2 * part; e < re; e += 2 * WPR) {
       const int e1 = min(e + 1, re - 1);    // (clamped; the odd half is masked off when the range has no edge e + 1)
@@ -169,7 +170,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
                  float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms,
-                 const int2* __restrict__ xg) {
+                 const int2* __restrict__ xg, const int* __restrict__ pair_ptr) {
   __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 3)];
   int part;
   const int i_ = wave_row_split<WPR>(gridDim.x, part);
@@ -187,7 +188,7 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     if (HAS_F) fi[k] = ld4(f_in + ((size_t)i * 3 + k) * NF + c4);
   }
   const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
-  const int mid = row_mid(col, beg, end, i, lane);
+  const int mid = row_mid_of(pair_ptr, col, beg, end, i, lane, active);
   // [beg, mid): pairs owned by the other endpoint -- g_u and the phi2 gather only
   for (int e = beg + 2 * part; e < mid; e += 2 * WPR) {
     const int e1 = min(e + 1, mid - 1);
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(64 * EDGE_ROWS)
 msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
                const int2* __restrict__ xg, const float* __restrict__ table,
                const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
-               float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms) {
+               float* __restrict__ g_m, float* __restrict__ g_x, int n_atoms, const int* __restrict__ pair_ptr) {
   __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 1)];
   int part;
   const int i_ = wave_row_split<WPR>(gridDim.x, part);
@@ -302,7 +303,7 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   const float4 gai = ld4(g_a + (size_t)i * NF + c4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
-  const int mid = row_mid(col, beg, end, i, lane);
+  const int mid = row_mid_of(pair_ptr, col, beg, end, i, lane, active);
   if (part == 0)
     for (int e = beg + lane; e < mid; e += 64) g_x[e] = 0.f;   // the pair's owner carries all of g_x
   if (NEED_GM) {
@@ -696,39 +697,39 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
 
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
                      const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg,
-                     hipStream_t s) {
+                     hipStream_t s, const int* pair_ptr) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   if (has_f)
-    EDGE_LAUNCH_B(force_fwd_kernel, true, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_fwd_kernel, true, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
   else
-    EDGE_LAUNCH_B(force_fwd_kernel, false, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_fwd_kernel, false, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, const int* xg, hipStream_t s) {
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
   if (has_f)
-    EDGE_LAUNCH_B(force_bwd_kernel, true, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_bwd_kernel, true, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
   else
-    EDGE_LAUNCH_B(force_bwd_kernel, false, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg));
+    EDGE_LAUNCH_B(force_bwd_kernel, false, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
-                   bool need_gm, hipStream_t s) {
+                   bool need_gm, hipStream_t s, const int* pair_ptr) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   if (need_gm)
-    EDGE_LAUNCH_B(msg_bwd_kernel, true, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms);
+    EDGE_LAUNCH_B(msg_bwd_kernel, true, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms, pair_ptr);
   else
-    EDGE_LAUNCH_B(msg_bwd_kernel, false, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms);
+    EDGE_LAUNCH_B(msg_bwd_kernel, false, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms, pair_ptr);
   LAUNCH_CHECK();
   return 0;
 }

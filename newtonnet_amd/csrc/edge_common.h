@@ -181,6 +181,17 @@ __device__ __forceinline__ void filter_value_deriv(const float* __restrict__ tab
   deps = fma4(d1, fw.dc, fma4(d0, fw.db, mul4(s0, fw.da)));
 }
 
+// The same split from the pair counts when the caller has them (pair_ptr = exclusive scan of the number of pairs a row owns, i.e. of
+// its upper edges, which are the LAST ones of the row): two scalar loads next to row_ptr's instead of a vector load of the
+// row's cols + ballot that the loops depend on -- one L2 round trip less at the head of every row.
+__device__ __forceinline__ int row_mid(const int* __restrict__ col, int beg, int end, int i, int lane);
+__device__ __forceinline__ int row_mid_of(const int* __restrict__ pair_ptr, const int* __restrict__ col, int beg, int end, int i,
+                                          int lane, bool active) {
+#ifndef EDGE_NO_PAIR_MID   // (tooling A/B: always take the ballot form)
+  if (pair_ptr) return active ? end - (pair_ptr[i + 1] - pair_ptr[i]) : end;
+#endif
+  return row_mid(col, beg, end, i, lane);
+}
 // First edge of row i whose sender is above i (cols ascend within a row: [beg, mid) are the pairs owned by the other
 // endpoint, [mid, end) the pairs this row owns).  One coalesced read of the row's cols per 64 edges.
 __device__ __forceinline__ int row_mid(const int* __restrict__ col, int beg, int end, int i, int lane) {

@@ -20,13 +20,14 @@ int launch_filter_tables(const float* const* edge_w, float* const* tables, int n
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
-                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg, hipStream_t s);
+                     const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg, hipStream_t s,
+                     const int* pair_ptr = nullptr);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, const int* xg, hipStream_t s);
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr = nullptr);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm,
-                   hipStream_t s);
+                   hipStream_t s, const int* pair_ptr = nullptr);
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
@@ -495,7 +496,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
                               const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                               size_t workspace_bytes, float* energy, float* forces, float* virial,
                               float* atom_energy_out, float* atom_node_out, float* force_node_out,
-                              const void* prepared, const int32_t* n_pairs_dev, void* stream_) {
+                              const void* prepared, const int32_t* n_pairs_dev, const int32_t* pair_ptr, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -525,6 +526,8 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     return NNHIP_E_INVALID;
   }
   const int P_ = E / 2;   // undirected pairs
+  // (pair_ptr: the pair counts per row, when the caller has them -- the row kernels then split a row into the pairs it owns and
+  // the others with two scalar loads)
   const size_t h2_off = (size_t)((P_ + 31) / 32 * 32) * NF;   // floats between the h1 and h2 regions of a layer
   WsInternal w;
   make_layout(N, E, B, L, w);
@@ -663,7 +666,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
       else
         TRY(launch_mlp(MODE_FWD, false, m1, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s, pair_ptr));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
@@ -773,7 +776,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
     TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
-                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s));
+                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));
     if (E > 0) {
       // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
       float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
@@ -796,7 +799,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     }
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, P(w.g_m),
-                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s));
+                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s, pair_ptr));
     // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
     // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
     // message_nodepart input is the embedding of z, which does not depend on the positions.
@@ -846,7 +849,21 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
                                    float* atom_energy_out, float* atom_node_out, float* force_node_out,
                                    const void* prepared, void* stream_) {
   return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, E, B, workspace, workspace_bytes,
-                            energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared, nullptr, stream_);
+                            energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared, nullptr, nullptr,
+                            stream_);
+}
+// nnhip_energy_forces for a caller that also has pair_ptr[N + 1] (nnhip_graph_count_pairs + nnhip_graph_pair_scan; what
+// newtonnet_amd/hip.py:build_graph keeps): same step, same results.
+extern "C" int nnhip_energy_forces_pp(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
+                                      const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
+                                      const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
+                                      const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
+                                      size_t workspace_bytes, float* energy, float* forces, float* virial,
+                                      float* atom_energy_out, float* atom_node_out, float* force_node_out,
+                                      const void* prepared, const int32_t* pair_ptr, void* stream_) {
+  return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, E, B, workspace, workspace_bytes,
+                            energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared, nullptr, pair_ptr,
+                            stream_);
 }
 // The same step queued BEFORE the host knows the edge count (NewtonNet.forward's steady state: no device->host round trip inside
 // a step).  `capacity` (even, > 0) sizes the per-edge arrays (nnhip_graph_finish_dev) and the workspace
@@ -865,7 +882,7 @@ extern "C" int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* 
   }
   return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, capacity, B, workspace,
                             workspace_bytes, energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared,
-                            n_pairs_dev, stream_);
+                            n_pairs_dev, n_pairs_dev - N, stream_);
 }
 
 // ---- the deferred step as one call -----------------------------------------------------------------------------
@@ -932,7 +949,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
     return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                               I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
-                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, stream_);
+                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_);
   }
   TRY(nnhip_graph_count_pairs(st->pos, st->cell, st->batch, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr, stream_));
   TRY(nnhip_check_species(st->z, N, status, stream_));
@@ -947,7 +964,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                             I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                             st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
-                            F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, stream_);
+                            F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_);
 }
 
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----

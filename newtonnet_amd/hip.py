@@ -171,6 +171,8 @@ def lib():
     L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp, vp]
+    L.nnhip_energy_forces_pp.argtypes = L.nnhip_energy_forces.argtypes[:-1] + [vp, vp]
+    L.nnhip_energy_forces_pp.restype = C.c_int
     L.nnhip_prepared_bytes.argtypes = [i32]
     L.nnhip_prepared_bytes.restype = sz
     L.nnhip_prepare.argtypes = [C.POINTER(Model), vp, sz, vp]
@@ -264,7 +266,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_prepare', 'nnhip_prepare_check', 'nnhip_check_species', 'nnhip_split_products', 'nnhip_build_flags', 'nnhip_graph_count_pairs',
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
-                    'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms')
+                    'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
+                    'nnhip_energy_forces_pp')
 
 
 def _check(rc: int, what: str):
@@ -653,6 +656,17 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
         out = alloc_outputs(N, B, dev, want_forces, want_virial, want_nodes)
     out['workspace'] = workspace
     pos, cell = _f32c(pos, 'pos'), _f32c(cell, 'cell')
+    pair_ptr = getattr(g, 'pair_ptr', None)
+    if pair_ptr is not None and E > 0:
+        # the same step through the entry point that also takes the per-row pair counts: the row kernels then split a row into the
+        # pairs it owns and the others with two scalar loads instead of a ballot over its cols
+        _check(L.nnhip_energy_forces_pp(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr),
+                                        g.edge_ptr('col'), g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'),
+                                        g.edge_ptr('disp'), N, E, B, _ptr(workspace), workspace.numel(), _ptr(out['energy']),
+                                        _ptr(out['forces']), _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
+                                        _ptr(out['force_node']), _ptr(prepared), _ptr(pair_ptr), _stream(dev)),
+               'nnhip_energy_forces_pp')
+        return out
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), g.edge_ptr('col'),
                                  g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'), g.edge_ptr('disp'), N, E, B,
                                  _ptr(workspace), workspace.numel(), _ptr(out['energy']), _ptr(out['forces']),
