@@ -286,7 +286,7 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  *       (row_ptr[n_atoms]) exceeds the capacity nothing was filled and the guard EMPTIES the graph on the device
  *       (row_ptr = pair_ptr = 0), so that the step below runs on zero edges, inside the arrays; likewise when the status word
  *       of nnhip_graph_count_pairs / nnhip_check_species carries bit 1 or 2 (the synchronous path raises on those BEFORE it
- *       runs the step: a broken batch vector can give an edge set without reverse edges).  count_copy: one scratch int32.
+ *       runs the step: a broken batch vector can give an edge set without reverse edges).
  *   nnhip_energy_forces_dev  = nnhip_energy_forces with n_edges := capacity (array / workspace sizes,
  *       nnhip_workspace_bytes(n_atoms, capacity, ...)) and the true number of undirected pairs read on the device from
  *       *n_pairs_dev (= &pair_ptr[n_atoms]).
@@ -294,11 +294,17 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  * likes (NewtonNet.forward: when a result of the call is first touched, or when the next call starts): count > capacity or a
  * stale prepared block => repeat the step the ordinary way; status bits 1 / 2 => the reference's ValueError / IndexError.
  * Species outside [0, 118] never index a table (the kernels clamp them; the status bit reports them). */
+/* nnhip_graph_count_pairs with the species check of nnhip_check_species riding in its molecule-extent kernel (z may be NULL) and
+ * pair_ptr scanned in the same two launches as row_ptr (pair_scan_scratch: n_atoms / 1024 + 1 ints) -- what the deferred step
+ * uses instead of nnhip_graph_count_pairs + nnhip_check_species + nnhip_graph_pair_scan (three launches less). */
+int nnhip_graph_count_pairs_z(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                              int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
+                              int32_t* pair_ptr, int32_t* pair_scan_scratch, void* stream);
 int nnhip_graph_finish_dev(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
                            int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                            float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                            const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                           int32_t envelope, const int32_t* status, int32_t* count_copy, void* stream);
+                           int32_t envelope, const int32_t* status, void* stream);
 int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                             const int32_t* mol_ptr,
                             const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
@@ -326,7 +332,7 @@ int nnhip_graph_small_max_atoms(void);
 typedef struct {
   size_t i32_count, f32_count;   /* elements of the two arenas (int32 / float32, both 256-byte aligned by the caller) */
   /* int32 arena */
-  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, count_copy, tail /* 2 ints */, xg, col, rev, pid;
+  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, tail /* 2 ints */, xg, col, rev, pid;
   /* float32 arena: edge geometry, then the small outputs */
   size_t geo, disp, energy, forces, virial, atom_energy;
 } nnhip_step_layout;

@@ -13,9 +13,13 @@
 // molecule extents from the (sorted) batch vector
 // ---------------------------------------------------------------------------------------------
 __global__ void mol_ptr_kernel(const int64_t* __restrict__ batch, int n_atoms, int n_mol, int* __restrict__ mol_ptr,
-                               int* __restrict__ status) {
+                               int* __restrict__ status, const int64_t* __restrict__ z = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms) return;
+  if (z) {   // (the species check of check_species_kernel, in the same pass: the deferred step's one launch less)
+    const long zi = z[i];
+    if (zi < 0 || zi >= NNHIP_N_ELEMENTS) atomicOr(status, 2);
+  }
   const long b = batch[i];
   const long bp = (i == 0) ? -1 : batch[i - 1];
   if (b < bp || b < 0 || b >= n_mol) {
@@ -234,15 +238,27 @@ __device__ __forceinline__ int block_reduce_sum_1024(int v, int* sh) {
   __syncthreads();
   return total;
 }
-__global__ void __launch_bounds__(SCAN_TILE) scan_partials_kernel(const int* deg, int n, int* tile_sums) {
+__global__ void __launch_bounds__(SCAN_TILE) scan_partials_kernel(const int* deg, int n, int* tile_sums, const int* deg2 = nullptr,
+                                                                  int* tile_sums2 = nullptr) {
   __shared__ int sh[17];
+  if (blockIdx.y) {   // (second array of a dual scan)
+    deg = deg2;
+    tile_sums = tile_sums2;
+  }
   const int k = blockIdx.x * SCAN_TILE + threadIdx.x;
   const int total = block_reduce_sum_1024(k < n ? deg[k] : 0, sh);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(SCAN_TILE) scan_apply_kernel(const int* deg, int n, const int* tile_sums, int* row_ptr) {
+__global__ void __launch_bounds__(SCAN_TILE) scan_apply_kernel(const int* deg, int n, const int* tile_sums, int* row_ptr,
+                                                               const int* deg2 = nullptr, const int* tile_sums2 = nullptr,
+                                                               int* row_ptr2 = nullptr) {
   __shared__ int sh[17];
   __shared__ int part[SCAN_TILE];
+  if (blockIdx.y) {
+    deg = deg2;
+    tile_sums = tile_sums2;
+    row_ptr = row_ptr2;
+  }
   const int t = threadIdx.x;
   int before = 0;
   for (int b = t; b < (int)blockIdx.x; b += SCAN_TILE) before += tile_sums[b];
@@ -270,6 +286,21 @@ static int launch_scan(const int* deg, int n, int* row_ptr, int* tile_sums, hipS
   scan_partials_kernel<<<nb, SCAN_TILE, 0, stream>>>(deg, n, tile_sums);
   LAUNCH_CHECK();
   scan_apply_kernel<<<nb, SCAN_TILE, 0, stream>>>(deg, n, tile_sums, row_ptr);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// two independent scans of the same length in the same two launches (row_ptr and pair_ptr of the deferred step)
+static int launch_scan2(const int* deg, int* row_ptr, int* tile_sums, const int* deg2, int* row_ptr2, int* tile_sums2, int n,
+                        hipStream_t stream) {
+  const int nb = cdiv(n, SCAN_TILE);
+  if (nb > SCAN_TILE * SCAN_TILE) {
+    nnhip_set_error("scan: n = %d too large", n);
+    return NNHIP_E_UNSUPPORTED;
+  }
+  scan_partials_kernel<<<dim3(nb, 2), SCAN_TILE, 0, stream>>>(deg, n, tile_sums, deg2, tile_sums2);
+  LAUNCH_CHECK();
+  scan_apply_kernel<<<dim3(nb, 2), SCAN_TILE, 0, stream>>>(deg, n, tile_sums, row_ptr, deg2, tile_sums2, row_ptr2);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
@@ -412,7 +443,8 @@ edge_finish_kernel(const int* __restrict__ row_ptr, const int* __restrict__ pair
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int graph_count_impl(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
-                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_);
+                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_,
+                            const int64_t* z = nullptr, int32_t* pair_scan_scratch = nullptr);
 extern "C" int nnhip_graph_count(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms,
                                  int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
                                  void* stream_) {
@@ -440,8 +472,20 @@ extern "C" int nnhip_graph_pair_scan(int32_t* pair_ptr, int32_t n_atoms, int32_t
   ScopedTimer tm(TC_GRAPH, (hipStream_t)stream_);
   return launch_scan(pair_ptr, n_atoms, pair_ptr, scan_scratch, (hipStream_t)stream_);
 }
+// z != NULL: the species check rides in mol_ptr_kernel; pair_scan_scratch != NULL (with pair_cnt): pair_cnt is scanned in place in
+// the same two launches as row_ptr (what nnhip_graph_pair_scan would do in two more)
+extern "C" int nnhip_graph_count_pairs_z(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                                         int32_t n_mol, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status,
+                                         int32_t* pair_ptr, int32_t* pair_scan_scratch, void* stream_) {
+  if (!pair_ptr || !pair_scan_scratch) {
+    nnhip_set_error("nnhip_graph_count_pairs_z: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  return graph_count_impl(pos, cell, batch, n_atoms, n_mol, cutoff, mol_ptr, row_ptr, status, pair_ptr, stream_, z, pair_scan_scratch);
+}
 static int graph_count_impl(const float* pos, const float* cell, const int64_t* batch, int32_t n_atoms, int32_t n_mol,
-                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_) {
+                            float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* status, int32_t* pair_cnt, void* stream_,
+                            const int64_t* z, int32_t* pair_scan_scratch) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_atoms < 0 || n_mol < 0 || !mol_ptr || !row_ptr || !status) {
     nnhip_set_error("nnhip_graph_count: bad arguments");
@@ -454,12 +498,14 @@ static int graph_count_impl(const float* pos, const float* cell, const int64_t* 
     LAUNCH_CHECK();
   }
   if (n_atoms == 0) return NNHIP_OK;
-  mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status);
+  mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status, z);
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
   graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), row_ptr,
                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, 0, pair_cnt);
   LAUNCH_CHECK();
+  if (pair_cnt && pair_scan_scratch)
+    return launch_scan2(row_ptr, row_ptr, status + 1, pair_cnt, pair_cnt, pair_scan_scratch, n_atoms, stream);
   {
     const int rc = launch_scan(row_ptr, n_atoms, row_ptr, status + 1, stream);   // status[1..] = scan scratch
     if (rc) return rc;
@@ -541,41 +587,35 @@ extern "C" int nnhip_graph_finish_early(const float* pos, const float* cell, con
 // A step that never waits for the host (nnhip_energy_forces_dev): nnhip_graph_finish_early + a guard.  When the edge count
 // turned out larger than the capacity the fill wrote nothing; the guard then EMPTIES the graph on the device (row_ptr = pair_ptr =
 // 0: every kernel of the step that follows sees zero edges and stays inside the arrays) -- the host finds count > capacity in the
-// (count, status) words it copied out BEFORE this call and repeats the step with the real count.  `count_copy` is a scratch word
-// (the guard must not read row_ptr[n_atoms] while other workgroups clear it).
+// (count, status) words it copied out BEFORE this call and repeats the step with the real count.
 // (an invalid batch vector or species -- status bits 1 / 2, which the synchronous path raises on BEFORE it runs the step -- empties
 // the graph too: with a broken batch vector the edge set need not be symmetric and pid would index out of the pair arrays)
-__global__ void graph_count_copy_kernel(const int* __restrict__ row_ptr, int n_atoms, int capacity, const int* __restrict__ status,
-                                        int* __restrict__ count_copy) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count_copy = ((status[0] & 3) || row_ptr[n_atoms] > capacity) ? -1 : row_ptr[n_atoms];
-}
+// "Empty" without touching row_ptr[n_atoms] (which other workgroups of this launch are reading): every row_ptr[k], k < n_atoms,
+// is set to the count itself, so every row is [count, count); pair_ptr, whose last entry the pair-row kernels read, goes to zero.
 __global__ void __launch_bounds__(256)
-graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, const int* __restrict__ count_copy) {
-  if (*count_copy >= 0) return;
+graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, int capacity, const int* __restrict__ status) {
+  const int count = row_ptr[n_atoms];
+  if (!(status[0] & 3) && count <= capacity) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i <= n_atoms) {
-    row_ptr[i] = 0;
-    pair_ptr[i] = 0;
-  }
+  if (i < n_atoms) row_ptr[i] = count;
+  if (i <= n_atoms) pair_ptr[i] = 0;
 }
 extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const int64_t* batch, const int32_t* mol_ptr,
                                       int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                                       float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                                       const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                                      int32_t envelope, const int32_t* status, int32_t* count_copy, void* stream_) {
+                                      int32_t envelope, const int32_t* status, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!count_copy || !status || capacity < 1) {
+  if (!status || capacity < 1) {
     nnhip_set_error("nnhip_graph_finish_dev: bad arguments");
     return NNHIP_E_INVALID;
   }
   if (n_atoms == 0) return NNHIP_OK;
   ScopedTimer tm(TC_GRAPH, stream);
-  graph_count_copy_kernel<<<1, 64, 0, stream>>>(row_ptr, n_atoms, capacity, status, count_copy);
-  LAUNCH_CHECK();
   const int rc = nnhip_graph_finish_early(pos, cell, batch, mol_ptr, row_ptr, pair_ptr, n_atoms, n_mol, capacity, cutoff, col, rev,
                                           pid, disp, edge_index, frequencies, n_basis, geo, rbf, drbf, xg, envelope, stream_);
   if (rc) return rc;
-  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, count_copy);
+  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, capacity, status);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }

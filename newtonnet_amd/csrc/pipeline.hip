@@ -904,7 +904,6 @@ extern "C" int nnhip_step_layout_of(int32_t N, int32_t B, int32_t cap, nnhip_ste
   out->status = out->row_ptr + N + 1;                  // (adjacent to row_ptr[N]: ONE 8-byte copy brings count and status)
   out->pair_ptr = take((size_t)N + 1);
   out->pair_scan = take(n_scan);
-  out->count_copy = take(1);
   out->tail = take(2);
   out->xg = take(2 * (size_t)cap);
   out->col = take(cap);
@@ -951,16 +950,15 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
                               F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_);
   }
-  TRY(nnhip_graph_count_pairs(st->pos, st->cell, st->batch, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr, stream_));
-  TRY(nnhip_check_species(st->z, N, status, stream_));
+  TRY(nnhip_graph_count_pairs_z(st->pos, st->cell, st->batch, st->z, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr,
+                                I + lay.pair_scan, stream_));
   TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, status, 4, stream_));
   // (count, status) -> pinned host memory, on the side
   HIP_TRY(hipMemcpyAsync(st->tail_host, row_ptr + N, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
-  TRY(nnhip_graph_pair_scan(pair_ptr, N, I + lay.pair_scan, stream_));
   TRY(nnhip_graph_finish_dev(st->pos, st->cell, st->batch, mol_ptr, row_ptr, pair_ptr, N, B, cap, model->cutoff, I + lay.col,
                              I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies, model->n_basis,
-                             F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, I + lay.count_copy, stream_));
+                             F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, stream_));
   return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                             I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                             st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,

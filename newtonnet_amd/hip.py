@@ -149,7 +149,7 @@ def lib():
     L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish_early.argtypes = L.nnhip_graph_finish.argtypes
-    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp, vp]
+    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp]
     L.nnhip_energy_forces_dev.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_mlp_forms.restype = C.c_int
@@ -267,7 +267,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
-                    'nnhip_energy_forces_pp')
+                    'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z')
 
 
 def _check(rc: int, what: str):
@@ -518,7 +518,7 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
 class StepLayout(C.Structure):
     """nnhip_step_layout."""
     _fields_ = [(n, C.c_size_t) for n in ('i32_count', 'f32_count', 'mol_ptr', 'row_ptr', 'status', 'pair_ptr', 'pair_scan',
-                                          'count_copy', 'tail', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
+                                          'tail', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
                                           'atom_energy')]
 
 
