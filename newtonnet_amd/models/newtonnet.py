@@ -32,6 +32,18 @@ _GRAPH_EARLY = os.environ.get('NNHIP_GRAPH_EARLY', '1') != '0'           # (sync
 _PREPARE_EVERY_CALL = os.environ.get('NNHIP_PREPARE_EVERY_CALL', '0') == '1'
 
 
+def _versions(tensors):
+    """In-place modification counters of the input tensors (inference tensors keep none: they cannot be modified in place
+    outside inference mode either, and inside it nothing can be told -- such inputs are taken as unchanged)."""
+    out = []
+    for t in tensors:
+        try:
+            out.append(t._version)
+        except RuntimeError:
+            out.append(None)
+    return tuple(out)
+
+
 class _Deferred:
     """One eval-mode forward call whose host-side checks are deferred (NewtonNet._forward_deferred).
 
@@ -81,7 +93,7 @@ class _Deferred:
             self.state, self.reported = _Deferred.DONE, True
             raise self.error
         if self.count > self.cap or (self.bad & hip.STATUS_PARAMS_CHANGED):
-            if tuple(t._version for t in self.inputs) != self.versions:
+            if _versions(self.inputs) != self.versions:
                 self.error = RuntimeError(
                     'this forward call has to be repeated (its edge count exceeded the capacity taken from the previous call, or a '
                     'parameter had changed), but one of its input tensors was modified in place before its outputs were read: '
@@ -477,7 +489,7 @@ class NewtonNet(nn.Module):
                              rec.want_forces, rec.want_virial, self.__dict__.get('_infer_ws'))
         self.__dict__['_infer_ws'] = st.workspace
         rec.res, rec.graph, rec.tail, rec.event, rec.cap = st, st, ring[0][k], ring[1][k], cap
-        rec.versions = tuple(t._version for t in rec.inputs)
+        rec.versions = _versions(rec.inputs)
         rec.state = _Deferred.QUEUED
         self.__dict__['_last_deferred'] = rec
         return True

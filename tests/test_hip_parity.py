@@ -95,6 +95,11 @@ def test_deferred_checks_errors_and_repeats():
     buf.seek(0)
     clone = torch.load(buf, weights_only=False)
     assert same(clone(z, pos, cell, batch), first) and same(clone(z, pos, cell, batch), first)
+    # inputs made under torch.inference_mode() keep no version counter: the deferred call must still work
+    with torch.inference_mode():
+        zi, pi, ci, bi = z.clone(), pos.clone(), cell.clone(), batch.clone()
+        oi = model(zi, pi, ci, bi)
+        assert torch.equal(oi.energy, first.energy) and torch.equal(oi.gradient_force, first.gradient_force)
     # (a) species outside the tables: raised at the first touch, every touch, and never indexed with on the device
     zbad = z.clone()
     zbad[5] = 200
