@@ -910,7 +910,9 @@ def main():
             'timing_anomaly': bool(classes and host_gap > 0.15 * kernel_sum),
             'timing_anomaly_rule': 'host_gap_ms = ms_per_step - kernel_sum_ms (event-timed classes edge_all + linear_mfma + other + '
                                    'graph of the same process); anomaly when it exceeds 15 % of kernel_sum_ms: the timed regions then '
-                                   'held time that no kernel of the step accounts for (host stalls, clocks, other tenants)',
+                                   'held time that no kernel of the step accounts for (host stalls, clocks, other tenants).  The events '
+                                   'around every launch of a class stretch it by a few per cent, so a healthy run shows a small '
+                                   'NEGATIVE gap; kernel_classes_rocprof.sum_ms_per_step is the un-instrumented sum of the committed trace',
             'kernel_classes_note': ('event-timed in instrumented passes after the timed regions, one pass per group of classes (only that '
                                     "group's launches are bracketed by HIP events); kernel_classes_rocprof holds the durations of the same "
                                     'kernels from the committed rocprofv3 trace'),

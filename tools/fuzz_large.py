@@ -37,6 +37,9 @@ for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3):
     cell = torch.zeros(len(zs), 3, 3)
     batch = torch.tensor(np.concatenate([[b] * len(q) for b, q in enumerate(zs)]), dtype=torch.long)
     out = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    again = model(z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())      # the deferred (steady-state) path: same bits
+    assert torch.equal(again.edge_index, out.edge_index) and torch.equal(again.energy, out.energy)
+    assert torch.equal(again.gradient_force, out.gradient_force) and torch.equal(again.atom_node, out.atom_node)
     want = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
     assert np.array_equal(out.edge_index.cpu().numpy(), want['edge_index'].numpy()), 'edge_index differs'
     e, f = want['energy'].numpy(), want['forces'].numpy()
