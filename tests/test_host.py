@@ -46,6 +46,41 @@ def test_train_ws_mirror_matches_header():
     assert C.sizeof(hip.TrainWs) == hip.lib().nnhip_train_ws_bytes()
 
 
+def _header_struct_members(name):
+    text = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'newtonnet_hip.h')).read()
+    body = text[:text.index('} %s;' % name)]
+    body = re.sub(r'/\*.*?\*/', '', body[body.rindex('typedef struct {'):], flags=re.S)
+    names = []
+    for stmt in body.split(';'):
+        stmt = stmt.replace('typedef struct {', '')
+        if not stmt.strip():
+            continue
+        decl = re.sub(r'^\s*(const\s+)?\w+\s*\*?\s*', '', stmt.strip())
+        names += [re.match(r'\*?\s*(\w+)', part.strip()).group(1) for part in decl.split(',')]
+    return names
+
+
+def test_deferred_step_structs_mirror_the_header():
+    """nnhip_step_layout / nnhip_step_dev (the one-call deferred step, nnhip_forward_dev): the ctypes mirrors list the header's
+    members in the header's order, and the layout the library computes is self-consistent (no overlaps, everything inside)."""
+    import ctypes as C
+    from newtonnet_amd import hip
+    assert _header_struct_members('nnhip_step_layout') == [n for n, _ in hip.StepLayout._fields_]
+    assert _header_struct_members('nnhip_step_dev') == [n for n, _ in hip.StepDev._fields_]
+    N, B, cap = 21504, 1024, 332826
+    lay = hip.step_layout(N, B, cap)
+    n_scan = (N + 1023) // 1024 + 1
+    ints = [(lay.mol_ptr, B + 1), (lay.row_ptr, N + 1 + 1 + n_scan), (lay.pair_ptr, N + 1), (lay.pair_scan, n_scan), (lay.tail, 2),
+            (lay.xg, 2 * cap), (lay.col, cap), (lay.rev, cap), (lay.pid, cap)]
+    flts = [(lay.geo, 4 * cap), (lay.disp, 3 * cap), (lay.energy, B), (lay.forces, 3 * N), (lay.virial, 9 * B), (lay.atom_energy, N)]
+    assert lay.status == lay.row_ptr + N + 1                     # (count, status) adjacent: one 8-byte copy
+    for spans, total in ((ints, lay.i32_count), (flts, lay.f32_count)):
+        spans = sorted(spans)
+        assert all(a % 4 == 0 for a, _ in spans)                 # 16-byte granules
+        assert all(a + n <= b for (a, n), (b, _) in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] <= total
+    assert hip.lib().nnhip_graph_small_max_atoms() == 1024
+
+
 def test_workspace_layout_is_consistent():
     from newtonnet_amd import hip
     lay = hip.workspace_layout(21504, 310406, 1024, 3)
