@@ -284,7 +284,7 @@ int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, const float*
  * the caller it serves is still NewtonNet.forward, newtonnet.py:74-104).
  *   nnhip_graph_finish_dev   = nnhip_graph_finish_early into arrays of `capacity` edges (even, > 0) + a guard: when the count
  *       (row_ptr[n_atoms]) exceeds the capacity nothing was filled and the guard EMPTIES the graph on the device
- *       (row_ptr = pair_ptr = 0), so that the step below runs on zero edges, inside the arrays; likewise when the status word
+ *       (every row becomes [count, count), pair_ptr all zero; graph.hip:graph_guard_kernel), so that the step below runs on zero edges, inside the arrays; likewise when the status word
  *       of nnhip_graph_count_pairs / nnhip_check_species carries bit 1 or 2 (the synchronous path raises on those BEFORE it
  *       runs the step: a broken batch vector can give an edge set without reverse edges).
  *   nnhip_energy_forces_dev  = nnhip_energy_forces with n_edges := capacity (array / workspace sizes,
@@ -316,7 +316,7 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
 /* The neighbor list of a small system (1 .. nnhip_graph_small_max_atoms() atoms) in ONE launch: everything nnhip_graph_count_pairs,
  * nnhip_check_species, nnhip_graph_pair_scan and nnhip_graph_finish_dev do, as the phases of one workgroup (same list, bit for
  * bit).  tail[0] = the true edge count, tail[1] = the status bits; when the count exceeds `capacity` or a status bit 1 / 2 is
- * set, row_ptr / pair_ptr come back all-zero (the emptied graph of nnhip_graph_finish_dev).  Used by nnhip_forward_dev. */
+ * set, row_ptr / pair_ptr come back all-zero (an emptied graph, as nnhip_graph_finish_dev leaves one).  Used by nnhip_forward_dev. */
 int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
                           int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
                           int32_t* pair_ptr, int32_t* tail, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
