@@ -6,9 +6,10 @@
 // and the reverse sweep torch.autograd.grad runs through them for the gradient force
 // (newtonnet/models/output.py:66-73)                                                      -> *_bwd_kernel
 //
-// Layout / mapping: the edge list is a CSR over the receiver i (graph.hip).  One 64-lane wavefront owns
-// one receiver row and walks its edges two at a time: the lower half-wave takes the even edge, the upper half the odd
-// one, and lane l of a half holds features 4l .. 4l+3, so every [F]=128-float row access is a 16-byte-per-lane
+// Layout / mapping: the edge list is a CSR over the receiver i (graph.hip).  A receiver row belongs to WPR = 1, 2 or 4
+// wavefronts of one workgroup (edge_common.h, "Split rows": the waves of a row take alternate edge pairs of each of its two
+// ranges and their partial row sums meet in LDS in wave order).  A wave walks its edges two at a time: the lower half-wave
+// takes the even edge, the upper half the odd one, and lane l of a half holds features 4l .. 4l+3, so every [F]=128-float row access is a 16-byte-per-lane
 // instruction covering two 512-byte rows (the texture addresser charges per instruction, not per byte).  The per-row
 // sums live in registers (the two halves are folded once per row): deterministic segmented reductions, no float atomics.  Sender-side scatters of the adjoint are turned into receiver-side
 // gathers (the edge set is symmetric).  Per-edge scalars (col, dir, table position) are wave-uniform and come
