@@ -171,8 +171,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache',
-                  '_step_cache'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
             state.pop(k, None)
         return state
 
@@ -457,12 +456,14 @@ class NewtonNet(nn.Module):
         count on the device); the (count, status) words travel to pinned host memory on the side and are looked at when a result
         of the call is first touched or when the next call starts (`_Deferred.settle`).  Returns False when the call has to
         take the synchronous path (no capacity yet for this atom count, no prepared block yet, a box the cell-list builder
-        serves, NNHIP_DEFERRED=0)."""
+        serves, NNHIP_DEFERRED=0 in the environment, or `model.deferred_checks = False` on this module: every call then
+        raises its data-dependent errors on the spot, as the reference does)."""
         z, pos, cell, batch = rec.inputs
         N, B = pos.shape[0], cell.shape[0]
         hint = self.__dict__.get('_edge_hint', (None, 0))
         cached = self.__dict__.get('_prep_block')
-        if (not _DEFERRED or _PREPARE_EVERY_CALL or hint[0] != N or hint[1] < 2 or cached is None
+        if (not _DEFERRED or not self.__dict__.get('deferred_checks', True) or _PREPARE_EVERY_CALL or hint[0] != N or hint[1] < 2
+                or cached is None
                 or cached[0] != self._prep_key(model, pos.device) or (B == 1 and N >= hip.CELL_LIST_MIN_ATOMS)
                 or self.__dict__.pop('_force_sync', False)):
             return False

@@ -126,7 +126,7 @@ def test_deferred_checks_errors_and_repeats():
         model(zbad, pos, cell, batch).energy
     got = model(z, pos, cell, batch)
     assert not torch.equal(got.energy, first.energy) and same(got, fresh_copy()(z, pos, cell, batch))
-    # ... the same through the synchronous path
+    # ... the same through the synchronous path (process-wide switch, and the per-module one: errors raised on the spot)
     with torch.no_grad():
         for q in model.parameters():
             q.mul_(1.0 - 2.0 ** -7)
@@ -138,6 +138,11 @@ def test_deferred_checks_errors_and_repeats():
         assert same(got, fresh_copy()(z, pos, cell, batch))
     finally:
         nn_mod._DEFERRED = True
+    model.deferred_checks = False
+    with pytest.raises(IndexError):
+        model(zbad, pos, cell, batch)
+    assert same(model(z, pos, cell, batch), got) and model.__dict__.get('_last_deferred') is None
+    del model.deferred_checks
     # (c) a repeat (capacity overflow) after the inputs were modified in place: an error, never numbers for other inputs
     ref_first = fresh_copy()(z, pos, cell, batch)
     mol_centre = torch.stack([pos[batch == b].mean(dim=0) for b in range(int(batch.max()) + 1)])[batch]
