@@ -165,8 +165,10 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
 //   g_phi1[p]   = sum_k (gf[i][k] - gf[j][k]) u_e[k]                      -> g_h12[p][0:F]   (feeds the MLP adjoint)
 //   g_phi2[p]   = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]     -> g_h12[p][F:2F]
 // ---------------------------------------------------------------------------------------------
+// (second launch bound: at least 4 waves per SIMD, i.e. at most 128 registers -- the split-row forms otherwise come out at 130 and
+// lose a quarter of their occupancy)
 template <bool HAS_F, int WPR>
-__global__ void __launch_bounds__(64 * EDGE_ROWS)
+__global__ void __launch_bounds__(64 * EDGE_ROWS, 4)
 force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, const float* __restrict__ phi2,
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
