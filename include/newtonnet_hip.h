@@ -304,7 +304,9 @@ int nnhip_graph_finish_dev(const float* pos, const float* cell, const int64_t* b
                            int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                            float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                            const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                           int32_t envelope, const int32_t* status, void* stream);
+                           int32_t envelope, const int32_t* status, int32_t* tail_host /* 4 ints, pinned host memory, or NULL */,
+                           const int32_t* changes /* nnhip_prepare_check_counter's counter, or NULL */,
+                           int32_t seq /* stored into tail_host[3] after the three words */, void* stream);
 int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                             const int32_t* mol_ptr,
                             const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
@@ -315,19 +317,20 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
 
 /* The neighbor list of a small system (1 .. nnhip_graph_small_max_atoms() atoms) in ONE launch: everything nnhip_graph_count_pairs,
  * nnhip_check_species, nnhip_graph_pair_scan and nnhip_graph_finish_dev do, as the phases of one workgroup (same list, bit for
- * bit).  tail[0] = the true edge count, tail[1] = the status bits; when the count exceeds `capacity` or a status bit 1 / 2 is
+ * bit).  tail[0] = the true edge count, tail[1] = the status bits, tail[2] = *changes; when the count exceeds `capacity` or a status bit 1 / 2 is
  * set, row_ptr / pair_ptr come back all-zero (an emptied graph, as nnhip_graph_finish_dev leaves one).  Used by nnhip_forward_dev. */
 int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
                           int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
-                          int32_t* pair_ptr, int32_t* tail, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                          int32_t* pair_ptr, int32_t* tail /* 4 ints; may be pinned host memory */,
+                          const int32_t* changes /* or NULL */, int32_t seq /* -> tail[3], last */, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
                           int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, int32_t* xg,
                           int32_t envelope, void* stream);
 int nnhip_graph_small_max_atoms(void);
 
 /* The whole deferred step in ONE call (what NewtonNet.forward issues in its steady state: the ~8 host calls of the pieces above
- * cost a small molecule more than its kernels): nnhip_graph_count_pairs, nnhip_check_species, nnhip_prepare_check (status bit
- * 4), the asynchronous copy of (edge count, status) into tail_host[2] (pinned host memory) followed by a record of `event` (a
- * hipEvent_t the caller waits on before reading the two words), nnhip_graph_pair_scan, nnhip_graph_finish_dev,
+ * cost a small molecule more than its kernels): nnhip_prepare_check_counter, the neighbor list (nnhip_graph_count_pairs_z +
+ * nnhip_graph_finish_dev, or nnhip_graph_small_dev for small systems) whose last kernel stores (edge count, status, change counter,
+ * seq) into tail_host[4] (pinned host memory; the caller polls tail_host[3] for its seq, or waits on the optional `event`), and
  * nnhip_energy_forces_dev.  Everything per-step lives in caller-allocated arenas laid out by nnhip_step_layout. */
 typedef struct {
   size_t i32_count, f32_count;   /* elements of the two arenas (int32 / float32, both 256-byte aligned by the caller) */
@@ -342,7 +345,8 @@ typedef struct {
   const float* pos;        /* [N][3] */
   const float* cell;       /* [B][3][3] */
   const int64_t* batch;    /* [N] */
-  int32_t n_atoms, n_mol, capacity /* even, > 0 */, want_forces, want_virial, pad_;
+  int32_t n_atoms, n_mol, capacity /* even, > 0 */, want_forces, want_virial;
+  int32_t seq;             /* the caller's sequence number of this step: stored into tail_host[3] AFTER the three words */
   int32_t* i32;            /* arena of nnhip_step_layout.i32_count ints */
   float* f32;              /* arena of nnhip_step_layout.f32_count floats */
   int64_t* edge_index;     /* [2 * capacity] or NULL */
@@ -352,8 +356,11 @@ typedef struct {
   size_t workspace_bytes;
   void* prepared;          /* nnhip_prepared_bytes(L), filled by nnhip_prepare */
   size_t prepared_bytes;
-  int32_t* tail_host;      /* pinned host memory, 2 ints: (edge count, status) */
-  void* event;             /* hipEvent_t recorded right behind the copy into tail_host */
+  int32_t* tail_host;      /* pinned host memory, 4 ints: (edge count, status, change counter of the prepared block: non-zero =
+                              a parameter changed since nnhip_prepare, seq) -- written by a kernel's own stores (zero-copy), seq
+                              last with release semantics: a host that reads tail_host[3] == seq may read the other three */
+  void* event;             /* optional hipEvent_t recorded behind that kernel (NULL: none -- a record is a marker packet in the
+                              stream, ~6 us of bubble per step; NewtonNet.forward polls tail_host[3] instead) */
 } nnhip_step_dev;
 int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* step, void* stream);
 
@@ -383,6 +390,12 @@ int nnhip_prepare(const nnhip_model* model, void* prepared, size_t prepared_byte
  * reference: torch modules keep no derived state. */
 int nnhip_prepare_check(const nnhip_model* model, void* prepared, size_t prepared_bytes, int32_t* status, int32_t bit,
                         void* stream);
+/* The same comparison reporting through an int32 counter INSIDE the block: zero after nnhip_prepare, one or more up for every
+ * check that finds a difference (so it stays non-zero until the block is refilled).  Nothing of the caller's has to be
+ * initialised for it.  *counter (optional) receives the counter's device address: the deferred step hands the value to the host
+ * next to the edge count (nnhip_graph_finish_dev / nnhip_graph_small_dev, `changes`). */
+int nnhip_prepare_check_counter(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter,
+                                void* stream);
 
 /* --------------------------------------------------------------------------
  * One dense 128 -> 128 linear on the matrix cores (fp32 MFMA, exact fp32):

@@ -592,9 +592,21 @@ extern "C" int nnhip_graph_finish_early(const float* pos, const float* cell, con
 // the graph too: with a broken batch vector the edge set need not be symmetric and pid would index out of the pair arrays)
 // "Empty" without touching row_ptr[n_atoms] (which other workgroups of this launch are reading): every row_ptr[k], k < n_atoms,
 // is set to the count itself, so every row is [count, count); pair_ptr, whose last entry the pair-row kernels read, goes to zero.
+// tail_host (optional): four int32 in pinned host memory (mapped into the device's address space) -- the count, the status bits
+// and the prepared block's change counter go to the host by a plain store of this kernel: no copy dispatch, no bubble behind it.
 __global__ void __launch_bounds__(256)
-graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, int capacity, const int* __restrict__ status) {
+graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_atoms, int capacity, const int* __restrict__ status,
+                   int* __restrict__ tail_host, const int* __restrict__ changes, int seq) {
   const int count = row_ptr[n_atoms];
+  if (tail_host && blockIdx.x == 0 && threadIdx.x == 0) {
+    tail_host[0] = count;
+    tail_host[1] = status[0];
+    tail_host[2] = changes ? changes[0] : 0;
+    __threadfence_system();
+    // the caller's sequence number LAST: a host that sees it sees the three words (it polls this word instead of waiting on an
+    // event -- an event record is a marker packet in the stream and cost a 5.8 us bubble per step)
+    __hip_atomic_store(tail_host + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (!(status[0] & 3) && count <= capacity) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_atoms) row_ptr[i] = count;
@@ -604,7 +616,8 @@ extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const
                                       int32_t* row_ptr, int32_t* pair_ptr, int32_t n_atoms, int32_t n_mol, int32_t capacity,
                                       float cutoff, int32_t* col, int32_t* rev, int32_t* pid, float* disp, int64_t* edge_index,
                                       const float* frequencies, int32_t n_basis, float* geo, float* rbf, float* drbf, int32_t* xg,
-                                      int32_t envelope, const int32_t* status, void* stream_) {
+                                      int32_t envelope, const int32_t* status, int32_t* tail_host, const int32_t* changes,
+                                      int32_t seq, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!status || capacity < 1) {
     nnhip_set_error("nnhip_graph_finish_dev: bad arguments");
@@ -615,7 +628,7 @@ extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const
   const int rc = nnhip_graph_finish_early(pos, cell, batch, mol_ptr, row_ptr, pair_ptr, n_atoms, n_mol, capacity, cutoff, col, rev,
                                           pid, disp, edge_index, frequencies, n_basis, geo, rbf, drbf, xg, envelope, stream_);
   if (rc) return rc;
-  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, capacity, status);
+  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, capacity, status, tail_host, changes, seq);
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
@@ -627,14 +640,17 @@ extern "C" int nnhip_graph_finish_dev(const float* pos, const float* cell, const
 // counts (one wave per row, the same ballot scan as graph_rows_kernel), both prefix scans in LDS, the capacity / status decision
 // (an emptied graph when the count does not fit or the status word carries an error bit), fill, reverse edges, pair ids and edge
 // embedding.  Same device functions, same order: the list is bit-identical to the multi-launch path (tested).
-// tail[0] = the TRUE edge count, tail[1] = the status bits (nnhip_prepare_check ORs its bit in behind this kernel).
+// tail[0] = the TRUE edge count, tail[1] = the status bits, tail[2] = the prepared block's change counter (`changes`, or 0),
+// tail[3] = `seq`, stored last; `tail` may be pinned host memory: the words then reach the host by this kernel's own stores.
 // ---------------------------------------------------------------------------------------------
 #define SG_MAX_ATOMS 1024
 #define SG_THREADS 1024
 struct SmallGraphArgs {
   const float* pos; const float* cell; const int64_t* batch; const int64_t* z;
   int n_atoms, n_mol, capacity; float cutoff, cut2;
-  int *mol_ptr, *row_ptr, *pair_ptr, *tail, *col, *rev, *pid;
+  int *mol_ptr, *row_ptr, *pair_ptr, *tail, *col, *rev, *pid;   // tail: 3 words, may be pinned HOST memory (count, status, changes)
+  const int* changes;                                            // the prepared block's change counter (may be NULL)
+  int seq;                                                       // stored into tail[3] after the three words (release, system scope)
   float* disp; int64_t* edge_index; const float* freq; int nb, env; float* geo; int2* xg;
 };
 __device__ __forceinline__ int sg_block_excl_scan(int v, int* wave_tot, int& total) {   // 1024 threads, one value each
@@ -724,6 +740,9 @@ __global__ void __launch_bounds__(SG_THREADS) graph_small_kernel(const SmallGrap
       s_ok = (!(st & 3) && total <= a.capacity) ? 1 : 0;
       a.tail[0] = total;
       a.tail[1] = st;
+      a.tail[2] = a.changes ? a.changes[0] : 0;
+      __threadfence_system();
+      __hip_atomic_store(a.tail + 3, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
@@ -783,7 +802,8 @@ __global__ void __launch_bounds__(SG_THREADS) graph_small_kernel(const SmallGrap
 }
 extern "C" int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
                                      int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
-                                     int32_t* pair_ptr, int32_t* tail, int32_t* col, int32_t* rev, int32_t* pid, float* disp,
+                                     int32_t* pair_ptr, int32_t* tail, const int32_t* changes, int32_t seq, int32_t* col, int32_t* rev,
+                                     int32_t* pid, float* disp,
                                      int64_t* edge_index, const float* frequencies, int32_t n_basis, float* geo, int32_t* xg,
                                      int32_t envelope, void* stream_) {
   if (n_atoms < 1 || n_atoms > SG_MAX_ATOMS || n_mol < 0 || capacity < 2 || !tail || !mol_ptr || !row_ptr || !pair_ptr || n_basis < 1 ||
@@ -793,7 +813,8 @@ extern "C" int nnhip_graph_small_dev(const float* pos, const float* cell, const 
   }
   ScopedTimer tm(TC_GRAPH, (hipStream_t)stream_);
   SmallGraphArgs a = {pos, cell, batch, z, n_atoms, n_mol, capacity, cutoff, cut2_of(cutoff), mol_ptr, row_ptr, pair_ptr, tail,
-                      col, rev, pid, disp, edge_index, frequencies, n_basis, envelope ? envelope : 9, geo, reinterpret_cast<int2*>(xg)};
+                      col, rev, pid, changes, seq, disp, edge_index, frequencies, n_basis, envelope ? envelope : 9, geo,
+                      reinterpret_cast<int2*>(xg)};
   graph_small_kernel<<<1, SG_THREADS, 0, (hipStream_t)stream_>>>(a);
   LAUNCH_CHECK();
   return NNHIP_OK;

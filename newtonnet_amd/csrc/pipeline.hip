@@ -158,6 +158,7 @@ struct PrepLayout {
   size_t img[NNHIP_MAX_LAYERS][IMG_PER_LAYER];
   size_t img_head[IMG_HEAD_COUNT];
   size_t snap;                     // the parameter values the block was last checked against (nnhip_prepare_check), fp32 words
+  size_t changes;                  // int32: bumped by nnhip_prepare_check_counter when a parameter differs from the snapshot; reset by nnhip_prepare
   size_t total;
 };
 static size_t prep_bytes(int L);
@@ -212,6 +213,7 @@ static void make_prep_layout(int L, PrepLayout& q) {
     for (int k = 0; k < IMG_PER_LAYER; ++k) q.img[l][k] = carve(off, WIMG_BYTES);
   for (int k = 0; k < IMG_HEAD_COUNT; ++k) q.img_head[k] = carve(off, WIMG_BYTES);
   q.snap = carve(off, snapshot_floats(L) * 4);
+  q.changes = carve(off, 4);
   q.total = off;
 }
 static size_t prep_bytes(int L) {
@@ -428,7 +430,11 @@ __global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t
       if (UPDATE) dst[e0 + q] = v[q];
       differs = 1;
     }
-  if (!UPDATE && __syncthreads_or(differs) && threadIdx.x == 0) atomicOr(status, bit);
+  // compare: bit `bit` into *status when bit != 0, else one more count in *status (nnhip_prepare_check_counter)
+  if (!UPDATE && __syncthreads_or(differs) && threadIdx.x == 0) {
+    if (bit) atomicOr(status, bit); else atomicAdd(status, 1);
+  }
+  if (UPDATE && status && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;   // (nnhip_prepare resets the counter)
 }
 static int make_param_table(const nnhip_model* model, ParamTable& t) {
   memset(&t, 0, sizeof(t));
@@ -481,8 +487,31 @@ extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t pr
   ParamTable t;
   TRY(make_param_table(model, t));
   param_check_kernel<true><<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
-      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), nullptr, 0);
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), reinterpret_cast<int*>((char*)prepared + pq.changes), 0);
   LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// nnhip_prepare_check reporting through a counter INSIDE the block instead of a caller's status word: the counter is zero after
+// nnhip_prepare and goes up whenever a check finds a parameter that differs from the snapshot (it keeps going up until the block
+// is refilled).  No word of the caller has to be initialised for it -- the deferred step runs it first and lets its last
+// neighbor-list kernel hand the counter to the host with the edge count.  *counter_out receives the counter's device address.
+extern "C" int nnhip_prepare_check_counter(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
+                                           void* stream_) {
+  TRY(check_model(model, "nnhip_prepare_check_counter"));
+  PrepLayout pq;
+  make_prep_layout(model->n_layers, pq);
+  if (!prepared || prepared_bytes < pq.total || ((uintptr_t)prepared & 255) != 0) {
+    nnhip_set_error("nnhip_prepare_check_counter: block of %zu bytes (need %zu, 256-byte aligned)", prepared_bytes, pq.total);
+    return NNHIP_E_WORKSPACE;
+  }
+  ParamTable t;
+  TRY(make_param_table(model, t));
+  int* counter = reinterpret_cast<int*>((char*)prepared + pq.changes);
+  param_check_kernel<false><<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), counter, 0);
+  LAUNCH_CHECK();
+  if (counter_out) *counter_out = counter;
   return NNHIP_OK;
 }
 
@@ -924,7 +953,7 @@ extern "C" int nnhip_step_layout_of(int32_t N, int32_t B, int32_t cap, nnhip_ste
 extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* st, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   TRY(check_model(model, "nnhip_forward_dev"));
-  if (!st || !st->i32 || !st->f32 || !st->tail_host || !st->event || !st->prepared || !st->atom_node || !st->force_node) {
+  if (!st || !st->i32 || !st->f32 || !st->tail_host || !st->prepared || !st->atom_node || !st->force_node) {
     nnhip_set_error("nnhip_forward_dev: bad arguments");
     return NNHIP_E_INVALID;
   }
@@ -938,13 +967,12 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   if (N >= 1 && N <= nnhip_graph_small_max_atoms() && !small_off) {
     // a small system: the whole neighbor list in one launch (graph.hip:graph_small_kernel), then the parameter check ORs its bit
     // into the status word behind the count, then the two words leave for the host
-    int32_t* tail = I + lay.tail;
-    TRY(nnhip_graph_small_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, tail,
-                              I + lay.col, I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies,
+    const int32_t* changes = nullptr;
+    TRY(nnhip_prepare_check_counter(model, st->prepared, st->prepared_bytes, &changes, stream_));
+    TRY(nnhip_graph_small_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, st->tail_host,
+                              changes, st->seq, I + lay.col, I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies,
                               model->n_basis, F + lay.geo, I + lay.xg, model->envelope, stream_));
-    TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, tail + 1, 4, stream_));
-    HIP_TRY(hipMemcpyAsync(st->tail_host, tail, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
+    if (st->event) HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
     return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                               I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
@@ -952,13 +980,13 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   }
   TRY(nnhip_graph_count_pairs_z(st->pos, st->cell, st->batch, st->z, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr,
                                 I + lay.pair_scan, stream_));
-  TRY(nnhip_prepare_check(model, st->prepared, st->prepared_bytes, status, 4, stream_));
-  // (count, status) -> pinned host memory, on the side
-  HIP_TRY(hipMemcpyAsync(st->tail_host, row_ptr + N, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
+  const int32_t* changes = nullptr;
+  TRY(nnhip_prepare_check_counter(model, st->prepared, st->prepared_bytes, &changes, stream_));
   TRY(nnhip_graph_finish_dev(st->pos, st->cell, st->batch, mol_ptr, row_ptr, pair_ptr, N, B, cap, model->cutoff, I + lay.col,
                              I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies, model->n_basis,
-                             F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, stream_));
+                             F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, st->tail_host, changes, st->seq, stream_));
+  // (the guard -- the last kernel of the neighbor list -- has written count / status / change counter / seq into the pinned slot)
+  if (st->event) HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
   return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                             I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                             st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,

@@ -149,7 +149,7 @@ def lib():
     L.nnhip_graph_finish_cells.argtypes = [vp, vp, i32, i32, f32, _fp] + [vp] * 9 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish.argtypes = [vp] * 6 + [i32, i32, i32, f32] + [vp] * 6 + [i32, vp, vp, vp, vp, i32, vp]
     L.nnhip_graph_finish_early.argtypes = L.nnhip_graph_finish.argtypes
-    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp]
+    L.nnhip_graph_finish_dev.argtypes = L.nnhip_graph_finish.argtypes[:-1] + [vp, vp, vp, i32, vp]
     L.nnhip_energy_forces_dev.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                           vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_mlp_forms.restype = C.c_int
@@ -267,7 +267,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
-                    'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z')
+                    'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter')
 
 
 def _check(rc: int, what: str):
@@ -525,7 +525,7 @@ class StepLayout(C.Structure):
 class StepDev(C.Structure):
     """nnhip_step_dev."""
     _fields_ = ([(n, C.c_void_p) for n in ('z', 'pos', 'cell', 'batch')]
-                + [(n, C.c_int32) for n in ('n_atoms', 'n_mol', 'capacity', 'want_forces', 'want_virial', 'pad_')]
+                + [(n, C.c_int32) for n in ('n_atoms', 'n_mol', 'capacity', 'want_forces', 'want_virial', 'seq')]
                 + [(n, C.c_void_p) for n in ('i32', 'f32', 'edge_index', 'atom_node', 'force_node', 'workspace')]
                 + [('workspace_bytes', C.c_size_t), ('prepared', C.c_void_p), ('prepared_bytes', C.c_size_t),
                    ('tail_host', C.c_void_p), ('event', C.c_void_p)])
@@ -582,10 +582,10 @@ class DevStep:
         return self.ei[:2 * E].view(2, E)
 
 
-def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Tensor, tail_host_ptr: int, event_handle: int,
-                want_forces: bool, want_virial: bool, workspace: Optional[torch.Tensor]) -> DevStep:
+def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Tensor, tail_host_ptr: int, seq: int,
+                want_forces: bool, want_virial: bool, workspace: Optional[torch.Tensor], event_handle: int = 0) -> DevStep:
     """The whole deferred step in one C call (nnhip_forward_dev): neighbor list into arrays of `cap` edges, the (count, status)
-    words on their way to the pinned slot `tail_host_ptr` with `event_handle` recorded behind them, energy / forces pipeline.
+    words stored into the pinned slot `tail_host_ptr` by the last neighbor-list kernel, `seq` behind them; energy / forces pipeline.
     Four allocations per step (two arenas, edge_index, the node states)."""
     L = lib()
     dev = pos.device
@@ -610,7 +610,7 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     a.atom_node, a.force_node = st.atom_node.data_ptr(), st.force_node.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
     a.prepared, a.prepared_bytes = prepared.data_ptr(), prepared.numel()
-    a.tail_host, a.event = tail_host_ptr, event_handle
+    a.tail_host, a.event, a.seq = tail_host_ptr, (event_handle or None), seq
     _check(L.nnhip_forward_dev(C.byref(model), C.byref(a), _stream(dev)), 'nnhip_forward_dev')
     return st
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 
 import os
+import time
 
 import torch
 from torch import nn
@@ -68,12 +69,26 @@ class _Deferred:
         self.state, self.reported = _Deferred.QUEUED, False
 
     def read_words(self):
-        """Wait for the (count, status) words of this call -- they leave the GPU right behind its counting kernels -- and take
-        them off the pinned slot.  No kernel is launched, nothing is repeated here."""
+        """Wait for the (count, status, change counter) words of this call -- the last neighbor-list kernel stores them into the
+        pinned slot, this call's sequence number behind them -- and take them off the slot.  No kernel is launched, nothing is
+        repeated here."""
         if self.state != _Deferred.QUEUED:
             return
-        self.event.synchronize()
-        self.count, self.bad = (int(v) for v in self.tail.tolist())
+        tail, seq = self.tail, self.event          # (a numpy view of the pinned slot; this call's sequence number)
+        if int(tail[3]) != seq:
+            # not there yet (the host is ahead of the GPU): poll -- the word arrives a few tens of microseconds into the step
+            t_end, spins = time.perf_counter() + 5.0, 0
+            while int(tail[3]) != seq:
+                spins += 1
+                if spins > 64:
+                    time.sleep(0)                  # (lets other Python threads run: the wait can last a whole step)
+                    if time.perf_counter() > t_end:    # (never in a healthy run: let the runtime say what went wrong)
+                        torch.cuda.synchronize(self.inputs[1].device)
+                        if int(tail[3]) != seq:
+                            raise hip.HipLibraryError('the deferred step never reported its edge count (sequence number missing)')
+        self.count, self.bad, changed = int(tail[0]), int(tail[1]), int(tail[2])
+        if changed:                        # (the prepared block's change counter: a parameter differs from its snapshot)
+            self.bad |= hip.STATUS_PARAMS_CHANGED
         self.tail = self.event = None
         self.state = _Deferred.WORDS
         if self.bad & 1:
@@ -468,28 +483,24 @@ class NewtonNet(nn.Module):
                 or self.__dict__.pop('_force_sync', False)):
             return False
         block, cap = cached[1], hint[1]
-        # pinned (count, status) slots and the events behind them: a ring of four per module (a slot is read by the next call at
-        # the latest, _settle_last)
+        # pinned (count, status, change counter, seq) slots: a ring of four per module (a slot is read by the next call at the
+        # latest, _settle_last).  No event: the last neighbor-list kernel stores the call's sequence number behind the three
+        # words and the host polls for it (_Deferred.read_words) -- an event record is a marker packet, ~6 us of bubble per step.
         ring = self.__dict__.get('_tail_ring')
-        if ring is None or ring[5] != pos.device:
-            tails = torch.empty(4, 2, dtype=torch.int32, pin_memory=True)
-            events = [torch.cuda.Event() for _ in range(4)]
-            handles = []
-            for ev in events:
-                ev.record(torch.cuda.current_stream(pos.device))      # (creates the hipEvent_t behind ev.cuda_event)
-                h = ev.cuda_event
-                handles.append(int(h.value if hasattr(h, 'value') else h))
-            ring = self.__dict__['_tail_ring'] = [tails, events, handles, 0, tails.data_ptr(), pos.device]
-        k = ring[3] & 3
-        ring[3] += 1
+        if ring is None or ring[3] != pos.device:
+            tails = torch.zeros(4, 4, dtype=torch.int32).pin_memory()
+            ring = self.__dict__['_tail_ring'] = [tails, tails.numpy(), 0, pos.device, tails.data_ptr()]
+        ring[2] = ring[2] % 0x3fffffff + 1           # (never 0: the slots start zeroed)
+        seq = ring[2]
+        k = seq & 3
         pd, cd = pos.detach(), cell.detach()
         if pd.dtype != torch.float32 or cd.dtype != torch.float32:
             raise NotImplementedError(f'the HIP path computes in float32 (got pos {pd.dtype}, cell {cd.dtype})')
         bt = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else batch.long().contiguous()
-        st = hip.forward_dev(model, rec.zc, pd.contiguous(), cd.contiguous(), bt, cap, block, ring[4] + 8 * k, ring[2][k],
+        st = hip.forward_dev(model, rec.zc, pd.contiguous(), cd.contiguous(), bt, cap, block, ring[4] + 16 * k, seq,
                              rec.want_forces, rec.want_virial, self.__dict__.get('_infer_ws'))
         self.__dict__['_infer_ws'] = st.workspace
-        rec.res, rec.graph, rec.tail, rec.event, rec.cap = st, st, ring[0][k], ring[1][k], cap
+        rec.res, rec.graph, rec.tail, rec.event, rec.cap = st, st, ring[1][k], seq, cap
         rec.versions = _versions(rec.inputs)
         rec.state = _Deferred.QUEUED
         self.__dict__['_last_deferred'] = rec
