@@ -315,7 +315,8 @@ int nnhip_energy_forces_dev(const nnhip_model* model, const int64_t* z, const fl
                             float* virial, float* atom_energy, float* atom_node, float* force_node,
                             const void* prepared, const int32_t* n_pairs_dev, void* stream);
 
-/* The neighbor list of a small system (1 .. nnhip_graph_small_max_atoms() atoms) in ONE launch: everything nnhip_graph_count_pairs,
+/* The neighbor list of a small system (1 .. 1024 atoms; nnhip_forward_dev uses it up to nnhip_graph_small_max_atoms() = 128, where one
+ * workgroup still beats fourteen parallel launches) in ONE launch: everything nnhip_graph_count_pairs,
  * nnhip_check_species, nnhip_graph_pair_scan and nnhip_graph_finish_dev do, as the phases of one workgroup (same list, bit for
  * bit).  tail[0] = the true edge count, tail[1] = the status bits, tail[2] = *changes; when the count exceeds `capacity` or a status bit 1 / 2 is
  * set, row_ptr / pair_ptr come back all-zero (an emptied graph, as nnhip_graph_finish_dev leaves one).  Used by nnhip_forward_dev. */

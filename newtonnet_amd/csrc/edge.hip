@@ -661,9 +661,11 @@ __global__ void __launch_bounds__(256) transpose128_kernel(TransposeList L) {
 // ---------------------------------------------------------------------------------------------
 static inline int row_blocks(int n_atoms, int wpr) { return cdiv(n_atoms, EDGE_ROWS / wpr); }
 // Small systems (the one-molecule MD step, small training batches) are bound by the latency chain of a row, not by traffic or
-// occupancy: below EDGE_SMALL_ATOMS rows every kernel gives a row four waves (NNHIP_EDGE_SMALL_ATOMS overrides, 0 = never).
+// occupancy: up to EDGE_SMALL_ATOMS rows every kernel gives a row four waves (NNHIP_EDGE_SMALL_ATOMS overrides, 0 = never).
+// Back-to-back aspirin batches, us per step with / without: 1008 atoms 389 / 404, 2016: 303 / 304, 3024: 390 / 383, 5376: 574 / 568
+// (profiles/r04_small_thresholds.txt).
 #ifndef EDGE_SMALL_ATOMS
-#define EDGE_SMALL_ATOMS 4096
+#define EDGE_SMALL_ATOMS 2048
 #endif
 static inline bool edge_small(int n_atoms) {
   static const int lim = getenv("NNHIP_EDGE_SMALL_ATOMS") ? atoi(getenv("NNHIP_EDGE_SMALL_ATOMS")) : EDGE_SMALL_ATOMS;

@@ -7,6 +7,8 @@
 // makes it a CSR over the receiver i; every later aggregation is a deterministic segmented sum
 // (no float atomics).  HBM-bound integer/float32 work: one thread per receiver row, molecule-local
 // position reads served by L1/L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -819,7 +821,18 @@ extern "C" int nnhip_graph_small_dev(const float* pos, const float* cell, const 
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
-extern "C" int nnhip_graph_small_max_atoms(void) { return SG_MAX_ATOMS; }
+// What the deferred step sends through the single launch: systems of at most this many atoms (the kernel itself serves up to
+// SG_MAX_ATOMS = 1024).  One workgroup walks the rows 16 at a time, so the launch loses to the parallel kernels beyond ~100-150
+// atoms (back-to-back aspirin batches, us per step, single launch vs fourteen: 21 atoms 182 vs 206, 84: 207 vs 216, 168: 218 vs 208,
+// 336: 257 vs 231, 1008: 390 vs 255; profiles/r04_small_thresholds.txt).  NNHIP_GRAPH_SMALL_ATOMS overrides (0 = never).
+extern "C" int nnhip_graph_small_max_atoms(void) {
+  static const int lim = [] {
+    const char* v = getenv("NNHIP_GRAPH_SMALL_ATOMS");
+    const int n = v ? atoi(v) : 128;
+    return n < 0 ? 0 : (n > SG_MAX_ATOMS ? SG_MAX_ATOMS : n);
+  }();
+  return lim;
+}
 
 // Radial-filter tables of one layer, nodes x_g = g / FT_G (row = g + 1; fp64 evaluation, one rounding per entry):
 //   T[g][f] = sum_n W_e[f][n] rbf_n(x_g)                         (values; node -1 = the analytic continuation to x < 0)

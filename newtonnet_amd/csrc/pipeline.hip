@@ -963,8 +963,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   int32_t* I = st->i32;
   float* F = st->f32;
   int32_t *mol_ptr = I + lay.mol_ptr, *row_ptr = I + lay.row_ptr, *status = I + lay.status, *pair_ptr = I + lay.pair_ptr;
-  static const bool small_off = getenv("NNHIP_GRAPH_SMALL") && atoi(getenv("NNHIP_GRAPH_SMALL")) == 0;   // (A/B, tests)
-  if (N >= 1 && N <= nnhip_graph_small_max_atoms() && !small_off) {
+  if (N >= 1 && N <= nnhip_graph_small_max_atoms()) {
     // a small system: the whole neighbor list in one launch (graph.hip:graph_small_kernel), then the parameter check ORs its bit
     // into the status word behind the count, then the two words leave for the host
     const int32_t* changes = nullptr;

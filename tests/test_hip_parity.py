@@ -240,6 +240,24 @@ def test_deferred_calls_random_stress():
     assert deferred >= 20 and raised >= 3
 
 
+def test_single_launch_neighbor_list_up_to_its_limit():
+    """The deferred step sends systems of up to nnhip_graph_small_max_atoms() (default 128) atoms through the single-launch
+    neighbor list (graph.hip:graph_small_kernel); the kernel itself serves up to 1024.  Run the golden cases and the random
+    stress with the limit raised to 1024 (NNHIP_GRAPH_SMALL_ATOMS, read once per process: a child pytest): every second call
+    of those tests compares the deferred result -- now built by the single launch for every case of up to 1024 atoms, periodic
+    boxes and zero-edge molecules included -- bit for bit with the synchronous first call and with the reference's lists."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNHIP_GRAPH_SMALL_ATOMS='1024')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_hip_parity.py'), '-q', '-m', 'gpu', '-x',
+                        '-k', 'test_golden_case or test_deferred_calls_random_stress or test_deferred_checks_errors_and_repeats'],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
+
+
 def test_host_delay_between_steps_costs_nothing():
     """No device->host round trip inside a steady-state step: the host queues a step ahead, so a host that dawdles for a
     millisecond between calls (1.6 ms of GPU work per step at BASELINE configs[1] size) must not lengthen the run -- VERDICT

@@ -78,7 +78,7 @@ def test_deferred_step_structs_mirror_the_header():
         spans = sorted(spans)
         assert all(a % 4 == 0 for a, _ in spans)                 # 16-byte granules
         assert all(a + n <= b for (a, n), (b, _) in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] <= total
-    assert hip.lib().nnhip_graph_small_max_atoms() == 1024
+    assert 0 <= hip.lib().nnhip_graph_small_max_atoms() <= 1024
 
 
 def test_workspace_layout_is_consistent():
