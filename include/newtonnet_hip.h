@@ -34,6 +34,7 @@ extern "C" {
 #define NNHIP_NB 20        /* the reference's default n_basis */
 #define NNHIP_MAX_NB 32    /* any 1 <= n_basis <= 32 runs: only the radial-filter table builder sees the basis */
 #define NNHIP_MAX_LAYERS 8
+#define NNHIP_MOL_STAGE_MAX 24 /* atoms of a molecule whose node rows the molecule-resident edge kernels stage in LDS */
 #define NNHIP_N_ELEMENTS 119 /* rows of node_embedding / scale / shift (z = 0..118) */
 /* cutoff envelope of the edge embedding: a positive value p = PolynomialCutoff(p) (representations.py:138-171; the model
  * uses p = 9, :17; 0 means 9), NNHIP_ENVELOPE_COSINE = CosineCutoff (representations.py:177-203) */
@@ -118,8 +119,9 @@ typedef struct {
  * over the RECEIVER i = edge_index[0].
  *
  * nnhip_graph_count: writes row_ptr[N+1] (exclusive scan of the in-degree) and
- *   mol_ptr[B+1].  status is int32[1 + ceil(n_atoms/1024)]: status[0] is set non-zero if `batch` is not sorted, the rest
- *   is scratch of the prefix scan.
+ *   mol_ptr[B+1].  status is int32[1 + ceil(n_atoms/1024)]: status[0] gets bit 1 if `batch` is not sorted (an error) and
+ *   bit 8 if a molecule has more than NNHIP_MOL_STAGE_MAX atoms (information for the choice of edge kernels, not an error);
+ *   the rest is scratch of the prefix scan.
  *   The caller reads E = row_ptr[N] (a device->host copy; the only sync).
  * nnhip_graph_fill: writes col[E] (sender j), rev[E] (index of the reverse
  *   edge (j,i); the edge set is symmetric), disp[E][3] = pos_i - pos_j (after
@@ -348,6 +350,8 @@ typedef struct {
   const int64_t* batch;    /* [N] */
   int32_t n_atoms, n_mol, capacity /* even, > 0 */, want_forces, want_virial;
   int32_t seq;             /* the caller's sequence number of this step: stored into tail_host[3] AFTER the three words */
+  int32_t flags, pad_;     /* bit 0: every molecule of the batch is expected to have at most NNHIP_MOL_STAGE_MAX atoms (the status
+                              word of the previous batch of this shape had bit 8 clear): the molecule-resident edge kernels may run */
   int32_t* i32;            /* arena of nnhip_step_layout.i32_count ints */
   float* f32;              /* arena of nnhip_step_layout.f32_count floats */
   int64_t* edge_index;     /* [2 * capacity] or NULL */
@@ -367,14 +371,16 @@ int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev* step, void
 
 /* nnhip_energy_forces for a caller that kept pair_ptr[n_atoms + 1] (the scan of the per-row pair counts): the row kernels then
  * find the split of a row into "pairs the other endpoint owns | pairs this row owns" with two scalar loads instead of a ballot
- * over its cols.  Same results. */
+ * over its cols.  Same results.  flags bit 0: no molecule of the batch has more than NNHIP_MOL_STAGE_MAX atoms (bit 8 of the
+ * status word nnhip_graph_count* left is clear): large batches then run force_fwd one workgroup per molecule with the molecule's
+ * node rows staged in LDS (edge.hip:force_fwd_mol_kernel; same sums in a different order than the row form, ~1e-7 relative). */
 int nnhip_energy_forces_pp(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                            const int32_t* mol_ptr,
                            const int32_t* row_ptr, const int32_t* col, const int32_t* rev, const int32_t* pid, const float* geo,
                            const int32_t* xg, const float* disp, int32_t n_atoms, int32_t n_edges,
                            int32_t n_mol, void* workspace, size_t workspace_bytes, float* energy, float* forces,
                            float* virial, float* atom_energy, float* atom_node, float* force_node,
-                           const void* prepared, const int32_t* pair_ptr, void* stream);
+                           const void* prepared, const int32_t* pair_ptr, int32_t flags, void* stream);
 
 /* Parameter-only preparation (transposed weights for the reverse sweep, radial-filter tables, layer 0's
  * message_nodepart per element): what the reference gets for free from nn.Module state.  `prepared` is a caller-owned

@@ -155,6 +155,74 @@ force_fwd_kernel(const float* __restrict__ phi1 /*[P][F]*/, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// force_fwd for batches of small molecules: one workgroup per MOLECULE with the molecule's f_in rows staged in LDS once.
+// The sender rows f_in[j][0..2] are 1.5 of the 2.5 KB a directed edge pulls through the L2 -> L1 path, and a molecule's atoms
+// gather the same rows ~14 times over; that stream, not HBM and not latency, bounds the row form of this kernel (DESIGN.md section 7:
+// 76 -> 60 us per launch at config 2).  Same per-row arithmetic as force_fwd_kernel<true, 1>: a wave per row, two edges per
+// instruction, the halves folded once.  A molecule of more than NNHIP_MOL_STAGE_MAX atoms (the caller launches this form only when
+// the previous batch of the same shape had none: status bit 8 of the count pass) keeps gathering from global memory.
+// ---------------------------------------------------------------------------------------------
+#define FM_WAVES 8
+__global__ void __launch_bounds__(64 * FM_WAVES)
+force_fwd_mol_kernel(const float* __restrict__ phi1, const float* __restrict__ phi2, const float* __restrict__ geo,
+                     const int* __restrict__ mol_ptr, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                     const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ f_out, int n_mol,
+                     const int2* __restrict__ xg) {
+  __shared__ __attribute__((aligned(16))) float fl[NNHIP_MOL_STAGE_MAX * 3 * NF];
+  const int b = xcd_tile(blockIdx.x, gridDim.x);
+  if (b >= n_mol) return;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
+  const bool staged = n <= NNHIP_MOL_STAGE_MAX;
+  if (staged) {
+    const float4* src = reinterpret_cast<const float4*>(f_in + (size_t)a0 * 3 * NF);
+    float4* dst = reinterpret_cast<float4*>(fl);
+    for (int t = threadIdx.x; t < n * 3 * (NF / 4); t += 64 * FM_WAVES) dst[t] = src[t];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c4 = 4 * (lane & 31);
+  const bool hi = lane >= 32;
+  for (int i = a0 + wave; i < a0 + n; i += FM_WAVES) {
+    float4 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      acc[k] = hi ? make_float4(0.f, 0.f, 0.f, 0.f)
+                  : (staged ? *reinterpret_cast<const float4*>(fl + ((i - a0) * 3 + k) * NF + c4) : ld4(f_in + ((size_t)i * 3 + k) * NF + c4));
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    for (int e = beg; e < end; e += 2) {
+      const int e1 = min(e + 1, end - 1);
+      const float4 g0 = reinterpret_cast<const float4*>(geo)[e];
+      const float4 g1 = reinterpret_cast<const float4*>(geo)[e1];
+      const int p0 = pid[e], p1 = pid[e1];
+      const int j0 = col[e], j1 = col[e1];
+      const float4 g = hi ? g1 : g0;
+      const size_t p = (size_t)(hi ? p1 : p0);
+      const int j = hi ? j1 : j0;
+      const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask; see force_fwd_kernel)
+      if ((!hi || e + 1 < end) && (hi ? gz1 : gz0) != FT_ZERO_ROW) {
+        const float4 v1 = ld4(phi1 + p * NF + c4);
+        const float4 v2 = ld4(phi2 + p * NF + c4);
+        acc[0] = fma4(v1, g.x, acc[0]);
+        acc[1] = fma4(v1, g.y, acc[1]);
+        acc[2] = fma4(v1, g.z, acc[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 fj = staged ? *reinterpret_cast<const float4*>(fl + ((j - a0) * 3 + k) * NF + c4)
+                                   : ld4(f_in + ((size_t)j * 3 + k) * NF + c4);
+          acc[k] = fma4(v2, fj, acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 o = add4(acc[k], upper_half(acc[k]));
+      if (!hi) st4(f_out + ((size_t)i * 3 + k) * NF + c4, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // adjoint of force_fwd for receiver row i, given gf = dE/d f_out (p = pid[e], the shared pair row):
 //   g_u[e][k]   = < gf[i][k] , phi1[p] >                                  (wave reduction, per directed edge)
 //   g_fin[i][k] = gf[i][k] + sum_{e in row i} phi2[p] * gf[j][k]
@@ -702,9 +770,17 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
 
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
                      const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg,
-                     hipStream_t s, const int* pair_ptr) {
+                     hipStream_t s, const int* pair_ptr, const int* mol_ptr, int n_mol) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
+  // batches of small molecules (the caller passes mol_ptr only when it may: see force_fwd_mol_kernel); NNHIP_FORCE_FWD_MOL=0: never
+  static const bool mol_off = getenv("NNHIP_FORCE_FWD_MOL") && atoi(getenv("NNHIP_FORCE_FWD_MOL")) == 0;
+  if (has_f && mol_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off && !edge_small(n_atoms)) {
+    force_fwd_mol_kernel<<<n_mol, 64 * FM_WAVES, 0, s>>>(phi1, phi2, geo, mol_ptr, row_ptr, col, pid, f_in, f_out, n_mol,
+                                                        reinterpret_cast<const int2*>(xg));
+    LAUNCH_CHECK();
+    return 0;
+  }
   if (has_f)
     EDGE_LAUNCH_B(force_fwd_kernel, true, EDGE_WPR_FORCE_FWD, phi1, phi2, geo, row_ptr, col, pid, f_in, f_out, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
   else

@@ -163,7 +163,7 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
                   const int* __restrict__ mol_ptr, int n_atoms, int n_mol, float cut2, int* __restrict__ deg,
                   const int* __restrict__ row_ptr, int* __restrict__ col, int* __restrict__ erow,
                   float* __restrict__ disp, int64_t* __restrict__ edge_index, int n_edges, int* __restrict__ upper = nullptr,
-                  const int* __restrict__ n_edges_dev = nullptr) {
+                  const int* __restrict__ n_edges_dev = nullptr, int* __restrict__ status = nullptr) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
   if (FILL && n_edges_dev) {   // early launch (nnhip_graph_finish_early): n_edges is the CAPACITY of the arrays, the count is on the device
@@ -181,6 +181,9 @@ graph_rows_kernel(const float* __restrict__ pos, const float* __restrict__ cell,
     return;
   }
   const int s = mol_ptr[b], e = mol_ptr[b + 1];
+  // status bit 8: a molecule too large for the molecule-resident kernels (edge.hip:force_fwd_mol_kernel stages a molecule's node
+  // rows in LDS); one atomic per such molecule, none in a batch of small ones
+  if (!FILL && status && lane == 0 && i == s && e - s > NNHIP_MOL_STAGE_MAX) atomicOr(status, 8);
   const CellInfo ci = load_cell(cell, b);
   const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
   int cnt = 0, cnt_up = 0;   // cnt_up: neighbors above i = the undirected pairs this row owns (section "Undirected pairs")
@@ -504,7 +507,7 @@ static int graph_count_impl(const float* pos, const float* cell, const int64_t* 
   LAUNCH_CHECK();
   // in-degrees are counted into row_ptr[0..N) and scanned in place
   graph_rows_kernel<false><<<cdiv(n_atoms, 4), 256, 0, stream>>>(pos, cell, batch, mol_ptr, n_atoms, n_mol, cut2_of(cutoff), row_ptr,
-                                                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, pair_cnt);
+                                                                   nullptr, nullptr, nullptr, nullptr, nullptr, 0, pair_cnt, nullptr, status);
   LAUNCH_CHECK();
   if (pair_cnt && pair_scan_scratch)
     return launch_scan2(row_ptr, row_ptr, status + 1, pair_cnt, pair_cnt, pair_scan_scratch, n_atoms, stream);
@@ -707,6 +710,7 @@ __global__ void __launch_bounds__(SG_THREADS) graph_small_kernel(const SmallGrap
     int cnt = 0, cnt_up = 0;
     if (b >= 0 && b < B) {
       const int s = a.mol_ptr[b], e = a.mol_ptr[b + 1];
+      if (lane == 0 && i == s && e - s > NNHIP_MOL_STAGE_MAX) atomicOr(&s_status, 8);   // (as graph_rows_kernel<false>)
       const CellInfo ci = load_cell(a.cell, b);
       const float xi = a.pos[3 * i], yi = a.pos[3 * i + 1], zi = a.pos[3 * i + 2];
       for (int j0 = s; j0 < e; j0 += 64) {

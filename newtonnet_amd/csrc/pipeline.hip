@@ -21,7 +21,7 @@ int launch_msg_fwd(const float* m, const int* xg, const float* table, const int*
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s);
 int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
                      const int* col, const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg, hipStream_t s,
-                     const int* pair_ptr = nullptr);
+                     const int* pair_ptr = nullptr, const int* mol_ptr = nullptr, int n_mol = 0);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
                      float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr = nullptr);
@@ -52,7 +52,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 104; }   // 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
+extern "C" int nnhip_version(void) { return 105; }   // 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
@@ -525,7 +525,8 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
                               const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                               size_t workspace_bytes, float* energy, float* forces, float* virial,
                               float* atom_energy_out, float* atom_node_out, float* force_node_out,
-                              const void* prepared, const int32_t* n_pairs_dev, const int32_t* pair_ptr, void* stream_) {
+                              const void* prepared, const int32_t* n_pairs_dev, const int32_t* pair_ptr, void* stream_,
+                              bool mol_kernels = false) {
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -695,7 +696,8 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
       else
         TRY(launch_mlp(MODE_FWD, false, m1, s));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s, pair_ptr));
+    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s, pair_ptr,
+                         mol_kernels ? mol_ptr : nullptr, B));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
@@ -882,17 +884,18 @@ extern "C" int nnhip_energy_forces(const nnhip_model* model, const int64_t* z, c
                             stream_);
 }
 // nnhip_energy_forces for a caller that also has pair_ptr[N + 1] (nnhip_graph_count_pairs + nnhip_graph_pair_scan; what
-// newtonnet_amd/hip.py:build_graph keeps): same step, same results.
+// newtonnet_amd/hip.py:build_graph keeps): same step, same results.  flags bit 0: no molecule has more than NNHIP_MOL_STAGE_MAX
+// atoms (the graph's status word has bit 8 clear): the molecule-resident edge kernels may run.
 extern "C" int nnhip_energy_forces_pp(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                                       const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
                                       const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
                                       const float* disp, int32_t N, int32_t E, int32_t B, void* workspace,
                                       size_t workspace_bytes, float* energy, float* forces, float* virial,
                                       float* atom_energy_out, float* atom_node_out, float* force_node_out,
-                                      const void* prepared, const int32_t* pair_ptr, void* stream_) {
+                                      const void* prepared, const int32_t* pair_ptr, int32_t flags, void* stream_) {
   return energy_forces_impl(model, z, pos, cell, mol_ptr, row_ptr, col, rev, pid, geo, xg, disp, N, E, B, workspace, workspace_bytes,
                             energy, forces, virial, atom_energy_out, atom_node_out, force_node_out, prepared, nullptr, pair_ptr,
-                            stream_);
+                            stream_, (flags & 1) != 0);
 }
 // The same step queued BEFORE the host knows the edge count (NewtonNet.forward's steady state: no device->host round trip inside
 // a step).  `capacity` (even, > 0) sizes the per-edge arrays (nnhip_graph_finish_dev) and the workspace
@@ -975,7 +978,8 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
     return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                               I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
-                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_);
+                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_,
+                            (st->flags & 1) != 0);
   }
   TRY(nnhip_graph_count_pairs_z(st->pos, st->cell, st->batch, st->z, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr,
                                 I + lay.pair_scan, stream_));
@@ -989,7 +993,8 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                             I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                             st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
-                            F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_);
+                            F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_,
+                            (st->flags & 1) != 0);
 }
 
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----

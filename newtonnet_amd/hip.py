@@ -171,7 +171,7 @@ def lib():
     L.nnhip_graph_pairs.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.nnhip_energy_forces.argtypes = [C.POINTER(Model), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz,
                                       vp, vp, vp, vp, vp, vp, vp, vp]
-    L.nnhip_energy_forces_pp.argtypes = L.nnhip_energy_forces.argtypes[:-1] + [vp, vp]
+    L.nnhip_energy_forces_pp.argtypes = L.nnhip_energy_forces.argtypes[:-1] + [vp, i32, vp]
     L.nnhip_energy_forces_pp.restype = C.c_int
     L.nnhip_prepared_bytes.argtypes = [i32]
     L.nnhip_prepared_bytes.restype = sz
@@ -354,6 +354,7 @@ def prepare(model: Model, device, block: Optional[torch.Tensor] = None) -> torch
     return buf
 
 
+STATUS_BIG_MOLECULE = 8     # bit of the graph status word: a molecule of more than NNHIP_MOL_STAGE_MAX atoms (informational)
 STATUS_PARAMS_CHANGED = 4   # bit of the graph status word: nnhip_prepare_check found a parameter that differs from its snapshot
 
 
@@ -476,7 +477,7 @@ def build_graph(pos: torch.Tensor, cell: torch.Tensor, batch: torch.Tensor, cuto
     if bad & 2:
         raise IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
     g.n_edges = E
-    g.status = bad
+    g.status = bad | (STATUS_BIG_MOLECULE if box is not None else 0)   # (the cell-list builder serves ONE large system)
     if early is not None and E <= int(edge_capacity):          # the early launch has done the work
         bind(early, int(edge_capacity), E)
         if E == 0:
@@ -525,7 +526,7 @@ class StepLayout(C.Structure):
 class StepDev(C.Structure):
     """nnhip_step_dev."""
     _fields_ = ([(n, C.c_void_p) for n in ('z', 'pos', 'cell', 'batch')]
-                + [(n, C.c_int32) for n in ('n_atoms', 'n_mol', 'capacity', 'want_forces', 'want_virial', 'seq')]
+                + [(n, C.c_int32) for n in ('n_atoms', 'n_mol', 'capacity', 'want_forces', 'want_virial', 'seq', 'flags', 'pad_')]
                 + [(n, C.c_void_p) for n in ('i32', 'f32', 'edge_index', 'atom_node', 'force_node', 'workspace')]
                 + [('workspace_bytes', C.c_size_t), ('prepared', C.c_void_p), ('prepared_bytes', C.c_size_t),
                    ('tail_host', C.c_void_p), ('event', C.c_void_p)])
@@ -583,7 +584,8 @@ class DevStep:
 
 
 def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Tensor, tail_host_ptr: int, seq: int,
-                want_forces: bool, want_virial: bool, workspace: Optional[torch.Tensor], event_handle: int = 0) -> DevStep:
+                want_forces: bool, want_virial: bool, workspace: Optional[torch.Tensor], event_handle: int = 0,
+                small_molecules: bool = False) -> DevStep:
     """The whole deferred step in one C call (nnhip_forward_dev): neighbor list into arrays of `cap` edges, the (count, status)
     words stored into the pinned slot `tail_host_ptr` by the last neighbor-list kernel, `seq` behind them; energy / forces pipeline.
     Four allocations per step (two arenas, edge_index, the node states)."""
@@ -610,7 +612,7 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     a.atom_node, a.force_node = st.atom_node.data_ptr(), st.force_node.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
     a.prepared, a.prepared_bytes = prepared.data_ptr(), prepared.numel()
-    a.tail_host, a.event, a.seq = tail_host_ptr, (event_handle or None), seq
+    a.tail_host, a.event, a.seq, a.flags = tail_host_ptr, (event_handle or None), seq, (1 if small_molecules else 0)
     _check(L.nnhip_forward_dev(C.byref(model), C.byref(a), _stream(dev)), 'nnhip_forward_dev')
     return st
 
@@ -664,7 +666,8 @@ def energy_forces(model: Model, z: torch.Tensor, pos: torch.Tensor, cell: torch.
                                         g.edge_ptr('col'), g.edge_ptr('rev'), g.edge_ptr('pid'), g.edge_ptr('geo'), g.edge_ptr('xg'),
                                         g.edge_ptr('disp'), N, E, B, _ptr(workspace), workspace.numel(), _ptr(out['energy']),
                                         _ptr(out['forces']), _ptr(out['virial']), _ptr(out['atom_energy']), _ptr(out['atom_node']),
-                                        _ptr(out['force_node']), _ptr(prepared), _ptr(pair_ptr), _stream(dev)),
+                                        _ptr(out['force_node']), _ptr(prepared), _ptr(pair_ptr),
+                                        0 if (g.status & STATUS_BIG_MOLECULE) else 1, _stream(dev)),
                'nnhip_energy_forces_pp')
         return out
     _check(L.nnhip_energy_forces(C.byref(model), _ptr(z), _ptr(pos), _ptr(cell), _ptr(g.mol_ptr), _ptr(g.row_ptr), g.edge_ptr('col'),

@@ -59,13 +59,14 @@ class _Deferred:
     instead of returning numbers for the wrong inputs."""
     QUEUED, WORDS, DONE = 0, 1, 2
     __slots__ = ('owner', 'inputs', 'zc', 'energy_idx', 'want_forces', 'want_virial', 'res', 'graph', 'tail', 'event', 'cap',
-                 'versions', 'state', 'error', 'reported', 'count', 'bad')
+                 'versions', 'state', 'error', 'reported', 'count', 'bad', 'small_molecules')
 
     def __init__(self, owner, inputs, zc, energy_idx, want_forces, want_virial):
         self.owner, self.inputs, self.zc, self.energy_idx = owner, inputs, zc, energy_idx
         self.want_forces, self.want_virial = want_forces, want_virial
         self.res = self.graph = self.tail = self.event = self.versions = self.error = None
         self.cap = self.count = self.bad = 0
+        self.small_molecules = True
         self.state, self.reported = _Deferred.QUEUED, False
 
     def read_words(self):
@@ -96,7 +97,7 @@ class _Deferred:
         elif self.bad & 2:
             self.error = IndexError('atomic numbers z must lie in [0, 118] (rows of node_embedding / scale / shift)')
         else:
-            self.owner._note_count(self.inputs[1].shape[0], self.count)
+            self.owner._note_count(self.inputs[1].shape[0], self.count, self.inputs[2].shape[0], self.bad)
 
     def settle(self):
         if self.state == _Deferred.DONE:
@@ -107,7 +108,10 @@ class _Deferred:
         if self.error is not None:
             self.state, self.reported = _Deferred.DONE, True
             raise self.error
-        if self.count > self.cap or (self.bad & hip.STATUS_PARAMS_CHANGED):
+        # (a call queued with the wrong guess about molecule sizes is repeated as well: its kernels were correct, but the
+        # synchronous path would have summed force_fwd's rows in another order -- results never depend on the path taken)
+        if (self.count > self.cap or (self.bad & hip.STATUS_PARAMS_CHANGED)
+                or self.small_molecules != (not (self.bad & hip.STATUS_BIG_MOLECULE))):
             if _versions(self.inputs) != self.versions:
                 self.error = RuntimeError(
                     'this forward call has to be repeated (its edge count exceeded the capacity taken from the previous call, or a '
@@ -186,7 +190,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
             state.pop(k, None)
         return state
 
@@ -440,7 +444,7 @@ class NewtonNet(nn.Module):
                             emb.edge_embedding.embedding.frequencies,
                             while_waiting=in_the_bubble, before_sync=before_sync,
                             z=zc, envelope=emb.edge_embedding.envelope_id, edge_capacity=cap)
-        self._note_count(pos.shape[0], g.n_edges)
+        self._note_count(pos.shape[0], g.n_edges, cell.shape[0], g.status)
         if refill:
             block = prep[0]
             self.__dict__['_prep_block'] = (key, block)
@@ -453,9 +457,13 @@ class NewtonNet(nn.Module):
         self.__dict__['_infer_ws'] = res['workspace']
         return res, g
 
-    def _note_count(self, n_atoms, n_edges):
+    def _note_count(self, n_atoms, n_edges, n_mol=0, status=0):
         """Capacity of the per-edge arrays for the next call with this atom count: the last count + 1/16 (+ 256), kept while
-        the counts stay inside it with some room to spare (a stable capacity = stable allocation sizes)."""
+        the counts stay inside it with some room to spare (a stable capacity = stable allocation sizes).  Also what the count pass
+        said about molecule sizes: while batches of this (atoms, molecules) shape hold no molecule above NNHIP_MOL_STAGE_MAX
+        atoms, the next deferred call may launch the molecule-resident edge kernels (they stay correct on a larger molecule,
+        only slow; the status word of that call switches them off again)."""
+        self.__dict__['_mol_hint'] = (n_atoms, n_mol, not (status & hip.STATUS_BIG_MOLECULE))
         hint = self.__dict__.get('_edge_hint', (None, 0))
         if n_edges <= 0:
             cap = 0
@@ -497,8 +505,10 @@ class NewtonNet(nn.Module):
         if pd.dtype != torch.float32 or cd.dtype != torch.float32:
             raise NotImplementedError(f'the HIP path computes in float32 (got pos {pd.dtype}, cell {cd.dtype})')
         bt = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else batch.long().contiguous()
+        small = rec.small_molecules = self.__dict__.get('_mol_hint') == (N, B, True)
         st = hip.forward_dev(model, rec.zc, pd.contiguous(), cd.contiguous(), bt, cap, block, ring[4] + 16 * k, seq,
-                             rec.want_forces, rec.want_virial, self.__dict__.get('_infer_ws'))
+                             rec.want_forces, rec.want_virial, self.__dict__.get('_infer_ws'),
+                             small_molecules=small)
         self.__dict__['_infer_ws'] = st.workspace
         rec.res, rec.graph, rec.tail, rec.event, rec.cap = st, st, ring[1][k], seq, cap
         rec.versions = _versions(rec.inputs)

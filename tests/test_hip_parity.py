@@ -240,6 +240,67 @@ def test_deferred_calls_random_stress():
     assert deferred >= 20 and raised >= 3
 
 
+def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
+    """force_fwd runs one workgroup per molecule (node rows staged in LDS) for large batches whose molecules all have at most
+    NNHIP_MOL_STAGE_MAX = 24 atoms -- bit 8 of the count pass's status word says when they do not.  A long-lived module walks through
+    batches of one (atoms, molecules) shape with and without a 30-atom molecule: every result must be bit for bit what a fresh
+    module (synchronous path, exact knowledge of the sizes) returns, the calls queued on a wrong guess are repeated, and the
+    molecule form itself agrees with the fp64 oracle (molecules are independent: three of them are checked alone)."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    a = util.load_npz('aspirin_frames.npz')
+    base = torch.from_numpy(a['train_pos'][0]).float()
+    zb = torch.from_numpy(a['z']).long()
+    gen = torch.Generator().manual_seed(5)
+    model, sd = make_model('ckpt')
+
+    def batch_of(sizes):
+        zs, ps, bs = [], [], []
+        for k, n in enumerate(sizes):
+            p = base + 0.05 * torch.randn(21, 3, generator=gen)
+            zz = zb
+            if n > 21:      # aspirin + the first atoms of a second copy 3.2 A away
+                p = torch.cat([p, p[:n - 21] + torch.tensor([3.2, 0.0, 0.0])])
+                zz = torch.cat([zb, zb[:n - 21]])
+            elif n < 21:
+                p, zz = p[:n], zb[:n]
+            zs.append(zz), ps.append(p + 40.0 * k), bs.append(torch.full((n,), k))
+        return (torch.cat(zs).cuda(), torch.cat(ps).cuda(), torch.zeros(len(sizes), 3, 3, device='cuda'), torch.cat(bs).cuda())
+
+    def fresh_result(args):
+        m = NewtonNet(output_properties=['energy', 'gradient_force'])
+        m.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        m = m.cuda()
+        m.eval()
+        o = m(*args)
+        return o.energy.clone(), o.gradient_force.clone(), o.edge_index.clone(), o.force_node.clone()
+
+    small = [21] * 100                       # 2100 atoms: above the small-batch threshold of the edge kernels
+    mixed = [30, 12] + [21] * 98             # the same 2100 atoms in 100 molecules, one of them too large to stage
+    sync_calls = []
+    inner = model._forward_sync
+    model._forward_sync = lambda *args, **kw: (sync_calls.append(1), inner(*args, **kw))[1]
+    expected_sync = [1, 0, 1, 0, 0, 1, 0]    # first call; guess right; wrong guess -> repeated; right; right; wrong again; right
+    for step, sizes in enumerate([small, small, mixed, mixed, mixed, small, small]):
+        args = batch_of(sizes)
+        want = fresh_result(args)
+        before = len(sync_calls)
+        out = model(*args)
+        got = (out.energy, out.gradient_force, out.edge_index, out.force_node)
+        for g, w in zip(got, want):
+            assert torch.equal(g, w), f'step {step}'
+        assert len(sync_calls) - before == expected_sync[step], f'step {step}: {len(sync_calls) - before} synchronous passes'
+        if sizes is small and step == 1:     # the molecule form against the oracle
+            z, pos, cell, batch = (t.cpu() for t in args)
+            pick = [0, 37, 99]
+            rows = torch.cat([torch.arange(21 * k, 21 * k + 21) for k in pick])
+            o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z[rows], pos[rows].double(),
+                                  torch.zeros(3, 3, 3, dtype=torch.float64), torch.repeat_interleave(torch.arange(3), 21))
+            check_forces(out.gradient_force.cpu().numpy()[rows.numpy()], o['forces'].numpy())
+            e_ref = o['energy'].numpy()
+            assert np.all(np.abs(out.energy.cpu().double().numpy()[pick] - e_ref) <= util.energy_tol(e_ref))
+
+
 def test_single_launch_neighbor_list_up_to_its_limit():
     """The deferred step sends systems of up to nnhip_graph_small_max_atoms() (default 128) atoms through the single-launch
     neighbor list (graph.hip:graph_small_kernel); the kernel itself serves up to 1024.  Run the golden cases and the random
