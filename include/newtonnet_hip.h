@@ -330,6 +330,23 @@ int nnhip_graph_small_dev(const float* pos, const float* cell, const int64_t* ba
                           int32_t envelope, void* stream);
 int nnhip_graph_small_max_atoms(void);
 
+/* The neighbor list of a batch of small molecules, one workgroup per molecule (graph.hip:graph_mol_count_kernel,
+ * graph_mol_fill_kernel): what nnhip_graph_count_pairs_z + nnhip_graph_finish_dev do in eight launches, in five (init, molecule
+ * extents + species check, counts, fill, the guard; four with initialised != 0: the caller has zeroed status[0] and
+ * mol_ptr[0 .. n_mol]).  Serves molecules of up to 1024 atoms; nnhip_forward_dev uses it when flags bit 0 says the batch holds small
+ * molecules only.  status: one int32 (bits 1 / 2 as nnhip_graph_count / nnhip_check_species; 8: a molecule above
+ * NNHIP_MOL_STAGE_MAX atoms; 16: a molecule above 1024 atoms -- the graph is emptied).  scratch: 2 n_mol + n_mol / 1024 + 4 ints
+ * (any content).  tail_host / changes / seq, the emptied graph and the list itself: as nnhip_graph_finish_dev (bit for bit the
+ * same list; geo / xg as nnhip_edge_embed without rbf). */
+int nnhip_graph_mol_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                        int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr, int32_t* pair_ptr,
+                        int32_t* status, int32_t* scratch, int32_t initialised, int32_t* tail_host, const int32_t* changes,
+                        int32_t seq, int32_t* col, int32_t* rev, int32_t* pid, float* disp, float* geo, int32_t* xg, void* stream);
+/* edge_index [2][n_edges] int64 (RadiusGraph's API array, representations.py:98-100) from the CSR list: row 0 = the receiver of
+ * each edge, row 1 = col.  n_edges_dev (optional): the count is read on the device, n_edges is then the capacity of the grid. */
+int nnhip_edge_index_from_csr(const int32_t* row_ptr, const int32_t* col, int32_t n_atoms, int32_t n_edges,
+                              int64_t* edge_index, const int32_t* n_edges_dev, void* stream);
+
 /* The whole deferred step in ONE call (what NewtonNet.forward issues in its steady state: the ~8 host calls of the pieces above
  * cost a small molecule more than its kernels): nnhip_prepare_check_counter, the neighbor list (nnhip_graph_count_pairs_z +
  * nnhip_graph_finish_dev, or nnhip_graph_small_dev for small systems) whose last kernel stores (edge count, status, change counter,
@@ -338,7 +355,7 @@ int nnhip_graph_small_max_atoms(void);
 typedef struct {
   size_t i32_count, f32_count;   /* elements of the two arenas (int32 / float32, both 256-byte aligned by the caller) */
   /* int32 arena */
-  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, tail /* 2 ints */, xg, col, rev, pid;
+  size_t mol_ptr, row_ptr, status, pair_ptr, pair_scan, tail /* 2 ints */, mol_scratch /* 2 n_mol + n_mol / 1024 + 4 ints */, xg, col, rev, pid;
   /* float32 arena: edge geometry, then the small outputs */
   size_t geo, disp, energy, forces, virial, atom_energy;
 } nnhip_step_layout;
@@ -354,7 +371,8 @@ typedef struct {
                               word of the previous batch of this shape had bit 8 clear): the molecule-resident edge kernels may run */
   int32_t* i32;            /* arena of nnhip_step_layout.i32_count ints */
   float* f32;              /* arena of nnhip_step_layout.f32_count floats */
-  int64_t* edge_index;     /* [2 * capacity] or NULL */
+  int64_t* edge_index;     /* [2 * capacity] or NULL (what newtonnet_amd/hip.py passes: it calls nnhip_edge_index_from_csr when a
+                              caller asks for the array); rows at stride = the TRUE edge count */
   float* atom_node;        /* [N][F] */
   float* force_node;       /* [N][3][F] */
   void* workspace;         /* nnhip_workspace_bytes(N, capacity, B, L) */

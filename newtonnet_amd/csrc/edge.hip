@@ -776,6 +776,8 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   // batches of small molecules (the caller passes mol_ptr only when it may: see force_fwd_mol_kernel); NNHIP_FORCE_FWD_MOL=0: never
   static const bool mol_off = getenv("NNHIP_FORCE_FWD_MOL") && atoi(getenv("NNHIP_FORCE_FWD_MOL")) == 0;
   if (has_f && mol_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off && !edge_small(n_atoms)) {
+    // (eight waves: 4 workgroups x 36 KB of LDS = the CU's 32 wave slots; 7 waves -- no idle slot in the last round of a 21-atom
+    // molecule -- 0.198 against 0.159 ms per step, 16 waves 0.173: profiles/r04_force_fwd_mol_waves_ab.txt)
     force_fwd_mol_kernel<<<n_mol, 64 * FM_WAVES, 0, s>>>(phi1, phi2, geo, mol_ptr, row_ptr, col, pid, f_in, f_out, n_mol,
                                                         reinterpret_cast<const int2*>(xg));
     LAUNCH_CHECK();

@@ -355,10 +355,10 @@ __device__ __forceinline__ void envelope_eval(double x, int env, double& e, doub
 // rounded once (E x nb values; the cost is negligible next to the [E,F] tensors and it removes the
 // cancellation of the p=9 polynomial envelope near x -> 1 from the fp32 error budget).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void edge_embed_one(int e, const float* __restrict__ disp, float cutoff, float cut2, int env_id,
-                                               const float* __restrict__ freq, int nb, float* __restrict__ geo,
-                                               float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
-  const double dx = disp[3 * (long)e], dy = disp[3 * (long)e + 1], dz = disp[3 * (long)e + 2];
+// geo / xg of one edge from its displacement (the part of the embedding every path needs); returns x = r / cutoff
+__device__ __forceinline__ double edge_embed_geo(int e, float fx, float fy, float fz, float cutoff, float cut2,
+                                                 float* __restrict__ geo, int2* __restrict__ xg, bool& inside) {
+  const double dx = fx, dy = fy, dz = fz;
   const double r = sqrt(dx * dx + dy * dy + dz * dz);
   const double ir = 1.0 / r;
   float4 g;
@@ -372,14 +372,20 @@ __device__ __forceinline__ void edge_embed_one(int e, const float* __restrict__ 
   // all-zero filter rows, are masked out of the force kernels and get an all-zero radial basis.  "Outside" is the neighbor
   // list's own fp32 predicate (pair_disp: the reference's `norm < r`), so an edge of the exact list is never masked,
   // whatever the fp64 value of x.
-  const float fx = disp[3 * (long)e], fy = disp[3 * (long)e + 1], fz = disp[3 * (long)e + 2];
-  const bool inside = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx)) < cut2;
+  inside = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx)) < cut2;
   if (xg) {  // position on the radial-filter table grid (edge.hip): interval index and fraction, fraction in fp64 accuracy
     const double t = x * (double)FT_G;
     int g0 = (int)floor(t);
     g0 = g0 < 0 ? 0 : (g0 > FT_G - 1 ? FT_G - 1 : g0);
     xg[e] = inside ? make_int2(g0, __float_as_int((float)(t - (double)g0))) : make_int2(FT_ZERO_ROW, 0);
   }
+  return x;
+}
+__device__ __forceinline__ void edge_embed_one(int e, const float* __restrict__ disp, float cutoff, float cut2, int env_id,
+                                               const float* __restrict__ freq, int nb, float* __restrict__ geo,
+                                               float* __restrict__ rbf, float* __restrict__ drbf, int2* __restrict__ xg) {
+  bool inside;
+  const double x = edge_embed_geo(e, disp[3 * (long)e], disp[3 * (long)e + 1], disp[3 * (long)e + 2], cutoff, cut2, geo, xg, inside);
   if (!rbf) return;
   if (!inside) {
     for (int n = 0; n < nb; ++n) {
@@ -612,7 +618,7 @@ graph_guard_kernel(int* __restrict__ row_ptr, int* __restrict__ pair_ptr, int n_
     // event -- an event record is a marker packet in the stream and cost a 5.8 us bubble per step)
     __hip_atomic_store(tail_host + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (!(status[0] & 3) && count <= capacity) return;
+  if (!(status[0] & (3 | 16 | 32)) && count <= capacity) return;     // (16 / 32: graph_mol_kernel could not build the list)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_atoms) row_ptr[i] = count;
   if (i <= n_atoms) pair_ptr[i] = 0;
@@ -836,6 +842,261 @@ extern "C" int nnhip_graph_small_max_atoms(void) {
     return n < 0 ? 0 : (n > SG_MAX_ATOMS ? SG_MAX_ATOMS : n);
   }();
   return lim;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The neighbor list of a batch of SMALL molecules, a workgroup per molecule, in TWO launches (the deferred step of
+// NewtonNet.forward when the previous batch of the shape had no molecule above NNHIP_MOL_STAGE_MAX atoms; the kernels themselves
+// serve molecules of up to MG_MAX_ATOMS).  What graph_rows_kernel<count> + two dual-scan launches + graph_rows_kernel<fill> +
+// edge_finish_kernel do in five launches of 5-11 us, the molecule's positions, row_ptr / pair_ptr and col staged in LDS:
+//   graph_mol_count_kernel: per-row degree and upper-edge counts (a wave per row, the same ballot scan), both prefix scans of the
+//     molecule in LDS -> row_ptr / pair_ptr of the molecule's rows RELATIVE to the molecule, and the molecule's edge total;
+//   graph_mol_fill_kernel: the molecule's offset = the sum of the totals before it (one coalesced pass over <= MG_SUM_MAX totals
+//     by the whole workgroup; above that a scan launch in between), row_ptr / pair_ptr made absolute, fill, edge embedding from the
+//     registers that hold each displacement, reverse edges and pair ids by a search over the LDS col.
+// A molecule's pairs = its edges / 2 (the edge set is symmetric), so one offset serves both arrays.  Same device functions, same
+// order: the list is bit-identical to the multi-launch path (tested).  (A single launch with a look-back over published totals was
+// built first: 24 us, of which 12 us waiting for words to cross between the XCDs' L2s -- and a workgroup counter for "who is
+// last" cost 33 us more: 1024 atomics on one address.  Two launches without any waiting: profiles/r04_graph_mol_*.)
+// status bits set here: 8 (a molecule above NNHIP_MOL_STAGE_MAX atoms), 16 (a molecule above MG_MAX_ATOMS: its rows are not
+// built -- graph_guard_kernel empties the graph).
+// ---------------------------------------------------------------------------------------------
+#define MG_MAX_ATOMS 1024
+#define MG_THREADS 512
+#define MG_LDS_EDGES 4096
+#define MG_SUM_MAX 8192
+struct MolGraphArgs {
+  const float* pos; const float* cell; const int* mol_ptr;
+  int n_atoms, n_mol, capacity; float cutoff, cut2;
+  int *row_ptr, *pair_ptr, *status; int* mol_edges; const int* mol_base;   // mol_base: the scanned totals (n_mol > MG_SUM_MAX) or NULL
+  int *col, *rev, *pid; float* disp; float* geo; int2* xg;
+};
+__device__ __forceinline__ int mg_extent(const MolGraphArgs& a, int b, int& s) {
+  s = a.mol_ptr[b];
+  int n = a.mol_ptr[b + 1] - s;
+  if (n > MG_MAX_ATOMS) n = -1;      // (rows not built: status bit 16)
+  return n;
+}
+__global__ void __launch_bounds__(MG_THREADS) graph_mol_count_kernel(const MolGraphArgs a) {
+  __shared__ int rp[MG_MAX_ATOMS + 1], pp[MG_MAX_ATOMS + 1];
+  __shared__ float spos[3 * MG_MAX_ATOMS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  int s;
+  int n = mg_extent(a, b, s);
+  if (n < 0) {
+    if (t == 0) atomicOr(a.status, 8 | 16);
+    n = 0;
+  }
+  if (t == 0 && n > NNHIP_MOL_STAGE_MAX) atomicOr(a.status, 8);
+  for (int k = t; k < 3 * n; k += MG_THREADS) spos[k] = a.pos[3 * (long)s + k];
+  const CellInfo ci = load_cell(a.cell, b);
+  __syncthreads();
+  // ---- degrees and upper-edge counts (graph_rows_kernel<false>)
+  for (int k = wave; k < n; k += MG_THREADS / 64) {
+    const float xi = spos[3 * k], yi = spos[3 * k + 1], zi = spos[3 * k + 2];
+    int cnt = 0, cnt_up = 0;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (j < n && j != k) hit = pair_disp(xi, yi, zi, spos[3 * j], spos[3 * j + 1], spos[3 * j + 2], ci, dx, dy, dz) < a.cut2;
+      cnt += __popcll(__ballot(hit));
+      cnt_up += __popcll(__ballot(hit && j > k));
+    }
+    if (lane == 0) {
+      rp[k] = cnt;
+      pp[k] = cnt_up;
+    }
+  }
+  __syncthreads();
+  // ---- both exclusive scans of the molecule, by one wave, 64 rows at a time
+  if (wave == 0) {
+    int run = 0, run_up = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      const int k = k0 + lane;
+      const int v = k < n ? rp[k] : 0, u = k < n ? pp[k] : 0;
+      int inc = v, inc_up = u;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(inc, o, WAVE), y = __shfl_up(inc_up, o, WAVE);
+        if (lane >= o) inc += x, inc_up += y;
+      }
+      if (k < n) {      // (relative to the molecule; graph_mol_fill_kernel adds its offset)
+        a.row_ptr[s + k] = run + inc - v;
+        a.pair_ptr[s + k] = run_up + inc_up - u;
+      }
+      run += __shfl(inc, 63, WAVE);
+      run_up += __shfl(inc_up, 63, WAVE);
+    }
+    if (lane == 0) a.mol_edges[b] = run;
+  }
+}
+__global__ void __launch_bounds__(MG_THREADS) graph_mol_fill_kernel(const MolGraphArgs a) {
+  __shared__ int rp[MG_MAX_ATOMS + 1], pp[MG_MAX_ATOMS + 1];
+  __shared__ float spos[3 * MG_MAX_ATOMS];       // the molecule's positions: the row pass reads nothing else from global memory
+  __shared__ int scol[MG_LDS_EDGES];             // the molecule's col (when it fits): the reverse-edge search stays in LDS
+  __shared__ int s_base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x, B = a.n_mol, N = a.n_atoms;
+  int s;
+  int n = mg_extent(a, b, s);
+  if (n < 0) n = 0;
+  if (t == 0) s_base = 0;
+  for (int k = t; k < 3 * n; k += MG_THREADS) spos[k] = a.pos[3 * (long)s + k];
+  for (int k = t; k < n; k += MG_THREADS) {
+    rp[k] = a.row_ptr[s + k];
+    pp[k] = a.pair_ptr[s + k];
+  }
+  const int total = a.mol_edges[b];
+  const CellInfo ci = load_cell(a.cell, b);
+  __syncthreads();
+  // ---- the molecule's offset in the edge list
+  int base;
+  if (a.mol_base) {
+    base = a.mol_base[b];
+  } else {
+    int part = 0;
+    for (int q = t; q < b; q += MG_THREADS) part += a.mol_edges[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+    if (lane == 0 && part) atomicAdd(&s_base, part);
+    __syncthreads();
+    base = s_base;
+  }
+  const int pair_base = base >> 1;
+  for (int k = t; k < n; k += MG_THREADS) {
+    rp[k] += base;
+    pp[k] += pair_base;
+    a.row_ptr[s + k] = rp[k];
+    a.pair_ptr[s + k] = pp[k];
+  }
+  if (t == 0) {
+    rp[n] = base + total;
+    pp[n] = pair_base + (total >> 1);
+    if (b == B - 1) {
+      a.row_ptr[N] = base + total;
+      a.pair_ptr[N] = pair_base + (total >> 1);
+    }
+  }
+  __syncthreads();
+  const int e0 = rp[0], e1 = rp[n];
+  if (e1 > a.capacity) return;             // (uniform; this molecule's edges would not lie inside the arrays: the guard empties the graph)
+  const bool lds_col = e1 - e0 <= MG_LDS_EDGES;
+  // ---- fill (graph_rows_kernel<true>) + the edge embedding of each edge from the registers that hold its displacement
+  for (int k = wave; k < n; k += MG_THREADS / 64) {
+    const float xi = spos[3 * k], yi = spos[3 * k + 1], zi = spos[3 * k + 2];
+    int w = rp[k];
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      float dx = 0.f, dy = 0.f, dz = 0.f;
+      if (j < n && j != k) hit = pair_disp(xi, yi, zi, spos[3 * j], spos[3 * j + 1], spos[3 * j + 2], ci, dx, dy, dz) < a.cut2;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int o = w + __popcll(mask & ((1ull << lane) - 1ull));
+        a.col[o] = s + j;
+        if (lds_col) scol[o - e0] = s + j;
+        a.disp[3 * (long)o] = dx;
+        a.disp[3 * (long)o + 1] = dy;
+        a.disp[3 * (long)o + 2] = dz;
+        bool inside;
+        edge_embed_geo(o, dx, dy, dz, a.cutoff, a.cut2, a.geo, a.xg, inside);
+      }
+      w += __popcll(mask);
+    }
+  }
+  __syncthreads();
+  // ---- reverse edge and pair id (edge_finish_kernel), row by row: the receiver is the row, the search runs over the LDS col
+  for (int k = wave; k < n; k += MG_THREADS / 64) {
+    const int i = s + k;
+    for (int e = rp[k] + lane; e < rp[k + 1]; e += 64) {
+      const int j = lds_col ? scol[e - e0] : a.col[e];
+      int lo = rp[j - s], hi = rp[j - s + 1] - 1, found = -1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = lds_col ? scol[mid - e0] : a.col[mid];
+        if (c == i) {
+          found = mid;
+          break;
+        }
+        if (c < i) lo = mid + 1; else hi = mid - 1;
+      }
+      a.rev[e] = found;
+      a.pid[e] = (j > i) ? pp[k + 1] - (rp[k + 1] - e) : pp[j - s + 1] - (rp[j - s + 1] - found);
+    }
+  }
+}
+// Launches: [graph_init_kernel (status, mol_ptr, row_ptr) unless `initialised`], mol_ptr_kernel (molecule extents + species check:
+// status bits 1 / 2), graph_mol_count_kernel, [a scan of the molecule totals when n_mol > MG_SUM_MAX], graph_mol_fill_kernel,
+// graph_guard_kernel.  scratch: 2 n_mol + n_mol / 1024 + 4 ints (any content).
+extern "C" int nnhip_graph_mol_dev(const float* pos, const float* cell, const int64_t* batch, const int64_t* z, int32_t n_atoms,
+                                   int32_t n_mol, int32_t capacity, float cutoff, int32_t* mol_ptr, int32_t* row_ptr,
+                                   int32_t* pair_ptr, int32_t* status, int32_t* scratch, int32_t initialised,
+                                   int32_t* tail_host, const int32_t* changes, int32_t seq, int32_t* col,
+                                   int32_t* rev, int32_t* pid, float* disp, float* geo, int32_t* xg, void* stream_) {
+  if (n_atoms < 1 || n_mol < 1 || capacity < 2 || !batch || !mol_ptr || !row_ptr || !pair_ptr || !status || !scratch || !col ||
+      !rev || !pid || !disp || !geo || !xg) {
+    nnhip_set_error("nnhip_graph_mol_dev: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  ScopedTimer tm(TC_GRAPH, stream);
+  if (!initialised) {
+    const int n_init = (n_mol > n_atoms ? n_mol : n_atoms) + 1;
+    graph_init_kernel<<<cdiv(n_init, 256), 256, 0, stream>>>(status, mol_ptr, n_mol + 1, row_ptr, n_atoms + 1);
+    LAUNCH_CHECK();
+  }
+  mol_ptr_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(batch, n_atoms, n_mol, mol_ptr, status, z);
+  LAUNCH_CHECK();
+  int* mol_edges = scratch;
+  int* mol_base = n_mol > MG_SUM_MAX ? scratch + n_mol + 1 : nullptr;
+  MolGraphArgs a = {pos, cell, mol_ptr, n_atoms, n_mol, capacity, cutoff, cut2_of(cutoff), row_ptr, pair_ptr, status, mol_edges,
+                    mol_base, col, rev, pid, disp, geo, reinterpret_cast<int2*>(xg)};
+  graph_mol_count_kernel<<<n_mol, MG_THREADS, 0, stream>>>(a);
+  LAUNCH_CHECK();
+  if (mol_base) {
+    const int rc = launch_scan(mol_edges, n_mol, mol_base, scratch + 2 * n_mol + 2, stream);
+    if (rc) return rc;
+  }
+  graph_mol_fill_kernel<<<n_mol, MG_THREADS, 0, stream>>>(a);
+  LAUNCH_CHECK();
+  graph_guard_kernel<<<cdiv(n_atoms + 1, 256), 256, 0, stream>>>(row_ptr, pair_ptr, n_atoms, capacity, status, tail_host, changes, seq);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// edge_index [2][E] int64 (the reference's API array) from the CSR list, for callers that ask for it after the fact (the deferred
+// step does not write it: most evaluation steps never look at it): row 0 = the receiver of edge e (binary search in row_ptr),
+// row 1 = col[e].
+__global__ void __launch_bounds__(256)
+edge_index_kernel(const int* __restrict__ row_ptr, const int* __restrict__ col, int n_atoms, int n_edges, int64_t* __restrict__ out,
+                  const int* __restrict__ n_edges_dev) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_edges_dev) {   // the grid covers the capacity of `out`, the count is on the device (row 1 starts at the TRUE count)
+    const int cap = n_edges;
+    n_edges = *n_edges_dev;
+    if (n_edges > cap) return;
+  }
+  if (e >= n_edges) return;
+  int lo = 0, hi = n_atoms - 1;          // the last row with row_ptr[i] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (row_ptr[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  out[e] = lo;
+  out[(long)n_edges + e] = col[e];
+}
+extern "C" int nnhip_edge_index_from_csr(const int32_t* row_ptr, const int32_t* col, int32_t n_atoms, int32_t n_edges,
+                                         int64_t* edge_index, const int32_t* n_edges_dev, void* stream_) {
+  if (n_atoms < 0 || n_edges < 0 || (n_edges && (!row_ptr || !col || !edge_index || n_atoms < 1))) {
+    nnhip_set_error("nnhip_edge_index_from_csr: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  edge_index_kernel<<<cdiv(n_edges, 256), 256, 0, (hipStream_t)stream_>>>(row_ptr, col, n_atoms, n_edges, edge_index, n_edges_dev);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
 }
 
 // Radial-filter tables of one layer, nodes x_g = g / FT_G (row = g + 1; fp64 evaluation, one rounding per entry):

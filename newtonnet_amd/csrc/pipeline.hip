@@ -409,9 +409,24 @@ struct ParamTable {
 // UPDATE = false: compare only -- OR `bit` into *status when a word differs (the snapshot is left alone, so a change stays
 // visible until nnhip_prepare refills the block: a caller that fails between the check and the refill cannot lose it);
 // UPDATE = true: copy the parameters into the snapshot (the tail of nnhip_prepare).
+// The blocks of column blockIdx.x == t.n (when the grid has it) clear the neighbor list's status word, molecule extents and
+// row_ptr instead (graph.hip:graph_init_kernel's job, riding in this launch: the deferred step's one launch less).
+struct GraphInit {
+  int* status; int* mol_ptr; int n_mol1; int* row_ptr; int n_atoms1;
+};
 template <bool UPDATE>
-__global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit) {
+__global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit,
+                                                          GraphInit gi = GraphInit{nullptr, nullptr, 0, nullptr, 0}) {
   const int k = blockIdx.x;
+  if (k == t.n) {
+    const int n_init = gi.n_mol1 > gi.n_atoms1 ? gi.n_mol1 : gi.n_atoms1;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n_init; i += 256 * gridDim.y) {
+      if (i == 0) gi.status[0] = 0;
+      if (i < gi.n_mol1) gi.mol_ptr[i] = 0;
+      if (i < gi.n_atoms1) gi.row_ptr[i] = 0;
+    }
+    return;
+  }
   const int n = t.count[k];
   const int e0 = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (blockIdx.y * 1024 >= n) return;   // (block-uniform)
@@ -496,8 +511,14 @@ extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t pr
 // nnhip_prepare and goes up whenever a check finds a parameter that differs from the snapshot (it keeps going up until the block
 // is refilled).  No word of the caller has to be initialised for it -- the deferred step runs it first and lets its last
 // neighbor-list kernel hand the counter to the host with the edge count.  *counter_out receives the counter's device address.
+static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
+                                      void* stream_, const GraphInit& gi);
 extern "C" int nnhip_prepare_check_counter(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
                                            void* stream_) {
+  return prepare_check_counter_impl(model, prepared, prepared_bytes, counter_out, stream_, GraphInit{nullptr, nullptr, 0, nullptr, 0});
+}
+static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
+                                      void* stream_, const GraphInit& gi) {
   TRY(check_model(model, "nnhip_prepare_check_counter"));
   PrepLayout pq;
   make_prep_layout(model->n_layers, pq);
@@ -508,8 +529,8 @@ extern "C" int nnhip_prepare_check_counter(const nnhip_model* model, void* prepa
   ParamTable t;
   TRY(make_param_table(model, t));
   int* counter = reinterpret_cast<int*>((char*)prepared + pq.changes);
-  param_check_kernel<false><<<dim3(t.n, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
-      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), counter, 0);
+  param_check_kernel<false><<<dim3(t.n + (gi.status ? 1 : 0), PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), counter, 0, gi);
   LAUNCH_CHECK();
   if (counter_out) *counter_out = counter;
   return NNHIP_OK;
@@ -937,6 +958,7 @@ extern "C" int nnhip_step_layout_of(int32_t N, int32_t B, int32_t cap, nnhip_ste
   out->pair_ptr = take((size_t)N + 1);
   out->pair_scan = take(n_scan);
   out->tail = take(2);
+  out->mol_scratch = take(2 * (size_t)B + (size_t)B / 1024 + 4);   // nnhip_graph_mol_dev: molecule totals (+ their scan)
   out->xg = take(2 * (size_t)cap);
   out->col = take(cap);
   out->rev = take(cap);
@@ -981,9 +1003,26 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
                               F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_,
                             (st->flags & 1) != 0);
   }
+  static const bool mol_graph_off = getenv("NNHIP_GRAPH_MOL") && atoi(getenv("NNHIP_GRAPH_MOL")) == 0;
+  const int32_t* changes = nullptr;
+  if ((st->flags & 1) && B >= 1 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX && !mol_graph_off) {
+    // a batch of small molecules: the list by one workgroup per molecule (graph.hip:graph_mol_*_kernel), five launches instead of nine
+    // (the parameter check's launch also clears status / mol_ptr / row_ptr)
+    TRY(prepare_check_counter_impl(model, st->prepared, st->prepared_bytes, &changes, stream_,
+                                   GraphInit{status, mol_ptr, B + 1, row_ptr, N + 1}));
+    TRY(nnhip_graph_mol_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, status,
+                            I + lay.mol_scratch, 1, st->tail_host, changes, st->seq, I + lay.col, I + lay.rev, I + lay.pid,
+                            F + lay.disp, F + lay.geo, I + lay.xg, stream_));
+    if (st->edge_index)
+      TRY(nnhip_edge_index_from_csr(row_ptr, I + lay.col, N, cap, st->edge_index, row_ptr + N, stream_));   // (hip.py passes NULL and builds it on demand)
+    if (st->event) HIP_TRY(hipEventRecord((hipEvent_t)st->event, s));
+    return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
+                              I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
+                              st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
+                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_, true);
+  }
   TRY(nnhip_graph_count_pairs_z(st->pos, st->cell, st->batch, st->z, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr,
                                 I + lay.pair_scan, stream_));
-  const int32_t* changes = nullptr;
   TRY(nnhip_prepare_check_counter(model, st->prepared, st->prepared_bytes, &changes, stream_));
   TRY(nnhip_graph_finish_dev(st->pos, st->cell, st->batch, mol_ptr, row_ptr, pair_ptr, N, B, cap, model->cutoff, I + lay.col,
                              I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies, model->n_basis,

@@ -173,6 +173,7 @@ def lib():
                                       vp, vp, vp, vp, vp, vp, vp, vp]
     L.nnhip_energy_forces_pp.argtypes = L.nnhip_energy_forces.argtypes[:-1] + [vp, i32, vp]
     L.nnhip_energy_forces_pp.restype = C.c_int
+    L.nnhip_edge_index_from_csr.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.nnhip_prepared_bytes.argtypes = [i32]
     L.nnhip_prepared_bytes.restype = sz
     L.nnhip_prepare.argtypes = [C.POINTER(Model), vp, sz, vp]
@@ -267,7 +268,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_pair_scan', 'nnhip_graph_finish', 'nnhip_graph_finish_early', 'nnhip_edge_refresh', 'nnhip_graph_count_cells_pairs',
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
-                    'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter')
+                    'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter', 'nnhip_graph_mol_dev',
+                    'nnhip_edge_index_from_csr')
 
 
 def _check(rc: int, what: str):
@@ -519,7 +521,7 @@ def refresh_graph(g: Graph, pos: torch.Tensor, cell: torch.Tensor, batch: torch.
 class StepLayout(C.Structure):
     """nnhip_step_layout."""
     _fields_ = [(n, C.c_size_t) for n in ('i32_count', 'f32_count', 'mol_ptr', 'row_ptr', 'status', 'pair_ptr', 'pair_scan',
-                                          'tail', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
+                                          'tail', 'mol_scratch', 'xg', 'col', 'rev', 'pid', 'geo', 'disp', 'energy', 'forces', 'virial',
                                           'atom_energy')]
 
 
@@ -579,6 +581,13 @@ class DevStep:
 
     @property
     def edge_index(self):
+        # RadiusGraph's [2][E] array, made when a caller asks for it (most evaluation steps never do): receiver = the row of the
+        # edge, sender = col (nnhip_edge_index_from_csr)
+        if self.ei is None:
+            E, lay = self.n_edges, self.lay
+            self.ei = torch.empty(2 * E, dtype=torch.int64, device=self.i32.device)
+            _check(lib().nnhip_edge_index_from_csr(_ptr(self.i32[lay.row_ptr:]), _ptr(self.i32[lay.col:]), self.N, E, _ptr(self.ei),
+                                                   None, _stream(self.i32.device)), 'nnhip_edge_index_from_csr')
         E = self.n_edges
         return self.ei[:2 * E].view(2, E)
 
@@ -588,7 +597,7 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
                 small_molecules: bool = False) -> DevStep:
     """The whole deferred step in one C call (nnhip_forward_dev): neighbor list into arrays of `cap` edges, the (count, status)
     words stored into the pinned slot `tail_host_ptr` by the last neighbor-list kernel, `seq` behind them; energy / forces pipeline.
-    Four allocations per step (two arenas, edge_index, the node states)."""
+    Four allocations per step (two arenas, the two node states); `edge_index` is made on demand (DevStep.edge_index)."""
     L = lib()
     dev = pos.device
     N, B = pos.shape[0], cell.shape[0]
@@ -598,7 +607,7 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     st.want_forces, st.want_virial = want_forces, want_virial
     st.i32 = torch.empty(lay.i32_count, dtype=torch.int32, device=dev)
     st.f32 = torch.empty(lay.f32_count, dtype=torch.float32, device=dev)
-    st.ei = torch.empty(2 * cap, dtype=torch.int64, device=dev)
+    st.ei = None
     st.atom_node = torch.empty(N, NNHIP_F, dtype=torch.float32, device=dev)
     st.force_node = torch.empty(N, 3, NNHIP_F, dtype=torch.float32, device=dev)
     need = L.nnhip_workspace_bytes(N, cap, B, model.n_layers)
@@ -608,7 +617,7 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     a = StepDev()
     a.z, a.pos, a.cell, a.batch = z.data_ptr(), pos.data_ptr(), cell.data_ptr(), batch.data_ptr()
     a.n_atoms, a.n_mol, a.capacity, a.want_forces, a.want_virial = N, B, cap, int(want_forces), int(want_virial)
-    a.i32, a.f32, a.edge_index = st.i32.data_ptr(), st.f32.data_ptr(), st.ei.data_ptr()
+    a.i32, a.f32, a.edge_index = st.i32.data_ptr(), st.f32.data_ptr(), None
     a.atom_node, a.force_node = st.atom_node.data_ptr(), st.force_node.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel()
     a.prepared, a.prepared_bytes = prepared.data_ptr(), prepared.numel()

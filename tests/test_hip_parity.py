@@ -259,7 +259,12 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
         for k, n in enumerate(sizes):
             p = base + 0.05 * torch.randn(21, 3, generator=gen)
             zz = zb
-            if n > 21:      # aspirin + the first atoms of a second copy 3.2 A away
+            if n > 42:      # a jittered lattice cluster (the per-molecule list kernel serves up to 1024 atoms)
+                m = int(round(n ** (1.0 / 3.0))) + 1
+                grid = torch.stack(torch.meshgrid(*[torch.arange(m)] * 3, indexing='ij'), dim=-1).reshape(-1, 3)[:n].float()
+                p = 2.2 * grid + 0.25 * torch.randn(n, 3, generator=gen)
+                zz = zb[torch.randint(0, 21, (n,), generator=gen)]
+            elif n > 21:    # aspirin + the first atoms of a second copy 3.2 A away
                 p = torch.cat([p, p[:n - 21] + torch.tensor([3.2, 0.0, 0.0])])
                 zz = torch.cat([zb, zb[:n - 21]])
             elif n < 21:
@@ -277,11 +282,13 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
 
     small = [21] * 100                       # 2100 atoms: above the small-batch threshold of the edge kernels
     mixed = [30, 12] + [21] * 98             # the same 2100 atoms in 100 molecules, one of them too large to stage
+    huge = [10] * 40 + [1100] + [10] * 58 + [20]   # ... one of them too large for the per-molecule neighbor-list kernel
     sync_calls = []
     inner = model._forward_sync
     model._forward_sync = lambda *args, **kw: (sync_calls.append(1), inner(*args, **kw))[1]
-    expected_sync = [1, 0, 1, 0, 0, 1, 0]    # first call; guess right; wrong guess -> repeated; right; right; wrong again; right
-    for step, sizes in enumerate([small, small, mixed, mixed, mixed, small, small]):
+    # first call; guess right; wrong guess -> repeated; right; right; wrong again; right; wrong (list not built) -> repeated; right
+    expected_sync = [1, 0, 1, 0, 0, 1, 0, 1, 0]
+    for step, sizes in enumerate([small, small, mixed, mixed, mixed, small, small, huge, huge]):
         args = batch_of(sizes)
         want = fresh_result(args)
         before = len(sync_calls)

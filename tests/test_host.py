@@ -71,6 +71,7 @@ def test_deferred_step_structs_mirror_the_header():
     lay = hip.step_layout(N, B, cap)
     n_scan = (N + 1023) // 1024 + 1
     ints = [(lay.mol_ptr, B + 1), (lay.row_ptr, N + 1 + 1 + n_scan), (lay.pair_ptr, N + 1), (lay.pair_scan, n_scan), (lay.tail, 2),
+            (lay.mol_scratch, 2 * B + B // 1024 + 4),
             (lay.xg, 2 * cap), (lay.col, cap), (lay.rev, cap), (lay.pid, cap)]
     flts = [(lay.geo, 4 * cap), (lay.disp, 3 * cap), (lay.energy, B), (lay.forces, 3 * N), (lay.virial, 9 * B), (lay.atom_energy, N)]
     assert lay.status == lay.row_ptr + N + 1                     # (count, status) adjacent: one 8-byte copy
