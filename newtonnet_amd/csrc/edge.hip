@@ -431,6 +431,88 @@ msg_bwd_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restri
   }
 }
 
+// msg_bwd for batches of small molecules: one workgroup per molecule, the molecule's m and g_a rows staged in LDS once (the
+// same idea as force_fwd_mol_kernel: the sender-row gathers m[j], g_a[j] are 1 KB of the 3.5 KB a directed edge pulls through the
+// vector memory path).  Per-row arithmetic of msg_bwd_kernel<NEED_GM, 1>.
+template <bool NEED_GM>
+__global__ void __launch_bounds__(64 * FM_WAVES)
+msg_bwd_mol_kernel(const float* __restrict__ g_msg /*[P][F]*/, const float* __restrict__ g_a, const float* __restrict__ m,
+                   const int2* __restrict__ xg, const float* __restrict__ table, const int* __restrict__ mol_ptr,
+                   const int* __restrict__ row_ptr, const int* __restrict__ col, const int* __restrict__ pid,
+                   float* __restrict__ g_m, float* __restrict__ g_x, int n_mol, const int* __restrict__ pair_ptr) {
+  __shared__ __attribute__((aligned(16))) float ml[NNHIP_MOL_STAGE_MAX * NF];
+  __shared__ __attribute__((aligned(16))) float gl[NNHIP_MOL_STAGE_MAX * NF];
+  const int b = xcd_tile(blockIdx.x, gridDim.x);
+  if (b >= n_mol) return;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
+  const bool staged = n <= NNHIP_MOL_STAGE_MAX;
+  if (staged) {
+    const float4* sm = reinterpret_cast<const float4*>(m + (size_t)a0 * NF);
+    const float4* sg = reinterpret_cast<const float4*>(g_a + (size_t)a0 * NF);
+    for (int t = threadIdx.x; t < n * (NF / 4); t += 64 * FM_WAVES) {
+      reinterpret_cast<float4*>(ml)[t] = sm[t];
+      reinterpret_cast<float4*>(gl)[t] = sg[t];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c4 = 4 * (lane & 31);
+  const bool hi = lane >= 32;
+  auto node = [&](const float* lds, const float* glob, int j) {
+    return staged ? *reinterpret_cast<const float4*>(lds + (j - a0) * NF + c4) : ld4(glob + (size_t)j * NF + c4);
+  };
+  for (int i = a0 + wave; i < a0 + n; i += FM_WAVES) {
+    const float4 mi = node(ml, m, i), gai = node(gl, g_a, i);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = row_ptr[i], end = row_ptr[i + 1];
+    const int mid = row_mid_of(pair_ptr, col, beg, end, i, lane, true);
+    for (int e = beg + lane; e < mid; e += 64) g_x[e] = 0.f;   // the pair's owner carries all of g_x
+    if (NEED_GM) {
+      for (int e = beg; e < mid; e += 2) {     // pairs owned by the other endpoint -- value table only
+        const int e1 = min(e + 1, mid - 1);
+        const int j0 = col[e], j1 = col[e1];
+        const int p0 = pid[e], p1 = pid[e1];
+        const int2 gx0 = xg[e], gx1 = xg[e1];
+        const int j = hi ? j1 : j0;
+        const size_t p = (size_t)(hi ? p1 : p0);
+        const int2 gx = hi ? gx1 : gx0;
+        if (!hi || e + 1 < mid) {
+          const float4 mj = node(ml, m, j), gaj = node(gl, g_a, j);
+          const float4 G = add4(add4(ld4p<EDGE_NT_GMSG != 0>(g_msg + p * NF + c4), gai), gaj);
+          const FilterW fw = filter_weights(__int_as_float(gx.y));
+          const float4 eps = filter_value(table, gx.x, c4, fw);
+          acc = fma4(mul4(G, eps), mj, acc);
+        }
+      }
+    }
+    for (int e = mid; e < end; e += 2) {       // pairs this row owns -- value and derivative, g_x
+      const int e1 = min(e + 1, end - 1);
+      const int j0 = col[e], j1 = col[e1];
+      const int p0 = pid[e], p1 = pid[e1];
+      const int2 gx0 = xg[e], gx1 = xg[e1];
+      const int j = hi ? j1 : j0;
+      const size_t p = (size_t)(hi ? p1 : p0);
+      const int2 gx = hi ? gx1 : gx0;
+      const int eh = hi ? e1 : e;
+      if (!hi || e + 1 < end) {
+        const float4 mj = node(ml, m, j), gaj = node(gl, g_a, j);
+        const float4 G = add4(add4(ld4(g_msg + p * NF + c4), gai), gaj);
+        const FilterW fw = filter_weights(__int_as_float(gx.y));
+        float4 eps, deps;
+        filter_value_deriv(table, gx.x, c4, fw, eps, deps);
+        const float gxs = half_sum_top(dot4(mul4(mul4(G, mi), mj), deps));
+        if ((lane & 31) == 31) g_x[eh] = gxs;
+        if (NEED_GM) acc = fma4(mul4(G, eps), mj, acc);
+      }
+    }
+    if (NEED_GM) {
+      acc = add4(acc, upper_half(acc));
+      if (!hi) st4(g_m + (size_t)i * NF + c4, acc);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // geometry adjoint -> forces (and virial).  For edge e = (i,j) with disp d = pos_i - pos_j, r = |d|, u = d/r,
 // x = r/rc:   g_d[e] = (g_x/rc) u + (g_u - (g_u.u) u)/r,  summed over layers.  pos_i enters row i's edges
@@ -806,9 +888,21 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
 
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms,
-                   bool need_gm, hipStream_t s, const int* pair_ptr) {
+                   bool need_gm, hipStream_t s, const int* pair_ptr, const int* mol_ptr, int n_mol) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
+  // batches of small molecules (see launch_force_fwd); NNHIP_MSG_BWD_MOL=0: never
+  static const bool mol_off = getenv("NNHIP_MSG_BWD_MOL") && atoi(getenv("NNHIP_MSG_BWD_MOL")) == 0;
+  if (mol_ptr && pair_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off && !edge_small(n_atoms)) {
+    if (need_gm)
+      msg_bwd_mol_kernel<true><<<n_mol, 64 * FM_WAVES, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, mol_ptr, row_ptr,
+                                                              col, pid, g_m, g_x, n_mol, pair_ptr);
+    else
+      msg_bwd_mol_kernel<false><<<n_mol, 64 * FM_WAVES, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, mol_ptr, row_ptr,
+                                                               col, pid, g_m, g_x, n_mol, pair_ptr);
+    LAUNCH_CHECK();
+    return 0;
+  }
   if (need_gm)
     EDGE_LAUNCH_B(msg_bwd_kernel, true, EDGE_WPR_MSG_BWD, g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, row_ptr, col, pid, g_m, g_x, n_atoms, pair_ptr);
   else

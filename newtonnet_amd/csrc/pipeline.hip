@@ -27,7 +27,7 @@ int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float
                      float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr = nullptr);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm,
-                   hipStream_t s, const int* pair_ptr = nullptr);
+                   hipStream_t s, const int* pair_ptr = nullptr, const int* mol_ptr = nullptr, int n_mol = 0);
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
@@ -851,7 +851,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     }
     // message adjoint -> g_m, g_x
     TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, P(w.g_m),
-                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s, pair_ptr));
+                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s, pair_ptr, mol_kernels ? mol_ptr : nullptr, B));
     // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
     // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
     // message_nodepart input is the embedding of z, which does not depend on the positions.
