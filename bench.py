@@ -334,9 +334,10 @@ def pmc_traffic(kernels):
                  + (f' [{notes[0]}]' if notes else ' [round-1 tree]'))
 
 
-EDGE_KERNELS = ('msg_fwd_kernel', 'force_fwd_kernel', 'force_bwd_kernel', 'msg_bwd_kernel')
-ROCPROF_CLASSES = {'edge_msg_fwd': ('msg_fwd_kernel',), 'edge_force_fwd': ('force_fwd_kernel',),
-                   'edge_force_bwd': ('force_bwd_kernel',), 'edge_msg_bwd': ('msg_bwd_kernel',),
+# (the *_mol_kernel forms -- one workgroup per molecule, node rows staged in LDS -- serve batches of small molecules: edge.hip)
+EDGE_KERNELS = ('msg_fwd_kernel', 'force_fwd_kernel', 'force_fwd_mol_kernel', 'force_bwd_kernel', 'msg_bwd_kernel', 'msg_bwd_mol_kernel')
+ROCPROF_CLASSES = {'edge_msg_fwd': ('msg_fwd_kernel',), 'edge_force_fwd': ('force_fwd_kernel', 'force_fwd_mol_kernel'),
+                   'edge_force_bwd': ('force_bwd_kernel',), 'edge_msg_bwd': ('msg_bwd_kernel', 'msg_bwd_mol_kernel'),
                    'mlp128': ('mlp128s_kernel', 'mlp128_kernel', 'mlp_regw_kernel'),
                    'node': ('node_fwd_split_kernel', 'node_bwd_split_kernel', 'node_fwd_kernel', 'node_bwd_kernel')}
 
@@ -748,6 +749,7 @@ def main():
                                        'step; rows keyed on kernel name and grid)')
                 hbm['counter_bytes_per_step'] = round(step_bytes)
                 hbm['traffic_per_instantiation'] = {k: round(b) for k, (n, b) in t.items()}
+                hbm['launches_per_instantiation'] = {k: round(n / steps_seen, 2) for k, (n, b) in t.items()}
                 cnt_gbs = step_bytes / (edge_ms * 1e-3) / 1e9
                 hbm['achieved_counter_bytes'] = round(cnt_gbs, 1)
                 hbm['frac_vs_counter_bytes'] = round(cnt_gbs / HBM_PEAK_GBS, 4)
@@ -775,25 +777,25 @@ def main():
         # step, `roofline_secondary` the next one; candidates: mlp128s_kernel, mlp_regw_kernel and each of the four edge kernels
         # (an object of its own, built from its row of per_kernel and its counter traffic).  The aggregate over the four edge
         # kernels stays in the line as `roofline_edge_kernels`.
-        edge_names = {'edge_msg_fwd': 'msg_fwd_kernel', 'edge_force_fwd': 'force_fwd_kernel', 'edge_force_bwd': 'force_bwd_kernel',
-                      'edge_msg_bwd': 'msg_bwd_kernel'}
+        edge_names = {cls: ROCPROF_CLASSES[cls] for cls in ('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd')}
 
         def edge_object(cls):
-            pk, name = per_kernel[cls], edge_names[cls]
+            pk, names = per_kernel[cls], edge_names[cls]
+            name = names[0]
             n = max(classes[cls]['launches_per_step'], 1)
             ms = classes[cls]['ms_per_step']
             gbs = pk['algorithmic_bytes_per_step'] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             o = {'bound': 'hbm', 'kernel': f'{name} (one wave per receiver row, two edges per instruction; every launch of a step, '
-                                           'first layer included)',
+                                           'first layer included' + (f'; with {names[1]} for batches of small molecules' if len(names) > 1 else '') + ')',
                  'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
                  'launches_per_step': n, 'avg_launch_us': round(1e3 * ms / n, 2),
                  'algorithmic_bytes_per_launch': round(pk['algorithmic_bytes_per_step'] / n), 'ms_per_step': round(ms, 4),
                  'algorithmic_note': 'bytes the pair-once layout must move (bench.py:edge_kernel_bytes; DESIGN.md section 4)'}
             tpi = hbm.get('traffic_per_instantiation')
             if tpi:
-                rows = [(k, b) for k, b in tpi.items() if _kernel_match(k, name)]
-                if rows:   # (instantiation <true> runs in layers 1-2, <false> in layer 0; msg_fwd has one form, three launches)
-                    w = {k: (1.0 if '<false' in k else 2.0 if '<true' in k else 3.0) for k, _ in rows}
+                rows = [(k, b) for k, b in tpi.items() if any(_kernel_match(k, nm) for nm in names)]
+                if rows:   # (weighted by the launches per step of each instantiation: layer 0 runs its own forms)
+                    w = {k: max(hbm['launches_per_instantiation'].get(k, 1.0), 1e-9) for k, _ in rows}
                     o['traffic'] = round(sum(w[k] * b for k, b in rows) / sum(w.values()))
                     o['traffic_source'] = hbm.get('traffic_source')
                     cg = o['traffic'] * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
