@@ -841,6 +841,14 @@ static inline size_t edge_lds() {
   return v;
 }
 
+// The molecule-resident kernels (force_fwd_mol_kernel, msg_bwd_mol_kernel: one 8-wave workgroup per molecule) need enough molecules
+// to fill the chip: same box, us per step with / without them -- 100 molecules 370 / 314, 256: 561 / 529, 384: 675 / 654,
+// 512: 845 / 842, 768: 1151 / 1169, 1024: 1535 / 1585 (profiles/r04_mol_kernels_crossover.txt).  NNHIP_MOL_KERNELS_MIN overrides.
+static bool mol_kernels_pay(int n_atoms, int n_mol) {
+  static const int min_mol = getenv("NNHIP_MOL_KERNELS_MIN") ? atoi(getenv("NNHIP_MOL_KERNELS_MIN")) : 640;
+  return n_mol >= min_mol && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX;
+}
+
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,
                    const int* pid, const float* a_in, float* msg, float* a_mid, int n_atoms, hipStream_t s) {
   ScopedTimer t0(TC_EDGE, s);
@@ -857,7 +865,7 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
   ScopedTimer t1(TC_EDGE_FWD_FORCE, s);
   // batches of small molecules (the caller passes mol_ptr only when it may: see force_fwd_mol_kernel); NNHIP_FORCE_FWD_MOL=0: never
   static const bool mol_off = getenv("NNHIP_FORCE_FWD_MOL") && atoi(getenv("NNHIP_FORCE_FWD_MOL")) == 0;
-  if (has_f && mol_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off && !edge_small(n_atoms)) {
+  if (has_f && mol_ptr && mol_kernels_pay(n_atoms, n_mol) && !mol_off) {
     // (eight waves: 4 workgroups x 36 KB of LDS = the CU's 32 wave slots; 7 waves -- no idle slot in the last round of a 21-atom
     // molecule -- 0.198 against 0.159 ms per step, 16 waves 0.173: profiles/r04_force_fwd_mol_waves_ab.txt)
     force_fwd_mol_kernel<<<n_mol, 64 * FM_WAVES, 0, s>>>(phi1, phi2, geo, mol_ptr, row_ptr, col, pid, f_in, f_out, n_mol,
@@ -893,7 +901,7 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   ScopedTimer t1(TC_EDGE_BWD_MSG, s);
   // batches of small molecules (see launch_force_fwd); NNHIP_MSG_BWD_MOL=0: never
   static const bool mol_off = getenv("NNHIP_MSG_BWD_MOL") && atoi(getenv("NNHIP_MSG_BWD_MOL")) == 0;
-  if (mol_ptr && pair_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off && !edge_small(n_atoms)) {
+  if (mol_ptr && pair_ptr && mol_kernels_pay(n_atoms, n_mol) && !mol_off) {
     if (need_gm)
       msg_bwd_mol_kernel<true><<<n_mol, 64 * FM_WAVES, 0, s>>>(g_msg, g_a, m, reinterpret_cast<const int2*>(xg), table, mol_ptr, row_ptr,
                                                               col, pid, g_m, g_x, n_mol, pair_ptr);
@@ -962,11 +970,12 @@ int launch_embed(const int64_t* z, const float* table, const float* m_table, int
 
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
-                    float* energy, hipStream_t s) {
+                    float* energy, hipStream_t s, bool small_molecules) {
   ScopedTimer t0(TC_OTHER, s);
   head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, act, atom_energy, g_e2);
   LAUNCH_CHECK();
-  const bool big = n_atoms > MOL_SPLIT && n_mol <= 4096;   // some molecule MAY be long (the host knows only the totals); few molecules: cheap
+  // some molecule MAY be long (the host knows only the totals, unless the count pass said so: small_molecules); few molecules: cheap
+  const bool big = n_atoms > MOL_SPLIT && n_mol <= 4096 && !small_molecules;
   mol_energy_kernel<<<cdiv(n_mol, ROWS_PER_BLOCK), 256, 0, s>>>(atom_energy, mol_ptr, n_mol, energy, big ? MOL_SPLIT : 0x7fffffff);
   LAUNCH_CHECK();
   if (big) {

@@ -40,7 +40,7 @@ int launch_embed(const int64_t* z, const float* table, const float* m_table, int
                  hipStream_t s);
 int launch_head_out(const float* e2, const float* w4, const float* b4, const float* scale, const float* shift,
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
-                    float* energy, hipStream_t s);
+                    float* energy, hipStream_t s, bool small_molecules = false);
 int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
 
 // ---- errors ------------------------------------------------------------------------------------------
@@ -778,7 +778,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
                                      model->head0_b, model->head2_b, act}, s));
   float* atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
   TRY(launch_head_out(P(w.pub.e2), model->head4_w, model->head4_b, model->scale, model->shift, z, mol_ptr, N, B,
-                      act, atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s));
+                      act, atom_energy, want_forces ? P(w.g_e) : nullptr, energy, s, mol_kernels));
   if (!want_forces) return NNHIP_OK;
 
   // ------------------------------------------------------------------ reverse sweep

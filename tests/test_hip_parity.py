@@ -280,9 +280,10 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
         o = m(*args)
         return o.energy.clone(), o.gradient_force.clone(), o.edge_index.clone(), o.force_node.clone()
 
-    small = [21] * 100                       # 2100 atoms: above the small-batch threshold of the edge kernels
-    mixed = [30, 12] + [21] * 98             # the same 2100 atoms in 100 molecules, one of them too large to stage
-    huge = [10] * 40 + [1100] + [10] * 58 + [20]   # ... one of them too large for the per-molecule neighbor-list kernel
+    small = [21] * 700                       # 14 700 atoms in 700 molecules: enough of them for the molecule-resident edge kernels
+    mixed = [30, 12] + [21] * 698            # the same atoms and molecules, one of them too large to stage
+    huge = [20] * 200 + [1100] + [20] * 119 + [19] * 380   # ... one of them too large for the per-molecule neighbor-list kernel
+    assert sum(mixed) == sum(huge) == sum(small) and len(mixed) == len(huge) == len(small)
     sync_calls = []
     inner = model._forward_sync
     model._forward_sync = lambda *args, **kw: (sync_calls.append(1), inner(*args, **kw))[1]
@@ -299,7 +300,7 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
         assert len(sync_calls) - before == expected_sync[step], f'step {step}: {len(sync_calls) - before} synchronous passes'
         if sizes is small and step == 1:     # the molecule form against the oracle
             z, pos, cell, batch = (t.cpu() for t in args)
-            pick = [0, 37, 99]
+            pick = [0, 37, 699]
             rows = torch.cat([torch.arange(21 * k, 21 * k + 21) for k in pick])
             o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z[rows], pos[rows].double(),
                                   torch.zeros(3, 3, 3, dtype=torch.float64), torch.repeat_interleave(torch.arange(3), 21))
