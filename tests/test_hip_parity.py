@@ -309,6 +309,48 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
             assert np.all(np.abs(out.energy.cpu().double().numpy()[pick] - e_ref) <= util.energy_tol(e_ref))
 
 
+def test_many_tiny_molecules_through_the_per_molecule_kernels():
+    """9000 molecules of 2-4 atoms (more than MG_SUM_MAX = 8192, so the per-molecule neighbor list scans its molecule totals in a
+    launch of its own; empty-neighborhood rows and two-atom molecules included): the deferred step -- per-molecule list kernels and
+    molecule-resident edge kernels -- must return bit for bit what the synchronous path of a fresh module returns, and its list must
+    be the oracle's."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    gen = torch.Generator().manual_seed(3)
+    B = 9000
+    sizes = torch.randint(2, 5, (B,), generator=gen)
+    N = int(sizes.sum())
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    start = torch.cumsum(sizes, 0) - sizes
+    local = torch.arange(N) - start[batch]
+    # a zig-zag chain 1.1 A apart, every tenth molecule stretched beyond the cutoff (rows without neighbors)
+    stretch = torch.where(torch.arange(B) % 10 == 9, 7.0, 1.0)[batch]
+    pos = torch.stack([1.1 * local * stretch, 0.4 * (local % 2).float(), torch.zeros(N)], dim=1) + 0.05 * torch.randn(N, 3, generator=gen)
+    pos = pos + 50.0 * torch.rand(B, 3, generator=gen)[batch]
+    z = torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (N,), generator=gen)]
+    args = (z.cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'), batch.cuda())
+    model, sd = make_model('ckpt')
+    first = model(*args)                                   # synchronous: learns the capacity and "small molecules"
+    want = (first.energy.clone(), first.gradient_force.clone(), first.edge_index.clone())
+    out = model(*args)                                     # deferred
+    rec = model.__dict__.get('_last_deferred')
+    assert rec is not None and rec.small_molecules
+    assert torch.equal(out.energy, want[0]) and torch.equal(out.gradient_force, want[1]) and torch.equal(out.edge_index, want[2])
+    pick = torch.arange(0, 300)
+    rows = torch.nonzero(batch < 300).flatten()
+    o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z[rows], pos[rows].double(),
+                          torch.zeros(300, 3, 3, dtype=torch.float64), batch[rows])
+    e_first = int((out.edge_index[0] < len(rows)).sum())
+    ei_ref, _ = ref.radius_graph(pos[rows], None, batch[rows], 5.0)             # fp32, as the model dtype
+    assert torch.equal(out.edge_index[:, :e_first].cpu(), ei_ref)
+    f_ref = o['forces'].numpy()
+    fscale = max(1.0, float(np.abs(f_ref).max()) / 5.0)     # (fragments 1.1 A apart: forces far above MD17's; as test_golden_case)
+    print(f'tiny molecules: max |F| {np.abs(f_ref).max():.1f} eV/A, tolerance scale {fscale:.1f}')
+    check_forces(out.gradient_force.cpu().numpy()[rows.numpy()], f_ref, fscale)
+    e_ref = o['energy'].numpy()
+    assert np.all(np.abs(out.energy.cpu().double().numpy()[pick.numpy()] - e_ref) <= util.energy_tol(e_ref))
+
+
 def test_single_launch_neighbor_list_up_to_its_limit():
     """The deferred step sends systems of up to nnhip_graph_small_max_atoms() (default 128) atoms through the single-launch
     neighbor list (graph.hip:graph_small_kernel); the kernel itself serves up to 1024.  Run the golden cases and the random
