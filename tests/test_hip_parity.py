@@ -351,6 +351,46 @@ def test_many_tiny_molecules_through_the_per_molecule_kernels():
     assert np.all(np.abs(out.energy.cpu().double().numpy()[pick.numpy()] - e_ref) <= util.energy_tol(e_ref))
 
 
+def test_periodic_batch_with_empty_molecule_slots_through_the_per_molecule_list():
+    """60 molecule slots, every seventh without atoms, the others 8 atoms in their own periodic box (orthorhombic or sheared): the
+    deferred step builds the list with a workgroup per molecule slot (graph_mol_*_kernel).  Same list as the oracle's, same numbers as
+    the synchronous path of a fresh module, bit for bit.  Reference: representations.py:57-100 on a batch with cells."""
+    from newtonnet_amd.models import NewtonNet
+    from oracle import newtonnet_ref as ref
+    gen = torch.Generator().manual_seed(21)
+    B = 60
+    zs, ps, bs = [], [], []
+    cell = torch.zeros(B, 3, 3)
+    grid = torch.stack(torch.meshgrid(*[torch.arange(2)] * 3, indexing='ij'), dim=-1).reshape(-1, 3).float()
+    for b in range(B):
+        cell[b] = 6.0 * torch.eye(3)
+        if b % 3 == 1:
+            cell[b, 1, 0] = 1.5          # sheared
+        if b % 7 == 3:
+            continue                     # an empty slot
+        ps.append(3.0 * grid + 0.4 * torch.randn(8, 3, generator=gen) + 0.7)
+        zs.append(torch.tensor([1, 6, 7, 8])[torch.randint(0, 4, (8,), generator=gen)])
+        bs.append(torch.full((8,), b))
+    z, pos, batch = torch.cat(zs), torch.cat(ps), torch.cat(bs)
+    assert pos.shape[0] > 128            # (beyond the single-launch list of small systems)
+    args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    model, sd = make_model('rand')
+    first = model(*args)
+    want = (first.energy.clone(), first.gradient_force.clone(), first.edge_index.clone())
+    out = model(*args)
+    rec = model.__dict__.get('_last_deferred')
+    assert rec is not None and rec.small_molecules
+    assert torch.equal(out.edge_index, want[2]) and torch.equal(out.energy, want[0]) and torch.equal(out.gradient_force, want[1])
+    ei_ref, _ = ref.radius_graph(pos, cell, batch, 5.0)
+    assert torch.equal(out.edge_index.cpu(), ei_ref)
+    o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    f_ref = o['forces'].numpy()
+    check_forces(out.gradient_force.cpu().numpy(), f_ref, max(1.0, float(np.abs(f_ref).max()) / 5.0))
+    e_ref = o['energy'].numpy()
+    assert np.all(np.abs(out.energy.cpu().double().numpy() - e_ref) <= util.energy_tol(e_ref))
+    assert torch.all(out.energy[torch.arange(B) % 7 == 3] == 0)
+
+
 def test_single_launch_neighbor_list_up_to_its_limit():
     """The deferred step sends systems of up to nnhip_graph_small_max_atoms() (default 128) atoms through the single-launch
     neighbor list (graph.hip:graph_small_kernel); the kernel itself serves up to 1024.  Run the golden cases and the random
