@@ -201,8 +201,11 @@ force_fwd_mol_kernel(const float* __restrict__ phi1, const float* __restrict__ p
       const int j = hi ? j1 : j0;
       const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask; see force_fwd_kernel)
       if ((!hi || e + 1 < end) && (hi ? gz1 : gz0) != FT_ZERO_ROW) {
-        const float4 v1 = ld4(phi1 + p * NF + c4);
-        const float4 v2 = ld4(phi2 + p * NF + c4);
+        // (the pair rows the other endpoint owns with the streaming hint, as the row form: step 1.491 -> 1.481 ms same box; the hint on
+        // EVERY pair row: this kernel 0.160 -> 0.182 ms per step -- profiles/r04_force_fwd_mol_nt_ab.txt)
+        const bool nt_ = j < i;
+        const float4 v1 = nt_ ? ld4_nt(phi1 + p * NF + c4) : ld4(phi1 + p * NF + c4);
+        const float4 v2 = nt_ ? ld4_nt(phi2 + p * NF + c4) : ld4(phi2 + p * NF + c4);
         acc[0] = fma4(v1, g.x, acc[0]);
         acc[1] = fma4(v1, g.y, acc[1]);
         acc[2] = fma4(v1, g.z, acc[2]);
