@@ -59,7 +59,7 @@ class _Deferred:
     instead of returning numbers for the wrong inputs."""
     QUEUED, WORDS, DONE = 0, 1, 2
     __slots__ = ('owner', 'inputs', 'zc', 'energy_idx', 'want_forces', 'want_virial', 'res', 'graph', 'tail', 'event', 'cap',
-                 'versions', 'state', 'error', 'reported', 'count', 'bad', 'small_molecules')
+                 'versions', 'state', 'error', 'reported', 'count', 'bad', 'small_molecules', 'param_stamp')
 
     def __init__(self, owner, inputs, zc, energy_idx, want_forces, want_virial):
         self.owner, self.inputs, self.zc, self.energy_idx = owner, inputs, zc, energy_idx
@@ -67,6 +67,7 @@ class _Deferred:
         self.res = self.graph = self.tail = self.event = self.versions = self.error = None
         self.cap = self.count = self.bad = 0
         self.small_molecules = True
+        self.param_stamp = None
         self.state, self.reported = _Deferred.QUEUED, False
 
     def read_words(self):
@@ -123,6 +124,14 @@ class _Deferred:
             z, pos, cell, batch = self.inputs
             with torch.no_grad():
                 model = owner._hip_model(self.energy_idx)
+                if self.param_stamp is not None and owner.__dict__.get('_param_stamp') != self.param_stamp:
+                    self.error = RuntimeError(
+                        'this forward call has to be repeated (its edge count exceeded the capacity taken from the previous call, or '
+                        'its guess about the molecule sizes was wrong), but a parameter of the module was modified in place before '
+                        'its outputs were read: read the outputs before updating the parameters, or call model.synchronize_checks() '
+                        'right after forward')
+                    self.state = _Deferred.DONE
+                    raise self.error
                 self.res, self.graph = owner._forward_sync(model, self.zc, pos, cell, batch, self.want_forces, self.want_virial)
         else:
             self.graph.n_edges, self.graph.status = self.count, self.bad
@@ -190,7 +199,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_param_stamp', '_param_epoch', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
             state.pop(k, None)
         return state
 
@@ -221,18 +230,28 @@ class NewtonNet(nn.Module):
                         break
                 if ok:
                     f32 = torch.float32
+                    vsum = 0
                     for (d, k), ptr in zip(c[3], c[4]):
                         t = d[k]
                         if t.data_ptr() != ptr or t.dtype is not f32 or not t.is_contiguous():
                             ok = False
                             break
+                        vsum += t._version
                     if ok:
+                        # (epoch of the cached struct, sum of the in-place version counters: what a deferred call that has to be
+                        # repeated compares, _Deferred.settle -- the parameter VALUES it ran on are gone once somebody wrote to them)
+                        self.__dict__['_param_stamp'] = (c[6], vsum)
                         return c[5]
         m = self._hip_model_build(energy_idx)
         try:
-            self.__dict__['_model_cache'] = self._model_cache_entry(energy_idx, m)
+            entry = self._model_cache_entry(energy_idx, m)
+            epoch = self.__dict__.get('_param_epoch', 0) + 1
+            self.__dict__['_param_epoch'] = epoch
+            self.__dict__['_model_cache'] = entry + (epoch,)
+            self.__dict__['_param_stamp'] = (epoch, sum(d[k]._version for d, k in entry[3]))
         except (KeyError, AttributeError):      # an unexpected module layout: no cache, the full walk serves every call
             self.__dict__.pop('_model_cache', None)
+            self.__dict__['_param_stamp'] = None
         return m
 
     def _model_cache_entry(self, energy_idx, m):
@@ -367,6 +386,7 @@ class NewtonNet(nn.Module):
             model = self._hip_model(energy_idx)
             zc = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
             rec = _Deferred(self, (z, pos, cell, batch), zc, energy_idx, want_forces, want_virial)
+            rec.param_stamp = self.__dict__.get('_param_stamp')
             if not self._forward_deferred(rec, model):
                 rec.res, rec.graph = self._forward_sync(model, zc, pos, cell, batch, want_forces, want_virial)
                 rec.state = _Deferred.DONE

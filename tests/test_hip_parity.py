@@ -159,6 +159,15 @@ def test_deferred_checks_errors_and_repeats():
     model(z, wide, cell, batch).energy
     late = model(z, p3, cell, batch)                         # untouched inputs: repeated, the right numbers
     assert same(late, ref_first)
+    # (d) ... and a repeat after a PARAMETER was modified in place: the values the call ran on are gone -- an error as well
+    model(z, wide, cell, batch).energy
+    model(z, wide, cell, batch).energy
+    late = model(z, pos, cell, batch)
+    with torch.no_grad():
+        next(model.parameters()).mul_(1.0 + 2.0 ** -7)
+    with pytest.raises(RuntimeError, match='parameter of the module was modified'):
+        late.energy
+    assert same(model(z, pos, cell, batch), fresh_copy()(z, pos, cell, batch))   # the module is fine afterwards (new parameters)
 
 
 def test_deferred_calls_random_stress():
@@ -185,11 +194,13 @@ def test_deferred_calls_random_stress():
         o = m(*args)
         return o.energy.clone(), o.gradient_force.clone(), o.edge_index.clone(), o.atom_node.clone()
 
-    pending = []          # (outputs, expectation or None for an invalid call, reads left to wait)
-    deferred = repeats = raised = 0
+    pending = []          # (outputs, expectation or None for an invalid call, reads left to wait, parameter epoch of the call)
+    deferred = repeats = raised = refused = epoch = 0
     for step in range(60):
         if step == 0 or rnd() < 0.25:      # (the capacity is remembered per atom count: sizes repeat in runs)
-            n_mol = int(torch.randint(1, 5, (1,), generator=gen)) * (16 if rnd() < 0.3 else 3)  # 3..12 or 16..64 molecules
+            # 3..12 or 16..64 molecules, now and then 340 or 680 (from 640 up: the molecule-resident edge kernels)
+            u = float(rnd())
+            n_mol = int(torch.randint(1, 5, (1,), generator=gen)) * (16 if u < 0.3 else 3) if u < 0.88 else (680 if u < 0.95 else 340)
         scale = float(0.9 + 0.9 * rnd())
         centre = base.mean(dim=0, keepdim=True)
         pos = torch.cat([centre + scale * (base - centre) + 0.05 * torch.randn(21, 3, generator=gen) + 30.0 * k
@@ -202,6 +213,7 @@ def test_deferred_calls_random_stress():
         batch = torch.repeat_interleave(torch.arange(n_mol), 21)
         cell = torch.zeros(n_mol, 3, 3)
         if rnd() < 0.15:
+            epoch += 1
             with torch.no_grad():
                 for q in model.parameters():
                     q.mul_(1.0 + 2.0 ** -9)
@@ -213,7 +225,7 @@ def test_deferred_calls_random_stress():
             # the error of an earlier invalid call nobody touched, or this call's own on the synchronous path
             raised += 1
             if 'PREVIOUS' in str(exc):
-                pending = [(o, w, d) for (o, w, d) in pending if w is not None]
+                pending = [p for p in pending if p[1] is not None]
                 out = model(*args) if not bad else None
                 if bad:
                     continue
@@ -222,21 +234,28 @@ def test_deferred_calls_random_stress():
                 continue
         rec = model.__dict__.get('_last_deferred')
         deferred += rec is not None and rec.state == rec.QUEUED
-        pending.append((out, want, int(torch.randint(0, 3, (1,), generator=gen)) if rnd() < 0.85 else 99))
+        pending.append((out, want, int(torch.randint(0, 3, (1,), generator=gen)) if rnd() < 0.85 else 99, epoch))
         keep = []
-        for o, w, d in pending:
+        for o, w, d, born in pending:
             if d > 0:
-                keep.append((o, w, d - 1))
+                keep.append((o, w, d - 1, born))
                 continue
             if w is None:
                 with pytest.raises(IndexError):
                     o.energy
                 raised += 1
                 continue
+            try:
+                o.energy
+            except RuntimeError as exc:
+                # a call that had to be repeated (capacity overflow) after the parameters it ran on were overwritten: refused
+                assert 'parameter of the module was modified' in str(exc) and epoch > born, step
+                refused += 1
+                continue
             assert torch.equal(o.edge_index, w[2]) and o.edge_index.is_contiguous(), step
             assert torch.equal(o.energy, w[0]) and torch.equal(o.gradient_force, w[1]) and torch.equal(o.atom_node, w[3]), step
         pending = [p for p in keep if p[2] < 50]      # (the 99s are never read)
-    print(f'deferred calls {deferred}, errors raised {raised}')
+    print(f'deferred calls {deferred}, errors raised {raised}, repeats refused after a parameter update {refused}')
     assert deferred >= 20 and raised >= 3
 
 
