@@ -934,11 +934,63 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
   return 0;
 }
 
+// force_direct_kernel for batches of small molecules: a workgroup per molecule forms g_d of each of the molecule's edges ONCE
+// into LDS (the row form evaluates it from both ends: every edge's per-layer g_x / g_u is read twice, the second time through
+// rev[]), then the same 16 lanes per atom add the same terms in the same order -- bit for bit the row form's forces.
+#define FD_MAX_EDGES (NNHIP_MOL_STAGE_MAX * (NNHIP_MOL_STAGE_MAX - 1))
+__global__ void __launch_bounds__(256)
+force_direct_mol_kernel(const float* __restrict__ g_x, const float* __restrict__ g_u, const float* __restrict__ geo,
+                        const int* __restrict__ mol_ptr, const int* __restrict__ row_ptr, const int* __restrict__ rev, int n_edges,
+                        int n_layers, float inv_rc, float* __restrict__ forces) {
+  __shared__ float4 sgd[FD_MAX_EDGES];
+  const int b = blockIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
+  const bool staged = n <= NNHIP_MOL_STAGE_MAX;
+  const int E0 = row_ptr[a0];
+  if (staged) {
+    const int nE = row_ptr[a0 + n] - E0;
+    for (int u = threadIdx.x; u < nE; u += 256) sgd[u] = gd_of_edge(g_x, g_u, geo, E0 + u, n_edges, n_layers, inv_rc);
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  for (int k0 = 0; k0 < n; k0 += 16) {
+    const int k = k0 + (threadIdx.x >> 4);
+    const int i = a0 + k;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (k < n) {
+      for (int e = row_ptr[i] + sub; e < row_ptr[i + 1]; e += 16) {
+        const float4 a = staged ? sgd[e - E0] : gd_of_edge(g_x, g_u, geo, e, n_edges, n_layers, inv_rc);
+        const float4 c = staged ? sgd[rev[e] - E0] : gd_of_edge(g_x, g_u, geo, rev[e], n_edges, n_layers, inv_rc);
+        fx -= (a.x - c.x);
+        fy -= (a.y - c.y);
+        fz -= (a.z - c.z);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      fx += __shfl_xor(fx, o, WAVE);
+      fy += __shfl_xor(fy, o, WAVE);
+      fz += __shfl_xor(fz, o, WAVE);
+    }
+    if (k < n && sub == 0) {
+      forces[3 * (size_t)i] = fx;
+      forces[3 * (size_t)i + 1] = fy;
+      forces[3 * (size_t)i + 2] = fz;
+    }
+  }
+}
+
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
-                        float* virial, hipStream_t s) {
+                        float* virial, hipStream_t s, bool small_molecules) {
   ScopedTimer t0(TC_OTHER, s);
+  static const bool mol_off = getenv("NNHIP_FORCE_DIRECT_MOL") && atoi(getenv("NNHIP_FORCE_DIRECT_MOL")) == 0;
+  if (!virial && small_molecules && mol_ptr && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off) {
+    force_direct_mol_kernel<<<n_mol, 256, 0, s>>>(g_x, g_u, geo, mol_ptr, row_ptr, rev, n_edges, n_layers, 1.0f / cutoff, forces);
+    LAUNCH_CHECK();
+    return 0;
+  }
   // (the one-launch form evaluates g_d twice per directed edge, once from each side: cheaper than a launch for molecular batches,
   // 1.6x dearer than the two launches on the 100k-atom box with its 54 neighbours per atom -- measured 441 vs ~280 us)
   if (!virial && n_edges <= (1 << 20)) {   // nobody reads g_d: one launch

@@ -31,7 +31,7 @@ int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const i
 int launch_geometry_bwd(const float* g_x, const float* g_u, const float* geo, const float* disp, const float* pos,
                         const float* cell, const int* row_ptr, const int* col, const int* rev, const int* mol_ptr,
                         int n_atoms, int n_edges, int n_mol, int n_layers, float cutoff, float* g_d, float* forces,
-                        float* virial, hipStream_t s);
+                        float* virial, hipStream_t s, bool small_molecules = false);
 int launch_layer_norm_fwd(float* a, const float* gamma, const float* beta, int n_atoms, float* xhat, float* rstd,
                           hipStream_t s);
 int launch_layer_norm_bwd(float* g_a, const float* gamma, const float* xhat, const float* rstd, int n_atoms,
@@ -889,7 +889,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     pp ^= 1;
   }
   TRY(launch_geometry_bwd(P(w.pub.g_x), P(w.pub.g_u), geo, disp, pos, cell, row_ptr, col, rev, mol_ptr, N, E, B, L,
-                          model->cutoff, P(w.g_d), forces, virial, s));
+                          model->cutoff, P(w.g_d), forces, virial, s, mol_kernels));
   return NNHIP_OK;
 }
 
