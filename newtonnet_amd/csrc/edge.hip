@@ -805,6 +805,42 @@ mol_energy_kernel(const float* __restrict__ atom_energy, const int* __restrict__
   if (lane == 0) energy[b] = (float)s;
 }
 
+// head_out_kernel + mol_energy_kernel in one launch for batches of small molecules: a workgroup per molecule, a wave per atom
+// (the same arithmetic per atom), then the molecule's first wave sums the atom energies its workgroup has just written -- the
+// same lane-strided fp64 partial sums and butterfly as mol_energy_kernel: bit for bit the same energies.
+#define HM_WAVES 8
+__global__ void __launch_bounds__(64 * HM_WAVES)
+head_out_mol_kernel(const float* __restrict__ e2, const float* __restrict__ w4, const float* __restrict__ b4,
+                    const float* __restrict__ scale, const float* __restrict__ shift, const int64_t* __restrict__ z,
+                    const int* __restrict__ mol_ptr, int act, float* atom_energy, float* __restrict__ g_e2,
+                    float* __restrict__ energy) {
+  const int b = blockIdx.x;
+  const int beg = mol_ptr[b], end = mol_ptr[b + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float2 w = ld2(w4 + 2 * lane);
+  const bool silu = act == NNHIP_ACT_SILU;   // uniform
+  for (int i = beg + wave; i < end; i += HM_WAVES) {
+    const float2 h = ld2(e2 + (size_t)i * NF + 2 * lane);
+    const float ax = silu ? silu_f(h.x) : act_f(h.x, act), ay = silu ? silu_f(h.y) : act_f(h.y, act);
+    const float s = wave_sum(fmaf(ax, w.x, ay * w.y));
+    const long zi = clamp_species(z[i]);
+    const float sc = scale ? scale[zi] : 1.0f;
+    const float sh = shift ? shift[zi] : 0.0f;
+    if (lane == 0) atom_energy[i] = fmaf(s + b4[0], sc, sh);
+    if (g_e2) {
+      const float dx = silu ? dsilu_f(h.x) : dact_f(h.x, act), dy = silu ? dsilu_f(h.y) : dact_f(h.y, act);
+      st2(g_e2 + (size_t)i * NF + 2 * lane, make_float2(sc * w.x * dx, sc * w.y * dy));
+    }
+  }
+  __syncthreads();     // (the atom energies of this molecule are written: same workgroup, lines nobody has read before)
+  if (wave == 0) {
+    double s = 0.0;
+    for (int i = beg + lane; i < end; i += 64) s += (double)atom_energy[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+    if (lane == 0) energy[b] = (float)s;
+  }
+}
+
 // out[m][n][k] = in[m][k][n] for a list of 128x128 matrices (weights for the adjoint GEMMs)
 struct TransposeList {
   const float* src[40];
@@ -1039,6 +1075,12 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s, bool small_molecules) {
   ScopedTimer t0(TC_OTHER, s);
+  static const bool mol_off = getenv("NNHIP_HEAD_OUT_MOL") && atoi(getenv("NNHIP_HEAD_OUT_MOL")) == 0;
+  if (small_molecules && n_mol > 0 && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && !mol_off) {
+    head_out_mol_kernel<<<n_mol, 64 * HM_WAVES, 0, s>>>(e2, w4, b4, scale, shift, z, mol_ptr, act, atom_energy, g_e2, energy);
+    LAUNCH_CHECK();
+    return 0;
+  }
   head_out_kernel<<<cdiv(n_atoms, ROWS_PER_BLOCK), 256, 0, s>>>(e2, w4, b4, scale, shift, z, n_atoms, act, atom_energy, g_e2);
   LAUNCH_CHECK();
   // some molecule MAY be long (the host knows only the totals, unless the count pass said so: small_molecules); few molecules: cheap
