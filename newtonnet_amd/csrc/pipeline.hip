@@ -414,10 +414,27 @@ struct ParamTable {
 struct GraphInit {
   int* status; int* mol_ptr; int n_mol1; int* row_ptr; int n_atoms1;
 };
+// ... and the columns behind that one do edge.hip:embed_kernel's job (atom_node = Embedding[z] and the first layer's m from its
+// per-element table: a gather that depends on nothing but z and the prepared block -- if this very launch finds the block stale,
+// the step is repeated anyway): the deferred step's one launch less.
+struct EmbedJob {
+  const int64_t* z; const float* table; const float* m_table; int n_atoms; float* a0; float* m0;
+};
 template <bool UPDATE>
 __global__ void __launch_bounds__(256) param_check_kernel(ParamTable t, uint32_t* __restrict__ snap, int* __restrict__ status, int bit,
-                                                          GraphInit gi = GraphInit{nullptr, nullptr, 0, nullptr, 0}) {
+                                                          GraphInit gi = GraphInit{nullptr, nullptr, 0, nullptr, 0},
+                                                          EmbedJob ej = EmbedJob{nullptr, nullptr, nullptr, 0, nullptr, nullptr}) {
   const int k = blockIdx.x;
+  const int first_embed = t.n + (gi.status ? 1 : 0);
+  if (k >= first_embed) {
+    const size_t e = ((size_t)(k - first_embed) * gridDim.y + blockIdx.y) * 256 + threadIdx.x;   // one float4 each
+    if (e >= (size_t)ej.n_atoms * (NF / 4)) return;
+    const int i = (int)(e / (NF / 4)), c = (int)(e % (NF / 4));
+    const size_t zi = (size_t)clamp_species(ej.z[i]);
+    reinterpret_cast<float4*>(ej.a0)[e] = reinterpret_cast<const float4*>(ej.table + zi * NF)[c];
+    reinterpret_cast<float4*>(ej.m0)[e] = reinterpret_cast<const float4*>(ej.m_table + zi * NF)[c];
+    return;
+  }
   if (k == t.n) {
     const int n_init = gi.n_mol1 > gi.n_atoms1 ? gi.n_mol1 : gi.n_atoms1;
     for (int i = blockIdx.y * 256 + threadIdx.x; i < n_init; i += 256 * gridDim.y) {
@@ -512,13 +529,14 @@ extern "C" int nnhip_prepare(const nnhip_model* model, void* prepared, size_t pr
 // is refilled).  No word of the caller has to be initialised for it -- the deferred step runs it first and lets its last
 // neighbor-list kernel hand the counter to the host with the edge count.  *counter_out receives the counter's device address.
 static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
-                                      void* stream_, const GraphInit& gi);
+                                      void* stream_, const GraphInit& gi,
+                                      const EmbedJob& ej = EmbedJob{nullptr, nullptr, nullptr, 0, nullptr, nullptr});
 extern "C" int nnhip_prepare_check_counter(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
                                            void* stream_) {
   return prepare_check_counter_impl(model, prepared, prepared_bytes, counter_out, stream_, GraphInit{nullptr, nullptr, 0, nullptr, 0});
 }
 static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, size_t prepared_bytes, const int32_t** counter_out,
-                                      void* stream_, const GraphInit& gi) {
+                                      void* stream_, const GraphInit& gi, const EmbedJob& ej) {
   TRY(check_model(model, "nnhip_prepare_check_counter"));
   PrepLayout pq;
   make_prep_layout(model->n_layers, pq);
@@ -529,8 +547,9 @@ static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, 
   ParamTable t;
   TRY(make_param_table(model, t));
   int* counter = reinterpret_cast<int*>((char*)prepared + pq.changes);
-  param_check_kernel<false><<<dim3(t.n + (gi.status ? 1 : 0), PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
-      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), counter, 0, gi);
+  const int embed_cols = ej.a0 ? (int)(((size_t)ej.n_atoms * (NF / 4) + 256 * PARAM_CHECK_MAX_CHUNKS - 1) / (256 * PARAM_CHECK_MAX_CHUNKS)) : 0;
+  param_check_kernel<false><<<dim3(t.n + (gi.status ? 1 : 0) + embed_cols, PARAM_CHECK_MAX_CHUNKS), 256, 0, (hipStream_t)stream_>>>(
+      t, reinterpret_cast<uint32_t*>((char*)prepared + pq.snap), counter, 0, gi, ej);
   LAUNCH_CHECK();
   if (counter_out) *counter_out = counter;
   return NNHIP_OK;
@@ -547,7 +566,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
                               size_t workspace_bytes, float* energy, float* forces, float* virial,
                               float* atom_energy_out, float* atom_node_out, float* force_node_out,
                               const void* prepared, const int32_t* n_pairs_dev, const int32_t* pair_ptr, void* stream_,
-                              bool mol_kernels = false) {
+                              bool mol_kernels = false, bool embedded = false) {
   hipStream_t s = (hipStream_t)stream_;
   if (!model || !energy || N < 0 || E < 0 || B < 0) {
     nnhip_set_error("nnhip_energy_forces: bad arguments");
@@ -685,7 +704,8 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
   // atoms' rows up, instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is not kept: its
   // adjoint is never needed, the embedding does not depend on the positions.)
-  TRY(launch_embed(z, model->node_embedding, Q(pq.m_tab), N, P(w.pub.a0), P(w.pub.m[0]), s));
+  // (embedded: the caller's parameter-check launch has done this gather already, nnhip_forward_dev)
+  if (!embedded) TRY(launch_embed(z, model->node_embedding, Q(pq.m_tab), N, P(w.pub.a0), P(w.pub.m[0]), s));
   const float* a_in = P(w.pub.a0);
   const float* f_in = nullptr;  // force_node == 0 entering the first layer (newtonnet.py:143)
   // the last layer writes atom_node / force_node straight into the caller's output arrays when they are given
@@ -988,11 +1008,25 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
   int32_t* I = st->i32;
   float* F = st->f32;
   int32_t *mol_ptr = I + lay.mol_ptr, *row_ptr = I + lay.row_ptr, *status = I + lay.status, *pair_ptr = I + lay.pair_ptr;
+  // the node-embedding gather (edge.hip:embed_kernel) rides in the parameter check's launch: it needs the workspace addresses
+  // energy_forces_impl will use (same layout function; the size / alignment checks it repeats come first here)
+  EmbedJob ej = EmbedJob{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  const GraphInit no_init = GraphInit{nullptr, nullptr, 0, nullptr, 0};
+  if (N >= 1 && model->n_features == NF && model->n_layers >= 1 && model->n_layers <= NNHIP_MAX_LAYERS) {
+    WsInternal w;
+    make_layout(N, cap, B, model->n_layers, w);
+    PrepLayout pq;
+    make_prep_layout(model->n_layers, pq);
+    if (st->workspace && st->workspace_bytes >= w.pub.total && ((uintptr_t)st->workspace & 255) == 0 && st->prepared_bytes >= pq.total)
+      ej = EmbedJob{st->z, model->node_embedding, (const float*)((const char*)st->prepared + pq.m_tab), N,
+                    (float*)((char*)st->workspace + w.pub.a0), (float*)((char*)st->workspace + w.pub.m[0])};
+  }
+  const bool embedded = ej.a0 != nullptr;
   if (N >= 1 && N <= nnhip_graph_small_max_atoms()) {
     // a small system: the whole neighbor list in one launch (graph.hip:graph_small_kernel), then the parameter check ORs its bit
     // into the status word behind the count, then the two words leave for the host
     const int32_t* changes = nullptr;
-    TRY(nnhip_prepare_check_counter(model, st->prepared, st->prepared_bytes, &changes, stream_));
+    TRY(prepare_check_counter_impl(model, st->prepared, st->prepared_bytes, &changes, stream_, no_init, ej));
     TRY(nnhip_graph_small_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, st->tail_host,
                               changes, st->seq, I + lay.col, I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies,
                               model->n_basis, F + lay.geo, I + lay.xg, model->envelope, stream_));
@@ -1001,7 +1035,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
                               I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
                               F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_,
-                            (st->flags & 1) != 0);
+                            (st->flags & 1) != 0, embedded);
   }
   static const bool mol_graph_off = getenv("NNHIP_GRAPH_MOL") && atoi(getenv("NNHIP_GRAPH_MOL")) == 0;
   const int32_t* changes = nullptr;
@@ -1009,7 +1043,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
     // a batch of small molecules: the list by one workgroup per molecule (graph.hip:graph_mol_*_kernel), five launches instead of nine
     // (the parameter check's launch also clears status / mol_ptr / row_ptr)
     TRY(prepare_check_counter_impl(model, st->prepared, st->prepared_bytes, &changes, stream_,
-                                   GraphInit{status, mol_ptr, B + 1, row_ptr, N + 1}));
+                                   GraphInit{status, mol_ptr, B + 1, row_ptr, N + 1}, ej));
     TRY(nnhip_graph_mol_dev(st->pos, st->cell, st->batch, st->z, N, B, cap, model->cutoff, mol_ptr, row_ptr, pair_ptr, status,
                             I + lay.mol_scratch, 1, st->tail_host, changes, st->seq, I + lay.col, I + lay.rev, I + lay.pid,
                             F + lay.disp, F + lay.geo, I + lay.xg, stream_));
@@ -1019,11 +1053,11 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
     return energy_forces_impl(model, st->z, st->pos, st->cell, mol_ptr, row_ptr, I + lay.col, I + lay.rev, I + lay.pid, F + lay.geo,
                               I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                               st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
-                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_, true);
+                              F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_, true, embedded);
   }
   TRY(nnhip_graph_count_pairs_z(st->pos, st->cell, st->batch, st->z, N, B, model->cutoff, mol_ptr, row_ptr, status, pair_ptr,
                                 I + lay.pair_scan, stream_));
-  TRY(nnhip_prepare_check_counter(model, st->prepared, st->prepared_bytes, &changes, stream_));
+  TRY(prepare_check_counter_impl(model, st->prepared, st->prepared_bytes, &changes, stream_, no_init, ej));
   TRY(nnhip_graph_finish_dev(st->pos, st->cell, st->batch, mol_ptr, row_ptr, pair_ptr, N, B, cap, model->cutoff, I + lay.col,
                              I + lay.rev, I + lay.pid, F + lay.disp, st->edge_index, model->frequencies, model->n_basis,
                              F + lay.geo, nullptr, nullptr, I + lay.xg, model->envelope, status, st->tail_host, changes, st->seq, stream_));
@@ -1033,7 +1067,7 @@ extern "C" int nnhip_forward_dev(const nnhip_model* model, const nnhip_step_dev*
                             I + lay.xg, F + lay.disp, N, cap, B, st->workspace, st->workspace_bytes, F + lay.energy,
                             st->want_forces ? F + lay.forces : nullptr, (st->want_forces && st->want_virial) ? F + lay.virial : nullptr,
                             F + lay.atom_energy, st->atom_node, st->force_node, st->prepared, pair_ptr + N, pair_ptr, stream_,
-                            (st->flags & 1) != 0);
+                            (st->flags & 1) != 0, embedded);
 }
 
 // ---- per-stage exports (include/newtonnet_hip.h, "Per-stage entry points"): thin wrappers over the launchers above ----
