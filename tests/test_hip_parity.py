@@ -410,6 +410,19 @@ def test_periodic_batch_with_empty_molecule_slots_through_the_per_molecule_list(
     assert torch.all(out.energy[torch.arange(B) % 7 == 3] == 0)
 
 
+def test_deferred_step_fuzz():
+    """tools/fuzz_deferred.py, 30 rounds: random molecule counts (1..1200) and sizes (1..30, now and then 40 or 1100 atoms), periodic
+    or not, two batches per shape whose molecule sizes differ (the deferred step's guess about them goes wrong both ways): every
+    call bit-equal to the synchronous path of a fresh module, every list equal to the CPU oracle's.  (7200 calls over three seeds ran
+    clean on the final tree of round 4: profiles/r04_deferred_fuzz.txt.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('fuzz_deferred', os.path.join(os.path.dirname(util.GOLDEN), os.pardir, 'tools', 'fuzz_deferred.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n_calls, n_def, n_rep = mod.main(30, 7)
+    assert n_calls == 180 and n_def >= 100
+
+
 def test_single_launch_neighbor_list_up_to_its_limit():
     """The deferred step sends systems of up to nnhip_graph_small_max_atoms() (default 128) atoms through the single-launch
     neighbor list (graph.hip:graph_small_kernel); the kernel itself serves up to 1024.  Run the golden cases and the random
