@@ -895,9 +895,12 @@ static inline size_t edge_lds() {
 // The molecule-resident kernels (force_fwd_mol_kernel, msg_bwd_mol_kernel: one 8-wave workgroup per molecule) need enough molecules
 // to fill the chip: same box, us per step with / without them -- 100 molecules 370 / 314, 256: 561 / 529, 384: 675 / 654,
 // 512: 845 / 842, 768: 1151 / 1169, 1024: 1535 / 1585 (profiles/r04_mol_kernels_crossover.txt).  NNHIP_MOL_KERNELS_MIN overrides.
+// ... and molecules large enough to have rows for the eight waves: 21.5k atoms in molecules of 3 / 6 / 9 / 12 / 16 / 21 atoms,
+// us per step with / without -- 694 / 672, 885 / 879, 1102 / 1107, 1307 / 1311, 1492 / 1518, 1781 / 1834
+// (profiles/r04_mol_kernels_by_molecule_size.txt): from an average of 8 atoms per molecule up.
 static bool mol_kernels_pay(int n_atoms, int n_mol) {
   static const int min_mol = getenv("NNHIP_MOL_KERNELS_MIN") ? atoi(getenv("NNHIP_MOL_KERNELS_MIN")) : 640;
-  return n_mol >= min_mol && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX;
+  return n_mol >= min_mol && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && (long)n_atoms >= 8L * n_mol;
 }
 
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,

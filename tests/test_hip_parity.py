@@ -330,9 +330,9 @@ def test_molecule_resident_force_fwd_follows_the_molecule_sizes():
 
 def test_many_tiny_molecules_through_the_per_molecule_kernels():
     """9000 molecules of 2-4 atoms (more than MG_SUM_MAX = 8192, so the per-molecule neighbor list scans its molecule totals in a
-    launch of its own; empty-neighborhood rows and two-atom molecules included): the deferred step -- per-molecule list kernels and
-    molecule-resident edge kernels -- must return bit for bit what the synchronous path of a fresh module returns, and its list must
-    be the oracle's."""
+    launch of its own; empty-neighborhood rows and two-atom molecules included): the deferred step -- per-molecule list kernels,
+    head and force kernels (the molecule-resident EDGE kernels start at an average of 8 atoms per molecule) -- must return bit for
+    bit what the synchronous path of a fresh module returns, and its list must be the oracle's."""
     from newtonnet_amd.models import NewtonNet
     from oracle import newtonnet_ref as ref
     gen = torch.Generator().manual_seed(3)
