@@ -759,11 +759,12 @@ int nnhip_mlp_forms(void);
  *          3-6 = msg_fwd / force_fwd / force_bwd / msg_bwd, 7 = graph build, 8 = fused edge-MLP kernel (mlp128),
  *          9 = single linears (lin128), 10 = the batched weight-gradient kernel of training (wgrad_kernel, without its
  *          slab reduction), 11 = the one-pass register-weights form of the two edge MLPs (mlp_regw_kernel; its launches are
- *          counted in class 8 as well).  Disabled (0) by default.  on = 1: every class; any other non-zero value is a mask,
+ *          counted in class 8 as well), 12 / 13 = the molecule-resident fused edge phase of a layer and its adjoint
+ *          (mol_edge_fwd_kernel / mol_edge_bwd_kernel).  Disabled (0) by default.  on = 1: every class; any other non-zero value is a mask,
  *          bit (k + 1) = class k: only those classes record events (bench.py times each class in a pass of its own, so that a
  *          kernel's duration is not stretched by the events of the kernels around it).
  * ------------------------------------------------------------------------ */
-#define NNHIP_N_TIMER_CLASSES 12
+#define NNHIP_N_TIMER_CLASSES 14
 int nnhip_timers_enable(int32_t on);
 int nnhip_timers_read(double* ms_per_class, int64_t* launches_per_class, int32_t reset);
 

@@ -45,7 +45,7 @@ void nnhip_set_error(const char* fmt, ...);
 
 // ---- timers (host) ---------------------------------------------------------
 enum { TC_EDGE = 0, TC_LIN = 1, TC_OTHER = 2, TC_EDGE_FWD_MSG = 3, TC_EDGE_FWD_FORCE = 4, TC_EDGE_BWD_FORCE = 5,
-       TC_EDGE_BWD_MSG = 6, TC_GRAPH = 7, TC_MLP = 8, TC_LIN1 = 9, TC_WGRAD = 10, TC_MLP_ONEPASS = 11 };
+       TC_EDGE_BWD_MSG = 6, TC_GRAPH = 7, TC_MLP = 8, TC_LIN1 = 9, TC_WGRAD = 10, TC_MLP_ONEPASS = 11, TC_MOL_FWD = 12, TC_MOL_BWD = 13 };
 struct ScopedTimer {
   int cls;
   hipStream_t s;

@@ -939,6 +939,11 @@ __global__ void __launch_bounds__(MG_THREADS) graph_mol_fill_kernel(const MolGra
   __shared__ int s_base;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x, B = a.n_mol, N = a.n_atoms;
+  // An invalid batch vector (bit 1: unsorted or out of range -- mol_ptr_kernel's racing writes can then leave molecule extents that
+  // overlap, so that two workgroups would fill the same rows from different offsets), a species outside the tables (2) or a
+  // molecule this kernel does not serve (16): the status word is final after the two launches before this one, the guard behind
+  // it empties the graph, the host raises what the synchronous path raises -- nothing is filled.  
+  if (a.status[0] & (1 | 2 | 16)) return;   // (uniform)
   int s;
   int n = mg_extent(a, b, s);
   if (n < 0) n = 0;
@@ -993,8 +998,8 @@ __global__ void __launch_bounds__(MG_THREADS) graph_mol_fill_kernel(const MolGra
       float dx = 0.f, dy = 0.f, dz = 0.f;
       if (j < n && j != k) hit = pair_disp(xi, yi, zi, spos[3 * j], spos[3 * j + 1], spos[3 * j + 2], ci, dx, dy, dz) < a.cut2;
       const unsigned long long mask = __ballot(hit);
-      if (hit) {
-        const int o = w + __popcll(mask & ((1ull << lane) - 1ull));
+      const int o = w + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && o < e1) {   // (o < e1 <= capacity always holds for consistent counts; the predicate keeps every store inside the arrays)
         a.col[o] = s + j;
         if (lds_col) scol[o - e0] = s + j;
         a.disp[3 * (long)o] = dx;

@@ -42,6 +42,16 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s, bool small_molecules = false);
 int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
+// molfuse.hip: the edge phase of a layer / its adjoint in one launch, a workgroup per molecule
+int launch_mol_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                        const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
+                        const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
+                        float* h1, float* h2, float* phi1, float* phi2, int n_mol, hipStream_t s);
+int launch_mol_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                        const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
+                        const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
+                        const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
+                        float* g_m, float* g_x, float* g_u, int n_mol, hipStream_t s);
 
 // ---- errors ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -52,7 +62,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 105; }   // 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
+extern "C" int nnhip_version(void) { return 106; }   // 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
@@ -559,6 +569,17 @@ static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, 
 // n_pairs_dev == NULL: E is the edge count.  Otherwise (nnhip_energy_forces_dev) E is the CAPACITY the per-edge arrays and the
 // workspace are sized for and *n_pairs_dev the true number of undirected pairs (= pair_ptr[N]): the row kernels walk row_ptr, the
 // per-edge kernels cover the capacity (rows beyond the count hold nothing anybody reads), the pair-row kernels read the count.
+// Where the fused molecule kernels (molfuse.hip) pay: NOWHERE on this hardware, as measured in round 5 -- the same box, aspirin
+// conformers, us per step row path / fused: 1 conformer 180 / 478, 48: 239 / 526, 128: 351 / 554, 512: 836 / 1243, 1024: 1467 / 2354
+// (profiles/r05_mol_fused_ab.txt).  One workgroup per CU (158 KB of LDS, 8 waves x 256 registers) runs its ~17 barrier-separated
+// phases as a latency chain with nothing to overlap them: 72 us per forward launch of ONE idle-chip molecule, of which the four
+// GEMM stages are 25 (profiles/r05_mol_fused_phase_clock.txt).  The form stays in the build, parity-tested,
+// behind NNHIP_MOL_FUSED=1; NNHIP_MOL_FUSED_MIN=<molecules> turns it on from a molecule count up without the switch.
+static bool mol_fused_pays(int n_atoms, int n_mol) {
+  static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : 0x7fffffff;
+  (void)n_atoms;
+  return n_mol >= min_mol;
+}
 static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                               const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
                               const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
@@ -624,6 +645,18 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
   auto Q = [&](size_t off) { return (float*)(pbase + off); };
   if (!prepared) TRY(run_prepare(model, pq, pbase, s));
   const bool split_nodes = split_products_enabled() && act == NNHIP_ACT_SILU;   // node128s.hip (images in the prepared block)
+  // The molecule-resident fused edge phase (molfuse.hip): batches of molecules of at most NNHIP_MOL_STAGE_MAX atoms (the caller's
+  // `mol_kernels`: bit 8 of the list's status word is clear), SiLU with split-f16 products (its weights are the prepared images).
+  // NNHIP_MOL_FUSED (read per call): 0 = never, 1 = both directions whenever eligible, 2 = forward only, 3 = adjoint only (tests
+  // swap one direction at a time against the row path -- every array between the two has the row path's layout).
+  int fused_mode = 0;
+  {
+    const char* ev = getenv("NNHIP_MOL_FUSED");
+    const int want = ev ? atoi(ev) : -1;
+    const bool eligible = mol_kernels && split_nodes && mol_ptr && pair_ptr && B > 0 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX;
+    if (eligible && want != 0) fused_mode = want > 0 ? want : (mol_fused_pays(N, B) ? 1 : 0);
+  }
+  const bool fused_fwd = fused_mode == 1 || fused_mode == 2, fused_bwd = fused_mode == 1 || fused_mode == 3;
 
   // ------------------------------------------------------------------ small systems: the whole step in ONE launch (small.hip)
   {
@@ -717,28 +750,36 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     // message_nodepart (hn = a W0^T + b0 ; m = silu(hn) W2^T + b2) was produced by the fused node kernel that closed the
     // previous layer (by the per-element table for l = 0)
     // messages + invariant update
-    TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
-    // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
-    if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
-      float* h12 = P(w.pub.h12[l]);   // h1 | h2: two pad32(P) x F regions, private to the MLP kernels (fragment order)
-      MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, NF, NF};
-      MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
-      m1.h_frag = m2.h_frag = 1;
-      m1.act = m2.act = act;
-      m1.M_dev = m2.M_dev = n_pairs_dev;
-      if (split_nodes) {   // (used by the row-local form only: small pair counts)
-        m1.W1_img = pbase + pq.img[l][IMG_EQ1_0];
-        m1.W2_img = pbase + pq.img[l][IMG_EQ1_2];
-        m2.W1_img = pbase + pq.img[l][IMG_EQ2_0];
-        m2.W2_img = pbase + pq.img[l][IMG_EQ2_2];
+    if (fused_fwd) {
+      // the whole edge phase of the layer in one launch, a workgroup per molecule (molfuse.hip)
+      TRY(launch_mol_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
+                              pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
+                              pbase + pq.img[l][IMG_EQ2_2], P(w.pub.a_mid[l]), F_OUT(l), P(w.pub.h12[l]), P(w.pub.h12[l]) + h2_off,
+                              P(w.pub.phi1[l]), P(w.pub.phi2[l]), B, s));
+    } else {
+      TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
+      // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
+      if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
+        float* h12 = P(w.pub.h12[l]);   // h1 | h2: two pad32(P) x F regions, private to the MLP kernels (fragment order)
+        MlpArgs m1 = {P(w.pub.msg[l]), lp.eq1_0_w, lp.eq1_2_w, h12, P(w.pub.phi1[l]), P_, NF, NF, NF};
+        MlpArgs m2 = {P(w.pub.msg[l]), lp.eq2_0_w, lp.eq2_2_w, h12 + h2_off, P(w.pub.phi2[l]), P_, NF, NF, NF};
+        m1.h_frag = m2.h_frag = 1;
+        m1.act = m2.act = act;
+        m1.M_dev = m2.M_dev = n_pairs_dev;
+        if (split_nodes) {   // (used by the row-local form only: small pair counts)
+          m1.W1_img = pbase + pq.img[l][IMG_EQ1_0];
+          m1.W2_img = pbase + pq.img[l][IMG_EQ1_2];
+          m2.W1_img = pbase + pq.img[l][IMG_EQ2_0];
+          m2.W2_img = pbase + pq.img[l][IMG_EQ2_2];
+        }
+        if (has_f)
+          TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
+        else
+          TRY(launch_mlp(MODE_FWD, false, m1, s));
       }
-      if (has_f)
-        TRY(launch_mlp_pair(MODE_FWD, m1, false, m2, false, s));
-      else
-        TRY(launch_mlp(MODE_FWD, false, m1, s));
+      TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s, pair_ptr,
+                           mol_kernels ? mol_ptr : nullptr, B));
     }
-    TRY(launch_force_fwd(has_f, P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_in, F_OUT(l), N, mask_xg, s, pair_ptr,
-                         mol_kernels ? mol_ptr : nullptr, B));
     // equiv_update + energy update + the next layer's message_nodepart: one row-local launch (node128.hip)
     {
       NodeFwdArgs na;
@@ -847,31 +888,40 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     const float* f_prev = has_f ? F_OUT(l - 1) : nullptr;
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
-    TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
-                         P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));
-    if (E > 0) {
-      // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
-      float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
+    if (fused_bwd) {
+      // the adjoint of the whole edge phase in one launch, a workgroup per molecule (molfuse.hip)
       float* h12 = P(w.pub.h12[l]);
-      MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, NF, NF};
-      MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
-      m1.h_frag = m2.h_frag = 1;
-      m1.act = m2.act = act;
-      m1.M_dev = m2.M_dev = n_pairs_dev;
-      if (split_nodes) {
-        m1.W1_img = pbase + pq.img[l][IMG_EQ1_2_T];
-        m1.W2_img = pbase + pq.img[l][IMG_EQ1_0_T];
-        m2.W1_img = pbase + pq.img[l][IMG_EQ2_2_T];
-        m2.W2_img = pbase + pq.img[l][IMG_EQ2_0_T];
+      TRY(launch_mol_edge_bwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, xg, P(w.gf_mid), P(w.pub.g_a), P(w.pub.m[l]),
+                              f_prev, Q(pq.ftab[l]), pbase + pq.img[l][IMG_EQ1_2_T], pbase + pq.img[l][IMG_EQ1_0_T],
+                              pbase + pq.img[l][IMG_EQ2_2_T], pbase + pq.img[l][IMG_EQ2_0_T], h12, h12 + h2_off, P(w.pub.phi1[l]),
+                              P(w.pub.phi2[l]), g_fin, P(w.g_m), P(w.pub.g_x) + (size_t)l * E, P(w.pub.g_u) + (size_t)l * E * 4, B, s));
+    } else {
+      TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
+                           P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));
+      if (E > 0) {
+        // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
+        float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)
+        float* h12 = P(w.pub.h12[l]);
+        MlpArgs m1 = {gp, Q(pq.wT[l][3]), Q(pq.wT[l][2]), h12, P(w.g_msg), P_, 2 * NF, NF, NF};
+        MlpArgs m2 = {gp + NF, Q(pq.wT[l][5]), Q(pq.wT[l][4]), h12 + h2_off, P(w.g_msg), P_, 2 * NF, NF, NF};
+        m1.h_frag = m2.h_frag = 1;
+        m1.act = m2.act = act;
+        m1.M_dev = m2.M_dev = n_pairs_dev;
+        if (split_nodes) {
+          m1.W1_img = pbase + pq.img[l][IMG_EQ1_2_T];
+          m1.W2_img = pbase + pq.img[l][IMG_EQ1_0_T];
+          m2.W1_img = pbase + pq.img[l][IMG_EQ2_2_T];
+          m2.W2_img = pbase + pq.img[l][IMG_EQ2_0_T];
+        }
+        if (has_f)
+          TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
+        else
+          TRY(launch_mlp(MODE_BWD, false, m1, s));
       }
-      if (has_f)
-        TRY(launch_mlp_pair(MODE_BWD, m1, false, m2, true, s));
-      else
-        TRY(launch_mlp(MODE_BWD, false, m1, s));
+      // message adjoint -> g_m, g_x
+      TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, P(w.g_m),
+                         P(w.pub.g_x) + (size_t)l * E, N, l > 0, s, pair_ptr, mol_kernels ? mol_ptr : nullptr, B));
     }
-    // message adjoint -> g_m, g_x
-    TRY(launch_msg_bwd(P(w.g_msg), P(w.pub.g_a), P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, P(w.g_m),
-                       P(w.pub.g_x) + (size_t)l * E, N, l > 0, s, pair_ptr, mol_kernels ? mol_ptr : nullptr, B));
     // message_nodepart adjoint of this layer (g_hn = (g_m W2) * silu'(hn); g_a += g_hn W0) + update adjoint of the
     // layer below (gf = G_f + g_a * q + (g_a * f) W_u): one row-local launch.  Nothing to do below the first layer: its
     // message_nodepart input is the embedding of z, which does not depend on the positions.

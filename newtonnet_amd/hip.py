@@ -24,9 +24,9 @@ NNHIP_MAX_NB = 32
 ACTIVATION_IDS = {'swish': 0, 'silu': 0, 'relu': 1, 'elu': 2, 'leaky_relu': 3, 'tanh': 4, 'sigmoid': 5, 'softplus': 6,
                   'gelu': 7, 'ssp': 8}
 NNHIP_MAX_LAYERS = 8
-N_TIMER_CLASSES = 12
+N_TIMER_CLASSES = 14
 TIMER_CLASSES = ('edge_all', 'linear_mfma', 'other', 'edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd',
-                 'edge_msg_bwd', 'graph', 'mlp128', 'lin128', 'wgrad', 'mlp_onepass')
+                 'edge_msg_bwd', 'graph', 'mlp128', 'lin128', 'wgrad', 'mlp_onepass', 'mol_fwd', 'mol_bwd')
 
 _fp = C.POINTER(C.c_float)
 

@@ -78,21 +78,32 @@ class _Deferred:
             return
         tail, seq = self.tail, self.event          # (a numpy view of the pinned slot; this call's sequence number)
         if int(tail[3]) != seq:
-            # not there yet (the host is ahead of the GPU): poll -- the word arrives a few tens of microseconds into the step
-            t_end, spins = time.perf_counter() + 5.0, 0
+            # not there yet (the host is ahead of the GPU): poll -- the word arrives a few tens of microseconds into the step.
+            # A short raw spin, then yields, then 20 us sleeps (a wait can last a whole step, and a core spinning
+            # per rank competes with the launch threads of the other ranks of a node).
+            t0, spins = time.perf_counter(), 0
             while int(tail[3]) != seq:
                 spins += 1
-                if spins > 64:
-                    time.sleep(0)                  # (lets other Python threads run: the wait can last a whole step)
-                    if time.perf_counter() > t_end:    # (never in a healthy run: let the runtime say what went wrong)
-                        torch.cuda.synchronize(self.inputs[1].device)
-                        if int(tail[3]) != seq:
-                            raise hip.HipLibraryError('the deferred step never reported its edge count (sequence number missing)')
+                if spins <= 64:
+                    continue
+                waited = time.perf_counter() - t0
+                if waited > 5.0:               # (never in a healthy run: let the runtime say what went wrong)
+                    torch.cuda.synchronize(self.inputs[1].device)
+                    if int(tail[3]) != seq:
+                        raise hip.HipLibraryError('the deferred step never reported its edge count (sequence number missing)')
+                    break
+                time.sleep(0 if waited < 50e-6 else 20e-6)
         self.count, self.bad, changed = int(tail[0]), int(tail[1]), int(tail[2])
         if changed:                        # (the prepared block's change counter: a parameter differs from its snapshot)
             self.bad |= hip.STATUS_PARAMS_CHANGED
         self.tail = self.event = None
         self.state = _Deferred.WORDS
+        # a step that ran on an emptied graph / a stale block / the wrong kernel forms is worth nothing until it is repeated: count
+        # them, whether or not anybody touches the result (bench.py reports the count next to its timings)
+        if (self.count > self.cap or (self.bad & (hip.STATUS_PARAMS_CHANGED | 3))
+                or self.small_molecules != (not (self.bad & hip.STATUS_BIG_MOLECULE))):
+            st = self.owner.__dict__.setdefault('_deferred_stats', {'deferred_calls': 0, 'repeats_needed': 0})
+            st['repeats_needed'] += 1
         if self.bad & 1:
             self.error = ValueError('batch must be non-decreasing with values in [0, cell.shape[0]) (PyG collation order)')
         elif self.bad & 2:
@@ -199,7 +210,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_param_stamp', '_param_epoch', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_param_stamp', '_param_epoch', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache', '_deferred_stats'):
             state.pop(k, None)
         return state
 
@@ -534,6 +545,7 @@ class NewtonNet(nn.Module):
         rec.versions = _versions(rec.inputs)
         rec.state = _Deferred.QUEUED
         self.__dict__['_last_deferred'] = rec
+        self.__dict__.setdefault('_deferred_stats', {'deferred_calls': 0, 'repeats_needed': 0})['deferred_calls'] += 1
         return True
 
     def _settle_last(self):
@@ -545,6 +557,18 @@ class NewtonNet(nn.Module):
             if rec.error is not None and not rec.reported:
                 rec.reported = True
                 raise type(rec.error)(f'(raised by the PREVIOUS forward call, whose checks were deferred) {rec.error}')
+
+    def deferred_stats(self, reset=False):
+        """{'deferred_calls': eval calls queued without waiting for the device, 'repeats_needed': how many of them ran on an emptied
+        graph, a stale prepared block, a wrong molecule-size guess or invalid inputs -- i.e. produced nothing usable until repeated}.
+        The last queued call is settled first."""
+        rec = self.__dict__.get('_last_deferred')
+        if rec is not None:
+            rec.read_words()
+        st = dict(self.__dict__.setdefault('_deferred_stats', {'deferred_calls': 0, 'repeats_needed': 0}))
+        if reset:
+            self.__dict__['_deferred_stats'] = {'deferred_calls': 0, 'repeats_needed': 0}
+        return st
 
     def synchronize_checks(self):
         """Settle the deferred host-side checks of the last eval-mode call now (raises what it would have raised)."""

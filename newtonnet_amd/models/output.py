@@ -52,7 +52,8 @@ class CustomOutputSet:
     def __getattr__(self, name):          # only reached when normal lookup fails
         lazy = self.__dict__.get('_lazy')
         if lazy is not None and name in lazy:
-            value = lazy.pop(name)()
+            value = lazy[name]()         # (a thunk that raises -- the deferred checks of the eval step -- stays registered: the
+            del lazy[name]               # same error at every touch, not an AttributeError at the second one)
             setattr(self, name, value)
             return value
         raise AttributeError(name)

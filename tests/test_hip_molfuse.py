@@ -1,0 +1,162 @@
+"""GPU parity tests of the molecule-resident fused edge phase (csrc/molfuse.hip: mol_edge_fwd_kernel / mol_edge_bwd_kernel --
+msg, both edge MLPs, the force-message aggregation and their adjoints in one launch per layer and direction, a workgroup per
+molecule; reference semantics newtonnet/models/newtonnet.py:207-227 and the autograd sweep of output.py:66-73).
+
+The form is chosen by the library (pipeline.hip: batches of molecules of at most NNHIP_MOL_STAGE_MAX atoms); NNHIP_MOL_FUSED, read
+per call, forces it on (1), off (0) or on for one direction only (2 forward, 3 adjoint) -- every array between the two
+directions has the row path's layout, so each direction is also checked against the three row-path launches it replaces.
+Tolerances as tests/test_hip_parity.py (fp32 path vs fp64 oracle): force MAE <= 1e-5, max <= 5e-5 eV/A, energy within 2 ulp."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.test_hip_parity import check_forces, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+class fused_mode:
+    def __init__(self, mode):
+        self.mode, self.old = str(mode), None
+
+    def __enter__(self):
+        self.old = os.environ.get('NNHIP_MOL_FUSED')
+        os.environ['NNHIP_MOL_FUSED'] = self.mode
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop('NNHIP_MOL_FUSED', None)
+        else:
+            os.environ['NNHIP_MOL_FUSED'] = self.old
+
+
+def fused_launches(fn):
+    """Run fn() with the library's event timers on; returns (result, launches of mol_edge_fwd, launches of mol_edge_bwd)."""
+    from newtonnet_amd import hip
+    hip.timers_enable(True, classes=('mol_fwd', 'mol_bwd'))
+    try:
+        res = fn()
+        torch.cuda.synchronize()
+        tm = hip.timers_read(reset=True)
+    finally:
+        hip.timers_enable(False)
+    return res, tm['mol_fwd'][1], tm['mol_bwd'][1]
+
+
+def molecule_zoo(gen):
+    """40 aspirin conformers; ethanol-sized and smaller fragments; single atoms and a far-apart pair (rows without edges); a
+    24-atom cluster with all 276 pairs inside the cutoff (two rounds of pair tiles in the fused kernels) and a 23-atom one."""
+    a = util.load_npz('aspirin_frames.npz')
+    base = torch.from_numpy(a['train_pos'][0]).float()
+    zb = torch.from_numpy(a['z']).long()
+    zs, ps = [], []
+    for k in range(40):
+        zs.append(zb), ps.append(base + 0.05 * torch.randn(21, 3, generator=gen))
+    for n in (9, 5, 3, 2, 1, 1):
+        zs.append(zb[:n]), ps.append(base[:n] + 0.05 * torch.randn(n, 3, generator=gen))
+    zs.append(zb[:2]), ps.append(torch.tensor([[0.0, 0.0, 0.0], [7.5, 0.0, 0.0]]))       # beyond the cutoff: no edge
+    for n in (24, 23):
+        # points on a jittered 3x3x3 lattice 1.15 A apart: diameter < 4.3 A, every pair an edge, no close contacts
+        grid = torch.stack(torch.meshgrid(*[torch.arange(3)] * 3, indexing='ij'), dim=-1).reshape(-1, 3)[:n].float()
+        zs.append(zb[torch.randint(0, 21, (n,), generator=gen)]), ps.append(1.15 * grid + 0.08 * torch.randn(n, 3, generator=gen))
+    sizes = [len(t) for t in zs]
+    ps = [p + 30.0 * k for k, p in enumerate(ps)]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    return torch.cat(zs), torch.cat(ps), torch.zeros(len(sizes), 3, 3), batch, sizes
+
+
+@pytest.mark.parametrize('which', ['rand', 'ckpt'])
+def test_fused_edge_phase_against_the_oracle(which):
+    from oracle import newtonnet_ref as ref
+    gen = torch.Generator().manual_seed(11)
+    z, pos, cell, batch, sizes = molecule_zoo(gen)
+    model, sd = make_model(which)
+    args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    with fused_mode(1):
+        out, n_fwd, n_bwd = fused_launches(lambda: model(*args))
+        assert (n_fwd, n_bwd) == (3, 3), f'the fused kernels did not run ({n_fwd} forward, {n_bwd} adjoint launches)'
+        e, f = out.energy.cpu().double().numpy(), out.gradient_force.cpu().numpy()
+        a_node, f_node = out.atom_node.cpu().double(), out.force_node.cpu().double()
+        again = model(*args)                      # the deferred path: same kernels, same bits
+        assert torch.equal(again.energy, out.energy) and torch.equal(again.gradient_force, out.gradient_force)
+    o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
+    assert np.array_equal(out.edge_index.cpu().numpy(), o['edge_index'].numpy())
+    pairs = np.bincount(batch.numpy()[o['edge_index'][0].numpy()], minlength=len(sizes)) // 2
+    assert pairs.max() == 276 and (pairs == 0).sum() >= 3, pairs     # the two-round molecule and the edge-free ones are in
+    f_ref = o['forces'].numpy()
+    fscale = max(1.0, float(np.abs(f_ref).max()) / 5.0)
+    d = np.abs(f.astype(np.float64) - f_ref)
+    print(f'fused edge phase ({which}): force MAE {d.mean():.2e} max {d.max():.2e} (max |F| {np.abs(f_ref).max():.1f})')
+    check_forces(f, f_ref, fscale)
+    e_ref = o['energy'].numpy()
+    # (the trained model explodes on the two dense lattice clusters -- energies of 1e20 eV, forces of 1e22 eV/A: a relative bound
+    # there, the 2-ulp bound everywhere else)
+    assert np.all(np.abs(e - e_ref) <= np.maximum(util.energy_tol(e_ref), 1e-5 * np.abs(e_ref))), np.abs(e - e_ref).max()
+    np.testing.assert_allclose(a_node.numpy(), o['atom_node'].numpy(), rtol=2e-4, atol=2e-5 * fscale)
+    np.testing.assert_allclose(f_node.numpy(), o['force_node'].numpy(), rtol=2e-4, atol=2e-5 * fscale)
+    # ... and next to the row path on the same inputs
+    with fused_mode(0):
+        row, n_fwd, n_bwd = fused_launches(lambda: model(*args))
+        assert (n_fwd, n_bwd) == (0, 0)
+    dd = (row.gradient_force - out.gradient_force).abs().max().item()
+    print(f'  fused vs row path: max |dF| {dd:.2e}, max |dE| {(row.energy - out.energy).abs().max().item():.2e}')
+    assert dd <= 2e-5 * fscale
+
+
+def test_fused_edge_phase_is_deterministic_and_ignores_the_order_of_the_molecules():
+    gen = torch.Generator().manual_seed(12)
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 96, 21
+    pos = torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    cell = torch.zeros(B, 3, 3, device='cuda')
+    model, _ = make_model('rand')
+    with fused_mode(1):
+        o1 = model(z, pos.cuda(), cell, batch)
+        e1, f1 = o1.energy.clone(), o1.gradient_force.clone()
+        o2 = model(z, pos.cuda(), cell, batch)
+        assert torch.equal(o2.energy, e1) and torch.equal(o2.gradient_force, f1)
+        perm = torch.randperm(B, generator=gen)
+        pos_p = pos.view(B, n, 3)[perm].reshape(-1, 3).contiguous().cuda()
+        o3 = model(z, pos_p, cell, batch)
+        assert torch.equal(o3.energy.cpu(), e1.cpu()[perm])
+        assert torch.equal(o3.gradient_force.cpu().view(B, n, 3), f1.cpu().view(B, n, 3)[perm])
+    net = f1.view(B, n, 3).sum(1).abs().max().item()
+    assert net < 2e-4, net
+
+
+def test_fused_directions_swap_with_the_row_path_at_full_size():
+    """BASELINE configs[1] at full size (1024 aspirin conformers; the row path runs its persistent edge-MLP kernels there, whose
+    silu'(h) scratch the fused kernels share): fused both ways, forward only, adjoint only and not at all -- four results that
+    must agree with each other to rounding and, on every 16th conformer, with the fp64 oracle."""
+    from oracle import newtonnet_ref as ref
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 1024, 21
+    gen = torch.Generator().manual_seed(0)
+    pos = torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)
+    z = torch.from_numpy(a['z']).long().repeat(B)
+    batch = torch.repeat_interleave(torch.arange(B), n)
+    model, sd = make_model('ckpt')
+    args = (z.cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'), batch.cuda())
+    res = {}
+    for mode, want in ((0, (0, 0)), (1, (3, 3)), (2, (3, 0)), (3, (0, 3))):
+        with fused_mode(mode):
+            out, n_fwd, n_bwd = fused_launches(lambda: model(*args))
+            assert (n_fwd, n_bwd) == want, (mode, n_fwd, n_bwd)
+            res[mode] = (out.energy.cpu().double(), out.gradient_force.cpu().double())
+    pick = torch.arange(0, B, 16)
+    ps = pos.view(B, n, 3)[pick].reshape(-1, 3).double()
+    o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z[:len(pick) * n], ps,
+                          torch.zeros(len(pick), 3, 3, dtype=torch.float64), torch.repeat_interleave(torch.arange(len(pick)), n))
+    e_ref = o['energy'].numpy()
+    for mode, (e, f) in res.items():
+        d = (f.view(B, n, 3)[pick].reshape(-1, 3) - o['forces']).abs()
+        dm = (f - res[0][1]).abs().max().item()
+        print(f'mode {mode}: force MAE vs fp64 {d.mean():.2e} max {d.max():.2e}; max |dF| vs the row path {dm:.2e}')
+        assert d.mean() <= util.FORCE_MAE_TOL and d.max() <= util.FORCE_MAX_TOL
+        assert np.all(np.abs(e[pick].numpy() - e_ref) <= util.energy_tol(e_ref))
+        assert dm <= 5e-6

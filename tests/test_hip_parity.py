@@ -410,6 +410,45 @@ def test_periodic_batch_with_empty_molecule_slots_through_the_per_molecule_list(
     assert torch.all(out.energy[torch.arange(B) % 7 == 3] == 0)
 
 
+def test_permuted_batch_vector_on_the_per_molecule_deferred_path():
+    """a batch vector that is a PERMUTATION of a valid one (every id in range, not sorted) reaches the per-molecule
+    list kernels on the deferred path with molecule extents that mol_ptr_kernel's racing writes may leave overlapping; the fill
+    kernel must not touch the arrays then (status bit 1 is final before it runs), the call must raise the synchronous path's
+    ValueError at the first touch, and the module must go on returning the right numbers afterwards."""
+    gen = torch.Generator().manual_seed(9)
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 40, 21                                  # 840 atoms (beyond the single-launch list of small systems), 21 per molecule
+    pos = (torch.from_numpy(a['train_pos'][0]).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)
+           + 30.0 * torch.repeat_interleave(torch.arange(B), n)[:, None]).cuda()
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    cell = torch.zeros(B, 3, 3, device='cuda')
+    model, _ = make_model('rand')
+    first = model(z, pos, cell, batch)
+    want = (first.energy.clone(), first.gradient_force.clone())
+    ok = model(z, pos, cell, batch)               # deferred, per-molecule list
+    rec = model.__dict__.get('_last_deferred')
+    assert rec is not None and rec.small_molecules
+    assert torch.equal(ok.energy, want[0]) and torch.equal(ok.gradient_force, want[1])
+    for trial in range(4):
+        perm = torch.randperm(B * n, generator=gen).cuda()
+        bad = model(z, pos, cell, batch[perm].contiguous())
+        with pytest.raises(ValueError):
+            bad.energy
+        with pytest.raises(ValueError):           # (ADVICE r04: raised at EVERY touch)
+            bad.energy
+        again = model(z, pos, cell, batch)
+        assert torch.equal(again.energy, want[0]) and torch.equal(again.gradient_force, want[1]), f'trial {trial}'
+    # the example of the advisory: [0, 0, 2, 0, 0, 1, 3]-like disorder inside an otherwise sorted vector
+    b2 = batch.clone()
+    b2[2], b2[5] = 2, 1
+    bad = model(z, pos, cell, b2)
+    with pytest.raises(ValueError):
+        bad.gradient_force
+    again = model(z, pos, cell, batch)
+    assert torch.equal(again.energy, want[0]) and torch.equal(again.gradient_force, want[1])
+
+
 def test_deferred_step_fuzz():
     """tools/fuzz_deferred.py, 30 rounds: random molecule counts (1..1200) and sizes (1..30, now and then 40 or 1100 atoms), periodic
     or not, two batches per shape whose molecule sizes differ (the deferred step's guess about them goes wrong both ways): every
