@@ -751,6 +751,12 @@ int nnhip_split_products(void);
  *   bit 2  ... the two-MLP forward launches too
  *   bit 3  the single-MLP adjoint (layer 0) runs in mlp_regw_kernel        bit 4  ... the single-MLP forward too */
 int nnhip_mlp_forms(void);
+/* Every form choice the library makes in this process -- neighbor-list builder thresholds, waves per receiver row, the
+ * molecule-per-workgroup forms and their thresholds, the edge-MLP forms, the fused edge phase -- as one JSON object written into
+ * buf (NUL-terminated; NNHIP_E_INVALID when n is too small: 2048 bytes are plenty), with the NNHIP_* environment switches that are
+ * set.  For bench lines and for tests that pin non-default forms; the reference has no counterpart (one eager path,
+ * newtonnet/models/newtonnet.py:74-104). */
+int nnhip_config(char* buf, size_t n);
 
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call

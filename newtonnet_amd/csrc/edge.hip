@@ -872,19 +872,36 @@ static inline bool edge_small(int n_atoms) {
   static const int lim = getenv("NNHIP_EDGE_SMALL_ATOMS") ? atoi(getenv("NNHIP_EDGE_SMALL_ATOMS")) : EDGE_SMALL_ATOMS;
   return n_atoms <= lim;
 }
+// NNHIP_EDGE_WPR=1|2|4 (read once per process) forces one split for every row kernel at every size: the non-default forms stay
+// reachable for tests (tests/test_hip_parity.py::test_non_default_forms_in_child_processes) without a tooling build.
+static inline int edge_wpr_forced() {
+  static const int v = [] {
+    const char* e = getenv("NNHIP_EDGE_WPR");
+    const int w = e ? atoi(e) : 0;
+    return (w == 1 || w == 2 || w == 4) ? w : 0;
+  }();
+  return v;
+}
+#define EDGE_LAUNCH_W(KERNEL_W, W_, ...) KERNEL_W<<<row_blocks(n_atoms, W_), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__)
 #define EDGE_LAUNCH(KERNEL, WPR_, ...)                                                                          \
   do {                                                                                                          \
-    if (edge_small(n_atoms))                                                                                    \
-      KERNEL<4><<<row_blocks(n_atoms, 4), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                        \
+    const int w_ = edge_wpr_forced() ? edge_wpr_forced() : (edge_small(n_atoms) ? 4 : WPR_);                    \
+    if (w_ == 4)                                                                                                \
+      EDGE_LAUNCH_W(KERNEL<4>, 4, __VA_ARGS__);                                                                 \
+    else if (w_ == 2)                                                                                           \
+      EDGE_LAUNCH_W(KERNEL<2>, 2, __VA_ARGS__);                                                                 \
     else                                                                                                        \
-      KERNEL<WPR_><<<row_blocks(n_atoms, WPR_), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                  \
+      EDGE_LAUNCH_W(KERNEL<1>, 1, __VA_ARGS__);                                                                 \
   } while (0)
 #define EDGE_LAUNCH_B(KERNEL, FLAG, WPR_, ...)                                                                  \
   do {                                                                                                          \
-    if (edge_small(n_atoms))                                                                                    \
-      KERNEL<FLAG, 4><<<row_blocks(n_atoms, 4), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);                  \
+    const int w_ = edge_wpr_forced() ? edge_wpr_forced() : (edge_small(n_atoms) ? 4 : WPR_);                    \
+    if (w_ == 4)                                                                                                \
+      EDGE_LAUNCH_W((KERNEL<FLAG, 4>), 4, __VA_ARGS__);                                                         \
+    else if (w_ == 2)                                                                                           \
+      EDGE_LAUNCH_W((KERNEL<FLAG, 2>), 2, __VA_ARGS__);                                                         \
     else                                                                                                        \
-      KERNEL<FLAG, WPR_><<<row_blocks(n_atoms, WPR_), 64 * EDGE_ROWS, edge_lds(), s>>>(__VA_ARGS__);            \
+      EDGE_LAUNCH_W((KERNEL<FLAG, 1>), 1, __VA_ARGS__);                                                         \
   } while (0)
 // tooling: NNHIP_EDGE_LDS=<bytes> attaches unused dynamic LDS to the edge kernels to cap their occupancy
 static inline size_t edge_lds() {
@@ -901,6 +918,16 @@ static inline size_t edge_lds() {
 static bool mol_kernels_pay(int n_atoms, int n_mol) {
   static const int min_mol = getenv("NNHIP_MOL_KERNELS_MIN") ? atoi(getenv("NNHIP_MOL_KERNELS_MIN")) : 640;
   return n_mol >= min_mol && (long)n_atoms <= (long)n_mol * NNHIP_MOL_STAGE_MAX && (long)n_atoms >= 8L * n_mol;
+}
+
+// what the launchers below decide with, for nnhip_config (pipeline.hip)
+void edge_config(int* small_atoms, int* mol_min, int* wpr /*[4]: msg_fwd, force_fwd, force_bwd, msg_bwd*/, int* mol_forms /*bits: force_fwd, msg_bwd, force_direct, head_out*/) {
+  *small_atoms = getenv("NNHIP_EDGE_SMALL_ATOMS") ? atoi(getenv("NNHIP_EDGE_SMALL_ATOMS")) : EDGE_SMALL_ATOMS;
+  *mol_min = getenv("NNHIP_MOL_KERNELS_MIN") ? atoi(getenv("NNHIP_MOL_KERNELS_MIN")) : 640;
+  wpr[0] = EDGE_WPR_MSG_FWD, wpr[1] = EDGE_WPR_FORCE_FWD, wpr[2] = EDGE_WPR_FORCE_BWD, wpr[3] = EDGE_WPR_MSG_BWD;
+  auto off = [](const char* name) { return getenv(name) && atoi(getenv(name)) == 0; };
+  *mol_forms = (off("NNHIP_FORCE_FWD_MOL") ? 0 : 1) | (off("NNHIP_MSG_BWD_MOL") ? 0 : 2) | (off("NNHIP_FORCE_DIRECT_MOL") ? 0 : 4) |
+               (off("NNHIP_HEAD_OUT_MOL") ? 0 : 8);
 }
 
 int launch_msg_fwd(const float* m, const int* xg, const float* table, const int* row_ptr, const int* col,

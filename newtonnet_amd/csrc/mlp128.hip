@@ -372,6 +372,10 @@ static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipS
   return NNHIP_E_INVALID;
 }
 
+int mlp_wide_max_tiles_silu() {   // (nnhip_config: below this many 32-row tiles the edge MLPs take the row-local form)
+  const int env_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : -1;
+  return env_max >= 0 ? env_max : (split_products_enabled() ? MLPS_WIDE_MAX_TILES : MLP_WIDE_MAX_TILES);
+}
 static bool mlp_use_wide(const MlpArgs& a) {
   static const int env_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : -1;
   const int wide_max = env_max >= 0 ? env_max

@@ -72,6 +72,63 @@ extern "C" int nnhip_build_flags(void) {
 #endif
 }
 
+// Every form choice the library makes, as one JSON object (bench.py prints it in its line; tests pin the non-default forms through
+// the switches it lists).  "env" holds the NNHIP_* switches that are SET in this process, whatever they say; the other keys are what
+// the code does with them (thresholds are in atoms / molecules / 32-row tiles).
+void edge_config(int* small_atoms, int* mol_min, int* wpr, int* mol_forms);   // edge.hip
+int mlp_wide_max_tiles_silu();                                                 // mlp128.hip
+extern "C" int nnhip_mlp_forms(void);
+extern "C" int nnhip_graph_small_max_atoms(void);
+extern "C" int nnhip_config(char* buf, size_t n) {
+  if (!buf || n < 64) {
+    nnhip_set_error("nnhip_config: buffer of at least 64 bytes");
+    return NNHIP_E_INVALID;
+  }
+  static const char* names[] = {"NNHIP_EDGE_LDS", "NNHIP_EDGE_SMALL_ATOMS", "NNHIP_EDGE_WPR", "NNHIP_FORCE_DIRECT_MOL", "NNHIP_FORCE_FWD_MOL", "NNHIP_GRAPH_MOL",
+                                "NNHIP_GRAPH_SMALL_ATOMS", "NNHIP_HEAD_OUT_MOL", "NNHIP_MLP_REGW", "NNHIP_MLP_REGW_SINGLE", "NNHIP_MLP_SPLIT",
+                                "NNHIP_MLP_WIDE_TILES", "NNHIP_MOL_FUSED", "NNHIP_MOL_FUSED_MIN", "NNHIP_MOL_KERNELS_MIN", "NNHIP_MSG_BWD_MOL",
+                                "NNHIP_SMALL_STEP", "NNHIP_WGRAD_FORM", "NNHIP_WGRAD_RPC"};
+  int small_atoms, mol_min, wpr[4], mol_forms;
+  edge_config(&small_atoms, &mol_min, wpr, &mol_forms);
+  const int forms = nnhip_mlp_forms();
+  const char* fused = getenv("NNHIP_MOL_FUSED");
+  const char* graph_mol = getenv("NNHIP_GRAPH_MOL");
+  size_t o = 0;
+  auto put = [&](const char* fmt, auto... a) {
+    if (o < n) {
+      const int k = snprintf(buf + o, n - o, fmt, a...);
+      o += k > 0 ? (size_t)k : 0;
+    }
+  };
+  put("{\"version\": %d, \"tooling_build\": %d, \"split_f16_products\": %d, ", nnhip_version(), nnhip_build_flags(), forms & 1);
+  put("\"neighbor_list\": {\"single_launch_max_atoms\": %d, \"per_molecule_kernels\": %d, \"cell_list\": \"one periodic molecule (host choice)\"}, ",
+      nnhip_graph_small_max_atoms(), (graph_mol && atoi(graph_mol) == 0) ? 0 : 1);
+  put("\"edge_rows\": {\"waves_per_row\": {\"msg_fwd\": %d, \"force_fwd\": %d, \"force_bwd\": %d, \"msg_bwd\": %d}, \"four_waves_per_row_up_to_atoms\": %d}, ",
+      wpr[0], wpr[1], wpr[2], wpr[3], small_atoms);
+  put("\"molecule_forms\": {\"max_atoms\": %d, \"edge_kernels_from_molecules\": %d, \"force_fwd\": %d, \"msg_bwd\": %d, \"force_direct\": %d, \"head_out\": %d, "
+      "\"fused_edge_phase\": \"%s\"}, ",
+      NNHIP_MOL_STAGE_MAX, mol_min, mol_forms & 1, (mol_forms >> 1) & 1, (mol_forms >> 2) & 1, (mol_forms >> 3) & 1,
+      fused ? (atoi(fused) == 0 ? "off" : atoi(fused) == 1 ? "on" : atoi(fused) == 2 ? "forward only" : "adjoint only")
+            : (getenv("NNHIP_MOL_FUSED_MIN") ? "from NNHIP_MOL_FUSED_MIN molecules" : "off (default)"));
+  put("\"edge_mlp\": {\"row_local_up_to_tiles\": %d, \"one_pass_adjoint\": %d, \"one_pass_forward\": %d, \"one_pass_single_adjoint\": %d, "
+      "\"one_pass_single_forward\": %d}, ",
+      mlp_wide_max_tiles_silu(), (forms >> 1) & 1, (forms >> 2) & 1, (forms >> 3) & 1, (forms >> 4) & 1);
+  put("\"radial_table_intervals\": %d, \"env\": {", FT_G);
+  bool first = true;
+  for (const char* nm : names) {
+    const char* v = getenv(nm);
+    if (!v) continue;
+    put("%s\"%s\": \"%.24s\"", first ? "" : ", ", nm, v);
+    first = false;
+  }
+  put("%s", "}}");
+  if (o >= n) {
+    nnhip_set_error("nnhip_config: buffer of %zu bytes is too small", n);
+    return NNHIP_E_INVALID;
+  }
+  return NNHIP_OK;
+}
+
 // ---- timers ------------------------------------------------------------------------------------------
 struct TimerRec {
   int cls;

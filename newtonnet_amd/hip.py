@@ -269,7 +269,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
                     'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter', 'nnhip_graph_mol_dev',
-                    'nnhip_edge_index_from_csr')
+                    'nnhip_edge_index_from_csr', 'nnhip_config')
 
 
 def _check(rc: int, what: str):
@@ -631,6 +631,17 @@ def mlp_forms() -> dict:
     v = lib().nnhip_mlp_forms()
     return {'split': bool(v & 1), 'regw_bwd': bool(v & 2), 'regw_fwd': bool(v & 4), 'regw_single_bwd': bool(v & 8),
             'regw_single_fwd': bool(v & 16)}
+
+
+def config() -> dict:
+    """Every form choice the library makes in this process (nnhip_config), as a dict."""
+    import json
+    L = lib()
+    L.nnhip_config.argtypes = [C.c_char_p, C.c_size_t]
+    L.nnhip_config.restype = C.c_int
+    buf = C.create_string_buffer(4096)
+    _check(L.nnhip_config(buf, 4096), 'nnhip_config')
+    return json.loads(buf.value.decode())
 
 
 def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:

@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes as C
 
 import os
+import threading
 import time
 
 import torch
@@ -43,6 +44,51 @@ def _versions(tensors):
         except RuntimeError:
             out.append(None)
     return tuple(out)
+
+
+_LOCK_CREATION = threading.Lock()
+
+
+class _CallGuard:
+    """One eval-mode call (or the repeat of one) at a time per module, ordered on the GPU behind the module's previous call.
+
+    The module keeps per-module state between calls -- the workspace, the prepared block, the pinned slots of the deferred
+    checks, the capacity hints -- and the reference's callers are single-threaded on one stream ("kernels launch on
+    the current stream, no global state").  Two things make other callers safe: a re-entrant lock around the host side of a call
+    (two Python threads sharing a module take turns), and, when the current stream is not the stream of the module's previous
+    call, `current.wait_stream(previous)` before anything is queued (the shared workspace is then never written by two streams
+    at once) plus `record_stream` on the cached tensors (the caching allocator must not hand their blocks out while this stream
+    still reads them).  Costs one dict lookup and an uncontended lock per call on the usual one-stream path."""
+    __slots__ = ('owner', 'device')
+
+    def __init__(self, owner, device):
+        self.owner, self.device = owner, device
+
+    def __enter__(self):
+        d = self.owner.__dict__
+        lock = d.get('_call_lock')
+        if lock is None:
+            with _LOCK_CREATION:
+                lock = d.setdefault('_call_lock', threading.RLock())
+        lock.acquire()
+        cur = torch.cuda.current_stream(self.device)
+        prev = d.get('_last_stream')
+        if prev is not None and prev != cur:
+            if prev.device == cur.device:
+                cur.wait_stream(prev)
+            for name in ('_infer_ws',):
+                t = d.get(name)
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
+            blk = d.get('_prep_block')
+            if blk is not None and isinstance(blk[1], torch.Tensor):
+                blk[1].record_stream(cur)
+        d['_last_stream'] = cur
+        return self
+
+    def __exit__(self, *exc):
+        self.owner.__dict__['_call_lock'].release()
+        return False
 
 
 class _Deferred:
@@ -113,6 +159,14 @@ class _Deferred:
 
     def settle(self):
         if self.state == _Deferred.DONE:
+            if self.error is not None:
+                raise self.error
+            return self
+        with _CallGuard(self.owner, self.inputs[1].device):     # (a repeat touches the module's workspace: same rules as a call)
+            return self._settle_locked()
+
+    def _settle_locked(self):
+        if self.state == _Deferred.DONE:                        # (another thread settled it while this one waited for the lock)
             if self.error is not None:
                 raise self.error
             return self
@@ -210,7 +264,7 @@ class NewtonNet(nn.Module):
     def __getstate__(self):
         """Whole-module pickles (trainer.py:219) carry parameters and structure only: the training workspaces stay behind."""
         state = self.__dict__.copy()
-        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_param_stamp', '_param_epoch', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache', '_deferred_stats'):
+        for k in ('_train_ws', '_static_train_graph', '_infer_ws', '_prep_block', '_edge_hint', '_mol_hint', '_param_stamp', '_param_epoch', '_tail_ring', '_last_deferred', '_force_sync', '_model_cache', '_deferred_stats', '_call_lock', '_last_stream'):
             state.pop(k, None)
         return state
 
@@ -390,7 +444,7 @@ class NewtonNet(nn.Module):
         if train_graph:
             return self._forward_train(z, pos, cell, batch, keys, energy_idx, make_displacement())
 
-        with torch.no_grad():
+        with torch.no_grad(), _CallGuard(self, pos.device):
             # bookkeeping of the previous deferred call (edge-count hint, stale prepared block); raises ITS deferred error when
             # nobody has looked at its outputs yet
             self._settle_last()

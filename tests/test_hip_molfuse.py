@@ -46,7 +46,7 @@ def fused_launches(fn):
     return res, tm['mol_fwd'][1], tm['mol_bwd'][1]
 
 
-def molecule_zoo(gen):
+def molecule_zoo(gen, clusters=True):
     """40 aspirin conformers; ethanol-sized and smaller fragments; single atoms and a far-apart pair (rows without edges); a
     24-atom cluster with all 276 pairs inside the cutoff (two rounds of pair tiles in the fused kernels) and a 23-atom one."""
     a = util.load_npz('aspirin_frames.npz')
@@ -58,7 +58,7 @@ def molecule_zoo(gen):
     for n in (9, 5, 3, 2, 1, 1):
         zs.append(zb[:n]), ps.append(base[:n] + 0.05 * torch.randn(n, 3, generator=gen))
     zs.append(zb[:2]), ps.append(torch.tensor([[0.0, 0.0, 0.0], [7.5, 0.0, 0.0]]))       # beyond the cutoff: no edge
-    for n in (24, 23):
+    for n in ((24, 23) if clusters else ()):
         # points on a jittered 3x3x3 lattice 1.15 A apart: diameter < 4.3 A, every pair an edge, no close contacts
         grid = torch.stack(torch.meshgrid(*[torch.arange(3)] * 3, indexing='ij'), dim=-1).reshape(-1, 3)[:n].float()
         zs.append(zb[torch.randint(0, 21, (n,), generator=gen)]), ps.append(1.15 * grid + 0.08 * torch.randn(n, 3, generator=gen))
@@ -72,7 +72,9 @@ def molecule_zoo(gen):
 def test_fused_edge_phase_against_the_oracle(which):
     from oracle import newtonnet_ref as ref
     gen = torch.Generator().manual_seed(11)
-    z, pos, cell, batch, sizes = molecule_zoo(gen)
+    # (the dense lattice clusters only with the random weights: the trained model explodes on them -- energies of 1e20 eV -- and
+    # nothing can be said about fp32 sums of such terms)
+    z, pos, cell, batch, sizes = molecule_zoo(gen, clusters=which == 'rand')
     model, sd = make_model(which)
     args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
     with fused_mode(1):
@@ -85,16 +87,14 @@ def test_fused_edge_phase_against_the_oracle(which):
     o = ref.energy_forces({k: v.double() for k, v in sd.items()}, z, pos.double(), cell.double(), batch)
     assert np.array_equal(out.edge_index.cpu().numpy(), o['edge_index'].numpy())
     pairs = np.bincount(batch.numpy()[o['edge_index'][0].numpy()], minlength=len(sizes)) // 2
-    assert pairs.max() == 276 and (pairs == 0).sum() >= 3, pairs     # the two-round molecule and the edge-free ones are in
+    assert pairs.max() == (276 if which == 'rand' else pairs.max()) and (pairs == 0).sum() >= 3, pairs     # the two-round molecule and the edge-free ones are in
     f_ref = o['forces'].numpy()
     fscale = max(1.0, float(np.abs(f_ref).max()) / 5.0)
     d = np.abs(f.astype(np.float64) - f_ref)
     print(f'fused edge phase ({which}): force MAE {d.mean():.2e} max {d.max():.2e} (max |F| {np.abs(f_ref).max():.1f})')
     check_forces(f, f_ref, fscale)
     e_ref = o['energy'].numpy()
-    # (the trained model explodes on the two dense lattice clusters -- energies of 1e20 eV, forces of 1e22 eV/A: a relative bound
-    # there, the 2-ulp bound everywhere else)
-    assert np.all(np.abs(e - e_ref) <= np.maximum(util.energy_tol(e_ref), 1e-5 * np.abs(e_ref))), np.abs(e - e_ref).max()
+    assert np.all(np.abs(e - e_ref) <= util.energy_tol(e_ref)), np.abs(e - e_ref).max()
     np.testing.assert_allclose(a_node.numpy(), o['atom_node'].numpy(), rtol=2e-4, atol=2e-5 * fscale)
     np.testing.assert_allclose(f_node.numpy(), o['force_node'].numpy(), rtol=2e-4, atol=2e-5 * fscale)
     # ... and next to the row path on the same inputs

@@ -449,6 +449,94 @@ def test_permuted_batch_vector_on_the_per_molecule_deferred_path():
     assert torch.equal(again.energy, want[0]) and torch.equal(again.gradient_force, want[1])
 
 
+def test_one_module_on_two_streams_and_from_two_threads():
+    """VERDICT r04 item 7 / SURVEY 8(b) "kernels launch on the current stream, no global state": the module keeps its workspace,
+    prepared block and deferred-check slots per MODULE.  Calls that alternate between two streams, and two Python threads that
+    share the module (each on its own stream, each with its own batch), must return bit for bit what a fresh module returns on
+    the default stream -- `_CallGuard` orders a call behind the module's previous one (wait_stream) and serialises the host side."""
+    import threading
+    from newtonnet_amd.models import NewtonNet
+    a = util.load_npz('aspirin_frames.npz')
+    gen = torch.Generator().manual_seed(17)
+    model, _ = make_model('rand')
+
+    def batch_of(B):
+        n = 21
+        pos = torch.from_numpy(a['train_pos'][0]).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)
+        return (torch.from_numpy(a['z']).long().repeat(B).cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'),
+                torch.repeat_interleave(torch.arange(B), n).cuda())
+
+    def fresh(args):
+        m = NewtonNet(output_properties=['energy', 'gradient_force'])
+        m.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        m = m.cuda()
+        m.eval()
+        o = m(*args)
+        return o.energy.clone(), o.gradient_force.clone()
+
+    batches = [batch_of(48), batch_of(48), batch_of(300), batch_of(7)]      # (two of one shape: the deferred path; two others)
+    want = [fresh(b) for b in batches]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # (1) one thread, alternating streams, results read on the stream that produced them
+    for k in range(16):
+        b = k % len(batches)
+        with torch.cuda.stream(streams[k % 2]):
+            o = model(*batches[b])
+            e, f = o.energy.clone(), o.gradient_force.clone()
+        streams[k % 2].synchronize()
+        assert torch.equal(e, want[b][0]) and torch.equal(f, want[b][1]), f'call {k} (batch {b}, stream {k % 2})'
+    # (2) two threads, one stream each, interleaving freely
+    errors = []
+
+    def worker(tid):
+        try:
+            with torch.cuda.stream(streams[tid]):
+                for k in range(24):
+                    b = (2 * k + tid) % len(batches)
+                    o = model(*batches[b])
+                    e, f = o.energy.clone(), o.gradient_force.clone()
+                    streams[tid].synchronize()
+                    if not (torch.equal(e, want[b][0]) and torch.equal(f, want[b][1])):
+                        errors.append(f'thread {tid} call {k} batch {b}: max |dF| {(f - want[b][1]).abs().max().item():.3e}')
+        except Exception as exc:  # noqa: BLE001
+            errors.append(f'thread {tid}: {type(exc).__name__}: {exc}')
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
+    # the module still serves the default stream afterwards
+    o = model(*batches[2])
+    assert torch.equal(o.energy, want[2][0]) and torch.equal(o.gradient_force, want[2][1])
+
+
+@pytest.mark.parametrize('tag,env', [
+    ('molecule forms off', {'NNHIP_FORCE_FWD_MOL': '0', 'NNHIP_MSG_BWD_MOL': '0', 'NNHIP_HEAD_OUT_MOL': '0', 'NNHIP_FORCE_DIRECT_MOL': '0',
+                            'NNHIP_GRAPH_MOL': '0'}),
+    ('one wave per row', {'NNHIP_EDGE_WPR': '1'}),
+    ('four waves per row', {'NNHIP_EDGE_WPR': '4'}),
+    ('fused edge phase', {'NNHIP_MOL_FUSED': '1'}),
+])
+def test_non_default_forms_in_child_processes(tag, env):
+    """VERDICT r04 item 7: the library picks one of several forms of most kernels by batch shape (hip.config() lists the choices);
+    the forms it does NOT pick by default stay reachable through NNHIP_* switches that are read once per process.  A child pytest
+    per switch set runs the golden cases, the random batches against the oracle, the deferred-step fuzz and the config-2-size
+    properties with that form forced, so the non-default forms are oracle-checked at scale too, not only A/B-timed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child_env = dict(os.environ, **env)
+    sel = 'test_golden_case or test_random_batches_against_oracle or test_deferred_step_fuzz or test_properties_config2_size'
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_hip_parity.py'), '-q', '-x', '-k', sel],
+                       cwd=root, env=child_env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout or '')[-2500:] + (r.stderr or '')[-1500:]
+    assert r.returncode == 0, f'[{tag}] {tail}'
+    assert ' passed' in r.stdout and 'failed' not in r.stdout.splitlines()[-1], f'[{tag}] {tail}'
+
+
 def test_deferred_step_fuzz():
     """tools/fuzz_deferred.py, 30 rounds: random molecule counts (1..1200) and sizes (1..30, now and then 40 or 1100 atoms), periodic
     or not, two batches per shape whose molecule sizes differ (the deferred step's guess about them goes wrong both ways): every

@@ -17,5 +17,6 @@ sha="$(cat profiles/.tree_sha 2>/dev/null || echo unknown)"
 { echo "# tree $sha"; echo "# cmd python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-leg (every row belongs to the inference step)"; python3 tools/rocpd_stats.py $out/${tag}_trace/t_results.db --by-grid; } > $out/${tag}_kernel_stats.txt
 { echo "# tree $sha"; echo "# cmd bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-leg"; python3 tools/rocpd_pmc.py $out/${tag}_fetch/f_results.db; } > $out/${tag}_pmc_fetch_size.txt
 { echo "# tree $sha"; echo "# cmd bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-leg"; python3 tools/rocpd_pmc.py $out/${tag}_write/w_results.db; } > $out/${tag}_pmc_write_size.txt
+python3 -c "import bench; print(bench.csrc_digest())" > $out/${tag}_csrc_sha.txt   # -> profiles/.csrc_sha when these summaries are committed
 rm -rf $out/${tag}_trace $out/${tag}_fetch $out/${tag}_write
 head -25 $out/${tag}_kernel_stats.txt; head -12 $out/${tag}_pmc_fetch_size.txt; head -12 $out/${tag}_pmc_write_size.txt
