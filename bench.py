@@ -317,7 +317,7 @@ def pmc_traffic(kernels):
     kernel (the config-2 batch) counts.  Returns ({kernel row name: (launches, bytes per launch)}, source) or (None, None)."""
     import glob
     def keep(f):      # the config-2 inference passes only
-        return not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_'))
+        return not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_', 'fused'))
     fetch = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')) if keep(f)), key=_profile_order)
     write = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')) if keep(f)), key=_profile_order)
     if not fetch or not write:
@@ -332,6 +332,32 @@ def pmc_traffic(kernels):
         return None, None
     return out, (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
                  + (f' [{notes[0]}]' if notes else ' [round-1 tree]'))
+
+
+def pmc_step_total():
+    """HBM bytes of ONE whole step (every kernel) from the latest stored config-2 PMC passes: sum over all rows of calls x
+    (2 x FETCH_SIZE + WRITE_SIZE) / steps seen (msg_fwd runs three times per step).  The passes run with --no-train-leg: every row
+    belongs to the inference step (its first synchronous calls and the parameter preparation included, a few per cent)."""
+    import glob
+    def keep(f):
+        return not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_', 'fused'))
+    fetch = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.txt')) if keep(f)), key=_profile_order)
+    write = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.txt')) if keep(f)), key=_profile_order)
+    if not fetch or not write:
+        return None
+    (tf, _), (tw, _) = _profile_table(fetch[-1]), _profile_table(write[-1])
+    steps = None
+    for name, grids in tf.items():
+        if _kernel_match(name, 'msg_fwd_kernel'):
+            steps = _largest_grid(grids)[0] / 3.0
+    if not steps:
+        return None
+    tot = 0.0
+    for name, grids in tf.items():
+        for g, v in grids.items():
+            w = tw.get(name, {}).get(g)
+            tot += v[0] * (2.0 * v[2] + (w[2] if w else 0.0)) * 1024.0
+    return tot / steps
 
 
 # (the *_mol_kernel forms -- one workgroup per molecule, node rows staged in LDS -- serve batches of small molecules: edge.hip)
@@ -350,7 +376,7 @@ def rocprof_classes():
     --no-train-leg (header note), where every row belongs to the inference step."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats.txt')), key=_profile_order)
-    files = [f for f in files if not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_'))]   # the config-2 inference passes only
+    files = [f for f in files if not any(t in os.path.basename(f) for t in ('train', 'box', 'interleaved', '_md_', 'fused'))]   # the config-2 inference passes only
     if not files:
         return None
     rows, notes = _profile_table(files[-1])
@@ -1091,7 +1117,8 @@ def main():
             'deferred': deferred,
             'timing_anomaly': bool((classes and host_gap > 0.15 * kernel_sum) or repeats > 0),
             'edge_kernel_frac': {k: v['frac_pair_bytes'] for k, v in (edge_all_roofline or {}).get('per_kernel', {}).items()},
-            'counter_GB_per_step': (round((edge_all_roofline or {}).get('counter_bytes_per_step', 0) / 1e9, 3) or None) if quotes_profiles else None,
+            'counter_GB_per_step': {'edge_kernels': round((edge_all_roofline or {}).get('counter_bytes_per_step', 0) / 1e9, 3) or None,
+                                    'whole_step': round((pmc_step_total() or 0) / 1e9, 3) or None} if quotes_profiles else None,
             'profiles': dict(pstate, quoted=quotes_profiles),
             'train_small': {'ms_per_step': train.get('ms_per_step'), 'allreduce_us': train.get('allreduce_us'),
                             'in_sync': train.get('replicas_in_sync'), 'error': train.get('error')} if train else None,

@@ -11,7 +11,7 @@ if [ "${1:-run}" = build ]; then
   NNHIP_LIB_NAME=libabl_ALL.so bash newtonnet_amd/csrc/build.sh -DEDGE_ABL_NOTAB -DEDGE_ABL_NOMJ -DEDGE_ABL_STORE > /dev/null && echo built ALL
 else
   for v in "${variants[@]}" NOTAB_NOMJ ALL; do
-    NNHIP_ALLOW_TOOLING_LIB=1 NNHIP_LIB_NAME=libabl_$v.so python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-leg 2>/dev/null | python3 -c "
+    NNHIP_ALLOW_TOOLING_LIB=1 NNHIP_LIB_NAME=libabl_$v.so python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-train-leg --no-strong-leg --no-box-leg 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); c=d['kernel_classes']
 print('$v', d['ms_per_step'], {k: round(v['ms_per_step'],3) for k,v in c.items() if k.startswith('edge')})"

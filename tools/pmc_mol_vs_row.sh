@@ -12,7 +12,7 @@ for form in mol row; do
   i=0
   for set in "TA_TA_BUSY_sum TCC_BUSY_sum GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" "MemUnitBusy MemUnitStalled" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $set -d $out/${tag}_${form}_p$i -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-leg --warm-seconds 0.1 --regions 1 > $out/${tag}_${form}_p$i.log 2>&1
+    rocprofv3 --kernel-trace --pmc $set -d $out/${tag}_${form}_p$i -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train-leg --no-strong-leg --no-box-leg --warm-seconds 0.1 --regions 1 > $out/${tag}_${form}_p$i.log 2>&1
     { echo "## $form form: $set"; python3 tools/rocpd_pmc.py $out/${tag}_${form}_p$i/p_results.db | grep -i "kernel \|force_fwd\|msg_bwd"; } >> $out/${tag}.txt 2>&1
     rm -rf $out/${tag}_${form}_p$i
   done
