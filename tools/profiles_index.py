@@ -33,7 +33,7 @@ PATTERNS = [
     (r'pmc_mfma\.txt$|pmc_sq_.*\.txt$', 'rocprofv3 matrix-pipe / SQ busy counters of the dense kernels'),
     (r'pmc_mol_vs_row.*\.txt$|split_rows_pmc.*\.txt$', 'rocprofv3 counters of two forms of an edge kernel side by side'),
     (r'phase_clock.*\.txt$', 'wall-clock stamps behind every workgroup barrier of a kernel (tooling build)'),
-    (r'timeline\.txt$', 'dispatch timeline of one step (start / end / gap of every kernel): idle time between launches'),
+    (r'timeline.*\.txt$', 'dispatch timeline of one step (start / end / gap of every kernel): idle time between launches'),
     (r'md_latency.*\.txt$', 'one-molecule latency path: model() / calculator step times (tools/bench_latency.py)'),
     (r'host_profile.*\.txt$', 'cProfile of the host side of a one-molecule call'),
     (r'sweep_.*\.txt$', 'throughput sweep over batch sizes / molecule shapes'),
