@@ -23,7 +23,7 @@ if [ ${#extra[@]} -gt 0 ]; then
   extra+=("-DNNHIP_TOOLING=1")
 fi
 mkdir -p "$objdir"
-srcs=(graph edge lin128 mlp128 mlp128s mlp128r node128 node128s pipeline train train_step heads small molfuse)
+srcs=(graph edge lin128 mlp128 mlp128s mlp128r node128 node128s pipeline train train_step heads small molfuse molfuse2)
 newest_header=$(ls -t "$here"/*.h "$here"/../../include/*.h | head -1)
 jobs="${NNHIP_BUILD_JOBS:-8}"
 pids=()

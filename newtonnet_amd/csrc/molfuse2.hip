@@ -1,0 +1,901 @@
+// Molecule-resident fused edge phase, second form (round 5): TWO workgroups per CU.
+//
+// molfuse.hip runs a molecule's edge phase as one 8-wave workgroup with a weight matrix in LDS -- 158 KB of LDS and the whole register
+// file of a CU, so nothing overlaps its ~17 barrier-separated phases.  This form spends half of each: a 4-wave
+// workgroup (256 threads x 256 registers), 80 KB of LDS, so that two molecules share a CU and one's latencies run under the other's
+// matrix work.  What makes it fit:
+//   * the edge MLPs stream the molecule's pair tiles ONE AT A TIME through a 17 KB operand tile (node128s.hip's row-local scheme:
+//     wave w = output block w of every GEMM, the weight fragments of its block resident in REGISTERS for all tiles of the molecule --
+//     2 x 64 registers per MLP, read once per workgroup from the fragment-order images; rows scaled by their maximum through a
+//     publish / commit exchange; the hidden tile and the phi tile share one LDS buffer);
+//   * the messages are formed row by row as msg_fwd_kernel does (m staged in LDS; msg rows go to the L2 and come back tile by tile
+//     microseconds later), so neither the radial-filter rows nor all message tiles ever sit in LDS together;
+//   * the force-message sums live in 36 registers per lane (wave w owns atoms w, w + 4, ...; a full wave per incidence, two features
+//     per lane), added tile by tile in pair order: deterministic, no float atomics.
+// Global formats are the row path's (a_mid, f_out, msg, phi1 / phi2 [P][128], silu'(h) in mlp128s.hip's fragment order by GLOBAL
+// pair tile), as in molfuse.hip: the adjoint of either path can follow.
+// Reference semantics: newtonnet/models/newtonnet.py:207-227.
+#include <stdlib.h>
+
+#include "common.h"
+
+#include "edge_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define M2_WAVES 4
+#define M2_THREADS (64 * M2_WAVES)
+#define M2_ATOMS NNHIP_MOL_STAGE_MAX
+#define M2_EDGES (M2_ATOMS * (M2_ATOMS - 1))
+#define M2_PAIRS (M2_EDGES / 2)
+#define M2_MAX_TILES ((M2_PAIRS + 31) / 32)           // 9
+#define M2_OWN ((M2_ATOMS + M2_WAVES - 1) / M2_WAVES) // atoms per wave: 6
+#define M2_PITCH 272                                  // bytes per row of one f16 plane (128 f16 + 16 pad: conflict-free ds_read_b128)
+#define M2_PLANE (32 * M2_PITCH)
+#define M2_TILE (2 * M2_PLANE)                        // 17 408
+#define M2_PHI_PITCH 132                              // floats per row of the fp32 phi tile (aliases the hidden tile)
+#define M2_WIMG_PLANE (NF * NF * 2)
+// LDS: operand tile | hidden tile (= phi tile) | row maxima | f_in | geo | xg | (spare) | rowb | pij;  m aliases the operand tile in pass 1
+#define M2_OFF_H M2_TILE
+#define M2_OFF_PMAX (2 * M2_TILE)
+#define M2_OFF_F (M2_OFF_PMAX + 8 * 32 * 4)
+#define M2_OFF_GEO (M2_OFF_F + 3 * M2_ATOMS * NF * 4)
+#define M2_OFF_XG (M2_OFF_GEO + M2_PAIRS * 16)
+#define M2_OFF_INC (M2_OFF_XG + M2_PAIRS * 8)
+#define M2_OFF_ROWB (M2_OFF_INC + M2_EDGES * 2)
+#define M2_OFF_PIJ (M2_OFF_ROWB + (M2_ATOMS + 1) * 4 + 4)
+#define M2_LDS (M2_OFF_PIJ + M2_PAIRS * 2 + 8)
+static_assert(M2_LDS <= 81920, "two workgroups per CU");
+static_assert(32 * M2_PHI_PITCH * 4 <= M2_TILE && M2_ATOMS * NF * 4 <= M2_TILE, "aliases: m over the operand tile, the fp32 tile over the hidden tile");
+
+// tooling (-DMF_CLOCK_DEBUG): wall-clock stamps (100 MHz) of the first workgroup
+struct M2Dbg {
+#ifdef MF_CLOCK_DEBUG
+  long long w[48];
+  int n;
+  __device__ __forceinline__ void init() { n = 0; w[n++] = wall_clock64(); }
+  __device__ __forceinline__ void stamp() { if (n < 48) w[n++] = wall_clock64(); }
+  __device__ __forceinline__ void print(const char* tag) {
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0) {
+      printf("%s b%d:", tag, (int)blockIdx.x);
+      for (int k = 1; k < n; ++k) printf(" %.2f", (double)(w[k] - w[k - 1]) / 100.0);
+      printf("  total %.2f us\n", (double)(w[n - 1] - w[0]) / 100.0);
+    }
+  }
+#else
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void stamp() {}
+  __device__ __forceinline__ void print(const char*) {}
+#endif
+};
+
+struct M2Frag {
+  h8 hi[8], lo[8];
+  float inv;
+};
+__device__ __forceinline__ void m2_pow2_scale(float m, float& S, float& inv) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+  const bool ok = e >= 40 && e < 255;
+  S = ok ? __uint_as_float((unsigned)(268 - e) << 23) : 1.0f;
+  inv = ok ? __uint_as_float((unsigned)(e - 14) << 23) : 1.0f;
+}
+// A fragments of output block nb from a fragment-order weight image (node128s.hip:load_wimg)
+__device__ __forceinline__ void m2_load_w(M2Frag& w, const char* __restrict__ img, int nb, int r, int h) {
+  const char* p = img + ((size_t)(nb * 8 * 64 + h * 32 + r) << 4);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    w.hi[T] = *reinterpret_cast<const h8*>(p + 1024 * T);
+    w.lo[T] = *reinterpret_cast<const h8*>(p + M2_WIMG_PLANE + 1024 * T);
+  }
+  w.inv = *reinterpret_cast<const float*>(img + 2 * M2_WIMG_PLANE);
+}
+__device__ __forceinline__ float m2_amax16(const float (&v)[16]) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m = fmaxf(m, fabsf(v[k]));
+  return m;
+}
+// after the barrier that follows the publish: row scale, split, write this lane's 16 values of row r into the fragment-ordered planes
+// v[4 q + c] = feature nb*32 + 8 q + 4 h + c  ->  k-slot (2 nb + (q >> 1)) * 16 + 8 h + 4 (q & 1) + c   (node128s.hip:tile_commit)
+__device__ __forceinline__ float m2_commit(const float (&v)[16], char* tile, const float* pmax, int nb, int r, int h) {
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, pmax[j * 32 + r]);
+  float S, inv;
+  m2_pow2_scale(m, S, inv);
+  char* row = tile + r * M2_PITCH + 2 * (nb * 32 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = v[4 * q + c] * S;
+      const _Float16 a = (_Float16)s;
+      hi[c] = a;
+      lo[c] = (_Float16)(s - (float)a);
+    }
+    const int off = 2 * ((q >> 1) * 16 + (q & 1) * 4);
+    *reinterpret_cast<h4*>(row + off) = hi;
+    *reinterpret_cast<h4*>(row + M2_PLANE + off) = lo;
+  }
+  return inv;
+}
+// block nb of D^T = W . X^T for the 32 rows of the LDS tile (node128s.hip:tile_gemm_s)
+__device__ __forceinline__ void m2_gemm(float (&out)[16], const char* tile, const M2Frag& w, float inv_row, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const char* xr = tile + r * M2_PITCH + 16 * h;
+  h8 bh0 = *reinterpret_cast<const h8*>(xr), bl0 = *reinterpret_cast<const h8*>(xr + M2_PLANE);
+  h8 bh1 = *reinterpret_cast<const h8*>(xr + 32), bl1 = *reinterpret_cast<const h8*>(xr + M2_PLANE + 32);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    h8 bh2, bl2;
+    if (T < 6) {
+      bh2 = *reinterpret_cast<const h8*>(xr + 32 * (T + 2));
+      bl2 = *reinterpret_cast<const h8*>(xr + M2_PLANE + 32 * (T + 2));
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bh0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.hi[T], bl0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.lo[T], bh0, acc, 0, 0, 0);
+    bh0 = bh1;
+    bl0 = bl1;
+    if (T < 6) {
+      bh1 = bh2;
+      bl1 = bl2;
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const float sc = inv_row * w.inv;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[k] = acc[k] * sc;
+}
+
+struct Mol2FwdArgs {
+  const int *mol_ptr, *row_ptr, *pair_ptr, *col, *pid;
+  const float* geo;
+  const int2* xg;
+  const float *m, *a_in, *f_in, *table;
+  const char *img10, *img12, *img20, *img22;
+  float *a_mid, *f_out, *h1, *h2, *phi1, *phi2, *msg;
+  int n_mol;
+};
+
+template <bool HAS_F>
+__global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2FwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* xt = lds;
+  char* ht = lds + M2_OFF_H;
+  float* phit = reinterpret_cast<float*>(lds + M2_OFF_H);
+  float* pmax = reinterpret_cast<float*>(lds + M2_OFF_PMAX);
+  float* sm_m = reinterpret_cast<float*>(lds);                       // pass 1 only
+  float* sm_f = reinterpret_cast<float*>(lds + M2_OFF_F);
+  float4* sm_geo = reinterpret_cast<float4*>(lds + M2_OFF_GEO);
+  int2* sm_xg = reinterpret_cast<int2*>(lds + M2_OFF_XG);
+  int* sm_rowb = reinterpret_cast<int*>(lds + M2_OFF_ROWB);
+  unsigned short* sm_pij = reinterpret_cast<unsigned short*>(lds + M2_OFF_PIJ);   // [pair] i | j << 8 (molecule-local)
+
+  const int b = blockIdx.x;
+  if (b >= A.n_mol) return;
+  const int a0 = A.mol_ptr[b], n = A.mol_ptr[b + 1] - a0;
+  if (n <= 0 || n > M2_ATOMS) return;                                // (uniform; see molfuse.hip:mf_molecule)
+  const int E0 = A.row_ptr[a0], nE = A.row_ptr[a0 + n] - E0;
+  const int P0 = A.pair_ptr[a0], nP = A.pair_ptr[a0 + n] - P0;
+  if (nE < 0 || nE > M2_EDGES || nP < 0 || nP > M2_PAIRS || nE != 2 * nP) return;
+  const int tid = threadIdx.x, lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
+  const bool hi = h != 0;
+  const int nT = (nP + 31) >> 5;
+
+  M2Dbg dbg;
+  dbg.init();
+  // ---- the first MLP's fragments are requested before anything else (they arrive under the list and message passes)
+  M2Frag w1, w2;
+  m2_load_w(w1, A.img10, nb, r, h);
+  m2_load_w(w2, A.img12, nb, r, h);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- lists: wave w walks the rows of ITS atoms (w, w + 4, ...), a lane per edge.  The row's incidence descriptors stay in
+  // the wave's registers (inc_k[k], lane l = edge l of the row; rt_k[k], lane t = how many of the row's pairs lie below tile t):
+  // the sums below fetch them with v_readlane -- no LDS round trip between an incidence and its rows.
+  if (tid <= n) sm_rowb[tid] = A.row_ptr[a0 + tid] - E0;
+  {
+    const float4* s = reinterpret_cast<const float4*>(A.m + (size_t)a0 * NF);
+    for (int t = tid; t < n * 32; t += M2_THREADS) reinterpret_cast<float4*>(sm_m)[t] = s[t];
+    if (HAS_F) {
+      const float4* sf = reinterpret_cast<const float4*>(A.f_in + (size_t)a0 * 3 * NF);
+      for (int t = tid; t < n * 96; t += M2_THREADS) reinterpret_cast<float4*>(sm_f)[t] = sf[t];
+    }
+  }
+  int inc_k[M2_OWN], rt_k[M2_OWN];
+  {
+    // (three rounds of independent loads: extents of the wave's six rows; their col / pid / geo / xg entries; then the arithmetic)
+    int beg_k[M2_OWN], deg_k[M2_OWN], col_k[M2_OWN], pid_k[M2_OWN];
+    float4 geo_k[M2_OWN];
+    int2 xg_k[M2_OWN];
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      beg_k[k] = a < n ? A.row_ptr[a0 + a] : 0;
+      deg_k[k] = a < n ? A.row_ptr[a0 + a + 1] - beg_k[k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int e = beg_k[k] + (lane < deg_k[k] ? lane : 0);
+      const bool on = lane < deg_k[k];
+      col_k[k] = on ? A.col[e] : 0;
+      pid_k[k] = on ? A.pid[e] : 0;
+      geo_k[k] = on ? reinterpret_cast<const float4*>(A.geo)[e] : make_float4(0.f, 0.f, 0.f, 1.f);
+      xg_k[k] = on ? A.xg[e] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      int inc = 0x7fff, rt = 0, p = 0x3fff;
+      if (lane < deg_k[k]) {
+        int j = col_k[k] - a0;
+        p = pid_k[k] - P0;
+        j = min(max(j, 0), n - 1);              // (a valid list never needs these; they keep every LDS index inside its array)
+        p = min(max(p, 0), max(nP - 1, 0));
+        const bool own = j > a;
+        inc = p | (j << 9) | (own ? (1 << 14) : 0);
+        if (own) {
+          sm_geo[p] = geo_k[k];
+          sm_xg[p] = xg_k[k];
+          sm_pij[p] = (unsigned short)(a | (j << 8));
+        }
+      }
+      if (a < n) {
+#pragma unroll
+        for (int t = 0; t <= M2_MAX_TILES; ++t) {
+          const int c = __popcll(__ballot(p < 32 * t));
+          if (lane == t) rt = c;
+        }
+      }
+      inc_k[k] = inc;
+      rt_k[k] = rt;
+    }
+  }
+  __syncthreads();
+  dbg.stamp();
+  // ---- pass 1: the messages, once per pair (a half-wave per pair, four pairs in flight: msg = eps * m[i] * m[j], newtonnet.py:210-211),
+  // a tile of 32 pairs at a time: rows to the L2 (the MLPs read them back tile by tile) and into an fp32 tile behind m, from which
+  // a_mid = a_in + sum of the messages of a's edges (newtonnet.py:213-215) is formed by the owner waves.  The radial-filter rows
+  // of the NEXT tile are requested before this tile's sums (they fly under them).
+  {
+    float2 acc_a[M2_OWN];
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) acc_a[k] = make_float2(0.f, 0.f);
+    float4 trow[4][4];
+    FilterW fw[4];
+    auto request = [&](int t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pl = 32 * t + 8 * u + 2 * nb + h;
+        const int2 gx = sm_xg[pl < nP ? pl : 0];
+        fw[u] = filter_weights(__int_as_float(gx.y));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) trow[u][q] = ld4(A.table + (size_t)(gx.x + q) * NF + c4);    // (edge_common.h:filter_value)
+      }
+    };
+    if (nT > 0) request(0);
+#pragma unroll 1
+    for (int t = 0; t < nT; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pl = 32 * t + 8 * u + 2 * nb + h;
+        if (pl < nP) {
+          float4 eps = mul4(trow[u][0], fw[u].w[0]);
+#pragma unroll
+          for (int q = 1; q < 4; ++q) eps = fma4(trow[u][q], fw[u].w[q], eps);
+          const int ij = sm_pij[pl];
+          const float4 v = mul4(mul4(eps, *reinterpret_cast<const float4*>(sm_m + (ij & 255) * NF + c4)),
+                                *reinterpret_cast<const float4*>(sm_m + (ij >> 8) * NF + c4));
+          st4(A.msg + (size_t)(P0 + pl) * NF + c4, v);
+          *reinterpret_cast<float4*>(phit + (pl - 32 * t) * M2_PHI_PITCH + c4) = v;
+        }
+      }
+      __syncthreads();
+      if (t + 1 < nT) request(t + 1);
+#pragma unroll
+      for (int k = 0; k < M2_OWN; ++k) {
+        const int a = nb + M2_WAVES * k;
+        if (a < n) {
+          const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
+          for (int l = eb; l < ee; l += 2) {
+            const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], min(l + 1, ee - 1));
+            const float2 v0 = *reinterpret_cast<const float2*>(phit + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+            const float2 v1 = *reinterpret_cast<const float2*>(phit + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+            acc_a[k] = acc_a[k] + v0;
+            if (l + 1 < ee) acc_a[k] = acc_a[k] + v1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      if (a < n) st2(A.a_mid + (size_t)(a0 + a) * NF + c2, ld2(A.a_in + (size_t)(a0 + a) * NF + c2) + acc_a[k]);
+    }
+  }
+  __syncthreads();          // msg rows written (this workgroup reads them back below), m is dead: the tiles take its place
+  dbg.stamp();
+
+  // ---- pass 2: the edge MLPs, tile by tile, and the force-message sums
+  auto run_mlp = [&](auto MLP_) {
+    constexpr int mlp = decltype(MLP_)::value;     // (compile-time: each instantiation carries only its own sums)
+    if (mlp == 1) {
+      m2_load_w(w1, A.img20, nb, r, h);
+      m2_load_w(w2, A.img22, nb, r, h);
+    }
+    float* Hk = mlp ? A.h2 : A.h1;
+    float* Y = mlp ? A.phi2 : A.phi1;
+    float2 acc[M2_OWN][3];
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[k][q] = make_float2(0.f, 0.f);
+    // this lane's 16 values of a row: features nb*32 + 8 q + 4 h + c
+    float x[16];
+    auto load_x = [&](int t) {
+      const int pl = 32 * t + r;
+      const float4* xp = reinterpret_cast<const float4*>(A.msg + (size_t)(P0 + min(pl, max(nP - 1, 0))) * NF + nb * 32 + 4 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = (pl < nP) ? xp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+      }
+    };
+    if (nT > 0) load_x(0);
+#pragma unroll 1
+    for (int t = 0; t < nT; ++t) {
+      const int pl = 32 * t + r;
+      const bool live = pl < nP;
+      const size_t pg = (size_t)P0 + pl;
+      const size_t tile_g = pg >> 5;
+      const int lane_g = 32 * h + (int)(pg & 31);
+      // operand tile of stage 1
+      if (t < 2) dbg.stamp();
+      pmax[(nb * 2 + h) * 32 + r] = m2_amax16(x);
+      __syncthreads();
+      const float inv_x = m2_commit(x, xt, pmax, nb, r, h);
+      __syncthreads();
+      if (t < 2) dbg.stamp();
+      float hv[16];
+      m2_gemm(hv, xt, w1, inv_x, r, h);
+      // keep silu'(h) for the adjoint (fragment order of mlp128s.hip, by global pair tile), activate
+      {
+        float4* hp = reinterpret_cast<float4*>(Hk) + (tile_g * 4 + nb) * 256 + lane_g;
+        float keep[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float v = hv[k], s = sigmoid_f(v);
+          keep[k] = s * (1.0f + v * (1.0f - s));
+          hv[k] = v * s;
+        }
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            st4_nt(reinterpret_cast<float*>(hp + 64 * q), make_float4(keep[4 * q], keep[4 * q + 1], keep[4 * q + 2], keep[4 * q + 3]));
+        }
+      }
+      if (t < 2) dbg.stamp();
+      pmax[(nb * 2 + h) * 32 + r] = m2_amax16(hv);
+      __syncthreads();                                    // (also: every wave is past its last read of the previous phi tile)
+      const float inv_h = m2_commit(hv, ht, pmax, nb, r, h);
+      __syncthreads();
+      if (t < 2) dbg.stamp();
+      float y[16];
+      m2_gemm(y, ht, w2, inv_h, r, h);
+      if (live) {
+        float4* yp = reinterpret_cast<float4*>(Y + pg * NF + nb * 32 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yp[2 * q] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+      __syncthreads();                                    // every wave is done reading the hidden tile: phi takes its place
+      {
+        float* yr = phit + r * M2_PHI_PITCH + nb * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(yr + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+      }
+      __syncthreads();
+      if (t < 2) dbg.stamp();
+      if (t + 1 < nT) load_x(t + 1);                     // (the next tile's rows fly under this tile's sums; x is dead since its commit)
+      // force-message sums of this tile: a full wave per incidence (two features per lane), the wave's atoms one after the other,
+      // two incidences in flight; the descriptors come out of the wave's own registers (v_readlane)
+#pragma unroll
+      for (int k = 0; k < M2_OWN; ++k) {
+        const int a = nb + M2_WAVES * k;
+        if (a < n) {
+          const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
+          for (int l = eb; l < ee; l += 2) {
+            const bool two = l + 1 < ee;
+            const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
+            const int p0 = i0 & 511, p1 = i1 & 511;
+            const float2 v0 = *reinterpret_cast<const float2*>(phit + (p0 - 32 * t) * M2_PHI_PITCH + c2);
+            float2 v1 = *reinterpret_cast<const float2*>(phit + (p1 - 32 * t) * M2_PHI_PITCH + c2);
+            if (!two) v1 = make_float2(0.f, 0.f);
+            if (mlp == 0) {
+              const float4 g0 = sm_geo[p0], g1 = sm_geo[p1];
+              const float s0 = (i0 >> 14) & 1 ? 1.0f : -1.0f, s1 = (i1 >> 14) & 1 ? 1.0f : -1.0f;   // u of the reverse direction is -u
+              acc[k][0] = fma2(v1, s1 * g1.x, fma2(v0, s0 * g0.x, acc[k][0]));
+              acc[k][1] = fma2(v1, s1 * g1.y, fma2(v0, s0 * g0.y, acc[k][1]));
+              acc[k][2] = fma2(v1, s1 * g1.z, fma2(v0, s0 * g0.z, acc[k][2]));
+            } else {
+              const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+                acc[k][q] = fma2(v1, *reinterpret_cast<const float2*>(sm_f + (j1 * 3 + q) * NF + c2),
+                                 fma2(v0, *reinterpret_cast<const float2*>(sm_f + (j0 * 3 + q) * NF + c2), acc[k][q]));
+            }
+          }
+        }
+      }
+    }
+    dbg.stamp();
+    // f_out = f_in + sum (first MLP), += sum (second MLP: what this very lane wrote)
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      if (a < n) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float* fo = A.f_out + ((size_t)(a0 + a) * 3 + q) * NF + c2;
+          float2 base = make_float2(0.f, 0.f);
+          if (mlp == 1)
+            base = ld2(fo);
+          else if (HAS_F)
+            base = *reinterpret_cast<const float2*>(sm_f + (a * 3 + q) * NF + c2);
+          st2(fo, base + acc[k][q]);
+        }
+      }
+    }
+  };
+  run_mlp(std::integral_constant<int, 0>());
+  if (HAS_F) run_mlp(std::integral_constant<int, 1>());
+  dbg.stamp();
+  dbg.print(HAS_F ? "mol2_fwd<1>" : "mol2_fwd<0>");
+}
+
+int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                         const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
+                         const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
+                         float* h1, float* h2, float* phi1, float* phi2, float* msg, int n_mol, hipStream_t s) {
+  ScopedTimer t0(TC_MOL_FWD, s);
+  static const hipError_t rc0 = hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS);
+  static const hipError_t rc1 = hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS);
+  HIP_TRY(rc0);
+  HIP_TRY(rc1);
+  if (n_mol <= 0) return 0;
+  Mol2FwdArgs A = {mol_ptr, row_ptr, pair_ptr, col, pid, geo, reinterpret_cast<const int2*>(xg), m, a_in, f_in, table,
+                   img10, img12, img20, img22, a_mid, f_out, h1, h2, phi1, phi2, msg, n_mol};
+  if (has_f)
+    mol2_edge_fwd_kernel<true><<<n_mol, M2_THREADS, M2_LDS, s>>>(A);
+  else
+    mol2_edge_fwd_kernel<false><<<n_mol, M2_THREADS, M2_LDS, s>>>(A);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// -----------------------------------------------------------------------------------------------------------------------
+// adjoint, same organisation (4-wave workgroups, two per CU).  Passes of one workgroup, each inside 80 KB of LDS:
+//   B1a  gf staged; per pair tile the kept phi1 / phi2 rows staged: g_u of both directions, g_phi1 rows (to the L2) and
+//        g_fin = gf + sum phi2 * gf[j] (owner waves, registers)                                  (edge.hip:force_bwd_kernel)
+//   B1b  f_in staged next to gf: g_phi2 rows (to the L2)
+//   B2   per MLP, tile by tile: (g_phi_k W_k2) * silu'(h_k) W_k0 with the weight fragments in registers; the first MLP's term goes
+//        to the L2 and is added by the second one's last stage                                   (mlp128s.hip, adjoint mode)
+//   B3   inside the last MLP's tile loop: G = g_msg + g_a[i] + g_a[j] through an fp32 tile -> g_x (Hermite derivative of the radial
+//        filter), G eps -> g_m sums (owner waves, registers)                                     (edge.hip:msg_bwd_kernel)
+// -----------------------------------------------------------------------------------------------------------------------
+#define M2B_OFF_F (3 * M2_ATOMS * NF * 4)                  // f_in behind gf (B1b); the two phi tiles of B1a lie here too
+#define M2B_OFF_PHI2 (M2B_OFF_F + 32 * M2_PHI_PITCH * 4)
+#define M2B_OFF_LIST (2 * 3 * M2_ATOMS * NF * 4)           // 73 728: geo | xg | pij | rowb | pairb
+#define M2B_OFF_XG (M2B_OFF_LIST + M2_PAIRS * 16)
+#define M2B_OFF_PIJ (M2B_OFF_XG + M2_PAIRS * 8)
+#define M2B_OFF_ROWB (M2B_OFF_PIJ + M2_PAIRS * 2)
+#define M2B_OFF_PAIRB (M2B_OFF_ROWB + (M2_ATOMS + 1) * 4)
+#define M2B_LDS (M2B_OFF_PAIRB + (M2_ATOMS + 1) * 4 + 8)
+#define M2B_OFF_M (2 * M2_TILE + 8 * 32 * 4)               // B2: operand tile | hidden / fp32 tile | row maxima | m | g_a
+#define M2B_OFF_GA (M2B_OFF_M + M2_ATOMS * NF * 4)
+static_assert(M2B_LDS <= 81920, "two workgroups per CU");
+static_assert(M2B_OFF_PHI2 + 32 * M2_PHI_PITCH * 4 <= M2B_OFF_LIST && M2B_OFF_GA + M2_ATOMS * NF * 4 <= M2B_OFF_LIST, "overlays");
+
+struct Mol2BwdArgs {
+  const int *mol_ptr, *row_ptr, *pair_ptr, *col, *pid, *rev;
+  const float* geo;
+  const int2* xg;
+  const float *gf, *g_a, *m, *f_in, *table;
+  const char *img12T, *img10T, *img22T, *img20T;
+  const float *h1, *h2, *phi1, *phi2;
+  float *g_fin, *g_m, *g_x, *g_u;
+  float* g_phi;     // [P][256] scratch: g_phi1 | g_phi2 rows between B1 and B2 (the row path's g_h12 array)
+  float* g_msg;     // [P][128] scratch: the first MLP's term of g_msg
+  int n_mol;
+};
+
+template <bool LOWER>
+__global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* sm_gf = reinterpret_cast<float*>(lds);
+  float* sm_f = reinterpret_cast<float*>(lds + M2B_OFF_F);
+  float* phi1t = reinterpret_cast<float*>(lds + M2B_OFF_F);
+  float* phi2t = reinterpret_cast<float*>(lds + M2B_OFF_PHI2);
+  float4* sm_geo = reinterpret_cast<float4*>(lds + M2B_OFF_LIST);
+  int2* sm_xg = reinterpret_cast<int2*>(lds + M2B_OFF_XG);
+  unsigned short* sm_pij = reinterpret_cast<unsigned short*>(lds + M2B_OFF_PIJ);
+  int* sm_rowb = reinterpret_cast<int*>(lds + M2B_OFF_ROWB);
+  int* sm_pairb = reinterpret_cast<int*>(lds + M2B_OFF_PAIRB);
+  char* xt = lds;
+  char* ht = lds + M2_OFF_H;
+  float* phit = reinterpret_cast<float*>(lds + M2_OFF_H);
+  float* pmax = reinterpret_cast<float*>(lds + M2_OFF_PMAX);
+  float* sm_m = reinterpret_cast<float*>(lds + M2B_OFF_M);
+  float* sm_ga = reinterpret_cast<float*>(lds + M2B_OFF_GA);
+
+  const int b = blockIdx.x;
+  if (b >= A.n_mol) return;
+  const int a0 = A.mol_ptr[b], n = A.mol_ptr[b + 1] - a0;
+  if (n <= 0 || n > M2_ATOMS) return;
+  const int E0 = A.row_ptr[a0], nE = A.row_ptr[a0 + n] - E0;
+  const int P0 = A.pair_ptr[a0], nP = A.pair_ptr[a0 + n] - P0;
+  if (nE < 0 || nE > M2_EDGES || nP < 0 || nP > M2_PAIRS || nE != 2 * nP) return;
+  const int tid = threadIdx.x, lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
+  const int nT = (nP + 31) >> 5;
+  M2Dbg dbg;
+  dbg.init();
+
+  // ---- lists (as the forward) + gf
+  if (tid <= n) {
+    sm_rowb[tid] = A.row_ptr[a0 + tid] - E0;
+    sm_pairb[tid] = A.pair_ptr[a0 + tid] - P0;
+  }
+  {
+    const float4* s = reinterpret_cast<const float4*>(A.gf + (size_t)a0 * 3 * NF);
+    for (int t = tid; t < n * 96; t += M2_THREADS) reinterpret_cast<float4*>(sm_gf)[t] = s[t];
+  }
+  int inc_k[M2_OWN], rt_k[M2_OWN];
+  {
+    int beg_k[M2_OWN], deg_k[M2_OWN], col_k[M2_OWN], pid_k[M2_OWN];
+    float4 geo_k[M2_OWN];
+    int2 xg_k[M2_OWN];
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      beg_k[k] = a < n ? A.row_ptr[a0 + a] : 0;
+      deg_k[k] = a < n ? A.row_ptr[a0 + a + 1] - beg_k[k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int e = beg_k[k] + (lane < deg_k[k] ? lane : 0);
+      const bool on = lane < deg_k[k];
+      col_k[k] = on ? A.col[e] : 0;
+      pid_k[k] = on ? A.pid[e] : 0;
+      geo_k[k] = on ? reinterpret_cast<const float4*>(A.geo)[e] : make_float4(0.f, 0.f, 0.f, 1.f);
+      xg_k[k] = on ? A.xg[e] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      int inc = 0x7fff, rt = 0, p = 0x3fff;
+      if (lane < deg_k[k]) {
+        int j = col_k[k] - a0;
+        p = pid_k[k] - P0;
+        j = min(max(j, 0), n - 1);
+        p = min(max(p, 0), max(nP - 1, 0));
+        const bool own = j > a;
+        inc = p | (j << 9) | (own ? (1 << 14) : 0);
+        if (own) {
+          sm_geo[p] = geo_k[k];
+          sm_xg[p] = xg_k[k];
+          sm_pij[p] = (unsigned short)(a | (j << 8));
+        }
+      }
+      if (a < n) {
+#pragma unroll
+        for (int t = 0; t <= M2_MAX_TILES; ++t) {
+          const int c = __popcll(__ballot(p < 32 * t));
+          if (lane == t) rt = c;
+        }
+      }
+      inc_k[k] = inc;
+      rt_k[k] = rt;
+    }
+  }
+  // the owner's directed edge of pair p (rows list their own pairs last, in pair order)
+  auto owner_edge = [&](int p, int i) { return E0 + sm_rowb[i + 1] - (sm_pairb[i + 1] - p); };
+  __syncthreads();
+  dbg.stamp();
+
+  // ---- B1a: per tile, the kept phi rows staged; g_u, g_phi1, g_fin
+  {
+    float2 acc[M2_OWN][3];
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[k][q] = make_float2(0.f, 0.f);
+    float4 s1[4], s2[4];
+    auto request = [&](int t) {          // 32 rows x 32 float4 per array, four per thread
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + M2_THREADS * u, row = idx >> 5;
+        const bool on = 32 * t + row < nP;
+        const size_t g = ((size_t)P0 + 32 * t + (on ? row : 0)) * (NF / 4) + (idx & 31);
+        s1[u] = on ? reinterpret_cast<const float4*>(A.phi1)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (LOWER) s2[u] = on ? reinterpret_cast<const float4*>(A.phi2)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    if (nT > 0) request(0);
+#pragma unroll 1
+    for (int t = 0; t < nT; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = tid + M2_THREADS * u;
+        *reinterpret_cast<float4*>(phi1t + (idx >> 5) * M2_PHI_PITCH + 4 * (idx & 31)) = s1[u];
+        if (LOWER) *reinterpret_cast<float4*>(phi2t + (idx >> 5) * M2_PHI_PITCH + 4 * (idx & 31)) = s2[u];
+      }
+      __syncthreads();
+      if (t + 1 < nT) request(t + 1);
+      // g_u of both directions and the g_phi1 row of every pair of the tile (a half-wave per pair)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pl = 32 * t + 8 * u + 2 * nb + h;
+        if (pl < nP) {
+          const int ij = sm_pij[pl], i = ij & 255, j = ij >> 8;
+          const float4 g = sm_geo[pl];
+          const float4 v1 = *reinterpret_cast<const float4*>(phi1t + (pl - 32 * t) * M2_PHI_PITCH + c4);
+          float si[3], sj[3];
+          float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float uk[3] = {g.x, g.y, g.z};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float4 gi = *reinterpret_cast<const float4*>(sm_gf + (i * 3 + k) * NF + c4);
+            const float4 gj = *reinterpret_cast<const float4*>(sm_gf + (j * 3 + k) * NF + c4);
+            si[k] = half_sum_top(dot4(gi, v1));
+            sj[k] = half_sum_top(dot4(gj, v1));
+            gp = fma4(sub4(gi, gj), uk[k], gp);
+          }
+          st4(A.g_phi + ((size_t)P0 + pl) * 2 * NF + c4, gp);
+          if (r == 31) {
+            const int e = owner_edge(pl, i);
+            reinterpret_cast<float4*>(A.g_u)[e] = make_float4(si[0], si[1], si[2], 0.f);
+            reinterpret_cast<float4*>(A.g_u)[A.rev[e]] = make_float4(sj[0], sj[1], sj[2], 0.f);
+          }
+        }
+      }
+      if (LOWER) {
+#pragma unroll
+        for (int k = 0; k < M2_OWN; ++k) {
+          const int a = nb + M2_WAVES * k;
+          if (a < n) {
+            const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
+            for (int l = eb; l < ee; l += 2) {
+              const bool two = l + 1 < ee;
+              const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
+              const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
+              const float2 v0 = *reinterpret_cast<const float2*>(phi2t + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+              float2 v1 = *reinterpret_cast<const float2*>(phi2t + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+              if (!two) v1 = make_float2(0.f, 0.f);
+#pragma unroll
+              for (int q = 0; q < 3; ++q)
+                acc[k][q] = fma2(v1, *reinterpret_cast<const float2*>(sm_gf + (j1 * 3 + q) * NF + c2),
+                                 fma2(v0, *reinterpret_cast<const float2*>(sm_gf + (j0 * 3 + q) * NF + c2), acc[k][q]));
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (LOWER) {
+#pragma unroll
+      for (int k = 0; k < M2_OWN; ++k) {
+        const int a = nb + M2_WAVES * k;
+        if (a < n) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            st2(A.g_fin + ((size_t)(a0 + a) * 3 + q) * NF + c2, *reinterpret_cast<const float2*>(sm_gf + (a * 3 + q) * NF + c2) + acc[k][q]);
+        }
+      }
+    }
+  }
+  dbg.stamp();
+  // ---- B1b: g_phi2[p] = sum_k gf[i][k] * f_in[j][k] + gf[j][k] * f_in[i][k]
+  if (LOWER) {
+    const float4* s = reinterpret_cast<const float4*>(A.f_in + (size_t)a0 * 3 * NF);
+    for (int t = tid; t < n * 96; t += M2_THREADS) reinterpret_cast<float4*>(sm_f)[t] = s[t];
+    __syncthreads();
+    for (int pl = 2 * nb + h; pl < nP; pl += 2 * M2_WAVES) {
+      const int ij = sm_pij[pl], i = ij & 255, j = ij >> 8;
+      float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        gp = fma4(*reinterpret_cast<const float4*>(sm_gf + (i * 3 + k) * NF + c4), *reinterpret_cast<const float4*>(sm_f + (j * 3 + k) * NF + c4), gp);
+        gp = fma4(*reinterpret_cast<const float4*>(sm_gf + (j * 3 + k) * NF + c4), *reinterpret_cast<const float4*>(sm_f + (i * 3 + k) * NF + c4), gp);
+      }
+      st4(A.g_phi + ((size_t)P0 + pl) * 2 * NF + NF + c4, gp);
+    }
+  }
+  __syncthreads();          // the g_phi rows are written (read back below), gf / f_in are dead
+  dbg.stamp();
+
+  // ---- B2 / B3
+  {
+    const float4* sm_ = reinterpret_cast<const float4*>(A.m + (size_t)a0 * NF);
+    const float4* sg_ = reinterpret_cast<const float4*>(A.g_a + (size_t)a0 * NF);
+    for (int t = tid; t < n * 32; t += M2_THREADS) {
+      reinterpret_cast<float4*>(sm_m)[t] = sm_[t];
+      reinterpret_cast<float4*>(sm_ga)[t] = sg_[t];
+    }
+  }
+  M2Frag w1, w2;
+  float2 acc_m[M2_OWN];
+#pragma unroll
+  for (int k = 0; k < M2_OWN; ++k) acc_m[k] = make_float2(0.f, 0.f);
+  auto run_mlp = [&](auto MLP_, auto LAST_) {
+    constexpr int mlp = decltype(MLP_)::value;
+    constexpr bool last = decltype(LAST_)::value;      // the MLP whose second stage completes g_msg: the message adjoint follows per tile
+    m2_load_w(w1, mlp ? A.img22T : A.img12T, nb, r, h);
+    m2_load_w(w2, mlp ? A.img20T : A.img10T, nb, r, h);
+    const float* Hk = mlp ? A.h2 : A.h1;
+    float x[16];
+    auto load_x = [&](int t) {
+      const int pl = 32 * t + r;
+      const float4* xp = reinterpret_cast<const float4*>(A.g_phi + ((size_t)P0 + min(pl, max(nP - 1, 0))) * 2 * NF + mlp * NF + nb * 32 + 4 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = (pl < nP) ? xp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+      }
+    };
+    if (nT > 0) load_x(0);
+#pragma unroll 1
+    for (int t = 0; t < nT; ++t) {
+      const int pl = 32 * t + r;
+      const bool live = pl < nP;
+      const size_t pg = (size_t)P0 + pl;
+      const size_t tile_g = pg >> 5;
+      const int lane_g = 32 * h + (int)(pg & 31);
+      pmax[(nb * 2 + h) * 32 + r] = m2_amax16(x);
+      __syncthreads();
+      const float inv_x = m2_commit(x, xt, pmax, nb, r, h);
+      __syncthreads();
+      float4 hin[4];
+      {
+        const float4* hp = reinterpret_cast<const float4*>(Hk) + (tile_g * 4 + nb) * 256 + lane_g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hin[q] = live ? ld4_nt(reinterpret_cast<const float*>(hp + 64 * q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float hv[16];
+      m2_gemm(hv, xt, w1, inv_x, r, h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hv[4 * q] *= hin[q].x;
+        hv[4 * q + 1] *= hin[q].y;
+        hv[4 * q + 2] *= hin[q].z;
+        hv[4 * q + 3] *= hin[q].w;
+      }
+      pmax[(nb * 2 + h) * 32 + r] = m2_amax16(hv);
+      __syncthreads();
+      const float inv_h = m2_commit(hv, ht, pmax, nb, r, h);
+      __syncthreads();
+      float4 add[4];
+      if (mlp == 1) {
+        const float4* ap = reinterpret_cast<const float4*>(A.g_msg + pg * NF + nb * 32 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) add[q] = live ? ap[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float y[16];
+      m2_gemm(y, ht, w2, inv_h, r, h);
+      if (mlp == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          y[4 * q] += add[q].x;
+          y[4 * q + 1] += add[q].y;
+          y[4 * q + 2] += add[q].z;
+          y[4 * q + 3] += add[q].w;
+        }
+      }
+      if (t + 1 < nT) load_x(t + 1);
+      if (!last) {
+        if (live) {
+          float4* yp = reinterpret_cast<float4*>(A.g_msg + pg * NF + nb * 32 + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) yp[2 * q] = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        }
+      } else {
+        // ---- B3: the message adjoint of this tile
+        __syncthreads();                                  // every wave is done reading the hidden tile: g_msg takes its place
+        {
+          float* yr = phit + r * M2_PHI_PITCH + nb * 32 + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(yr + 8 * q) = make_float4(y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pq = 32 * t + 8 * u + 2 * nb + h;
+          if (pq < nP) {
+            const int ij = sm_pij[pq], i = ij & 255, j = ij >> 8;
+            const int2 gx = sm_xg[pq];
+            const FilterW fw = filter_weights(__int_as_float(gx.y));
+            float4 eps, deps;
+            filter_value_deriv(A.table, gx.x, c4, fw, eps, deps);
+            float* row = phit + (pq - 32 * t) * M2_PHI_PITCH + c4;
+            const float4 G = add4(add4(*reinterpret_cast<const float4*>(row), *reinterpret_cast<const float4*>(sm_ga + i * NF + c4)),
+                                  *reinterpret_cast<const float4*>(sm_ga + j * NF + c4));
+            const float4 mi = *reinterpret_cast<const float4*>(sm_m + i * NF + c4), mj = *reinterpret_cast<const float4*>(sm_m + j * NF + c4);
+            const float gxs = half_sum_top(dot4(mul4(mul4(G, mi), mj), deps));
+            if (r == 31) {     // the owner's edge carries all of g_x (edge.hip:msg_bwd_kernel)
+              const int e = owner_edge(pq, i);
+              A.g_x[e] = gxs;
+              A.g_x[A.rev[e]] = 0.f;
+            }
+            if (LOWER) *reinterpret_cast<float4*>(row) = mul4(G, eps);
+          }
+        }
+        if (LOWER) {
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < M2_OWN; ++k) {
+            const int a = nb + M2_WAVES * k;
+            if (a < n) {
+              const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
+              for (int l = eb; l < ee; l += 2) {
+                const bool two = l + 1 < ee;
+                const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
+                const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
+                const float2 v0 = *reinterpret_cast<const float2*>(phit + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+                float2 v1 = *reinterpret_cast<const float2*>(phit + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
+                if (!two) v1 = make_float2(0.f, 0.f);
+                acc_m[k] = fma2(v1, *reinterpret_cast<const float2*>(sm_m + j1 * NF + c2),
+                                fma2(v0, *reinterpret_cast<const float2*>(sm_m + j0 * NF + c2), acc_m[k]));
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  if (LOWER) {
+    run_mlp(std::integral_constant<int, 0>(), std::false_type());
+    __syncthreads();        // (the first term's rows are in the L2 before any wave reads one back)
+    run_mlp(std::integral_constant<int, 1>(), std::true_type());
+#pragma unroll
+    for (int k = 0; k < M2_OWN; ++k) {
+      const int a = nb + M2_WAVES * k;
+      if (a < n) st2(A.g_m + (size_t)(a0 + a) * NF + c2, acc_m[k]);
+    }
+  } else {
+    run_mlp(std::integral_constant<int, 0>(), std::true_type());
+  }
+  dbg.stamp();
+  dbg.print(LOWER ? "mol2_bwd<1>" : "mol2_bwd<0>");
+}
+
+int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                         const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
+                         const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
+                         const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
+                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, int n_mol, hipStream_t s) {
+  ScopedTimer t0(TC_MOL_BWD, s);
+  static const hipError_t rc0 = hipFuncSetAttribute((const void*)mol2_edge_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, M2B_LDS);
+  static const hipError_t rc1 = hipFuncSetAttribute((const void*)mol2_edge_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, M2B_LDS);
+  HIP_TRY(rc0);
+  HIP_TRY(rc1);
+  if (n_mol <= 0) return 0;
+  Mol2BwdArgs A = {mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, reinterpret_cast<const int2*>(xg), gf, g_a, m, f_in, table,
+                   img12T, img10T, img22T, img20T, h1, h2, phi1, phi2, g_fin, g_m, g_x, g_u, g_phi, g_msg, n_mol};
+  if (lower)
+    mol2_edge_bwd_kernel<true><<<n_mol, M2_THREADS, M2B_LDS, s>>>(A);
+  else
+    mol2_edge_bwd_kernel<false><<<n_mol, M2_THREADS, M2B_LDS, s>>>(A);
+  LAUNCH_CHECK();
+  return 0;
+}

@@ -47,6 +47,15 @@ int launch_mol_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, cons
                         const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
                         const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
                         float* h1, float* h2, float* phi1, float* phi2, int n_mol, hipStream_t s);
+int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                         const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
+                         const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
+                         float* h1, float* h2, float* phi1, float* phi2, float* msg, int n_mol, hipStream_t s);   // molfuse2.hip
+int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
+                         const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
+                         const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
+                         const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
+                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, int n_mol, hipStream_t s);   // molfuse2.hip
 int launch_mol_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
                         const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
                         const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
@@ -108,7 +117,9 @@ extern "C" int nnhip_config(char* buf, size_t n) {
   put("\"molecule_forms\": {\"max_atoms\": %d, \"edge_kernels_from_molecules\": %d, \"force_fwd\": %d, \"msg_bwd\": %d, \"force_direct\": %d, \"head_out\": %d, "
       "\"fused_edge_phase\": \"%s\"}, ",
       NNHIP_MOL_STAGE_MAX, mol_min, mol_forms & 1, (mol_forms >> 1) & 1, (mol_forms >> 2) & 1, (mol_forms >> 3) & 1,
-      fused ? (atoi(fused) == 0 ? "off" : atoi(fused) == 1 ? "on" : atoi(fused) == 2 ? "forward only" : "adjoint only")
+      fused ? (atoi(fused) == 0 ? "off" : atoi(fused) == 1 ? "on" : atoi(fused) == 2 ? "forward only" : atoi(fused) == 3 ? "adjoint only" :
+               atoi(fused) == 4 ? "second form, forward only" : atoi(fused) == 5 ? "second form forward, first form adjoint" :
+               atoi(fused) == 6 ? "second form" : "second form, adjoint only")
             : (getenv("NNHIP_MOL_FUSED_MIN") ? "from NNHIP_MOL_FUSED_MIN molecules" : "off (default)"));
   put("\"edge_mlp\": {\"row_local_up_to_tiles\": %d, \"one_pass_adjoint\": %d, \"one_pass_forward\": %d, \"one_pass_single_adjoint\": %d, "
       "\"one_pass_single_forward\": %d}, ",
@@ -713,7 +724,10 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     const bool eligible = mol_kernels && split_nodes && mol_ptr && pair_ptr && B > 0 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX;
     if (eligible && want != 0) fused_mode = want > 0 ? want : (mol_fused_pays(N, B) ? 1 : 0);
   }
-  const bool fused_fwd = fused_mode == 1 || fused_mode == 2, fused_bwd = fused_mode == 1 || fused_mode == 3;
+  // 4 .. 7: the second form (molfuse2.hip: 4-wave workgroups, two per CU) -- 4 / 5: its forward with the row path's / molfuse.hip's
+  // adjoint, 6: both directions, 7: its adjoint behind the row path's forward
+  const bool fused_fwd2 = fused_mode >= 4 && fused_mode <= 6, fused_bwd2 = fused_mode == 6 || fused_mode == 7;
+  const bool fused_fwd = fused_mode == 1 || fused_mode == 2, fused_bwd = fused_mode == 1 || fused_mode == 3 || fused_mode == 5;
 
   // ------------------------------------------------------------------ small systems: the whole step in ONE launch (small.hip)
   {
@@ -807,7 +821,12 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     // message_nodepart (hn = a W0^T + b0 ; m = silu(hn) W2^T + b2) was produced by the fused node kernel that closed the
     // previous layer (by the per-element table for l = 0)
     // messages + invariant update
-    if (fused_fwd) {
+    if (fused_fwd2) {
+      TRY(launch_mol2_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
+                               pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
+                               pbase + pq.img[l][IMG_EQ2_2], P(w.pub.a_mid[l]), F_OUT(l), P(w.pub.h12[l]), P(w.pub.h12[l]) + h2_off,
+                               P(w.pub.phi1[l]), P(w.pub.phi2[l]), P(w.pub.msg[l]), B, s));
+    } else if (fused_fwd) {
       // the whole edge phase of the layer in one launch, a workgroup per molecule (molfuse.hip)
       TRY(launch_mol_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
                               pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
@@ -945,7 +964,14 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     const float* f_prev = has_f ? F_OUT(l - 1) : nullptr;
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
-    if (fused_bwd) {
+    if (fused_bwd2) {
+      float* h12 = P(w.pub.h12[l]);
+      TRY(launch_mol2_edge_bwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, xg, P(w.gf_mid), P(w.pub.g_a), P(w.pub.m[l]),
+                               f_prev, Q(pq.ftab[l]), pbase + pq.img[l][IMG_EQ1_2_T], pbase + pq.img[l][IMG_EQ1_0_T],
+                               pbase + pq.img[l][IMG_EQ2_2_T], pbase + pq.img[l][IMG_EQ2_0_T], h12, h12 + h2_off, P(w.pub.phi1[l]),
+                               P(w.pub.phi2[l]), g_fin, P(w.g_m), P(w.pub.g_x) + (size_t)l * E, P(w.pub.g_u) + (size_t)l * E * 4,
+                               P(w.g_h12), P(w.g_msg), B, s));
+    } else if (fused_bwd) {
       // the adjoint of the whole edge phase in one launch, a workgroup per molecule (molfuse.hip)
       float* h12 = P(w.pub.h12[l]);
       TRY(launch_mol_edge_bwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, xg, P(w.gf_mid), P(w.pub.g_a), P(w.pub.m[l]),

@@ -68,8 +68,10 @@ def molecule_zoo(gen, clusters=True):
     return torch.cat(zs), torch.cat(ps), torch.zeros(len(sizes), 3, 3), batch, sizes
 
 
-@pytest.mark.parametrize('which', ['rand', 'ckpt'])
-def test_fused_edge_phase_against_the_oracle(which):
+@pytest.mark.parametrize('which,mode', [('rand', 1), ('ckpt', 1), ('rand', 5), ('ckpt', 5), ('rand', 6), ('ckpt', 6)])
+def test_fused_edge_phase_against_the_oracle(which, mode):
+    """mode 1: molfuse.hip both directions; mode 5: the forward in its second form (molfuse2.hip: 4-wave workgroups, the pair tiles
+    streamed one at a time) with molfuse.hip's adjoint; mode 6: molfuse2.hip both directions."""
     from oracle import newtonnet_ref as ref
     gen = torch.Generator().manual_seed(11)
     # (the dense lattice clusters only with the random weights: the trained model explodes on them -- energies of 1e20 eV -- and
@@ -77,7 +79,7 @@ def test_fused_edge_phase_against_the_oracle(which):
     z, pos, cell, batch, sizes = molecule_zoo(gen, clusters=which == 'rand')
     model, sd = make_model(which)
     args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
-    with fused_mode(1):
+    with fused_mode(mode):
         out, n_fwd, n_bwd = fused_launches(lambda: model(*args))
         assert (n_fwd, n_bwd) == (3, 3), f'the fused kernels did not run ({n_fwd} forward, {n_bwd} adjoint launches)'
         e, f = out.energy.cpu().double().numpy(), out.gradient_force.cpu().numpy()
@@ -91,7 +93,7 @@ def test_fused_edge_phase_against_the_oracle(which):
     f_ref = o['forces'].numpy()
     fscale = max(1.0, float(np.abs(f_ref).max()) / 5.0)
     d = np.abs(f.astype(np.float64) - f_ref)
-    print(f'fused edge phase ({which}): force MAE {d.mean():.2e} max {d.max():.2e} (max |F| {np.abs(f_ref).max():.1f})')
+    print(f'fused edge phase ({which}, mode {mode}): force MAE {d.mean():.2e} max {d.max():.2e} (max |F| {np.abs(f_ref).max():.1f})')
     check_forces(f, f_ref, fscale)
     e_ref = o['energy'].numpy()
     assert np.all(np.abs(e - e_ref) <= util.energy_tol(e_ref)), np.abs(e - e_ref).max()
@@ -106,7 +108,8 @@ def test_fused_edge_phase_against_the_oracle(which):
     assert dd <= 2e-5 * fscale
 
 
-def test_fused_edge_phase_is_deterministic_and_ignores_the_order_of_the_molecules():
+@pytest.mark.parametrize('mode', [1, 5, 6])
+def test_fused_edge_phase_is_deterministic_and_ignores_the_order_of_the_molecules(mode):
     gen = torch.Generator().manual_seed(12)
     a = util.load_npz('aspirin_frames.npz')
     B, n = 96, 21
@@ -115,7 +118,7 @@ def test_fused_edge_phase_is_deterministic_and_ignores_the_order_of_the_molecule
     batch = torch.repeat_interleave(torch.arange(B), n).cuda()
     cell = torch.zeros(B, 3, 3, device='cuda')
     model, _ = make_model('rand')
-    with fused_mode(1):
+    with fused_mode(mode):
         o1 = model(z, pos.cuda(), cell, batch)
         e1, f1 = o1.energy.clone(), o1.gradient_force.clone()
         o2 = model(z, pos.cuda(), cell, batch)
@@ -143,7 +146,7 @@ def test_fused_directions_swap_with_the_row_path_at_full_size():
     model, sd = make_model('ckpt')
     args = (z.cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'), batch.cuda())
     res = {}
-    for mode, want in ((0, (0, 0)), (1, (3, 3)), (2, (3, 0)), (3, (0, 3))):
+    for mode, want in ((0, (0, 0)), (1, (3, 3)), (2, (3, 0)), (3, (0, 3)), (4, (3, 0)), (5, (3, 3)), (6, (3, 3)), (7, (0, 3))):
         with fused_mode(mode):
             out, n_fwd, n_bwd = fused_launches(lambda: model(*args))
             assert (n_fwd, n_bwd) == want, (mode, n_fwd, n_bwd)

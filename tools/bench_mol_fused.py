@@ -10,7 +10,7 @@ from newtonnet_amd import hip
 from newtonnet_amd.models import NewtonNet
 
 sizes = [int(a) for a in sys.argv[1:]] or [1, 8, 48, 128, 256, 512, 1024, 2048]
-modes = os.environ.get('AB_MODES', '0,1').split(',')
+modes = os.environ.get('AB_MODES', '0,1').split(',')     # 0 row path, 1 molfuse both ways, 2 / 3 one direction, 4 molfuse2 forward + row adjoint, 5 molfuse2 forward + molfuse adjoint
 torch.manual_seed(0)
 model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
 model.eval()

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from newtonnet_amd.models import NewtonNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-os.environ['NNHIP_MOL_FUSED'] = '1'
+os.environ.setdefault('NNHIP_MOL_FUSED', '1')
 torch.manual_seed(0)
 model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
 model.eval()
