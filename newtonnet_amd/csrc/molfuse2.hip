@@ -15,6 +15,13 @@
 // Global formats are the row path's (a_mid, f_out, msg, phi1 / phi2 [P][128], silu'(h) in mlp128s.hip's fragment order by GLOBAL
 // pair tile), as in molfuse.hip: the adjoint of either path can follow.
 // Reference semantics: newtonnet/models/newtonnet.py:207-227.
+//
+// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (build.sh: -target-feature -packed-fp32-ops).  Compiled with
+// them (v_pk_fma_f32 / v_pk_mul_f32 chains for the float4 arithmetic), about one step in 200 of 1024 molecules returned ONE molecule
+// slightly wrong -- always a workgroup of the first dispatch round placed second on its CU, and always the low half of one packed
+// register pair x 16 lanes: a radial-filter value short of exactly one of its four interpolation terms.  Without the packed
+// instructions: 0 wrong molecules in 38 000 steps (both directions).  The mechanism behind it is not established
+// (profiles/r05_mol_fused2_soak.txt has the record); the forms stay opt-in.
 #include <stdlib.h>
 
 #include "common.h"
@@ -34,6 +41,13 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define M2_PITCH 272                                  // bytes per row of one f16 plane (128 f16 + 16 pad: conflict-free ds_read_b128)
 #define M2_PLANE (32 * M2_PITCH)
 #define M2_TILE (2 * M2_PLANE)                        // 17 408
+#ifndef M2_KNOWN_MAX
+#define M2_KNOWN_MAX 1                                // the forward's operand rows carry their maximum from the message pass (no exchange)
+#endif
+#ifndef M2_AGG
+#define M2_AGG 2                                      // incidences an owner wave keeps in flight per LDS round trip (4 is no faster and raises
+                                                      // the rate of the intermittent error described in the header ~10x)
+#endif
 #define M2_PHI_PITCH 132                              // floats per row of the fp32 phi tile (aliases the hidden tile)
 #define M2_WIMG_PLANE (NF * NF * 2)
 // LDS: operand tile | hidden tile (= phi tile) | row maxima | f_in | geo | xg | (spare) | rowb | pij;  m aliases the operand tile in pass 1
@@ -153,6 +167,39 @@ __device__ __forceinline__ void m2_gemm(float (&out)[16], const char* tile, cons
   const float sc = inv_row * w.inv;
 #pragma unroll
   for (int k = 0; k < 16; ++k) out[k] = acc[k] * sc;
+}
+
+// max over the 32 lanes of a half-wave, valid in lanes 31 / 63 (the DPP ladder of common.h:half_sum_top with fmaxf)
+#define M2_DPP_MAX(v, ctrl, row_mask) \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xF, false)))
+__device__ __forceinline__ float m2_half_max_top(float v) {      // v >= 0
+  M2_DPP_MAX(v, 0xB1, 0xF);
+  M2_DPP_MAX(v, 0x4E, 0xF);
+  M2_DPP_MAX(v, 0x141, 0xF);
+  M2_DPP_MAX(v, 0x140, 0xF);
+  M2_DPP_MAX(v, 0x142, 0xA);
+  return v;
+}
+// m2_commit with the row maximum already known (written by the half-wave that produced the row): no publish / barrier round
+__device__ __forceinline__ float m2_commit_known(const float (&v)[16], char* tile, float m, int nb, int r, int h) {
+  float S, inv;
+  m2_pow2_scale(m, S, inv);
+  char* row = tile + r * M2_PITCH + 2 * (nb * 32 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h4 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = v[4 * q + c] * S;
+      const _Float16 a = (_Float16)s;
+      hi[c] = a;
+      lo[c] = (_Float16)(s - (float)a);
+    }
+    const int off = 2 * ((q >> 1) * 16 + (q & 1) * 4);
+    *reinterpret_cast<h4*>(row + off) = hi;
+    *reinterpret_cast<h4*>(row + M2_PLANE + off) = lo;
+  }
+  return inv;
 }
 
 struct Mol2FwdArgs {
@@ -297,6 +344,9 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
                                 *reinterpret_cast<const float4*>(sm_m + (ij >> 8) * NF + c4));
           st4(A.msg + (size_t)(P0 + pl) * NF + c4, v);
           *reinterpret_cast<float4*>(phit + (pl - 32 * t) * M2_PHI_PITCH + c4) = v;
+          // the row's largest magnitude, for the MLPs' operand scale (geo.w -- r -- is not used by this kernel)
+          const float mx = m2_half_max_top(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+          if (r == 31) reinterpret_cast<float*>(sm_geo + pl)[3] = mx;
         }
       }
       __syncthreads();
@@ -306,12 +356,17 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
         const int a = nb + M2_WAVES * k;
         if (a < n) {
           const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
-          for (int l = eb; l < ee; l += 2) {
-            const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], min(l + 1, ee - 1));
-            const float2 v0 = *reinterpret_cast<const float2*>(phit + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-            const float2 v1 = *reinterpret_cast<const float2*>(phit + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-            acc_a[k] = acc_a[k] + v0;
-            if (l + 1 < ee) acc_a[k] = acc_a[k] + v1;
+          for (int l = eb; l < ee; l += M2_AGG) {      // (M2_AGG incidences in flight: one LDS round trip serves most atoms)
+            float2 v[M2_AGG];
+#pragma unroll
+            for (int u = 0; u < M2_AGG; ++u) {
+              const bool on = l + u < ee;
+              const int iu = __builtin_amdgcn_readlane(inc_k[k], on ? l + u : l);
+              v[u] = *reinterpret_cast<const float2*>(phit + ((iu & 511) - 32 * t) * M2_PHI_PITCH + c2);
+              if (!on) v[u] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < M2_AGG; ++u) acc_a[k] = acc_a[k] + v[u];
           }
         }
       }
@@ -361,9 +416,15 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
       const int lane_g = 32 * h + (int)(pg & 31);
       // operand tile of stage 1
       if (t < 2) dbg.stamp();
+      // (every wave is past stage 1 of the previous tile -- four barriers ago -- so the operand tile is free; the row maxima were
+      // left in geo.w by the message pass: no publish / barrier round for this commit)
+#if M2_KNOWN_MAX
+      const float inv_x = m2_commit_known(x, xt, live ? sm_geo[32 * t + r].w : 0.f, nb, r, h);
+#else
       pmax[(nb * 2 + h) * 32 + r] = m2_amax16(x);
       __syncthreads();
       const float inv_x = m2_commit(x, xt, pmax, nb, r, h);
+#endif
       __syncthreads();
       if (t < 2) dbg.stamp();
       float hv[16];
@@ -414,25 +475,37 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
         const int a = nb + M2_WAVES * k;
         if (a < n) {
           const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
-          for (int l = eb; l < ee; l += 2) {
-            const bool two = l + 1 < ee;
-            const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
-            const int p0 = i0 & 511, p1 = i1 & 511;
-            const float2 v0 = *reinterpret_cast<const float2*>(phit + (p0 - 32 * t) * M2_PHI_PITCH + c2);
-            float2 v1 = *reinterpret_cast<const float2*>(phit + (p1 - 32 * t) * M2_PHI_PITCH + c2);
-            if (!two) v1 = make_float2(0.f, 0.f);
-            if (mlp == 0) {
-              const float4 g0 = sm_geo[p0], g1 = sm_geo[p1];
-              const float s0 = (i0 >> 14) & 1 ? 1.0f : -1.0f, s1 = (i1 >> 14) & 1 ? 1.0f : -1.0f;   // u of the reverse direction is -u
-              acc[k][0] = fma2(v1, s1 * g1.x, fma2(v0, s0 * g0.x, acc[k][0]));
-              acc[k][1] = fma2(v1, s1 * g1.y, fma2(v0, s0 * g0.y, acc[k][1]));
-              acc[k][2] = fma2(v1, s1 * g1.z, fma2(v0, s0 * g0.z, acc[k][2]));
-            } else {
-              const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
+          for (int l = eb; l < ee; l += M2_AGG) {
+            float2 v[M2_AGG];
+            int iu[M2_AGG];
 #pragma unroll
-              for (int q = 0; q < 3; ++q)
-                acc[k][q] = fma2(v1, *reinterpret_cast<const float2*>(sm_f + (j1 * 3 + q) * NF + c2),
-                                 fma2(v0, *reinterpret_cast<const float2*>(sm_f + (j0 * 3 + q) * NF + c2), acc[k][q]));
+            for (int u = 0; u < M2_AGG; ++u) {
+              const bool on = l + u < ee;
+              iu[u] = __builtin_amdgcn_readlane(inc_k[k], on ? l + u : l);
+              v[u] = *reinterpret_cast<const float2*>(phit + ((iu[u] & 511) - 32 * t) * M2_PHI_PITCH + c2);
+              if (!on) v[u] = make_float2(0.f, 0.f);
+            }
+            if (mlp == 0) {
+              float4 g[M2_AGG];
+#pragma unroll
+              for (int u = 0; u < M2_AGG; ++u) g[u] = sm_geo[iu[u] & 511];
+#pragma unroll
+              for (int u = 0; u < M2_AGG; ++u) {
+                const float sg = (iu[u] >> 14) & 1 ? 1.0f : -1.0f;       // u of the reverse direction is -u
+                acc[k][0] = fma2(v[u], sg * g[u].x, acc[k][0]);
+                acc[k][1] = fma2(v[u], sg * g[u].y, acc[k][1]);
+                acc[k][2] = fma2(v[u], sg * g[u].z, acc[k][2]);
+              }
+            } else {
+              float2 fj[M2_AGG][3];
+#pragma unroll
+              for (int u = 0; u < M2_AGG; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fj[u][q] = *reinterpret_cast<const float2*>(sm_f + (((iu[u] >> 9) & 31) * 3 + q) * NF + c2);
+#pragma unroll
+              for (int u = 0; u < M2_AGG; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[k][q] = fma2(v[u], fj[u][q], acc[k][q]);
             }
           }
         }
@@ -475,10 +548,17 @@ int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, con
   if (n_mol <= 0) return 0;
   Mol2FwdArgs A = {mol_ptr, row_ptr, pair_ptr, col, pid, geo, reinterpret_cast<const int2*>(xg), m, a_in, f_in, table,
                    img10, img12, img20, img22, a_mid, f_out, h1, h2, phi1, phi2, msg, n_mol};
+#ifdef M2_DBG_ONE_PER_CU   // tooling: 100 KB of LDS per workgroup = one workgroup per CU
+  const size_t lds_bytes = 102400;
+  (void)hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  (void)hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#else
+  const size_t lds_bytes = M2_LDS;
+#endif
   if (has_f)
-    mol2_edge_fwd_kernel<true><<<n_mol, M2_THREADS, M2_LDS, s>>>(A);
+    mol2_edge_fwd_kernel<true><<<n_mol, M2_THREADS, lds_bytes, s>>>(A);
   else
-    mol2_edge_fwd_kernel<false><<<n_mol, M2_THREADS, M2_LDS, s>>>(A);
+    mol2_edge_fwd_kernel<false><<<n_mol, M2_THREADS, lds_bytes, s>>>(A);
   LAUNCH_CHECK();
   return 0;
 }
@@ -662,7 +742,9 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
             gp = fma4(sub4(gi, gj), uk[k], gp);
           }
           st4(A.g_phi + ((size_t)P0 + pl) * 2 * NF + c4, gp);
+          const float mx = m2_half_max_top(fmaxf(fmaxf(fabsf(gp.x), fabsf(gp.y)), fmaxf(fabsf(gp.z), fabsf(gp.w))));
           if (r == 31) {
+            reinterpret_cast<float*>(sm_geo + pl)[3] = mx;      // the row's largest magnitude: the first MLP's operand scale (geo.w is free)
             const int e = owner_edge(pl, i);
             reinterpret_cast<float4*>(A.g_u)[e] = make_float4(si[0], si[1], si[2], 0.f);
             reinterpret_cast<float4*>(A.g_u)[A.rev[e]] = make_float4(sj[0], sj[1], sj[2], 0.f);
@@ -675,17 +757,21 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
           const int a = nb + M2_WAVES * k;
           if (a < n) {
             const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
-            for (int l = eb; l < ee; l += 2) {
-              const bool two = l + 1 < ee;
-              const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
-              const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
-              const float2 v0 = *reinterpret_cast<const float2*>(phi2t + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-              float2 v1 = *reinterpret_cast<const float2*>(phi2t + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-              if (!two) v1 = make_float2(0.f, 0.f);
+            for (int l = eb; l < ee; l += M2_AGG) {
+              float2 v[M2_AGG], gj[M2_AGG][3];
 #pragma unroll
-              for (int q = 0; q < 3; ++q)
-                acc[k][q] = fma2(v1, *reinterpret_cast<const float2*>(sm_gf + (j1 * 3 + q) * NF + c2),
-                                 fma2(v0, *reinterpret_cast<const float2*>(sm_gf + (j0 * 3 + q) * NF + c2), acc[k][q]));
+              for (int u = 0; u < M2_AGG; ++u) {
+                const bool on = l + u < ee;
+                const int iu = __builtin_amdgcn_readlane(inc_k[k], on ? l + u : l);
+                v[u] = *reinterpret_cast<const float2*>(phi2t + ((iu & 511) - 32 * t) * M2_PHI_PITCH + c2);
+                if (!on) v[u] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gj[u][q] = *reinterpret_cast<const float2*>(sm_gf + (((iu >> 9) & 31) * 3 + q) * NF + c2);
+              }
+#pragma unroll
+              for (int u = 0; u < M2_AGG; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[k][q] = fma2(v[u], gj[u][q], acc[k][q]);
             }
           }
         }
@@ -761,9 +847,14 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       const size_t pg = (size_t)P0 + pl;
       const size_t tile_g = pg >> 5;
       const int lane_g = 32 * h + (int)(pg & 31);
-      pmax[(nb * 2 + h) * 32 + r] = m2_amax16(x);
-      __syncthreads();
-      const float inv_x = m2_commit(x, xt, pmax, nb, r, h);
+      float inv_x;
+      if (mlp == 0) {       // (row maxima of g_phi1 left in geo.w by B1a: no exchange)
+        inv_x = m2_commit_known(x, xt, live ? sm_geo[32 * t + r].w : 0.f, nb, r, h);
+      } else {
+        pmax[(nb * 2 + h) * 32 + r] = m2_amax16(x);
+        __syncthreads();
+        inv_x = m2_commit(x, xt, pmax, nb, r, h);
+      }
       __syncthreads();
       float4 hin[4];
       {
@@ -847,15 +938,18 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
             const int a = nb + M2_WAVES * k;
             if (a < n) {
               const int eb = __builtin_amdgcn_readlane(rt_k[k], t), ee = __builtin_amdgcn_readlane(rt_k[k], t + 1);
-              for (int l = eb; l < ee; l += 2) {
-                const bool two = l + 1 < ee;
-                const int i0 = __builtin_amdgcn_readlane(inc_k[k], l), i1 = __builtin_amdgcn_readlane(inc_k[k], two ? l + 1 : l);
-                const int j0 = (i0 >> 9) & 31, j1 = (i1 >> 9) & 31;
-                const float2 v0 = *reinterpret_cast<const float2*>(phit + ((i0 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-                float2 v1 = *reinterpret_cast<const float2*>(phit + ((i1 & 511) - 32 * t) * M2_PHI_PITCH + c2);
-                if (!two) v1 = make_float2(0.f, 0.f);
-                acc_m[k] = fma2(v1, *reinterpret_cast<const float2*>(sm_m + j1 * NF + c2),
-                                fma2(v0, *reinterpret_cast<const float2*>(sm_m + j0 * NF + c2), acc_m[k]));
+              for (int l = eb; l < ee; l += M2_AGG) {
+                float2 v[M2_AGG], mj[M2_AGG];
+#pragma unroll
+                for (int u = 0; u < M2_AGG; ++u) {
+                  const bool on = l + u < ee;
+                  const int iu = __builtin_amdgcn_readlane(inc_k[k], on ? l + u : l);
+                  v[u] = *reinterpret_cast<const float2*>(phit + ((iu & 511) - 32 * t) * M2_PHI_PITCH + c2);
+                  if (!on) v[u] = make_float2(0.f, 0.f);
+                  mj[u] = *reinterpret_cast<const float2*>(sm_m + ((iu >> 9) & 31) * NF + c2);
+                }
+#pragma unroll
+                for (int u = 0; u < M2_AGG; ++u) acc_m[k] = fma2(v[u], mj[u], acc_m[k]);
               }
             }
           }
