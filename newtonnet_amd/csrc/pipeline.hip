@@ -643,6 +643,9 @@ static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, 
 // phases as a latency chain with nothing to overlap them: 72 us per forward launch of ONE idle-chip molecule, of which the four
 // GEMM stages are 25 (profiles/r05_mol_fused_phase_clock.txt).  The form stays in the build, parity-tested,
 // behind NNHIP_MOL_FUSED=1; NNHIP_MOL_FUSED_MIN=<molecules> turns it on from a molecule count up without the switch.
+// The second form (molfuse2.hip, NNHIP_MOL_FUSED=4..7: two 4-wave workgroups per CU) does pay from ~400 conformers -- 512: 798 vs 877 us,
+// 1024: 1491 vs 1519, 4096: 5735 vs 5933 -- but not below (128: 547 vs 353) nor just above a multiple of 512 (640: 1180 vs 1029), and it
+// is correct only when compiled without packed fp32 for a reason not understood (profiles/r05_mol_fused2_soak.txt): opt-in as well.
 static bool mol_fused_pays(int n_atoms, int n_mol) {
   static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : 0x7fffffff;
   (void)n_atoms;
@@ -723,6 +726,13 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     const int want = ev ? atoi(ev) : -1;
     const bool eligible = mol_kernels && split_nodes && mol_ptr && pair_ptr && B > 0 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX;
     if (eligible && want != 0) fused_mode = want > 0 ? want : (mol_fused_pays(N, B) ? 1 : 0);
+    // A mixed mode hands silu'(h) from a fused kernel to the row path or back in mlp128s.hip's fragment order, which the row path
+    // keeps only in its persistent edge-MLP kernels: below their threshold (the row-local kernels, H row-major) a mixed request
+    // runs both directions in the fused form it names.
+    if (cdiv(P_, 32) <= mlp_wide_max_tiles_silu()) {
+      if (fused_mode == 2 || fused_mode == 3) fused_mode = 1;
+      if (fused_mode == 4 || fused_mode == 7) fused_mode = 6;
+    }
   }
   // 4 .. 7: the second form (molfuse2.hip: 4-wave workgroups, two per CU) -- 4 / 5: its forward with the row path's / molfuse.hip's
   // adjoint, 6: both directions, 7: its adjoint behind the row path's forward

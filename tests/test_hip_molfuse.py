@@ -132,6 +132,32 @@ def test_fused_edge_phase_is_deterministic_and_ignores_the_order_of_the_molecule
     assert net < 2e-4, net
 
 
+@pytest.mark.parametrize('mode,whole', [(2, 1), (3, 1), (4, 6), (7, 6)])
+def test_a_mixed_mode_below_the_persistent_regime_runs_the_whole_fused_form(mode, whole):
+    """The one-direction modes exchange silu'(h) with the row path in the fragment order its PERSISTENT edge-MLP kernels keep; a small
+    batch runs the row-local kernels (H row-major), so there the library runs both directions fused (pipeline.hip).  48 conformers:
+    bitwise the result of the whole-form mode, three launches per direction, and next to the row path."""
+    gen = torch.Generator().manual_seed(3)
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 48, 21
+    pos = (torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)).cuda()
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    cell = torch.zeros(B, 3, 3, device='cuda')
+    model, _ = make_model('rand')
+    with fused_mode(0):
+        row = model(z, pos, cell, batch)
+        f_row = row.gradient_force.clone()
+    with fused_mode(whole):
+        ref_out = model(z, pos, cell, batch)
+        e_ref, f_ref = ref_out.energy.clone(), ref_out.gradient_force.clone()
+    with fused_mode(mode):
+        out, n_fwd, n_bwd = fused_launches(lambda: model(z, pos, cell, batch))
+    assert (n_fwd, n_bwd) == (3, 3), (n_fwd, n_bwd)
+    assert torch.equal(out.energy, e_ref) and torch.equal(out.gradient_force, f_ref)
+    assert (out.gradient_force - f_row).abs().max().item() <= 2e-5
+
+
 def test_fused_directions_swap_with_the_row_path_at_full_size():
     """BASELINE configs[1] at full size (1024 aspirin conformers; the row path runs its persistent edge-MLP kernels there, whose
     silu'(h) scratch the fused kernels share): fused both ways, forward only, adjoint only and not at all -- four results that
