@@ -1,0 +1,173 @@
+// Probe: does a chain of dependent v_pk_*_f32 instructions, separated by the ONE wait state the compiler inserts, always see
+// its predecessor's result?  (profiles/r05_mol_fused2_soak.txt, section 6: in mol2_edge_fwd_kernel a radial-filter value came
+// out short of exactly one of its four terms, low half of the register pair, lanes 16..31, about once per 1e8 chains, only with
+// two 4-wave workgroups per CU in their first dispatch round.)
+//
+// The kernel imitates that message pass: 4-wave workgroups with 81 KB of LDS (two per CU), 512 of them per launch; per "tile"
+// four pairs per half-wave; the table rows of the next tile are requested (global_load_dwordx4, L2-resident table) before the
+// sums of this one; per pair  eps = w.b T0 + w.a T1 + w.d T2 + w.c T3  as the compiler's chain (inline asm, SEP between the
+// instructions), times two LDS rows (ds_read_b128), stored to global and LDS, row maximum by DPP.  The same value is formed with
+// v_mul_f32 / v_fma_f32 (bitwise the same arithmetic) and compared.
+// build: hipcc --offload-arch=gfx950 -O2 tools/probes/pk_chain_probe.hip -o /tmp/pk_probe ; run: /tmp/pk_probe [launches]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define NF 128
+#define TILES 5
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct Bad { unsigned long long n, low_half, lanes16_31, one_term_short; };
+
+template <int SEP>   // 0: s_nop 0 (what the compiler emits), 1: s_nop 1, 2: nothing between the instructions
+__device__ __forceinline__ f2 chain(f2 t0, f2 t1, f2 t2, f2 t3, f2 wab, f2 wcd) {
+  f2 d;
+  if (SEP == 0)
+    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\ts_nop 0\n\t"
+                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
+  else if (SEP == 1)
+    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\ts_nop 1\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\ts_nop 1\n\t"
+                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\ts_nop 1\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
+  else
+    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
+  return d;
+}
+
+__device__ __forceinline__ float chain_ref(float t0, float t1, float t2, float t3, float wa, float wb, float wc, float wd) {
+  float r;
+  asm volatile("v_mul_f32 %0, %1, %6\n\ts_nop 1\n\tv_fma_f32 %0, %2, %5, %0\n\ts_nop 1\n\tv_fma_f32 %0, %3, %8, %0\n\ts_nop 1\n\tv_fma_f32 %0, %4, %7, %0"
+               : "=&v"(r) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wa), "v"(wb), "v"(wc), "v"(wd));
+  return r;
+}
+
+__device__ __forceinline__ float half_max(float v) {
+  for (int o = 1; o < 32; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <int SEP>
+__global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__ table, int rows, const float* __restrict__ nodes,
+                                                       float* __restrict__ out, Bad* bad, uint32_t seed) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  float* sm_m = reinterpret_cast<float*>(lds);                 // 24 node rows
+  float* tile = reinterpret_cast<float*>(lds + 24 * NF * 4);   // 32 rows x 132
+  const int tid = threadIdx.x, lane = tid & 63, nb = tid >> 6, h = lane >> 5, c4 = 4 * (lane & 31);
+  const int b = blockIdx.x;
+  for (int t = tid; t < 24 * 32; t += 256) reinterpret_cast<float4*>(sm_m)[t] = reinterpret_cast<const float4*>(nodes)[(size_t)(b % 64) * 24 * 32 + t];
+  __syncthreads();
+  uint32_t s = seed ^ (uint32_t)(b * 2654435761u);
+  auto pair_of = [&](int t, int u, int& row, float4& w, int& i, int& j) {      // per-pair "geometry": uniform over the half-wave
+    uint32_t k = s ^ (uint32_t)((t * 4 + u) * 8 + 2 * nb + h) * 0x9E3779B9u;
+    k ^= k >> 15, k *= 0x2c1b3c6du, k ^= k >> 12;
+    row = (int)(k % (uint32_t)(rows - 4));
+    const float x = (float)((k >> 8) & 1023) * (1.f / 1024.f);
+    w = make_float4(-x * (x - 1.f) * (x - 2.f) * (1.f / 6.f), (x + 1.f) * (x - 1.f) * (x - 2.f) * 0.5f, -(x + 1.f) * x * (x - 2.f) * 0.5f,
+                    (x + 1.f) * x * (x - 1.f) * (1.f / 6.f));
+    i = (int)((k >> 3) % 24u), j = (int)((k >> 19) % 24u);
+  };
+  float4 T[4][4];
+  auto request = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int row, i, j;
+      float4 w;
+      pair_of(t, u, row, w, i, j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[u][q] = *reinterpret_cast<const float4*>(table + (size_t)(row + q) * NF + c4);
+    }
+  };
+  unsigned long long nbad = 0, nlow = 0, n1631 = 0, nshort = 0;
+  float acc = 0.f;
+  request(0);
+#pragma unroll 1
+  for (int t = 0; t < TILES; ++t) {
+    const int live = (t + 1 < TILES) ? 4 : 3;          // the last tile is partly empty, as a molecule's last tile is
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u < live || h == 0) {
+        int row, i, j;
+        float4 w;
+        pair_of(t, u, row, w, i, j);
+        const f2 wab = {w.x, w.y}, wcd = {w.z, w.w};
+        const f2 xy = chain<SEP>(f2{T[u][0].x, T[u][0].y}, f2{T[u][1].x, T[u][1].y}, f2{T[u][2].x, T[u][2].y}, f2{T[u][3].x, T[u][3].y}, wab, wcd);
+        const float4 mi = *reinterpret_cast<const float4*>(sm_m + i * NF + c4);
+        const f2 zw = chain<SEP>(f2{T[u][0].z, T[u][0].w}, f2{T[u][1].z, T[u][1].w}, f2{T[u][2].z, T[u][2].w}, f2{T[u][3].z, T[u][3].w}, wab, wcd);
+        const float4 mj = *reinterpret_cast<const float4*>(sm_m + j * NF + c4);
+        const float got[4] = {xy.x, xy.y, zw.x, zw.y};
+        const float tq[4][4] = {{T[u][0].x, T[u][1].x, T[u][2].x, T[u][3].x}, {T[u][0].y, T[u][1].y, T[u][2].y, T[u][3].y},
+                                {T[u][0].z, T[u][1].z, T[u][2].z, T[u][3].z}, {T[u][0].w, T[u][1].w, T[u][2].w, T[u][3].w}};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float want = chain_ref(tq[c][0], tq[c][1], tq[c][2], tq[c][3], w.x, w.y, w.z, w.w);
+          if (__float_as_uint(got[c]) != __float_as_uint(want)) {
+            ++nbad;
+            if ((c & 1) == 0) ++nlow;
+            if ((lane & 16) != 0) ++n1631;
+            // short of one term?  (the four terms in the chain's order: T0 w.b, T1 w.a, T2 w.d, T3 w.c)
+            const float term[4] = {tq[c][0] * w.y, tq[c][1] * w.x, tq[c][2] * w.w, tq[c][3] * w.z};
+            for (int q = 0; q < 4; ++q)
+              if (fabsf((want - got[c]) - term[q]) <= 1e-3f * fabsf(term[q]) + 1e-12f) { ++nshort; break; }
+          }
+        }
+        const float4 v = make_float4(got[0] * mi.x * mj.x, got[1] * mi.y * mj.y, got[2] * mi.z * mj.z, got[3] * mi.w * mj.w);
+        const int pl = 8 * u + 2 * nb + h;
+        *reinterpret_cast<float4*>(out + ((size_t)b * 32 * TILES + 32 * t + pl) * NF + c4) = v;
+        *reinterpret_cast<float4*>(tile + pl * 132 + c4) = v;
+        acc += half_max(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+    }
+    __syncthreads();
+    if (t + 1 < TILES) request(t + 1);
+    for (int r = nb; r < 32; r += 4) acc += tile[r * 132 + lane] + tile[r * 132 + 64 + lane];       // "sums" under which the rows fly
+    __syncthreads();
+  }
+  if (acc == 123.456f) out[0] = acc;
+  if (nbad) {
+    atomicAdd(&bad->n, nbad), atomicAdd(&bad->low_half, nlow), atomicAdd(&bad->lanes16_31, n1631), atomicAdd(&bad->one_term_short, nshort);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int launches = argc > 1 ? atoi(argv[1]) : 20000;
+  const int rows = 3072, grid = 512;
+  float *table, *nodes, *out;
+  Bad* bad;
+  CHECK(hipMalloc(&table, (size_t)rows * NF * 4));
+  CHECK(hipMalloc(&nodes, (size_t)64 * 24 * NF * 4));
+  CHECK(hipMalloc(&out, (size_t)grid * 32 * TILES * NF * 4));
+  CHECK(hipMalloc(&bad, sizeof(Bad)));
+  {
+    float* h = (float*)malloc((size_t)rows * NF * 4);
+    uint32_t s = 12345u;
+    for (size_t i = 0; i < (size_t)rows * NF; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((float)(s >> 8) / 16777216.f - 0.5f) * expf(-(float)(i / NF) / 900.f); }
+    CHECK(hipMemcpy(table, h, (size_t)rows * NF * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < (size_t)64 * 24 * NF; ++i) { s = s * 1664525u + 1013904223u; h[i] = (float)(s >> 8) / 16777216.f - 0.5f; }
+    CHECK(hipMemcpy(nodes, h, (size_t)64 * 24 * NF * 4, hipMemcpyHostToDevice));
+    free(h);
+  }
+  const size_t lds = 81000;
+  CHECK(hipFuncSetAttribute((const void*)probe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CHECK(hipFuncSetAttribute((const void*)probe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CHECK(hipFuncSetAttribute((const void*)probe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int sep = 0; sep < 3; ++sep) {
+    CHECK(hipMemset(bad, 0, sizeof(Bad)));
+    for (int k = 0; k < launches; ++k) {
+      if (sep == 0) probe_kernel<0><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
+      else if (sep == 1) probe_kernel<1><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
+      else probe_kernel<2><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
+    }
+    CHECK(hipDeviceSynchronize());
+    Bad hb;
+    CHECK(hipMemcpy(&hb, bad, sizeof(Bad), hipMemcpyDeviceToHost));
+    const double chains = (double)launches * grid * 256 * (TILES * 4 - 0.5) * 2;
+    printf("separator %s: %.3g chain executions (x 2 values each), %llu wrong values: %llu in the low half, %llu in lanes 16..31 / 48..63, %llu short of exactly one term\n",
+           sep == 0 ? "s_nop 0" : sep == 1 ? "s_nop 1" : "none   ", chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short);
+  }
+  return 0;
+}
