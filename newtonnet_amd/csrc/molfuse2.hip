@@ -808,6 +808,9 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
     }
   }
   __syncthreads();          // the g_phi rows are written (read back below), gf / f_in are dead
+#ifdef M2_DBG_B1_ONLY     // tooling: time B1 alone (results are then wrong)
+  return;
+#endif
   dbg.stamp();
 
   // ---- B2 / B3
