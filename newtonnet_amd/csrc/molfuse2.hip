@@ -379,6 +379,9 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
     }
   }
   __syncthreads();          // msg rows written (this workgroup reads them back below), m is dead: the tiles take its place
+#ifdef M2_DBG_P1_ONLY     // tooling: time the message pass alone (a pair-once, molecule-resident msg_fwd; results are then wrong)
+  return;
+#endif
   dbg.stamp();
 
   // ---- pass 2: the edge MLPs, tile by tile, and the force-message sums

@@ -7,7 +7,7 @@ torch.manual_seed(0)
 model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda'); model.eval()
 for B in (512, 1024, 2048):
     args = bench.synthetic_aspirin(B, 0, 'cuda')
-    for mode in ('0', '7'):
+    for mode in os.environ.get('B1_MODES', '0,7').split(','):
         os.environ['NNHIP_MOL_FUSED'] = mode
         for _ in range(3): model(*args)
         torch.cuda.synchronize()
