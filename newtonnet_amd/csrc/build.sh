@@ -34,10 +34,7 @@ for s in "${srcs[@]}"; do
   obj="$objdir/$s.o"
   [ -f "$src" ] || continue
   if [ $force -eq 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$newest_header" -nt "$obj" ] || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
-    per_file=()
-    # molfuse2.hip is compiled without packed-fp32 instructions (v_pk_fma_f32 ...): profiles/r05_mol_fused2_soak.txt
-    if [ "$s" = "molfuse2" ] && [ -z "${NNHIP_MOLFUSE2_PACKED:-}" ]; then per_file=(-Xclang -target-feature -Xclang -packed-fp32-ops); fi
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" ${per_file[@]+"${per_file[@]}"} ${extra[@]+"${extra[@]}"} &
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" ${extra[@]+"${extra[@]}"} &
     pids+=($!)
     running=$((running + 1))
     if [ $running -ge "$jobs" ]; then

@@ -16,12 +16,16 @@
 // pair tile), as in molfuse.hip: the adjoint of either path can follow.
 // Reference semantics: newtonnet/models/newtonnet.py:207-227.
 //
-// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (build.sh: -target-feature -packed-fp32-ops).  Compiled with
+// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (the target attribute below; -DM2_PACKED_FP32 restores them for
+// the A/B of profiles/r05_mol_fused2_soak.txt).  Compiled with
 // them (v_pk_fma_f32 / v_pk_mul_f32 chains for the float4 arithmetic), about one step in 200 of 1024 molecules returned ONE molecule
 // slightly wrong -- always a workgroup of the first dispatch round placed second on its CU, and always the low half of one packed
 // register pair x 16 lanes: a radial-filter value short of exactly one of its four interpolation terms.  Without the packed
 // instructions: 0 wrong molecules in 38 000 steps (both directions).  The mechanism behind it is not established
 // (profiles/r05_mol_fused2_soak.txt has the record); the forms stay opt-in.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(M2_PACKED_FP32)      // (device pass only: the host pass does not know the feature)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
 #include <stdlib.h>
 
 #include "common.h"
@@ -696,6 +700,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
   __syncthreads();
   dbg.stamp();
 
+#ifndef M2_DBG_B3_ONLY    // (tooling: the message adjoint alone, fed by the row path's g_msg rows -- a pair-once, molecule-resident msg_bwd)
   // ---- B1a: per tile, the kept phi rows staged; g_u, g_phi1, g_fin
   {
     float2 acc[M2_OWN][3];
@@ -810,6 +815,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       st4(A.g_phi + ((size_t)P0 + pl) * 2 * NF + NF + c4, gp);
     }
   }
+#endif
   __syncthreads();          // the g_phi rows are written (read back below), gf / f_in are dead
 #ifdef M2_DBG_B1_ONLY     // tooling: time B1 alone (results are then wrong)
   return;
@@ -832,13 +838,19 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
   auto run_mlp = [&](auto MLP_, auto LAST_) {
     constexpr int mlp = decltype(MLP_)::value;
     constexpr bool last = decltype(LAST_)::value;      // the MLP whose second stage completes g_msg: the message adjoint follows per tile
+#ifndef M2_DBG_B3_ONLY
     m2_load_w(w1, mlp ? A.img22T : A.img12T, nb, r, h);
     m2_load_w(w2, mlp ? A.img20T : A.img10T, nb, r, h);
+#endif
     const float* Hk = mlp ? A.h2 : A.h1;
     float x[16];
     auto load_x = [&](int t) {
       const int pl = 32 * t + r;
+#ifdef M2_DBG_B3_ONLY
+      const float4* xp = reinterpret_cast<const float4*>(A.g_msg + ((size_t)P0 + min(pl, max(nP - 1, 0))) * NF + nb * 32 + 4 * h);
+#else
       const float4* xp = reinterpret_cast<const float4*>(A.g_phi + ((size_t)P0 + min(pl, max(nP - 1, 0))) * 2 * NF + mlp * NF + nb * 32 + 4 * h);
+#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = (pl < nP) ? xp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -853,6 +865,12 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       const size_t pg = (size_t)P0 + pl;
       const size_t tile_g = pg >> 5;
       const int lane_g = 32 * h + (int)(pg & 31);
+#ifdef M2_DBG_B3_ONLY
+      float y[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) y[q] = x[q];
+      (void)Hk, (void)tile_g, (void)lane_g;
+#else
       float inv_x;
       if (mlp == 0) {       // (row maxima of g_phi1 left in geo.w by B1a: no exchange)
         inv_x = m2_commit_known(x, xt, live ? sm_geo[32 * t + r].w : 0.f, nb, r, h);
@@ -898,6 +916,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
           y[4 * q + 3] += add[q].w;
         }
       }
+#endif
       if (t + 1 < nT) load_x(t + 1);
       if (!last) {
         if (live) {
@@ -964,7 +983,9 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
     }
   };
   if (LOWER) {
+#ifndef M2_DBG_B3_ONLY
     run_mlp(std::integral_constant<int, 0>(), std::false_type());
+#endif
     __syncthreads();        // (the first term's rows are in the L2 before any wave reads one back)
     run_mlp(std::integral_constant<int, 1>(), std::true_type());
 #pragma unroll
@@ -999,3 +1020,7 @@ int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, con
   LAUNCH_CHECK();
   return 0;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(M2_PACKED_FP32)
+#pragma clang attribute pop
+#endif
