@@ -58,6 +58,73 @@ def test_golden_case(case):
     assert torch.equal(again.atom_node, out.atom_node) and torch.equal(again.force_node, out.force_node)
 
 
+@pytest.mark.parametrize('case', ['pbc216_rand', 'aspirin1_rand', 'aspirin1_ckpt'])
+@pytest.mark.parametrize('shuffle', [False, True])
+def test_golden_case_in_internal_spatial_order(case, shuffle):
+    """One big system runs on its atoms in Morton order of cutoff-sized cells (models/newtonnet.py:spatial_order; on from 8192 atoms of
+    a single molecule, forced on here for the single-molecule fixtures).  What the caller sees must not change: the neighbor list
+    bit-exact in the reference's order, energy / forces / node states against the fp64 fixture -- also when the caller's own atom
+    order is a random shuffle of the fixture's (every expected array shuffled alike)."""
+    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
+    n = z.shape[0]
+    sh = torch.randperm(n, generator=torch.Generator().manual_seed(5)) if shuffle else torch.arange(n)
+    inv = torch.empty_like(sh)
+    inv[sh] = torch.arange(n)
+    model, _ = make_model(case.split('_')[-1])
+    model.__dict__['_spatial_order_min'] = 1
+    out = model(z[sh].cuda(), pos[sh].cuda(), cell.cuda(), batch.cuda())
+    # the fixture's list for the shuffled order: endpoints renamed, rows re-sorted (i ascending, then j)
+    ei = torch.from_numpy(c['f32_edge_index'])
+    i, j = inv[ei[0]], inv[ei[1]]
+    order = torch.argsort(i * n + j)
+    want_ei = torch.stack((i[order], j[order]))
+    assert out.edge_index.dtype == torch.int64 and torch.equal(out.edge_index.cpu(), want_ei)
+    e = out.energy.cpu().numpy().astype(np.float64)
+    assert np.all(np.abs(e - c['f64_energy']) <= util.energy_tol(c['f64_energy'])), (e, c['f64_energy'])
+    fscale = max(1.0, np.abs(c['f64_forces']).max() / 5.0)
+    check_forces(out.gradient_force.cpu().numpy(), c['f64_forces'][sh.numpy()], fscale)
+    if 'f64_atom_node_2' in c:
+        np.testing.assert_allclose(out.atom_node.cpu().numpy(), c['f64_atom_node_2'][sh.numpy()], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(out.force_node.cpu().numpy(), c['f64_force_node_2'][sh.numpy()], rtol=2e-4, atol=2e-5)
+    assert torch.equal(out.z.cpu(), z[sh]) and torch.equal(out.pos.detach().cpu(), pos[sh])
+    # same bits on the next call; and the same numbers as the module without the internal order, to rounding
+    again = model(z[sh].cuda(), pos[sh].cuda(), cell.cuda(), batch.cuda())
+    assert torch.equal(again.energy, out.energy) and torch.equal(again.gradient_force, out.gradient_force)
+    assert torch.equal(again.edge_index, out.edge_index)
+    model.__dict__['_spatial_order_min'] = 0
+    plain = model(z[sh].cuda(), pos[sh].cuda(), cell.cuda(), batch.cuda())
+    assert torch.equal(plain.edge_index, out.edge_index)
+    assert (plain.gradient_force - out.gradient_force).abs().max().item() <= 2e-5 * fscale
+
+
+def test_internal_spatial_order_virial_and_direct_force():
+    """The strain derivative is a sum over atoms (order-free), direct_force is per atom (re-ordered back): the periodic virial fixture
+    and a direct_force model with the internal order forced on, against the same module without it."""
+    from newtonnet_amd.models import NewtonNet
+    z, pos, cell, batch, c = util.case_inputs('pbc216_rand', torch.float32)
+    sd = util.load_state('rand', torch.float32)
+    model = NewtonNet(output_properties=['energy', 'gradient_force', 'virial', 'stress'])
+    model.load_state_dict(sd)
+    model = model.cuda()
+    model.eval()            # (a statement: the reference's eval() returns None, newtonnet.py:106-113)
+    args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
+    plain = model(*args)
+    v0, s0, f0 = plain.virial.clone(), plain.stress.clone(), plain.gradient_force.clone()
+    model.__dict__['_spatial_order_min'] = 1
+    out = model(*args)
+    scale = max(1.0, v0.abs().max().item())
+    assert (out.virial - v0).abs().max().item() <= 2e-5 * scale and (out.stress - s0).abs().max().item() <= 2e-5 * max(1.0, s0.abs().max().item())
+    assert (out.gradient_force - f0).abs().max().item() <= 2e-4
+    assert torch.equal(out.pos_grad, -out.gradient_force)
+    torch.manual_seed(0)
+    dm = NewtonNet(output_properties=['energy', 'direct_force']).cuda()
+    dm.eval()
+    d0 = dm(*args).direct_force.clone()
+    dm.__dict__['_spatial_order_min'] = 1
+    d1 = dm(*args).direct_force
+    assert d1.shape == d0.shape and (d1 - d0).abs().max().item() <= 2e-5 * max(1.0, d0.abs().max().item())
+
+
 def test_deferred_checks_errors_and_repeats():
     """The steady-state eval call returns before the host has seen the edge count or the status word
     (NewtonNet._forward_deferred; the reference's forward, newtonnet.py:74-104, is synchronous).  Whatever the synchronous call
