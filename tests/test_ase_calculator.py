@@ -103,9 +103,12 @@ def test_md_loop_path_follows_K1_trajectory(capture):
 
 
 @pytest.mark.gpu
-def test_md_loop_path_periodic_with_stress():
+@pytest.mark.parametrize('spatial_order', [False, True])
+def test_md_loop_path_periodic_with_stress(spatial_order):
     """Periodic box drifting through the cell boundary: wrapped positions jump by a lattice vector while the skin criterion
-    follows the unwrapped ones; energy / forces / stress must match the exact-list path at every step."""
+    follows the unwrapped ones; energy / forces / stress must match the exact-list path at every step.  spatial_order: the MD
+    path keeps a big system in Morton order of its cells between list rebuilds (forced on for this small box, atoms shuffled so
+    that the order matters); forces must come back in the Atoms object's order."""
     from newtonnet_amd.models import NewtonNet
     from newtonnet_amd.utils import MLAseCalculator
     torch.manual_seed(5)
@@ -113,13 +116,17 @@ def test_md_loop_path_periodic_with_stress():
     n, box = 64, 9.5
     grid = np.stack(np.meshgrid(*[np.arange(4)] * 3, indexing='ij'), -1).reshape(-1, 3) * (box / 4)
     pos = grid + rng.normal(0, 0.15, grid.shape)
+    if spatial_order:
+        pos = pos[rng.permutation(n)]
     numbers = rng.choice([1, 6, 8], n)
     cell = np.diag([box] * 3)
     vel = rng.normal(0, 0.02, pos.shape) + np.array([0.05, 0.0, 0.0])     # net drift: atoms cross the boundary
     def make(skin):
         torch.manual_seed(5)
         m = NewtonNet(output_properties=['energy', 'gradient_force', 'stress'])
-        return MLAseCalculator(m, properties=['energy', 'forces', 'stress'], device='cuda', skin=skin)
+        calc = MLAseCalculator(m, properties=['energy', 'forces', 'stress'], device='cuda', skin=skin)
+        calc.model.__dict__['_spatial_order_min'] = 1 if (spatial_order and skin > 0) else 0
+        return calc
     fast, exact = make(0.6), make(0.0)
     for step in range(30):
         # NPT-like breathing of the box (positions scale with it): the list survives small strains, see _calculate_md
@@ -132,6 +139,7 @@ def test_md_loop_path_periodic_with_stress():
         assert fast.results['stress'].shape == (6,)
         assert np.abs(fast.results['stress'] - exact.results['stress']).max() < 1e-6
     assert 1 <= fast.md_stats['rebuilds'] < 15
+    assert (fast._md['order'] is not None) == spatial_order
 
 
 @pytest.mark.gpu

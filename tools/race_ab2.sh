@@ -1,3 +1,4 @@
+# (the packed tooling build: NNHIP_LIB_NAME=libnewtonnet_hip_pk.so bash newtonnet_amd/csrc/build.sh -DM2_PACKED_FP32)
 # final soak of the committed tree + speed A/B of molfuse2 with and without packed fp32
 bash tools/race_ab.sh
 echo "== speed, committed (no packed fp32 in molfuse2.hip)"
