@@ -1,41 +1,62 @@
-// Probe: does a chain of dependent v_pk_*_f32 instructions, separated by the ONE wait state the compiler inserts, always see
-// its predecessor's result?  (profiles/r05_mol_fused2_soak.txt, section 6: in mol2_edge_fwd_kernel a radial-filter value came
-// out short of exactly one of its four terms, low half of the register pair, lanes 16..31, about once per 1e8 chains, only with
-// two 4-wave workgroups per CU in their first dispatch round.)
+// Stand-alone reproducer: a chain of dependent PACKED fp32 instructions with op_sel modifiers
+//     v_pk_mul_f32 d, t0, w op_sel:[0,1] ; v_pk_fma_f32 d, t1, w, d op_sel_hi:[1,0,1] ; v_pk_fma_f32 d, t2, w', d op_sel:[0,1,0] ;
+//     v_pk_fma_f32 d, t3, w', d op_sel_hi:[1,0,1]                      (what hipcc emits for a 4-point interpolation of float2 rows)
+// returns, on MI355X, a wrong LOW half in lanes 16..31 / 48..63 -- the value short of exactly one of its four terms -- about once
+// per 2e6 executions, for SOME alignments of the code and only with two or more waves per SIMD.  The same arithmetic as
+// v_mul_f32 / v_fma_f32 never fails.  Each value is computed twice with each form: "the packed chain evaluated twice differs"
+// counts packed-vs-packed disagreements (no reference needed), "the v_fma_f32 chain evaluated twice differs" stays 0.
 //
-// The kernel imitates that message pass: 4-wave workgroups with 81 KB of LDS (two per CU), 512 of them per launch; per "tile"
-// four pairs per half-wave; the table rows of the next tile are requested (global_load_dwordx4, L2-resident table) before the
-// sums of this one; per pair  eps = w.b T0 + w.a T1 + w.d T2 + w.c T3  as the compiler's chain (inline asm, SEP between the
-// instructions), times two LDS rows (ds_read_b128), stored to global and LDS, row maximum by DPP.  The same value is formed with
-// v_mul_f32 / v_fma_f32 (bitwise the same arithmetic) and compared.
-// build: hipcc --offload-arch=gfx950 -O2 tools/probes/pk_chain_probe.hip -o /tmp/pk_probe ; run: /tmp/pk_probe [launches]
+// The kernel imitates the message pass of mol2_edge_fwd_kernel, where this was first seen (profiles/r05_mol_fused2_soak.txt):
+// 512 four-wave workgroups, table rows prefetched one tile ahead (global_load_dwordx4), operands from LDS (ds_read_b128), global +
+// LDS stores, a DPP maximum, a half-empty last tile, then a short MFMA phase; two rounds of that per launch.
+// -DPAD=<k> puts k dwords of s_nop ahead of the kernel body: tools/probes/run_pad_sweep.sh compiles k = 0..15 and runs each --
+// on the boxes of this pool k = 0, 7, 8, 15 fail (period 32 bytes), the others are clean (profiles/r05_pk_pad_sweep.txt).
+// build: hipcc --offload-arch=gfx950 -O2 -DPAD=0 tools/probes/pk_chain_probe.hip -o /tmp/pk_probe ; run: /tmp/pk_probe [launches]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#ifndef PAD
+#define PAD 0
+#endif
 #define NF 128
+#define PAD_STR2(x) #x
+#define PAD_STR1(x) PAD_STR2(x)
+#define PAD_STR PAD_STR1(PAD)
 #define TILES 5
+#define ROUNDS 2          // (message-pass-like phase, matrix phase) per launch
+#define MFMA_STEPS 96     // MFMAs per wave in the matrix phase (~4 us)
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct Bad { unsigned long long n, low_half, lanes16_31, one_term_short; };
+struct Bad { unsigned long long n, low_half, lanes16_31, one_term_short, pk_twice_differ, fma_twice_differ; };
 
-template <int SEP>   // 0: s_nop 0 (what the compiler emits), 1: s_nop 1, 2: nothing between the instructions
+// SEP: 0 s_nop 0 (what the compiler emits) | 1 s_nop 1 | 2 nothing | 3 s_nop 3 | 4 s_nop 7 | 5 two s_nop 7 |
+//      6 no op_sel (weights broadcast to both halves), s_nop 0 | 7 no op_sel, nothing between
+#define PK_CHAIN(SEPSTR)                                                                                                          \
+  asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\t" SEPSTR "v_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\t" SEPSTR        \
+               "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\t" SEPSTR "v_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"             \
+               : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd))
+#define PK_CHAIN_PLAIN(SEPSTR)                                                                                                    \
+  asm volatile("v_pk_mul_f32 %0, %1, %5\n\t" SEPSTR "v_pk_fma_f32 %0, %2, %6, %0\n\t" SEPSTR                                       \
+               "v_pk_fma_f32 %0, %3, %7, %0\n\t" SEPSTR "v_pk_fma_f32 %0, %4, %8, %0"                                             \
+               : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wbb), "v"(waa), "v"(wdd), "v"(wcc))
+template <int SEP>
 __device__ __forceinline__ f2 chain(f2 t0, f2 t1, f2 t2, f2 t3, f2 wab, f2 wcd) {
   f2 d;
-  if (SEP == 0)
-    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\ts_nop 0\n\t"
-                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
-                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
-  else if (SEP == 1)
-    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\ts_nop 1\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\ts_nop 1\n\t"
-                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\ts_nop 1\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
-                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
-  else
-    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 %0, %3, %6, %0 op_sel:[0,1,0]\n\tv_pk_fma_f32 %0, %4, %6, %0 op_sel_hi:[1,0,1]"
-                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wcd));
+  const f2 waa = {wab.x, wab.x}, wbb = {wab.y, wab.y}, wcc = {wcd.x, wcd.x}, wdd = {wcd.y, wcd.y};
+  (void)waa, (void)wbb, (void)wcc, (void)wdd;
+  if (SEP == 0) PK_CHAIN("s_nop 0\n\t");
+  else if (SEP == 1) PK_CHAIN("s_nop 1\n\t");
+  else if (SEP == 2) PK_CHAIN("");
+  else if (SEP == 3) PK_CHAIN("s_nop 3\n\t");
+  else if (SEP == 4) PK_CHAIN("s_nop 7\n\t");
+  else if (SEP == 5) PK_CHAIN("s_nop 7\n\ts_nop 7\n\t");
+  else if (SEP == 6) PK_CHAIN_PLAIN("s_nop 0\n\t");
+  else PK_CHAIN_PLAIN("");
   return d;
 }
 
@@ -53,7 +74,10 @@ __device__ __forceinline__ float half_max(float v) {
 
 template <int SEP>
 __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__ table, int rows, const float* __restrict__ nodes,
-                                                       float* __restrict__ out, Bad* bad, uint32_t seed) {
+                                                       float* __restrict__ out, Bad* bad, uint32_t seed, int mfma_mode) {
+#ifdef PAD
+  asm volatile(".rept " PAD_STR "\n\ts_nop 0\n\t.endr" :::);
+#endif
   extern __shared__ __attribute__((aligned(16))) char lds[];
   float* sm_m = reinterpret_cast<float*>(lds);                 // 24 node rows
   float* tile = reinterpret_cast<float*>(lds + 24 * NF * 4);   // 32 rows x 132
@@ -82,8 +106,11 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
       for (int q = 0; q < 4; ++q) T[u][q] = *reinterpret_cast<const float4*>(table + (size_t)(row + q) * NF + c4);
     }
   };
-  unsigned long long nbad = 0, nlow = 0, n1631 = 0, nshort = 0;
+  unsigned long long nbad = 0, nlow = 0, n1631 = 0, nshort = 0, npk2 = 0, nfma2 = 0;
   float acc = 0.f;
+#pragma unroll 1
+  for (int round = 0; round < ROUNDS; ++round) {
+  s = s * 1664525u + 1013904223u;
   request(0);
 #pragma unroll 1
   for (int t = 0; t < TILES; ++t) {
@@ -100,11 +127,17 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
         const f2 zw = chain<SEP>(f2{T[u][0].z, T[u][0].w}, f2{T[u][1].z, T[u][1].w}, f2{T[u][2].z, T[u][2].w}, f2{T[u][3].z, T[u][3].w}, wab, wcd);
         const float4 mj = *reinterpret_cast<const float4*>(sm_m + j * NF + c4);
         const float got[4] = {xy.x, xy.y, zw.x, zw.y};
+        const f2 xy2 = chain<SEP>(f2{T[u][0].x, T[u][0].y}, f2{T[u][1].x, T[u][1].y}, f2{T[u][2].x, T[u][2].y}, f2{T[u][3].x, T[u][3].y}, wab, wcd);
+        const f2 zw2 = chain<SEP>(f2{T[u][0].z, T[u][0].w}, f2{T[u][1].z, T[u][1].w}, f2{T[u][2].z, T[u][2].w}, f2{T[u][3].z, T[u][3].w}, wab, wcd);
+        const float got2[4] = {xy2.x, xy2.y, zw2.x, zw2.y};
         const float tq[4][4] = {{T[u][0].x, T[u][1].x, T[u][2].x, T[u][3].x}, {T[u][0].y, T[u][1].y, T[u][2].y, T[u][3].y},
                                 {T[u][0].z, T[u][1].z, T[u][2].z, T[u][3].z}, {T[u][0].w, T[u][1].w, T[u][2].w, T[u][3].w}};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float want = chain_ref(tq[c][0], tq[c][1], tq[c][2], tq[c][3], w.x, w.y, w.z, w.w);
+          const float want2 = chain_ref(tq[c][0], tq[c][1], tq[c][2], tq[c][3], w.x, w.y, w.z, w.w);
+          if (__float_as_uint(got[c]) != __float_as_uint(got2[c])) ++npk2;
+          if (__float_as_uint(want) != __float_as_uint(want2)) ++nfma2;
           if (__float_as_uint(got[c]) != __float_as_uint(want)) {
             ++nbad;
             if ((c & 1) == 0) ++nlow;
@@ -127,9 +160,28 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
     for (int r = nb; r < 32; r += 4) acc += tile[r * 132 + lane] + tile[r * 132 + 64 + lane];       // "sums" under which the rows fly
     __syncthreads();
   }
+  // the matrix phase of the edge MLPs: every wave of the workgroup on the MFMA pipe (the co-resident workgroup, dispatched a little
+  // later, is still in its message pass when this starts)
+  if (mfma_mode == 0 || true) {
+    f16v c0, c1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c0[k] = 0.f, c1[k] = 0.f;
+    h8v a, bq;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (_Float16)(0.001f * (float)(lane + k)), bq[k] = (_Float16)(0.002f * (float)(k + nb));
+#pragma unroll 1
+    for (int k = 0; k < MFMA_STEPS; k += 2) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, a, c1, 0, 0, 0);
+    }
+    acc += c0[0] + c1[3];
+    __syncthreads();
+  }
+  }
   if (acc == 123.456f) out[0] = acc;
-  if (nbad) {
+  if (nbad | npk2 | nfma2) {
     atomicAdd(&bad->n, nbad), atomicAdd(&bad->low_half, nlow), atomicAdd(&bad->lanes16_31, n1631), atomicAdd(&bad->one_term_short, nshort);
+    atomicAdd(&bad->pk_twice_differ, npk2), atomicAdd(&bad->fma_twice_differ, nfma2);
   }
 }
 
@@ -151,23 +203,24 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(nodes, h, (size_t)64 * 24 * NF * 4, hipMemcpyHostToDevice));
     free(h);
   }
-  const size_t lds = 81000;
-  CHECK(hipFuncSetAttribute((const void*)probe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CHECK(hipFuncSetAttribute((const void*)probe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CHECK(hipFuncSetAttribute((const void*)probe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for (int sep = 0; sep < 3; ++sep) {
+  const size_t lds_two = 81000, lds_one = 100000;      // two workgroups per CU / one
+  typedef void (*K)(const float*, int, const float*, float*, Bad*, uint32_t, int);
+  const K kernels[8] = {probe_kernel<0>, probe_kernel<1>, probe_kernel<2>, probe_kernel<3>, probe_kernel<4>, probe_kernel<5>, probe_kernel<6>, probe_kernel<7>};
+  const char* names[8] = {"s_nop 0 (compiler)", "s_nop 1", "nothing", "s_nop 3", "s_nop 7", "2 x s_nop 7", "no op_sel, s_nop 0", "no op_sel, nothing"};
+  for (int k = 0; k < 8; ++k) CHECK(hipFuncSetAttribute((const void*)kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one));
+  // (separator, matrix phase on / off, workgroups per CU)
+  const int runs[][3] = {{0, 0, 2}, {0, 0, 1}, {0, 0, 3}, {0, 0, 4}};      // (.., .., workgroups per CU by LDS size)
+  for (const auto& r : runs) {
     CHECK(hipMemset(bad, 0, sizeof(Bad)));
-    for (int k = 0; k < launches; ++k) {
-      if (sep == 0) probe_kernel<0><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
-      else if (sep == 1) probe_kernel<1><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
-      else probe_kernel<2><<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k);
-    }
+    const size_t lds = r[2] == 2 ? lds_two : r[2] == 1 ? lds_one : r[2] == 3 ? 52000 : 30000;
+    for (int k = 0; k < launches; ++k) kernels[r[0]]<<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k, r[1]);
     CHECK(hipDeviceSynchronize());
     Bad hb;
     CHECK(hipMemcpy(&hb, bad, sizeof(Bad), hipMemcpyDeviceToHost));
-    const double chains = (double)launches * grid * 256 * (TILES * 4 - 0.5) * 2;
-    printf("separator %s: %.3g chain executions (x 2 values each), %llu wrong values: %llu in the low half, %llu in lanes 16..31 / 48..63, %llu short of exactly one term\n",
-           sep == 0 ? "s_nop 0" : sep == 1 ? "s_nop 1" : "none   ", chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short);
+    const double chains = (double)launches * grid * 256 * (TILES * 4 - 0.5) * 2 * ROUNDS;
+    printf("pad %2d dwords, LDS for %d workgroup(s) per CU: %.3g chains; packed vs v_fma_f32 chain differ %llu (%llu low half, %llu lanes 16..31 / 48..63, %llu one term short); the packed chain evaluated twice differs %llu; the v_fma_f32 chain evaluated twice differs %llu\n",
+           PAD, r[2], chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short, hb.pk_twice_differ, hb.fma_twice_differ);
+    fflush(stdout);
   }
   return 0;
 }
