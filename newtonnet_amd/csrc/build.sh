@@ -25,6 +25,17 @@ fi
 mkdir -p "$objdir"
 srcs=(graph edge lin128 mlp128 mlp128s mlp128r node128 node128s pipeline train train_step heads small molfuse molfuse2)
 newest_header=$(ls -t "$here"/*.h "$here"/../../include/*.h | head -1)
+# No packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) in any kernel.  On MI355X a chain of dependent v_pk_*_f32
+# instructions with op_sel modifiers returns a wrong LOW half for lanes 16..31 / 48..63 about once per 2e6 executions -- the value
+# short of exactly one term of the chain -- for some alignments of the code (period 32 bytes) and only with two or more waves per
+# SIMD; the same arithmetic as v_fma_f32 never fails (tools/probes/pk_chain_probe.hip + run_pad_sweep.sh: the stand-alone
+# reproducer; profiles/r05_mol_fused2_soak.txt: how it was found, in molfuse2.hip).  Which kernels are exposed changes with every
+# recompile, so the instruction class is off for all of them.  Cost: none (profiles/r05_no_packed_fp32_ab.txt).  The flag reaches
+# the host pass too, which answers "not a recognized feature" once per file (filtered below).  A per-function
+# target("no-packed-fp32-ops") attribute does the same job 10 % slower (the edge kernels lose their inlining): not used.
+# NNHIP_PACKED_FP32=1 bash build.sh: the library with packed fp32, for A/B.
+nopk=(-Xclang -target-feature -Xclang -packed-fp32-ops)
+[ -n "${NNHIP_PACKED_FP32:-}" ] && nopk=()
 jobs="${NNHIP_BUILD_JOBS:-8}"
 pids=()
 fail=0
@@ -34,7 +45,8 @@ for s in "${srcs[@]}"; do
   obj="$objdir/$s.o"
   [ -f "$src" ] || continue
   if [ $force -eq 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$newest_header" -nt "$obj" ] || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" ${extra[@]+"${extra[@]}"} &
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o "$obj" ${nopk[@]+"${nopk[@]}"} ${extra[@]+"${extra[@]}"} \
+      2> >(grep -v "is not a recognized feature for this target" >&2) &
     pids+=($!)
     running=$((running + 1))
     if [ $running -ge "$jobs" ]; then

@@ -19,7 +19,6 @@
 // so they are stored once per undirected pair p = pid[e] ([P = E/2][128] arrays).  The row of the LOWER endpoint owns
 // the pair (its upper edges i < j map to a contiguous run of pair rows) and is the only writer of msg[p] and
 // g_phi[p]; both endpoints read.
-#include "nopk_begin.h"
 #include <stdlib.h>
 
 #include <type_traits>
@@ -1195,5 +1194,3 @@ extern "C" int nnhip_gather_rows(const float* x, const int32_t* idx, int32_t n_o
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
-
-#include "nopk_end.h"

@@ -7,7 +7,6 @@
 // makes it a CSR over the receiver i; every later aggregation is a deterministic segmented sum
 // (no float atomics).  HBM-bound integer/float32 work: one thread per receiver row, molecule-local
 // position reads served by L1/L2.
-#include "nopk_begin.h"
 #include <stdlib.h>
 
 #include "common.h"
@@ -1707,5 +1706,3 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
-
-#include "nopk_end.h"

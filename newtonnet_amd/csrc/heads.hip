@@ -7,7 +7,6 @@
 //     reverse sweep (csrc/train_step.hip) -- that sweep is linear in its seeds, so the interaction layers' gradients of the
 //     direct-force loss come out of the same launches as those of the energy / gradient-force loss.
 // Forward: nnhip_direct_force (node128.hip) with the caller KEEPING its scratch = (pre1 | pre2 | d3), [3][N][F].
-#include "nopk_begin.h"
 #include <string.h>
 
 #include "common.h"
@@ -107,5 +106,3 @@ extern "C" int nnhip_direct_force_bwd(const float* g_out, const float* force_nod
     return nnhip_species_sum(sc4, 4, 4, z, n_atoms, sp_scratch, g_scale, 0, 1, 1, nullptr, 0, 0, 0, nullptr, 0, s);
   return NNHIP_OK;
 }
-
-#include "nopk_end.h"

@@ -19,7 +19,6 @@
 //     operands are 16-byte vector accesses and the two halves of a row read one contiguous 32-byte run per load;
 //   * SiLU / SiLU' / bias / accumulate are fused as prologue / epilogue so activations never make an extra
 //     HBM round trip.
-#include "nopk_begin.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -255,5 +254,3 @@ extern "C" int nnhip_linear128(const float* A, int32_t lda, const float* W, floa
   a.ldh = ldh;
   return launch_lin(prologue, epilogue, a, 1, (hipStream_t)stream);
 }
-
-#include "nopk_end.h"

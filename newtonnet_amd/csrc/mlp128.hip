@@ -21,7 +21,6 @@
 // One persistent 8-wave workgroup per CU keeps BOTH weight matrices in LDS (2 x 66 KiB, 16-B row pad -> conflict-free
 // ds_read_b128); each wave owns 32-edge tiles; the next tile's X fragment is requested right after stage 1 (its
 // registers are dead during stage 2), so the 256 stage-2 MFMAs cover its latency.
-#include "nopk_begin.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -525,5 +524,3 @@ extern "C" int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* d0, const nnhip_mlp_de
   }
   return launch_mlp_pair(d0->mode, a0, false, a1, d1->accumulate != 0, (hipStream_t)stream);
 }
-
-#include "nopk_end.h"

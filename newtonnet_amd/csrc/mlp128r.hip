@@ -28,7 +28,6 @@
 // (tests/test_hip_parity.py::test_one_pass_edge_mlp_form_agrees_with_the_two_phase_form holds both against float64).
 // The kernel is bound by VALU issue (~760 wave-instructions per wave and tile, 1.5x mlp128s.hip -- the price of passing
 // activations through LDS instead of handing them over in registers), which is why only the adjoint launches take it by default.
-#include "nopk_begin.h"
 #include <stdlib.h>
 
 #include "common.h"
@@ -424,5 +423,3 @@ int launch_mlp_regw(int mode, const MlpPair& P, hipStream_t s) {
   if (P.n == 1) return mode == MODE_FWD ? launch_regw_t<MODE_FWD, true>(P, s) : launch_regw_t<MODE_BWD, true>(P, s);
   return mode == MODE_FWD ? launch_regw_t<MODE_FWD, false>(P, s) : launch_regw_t<MODE_BWD, false>(P, s);
 }
-
-#include "nopk_end.h"

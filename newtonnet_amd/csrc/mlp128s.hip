@@ -22,7 +22,6 @@
 // ds_read_b128), with the k-slots permuted so that the 8 slots a lane feeds to one MFMA are contiguous AND match what that
 // lane already holds of the activations (features 16T + 4h + {0..3} and 16T + 8 + 4h + {0..3} for MFMA T, lane half h): the
 // global loads of X and the stage-1 -> stage-2 register hand-over are exactly those of mlp128.hip.
-#include "nopk_begin.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -404,5 +403,3 @@ int launch_mlp_split(int mode, bool accum_last, const MlpPair& P, hipStream_t s)
   nnhip_set_error("launch_mlp_split: unsupported mode %d/%d", mode, (int)accum_last);
   return NNHIP_E_INVALID;
 }
-
-#include "nopk_end.h"

@@ -29,7 +29,6 @@
 // Formats: every array this pair of kernels reads or writes in global memory has the layout of the row path (a_mid, f_out,
 // phi1 / phi2 [P][128], silu'(h) in the fragment order of mlp128s.hip's h_frag region indexed by GLOBAL pair tile, g_fin, g_m,
 // g_x, g_u), so either direction can be swapped for the three launches it replaces (tests do exactly that).
-#include "nopk_begin.h"
 #include <stdlib.h>
 
 #include "common.h"
@@ -760,5 +759,3 @@ int launch_mol_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, cons
   LAUNCH_CHECK();
   return 0;
 }
-
-#include "nopk_end.h"

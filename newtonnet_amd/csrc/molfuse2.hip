@@ -16,14 +16,13 @@
 // pair tile), as in molfuse.hip: the adjoint of either path can follow.
 // Reference semantics: newtonnet/models/newtonnet.py:207-227.
 //
-// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (nopk_begin.h, like every file of the library since; -DNNHIP_PACKED_FP32 restores them for
+// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (build.sh: -target-feature -packed-fp32-ops, for every file of the library since; NNHIP_PACKED_FP32=1 bash build.sh restores them for
 // the A/B of profiles/r05_mol_fused2_soak.txt).  Compiled with
 // them (v_pk_fma_f32 / v_pk_mul_f32 chains for the float4 arithmetic), about one step in 200 of 1024 molecules returned ONE molecule
 // slightly wrong -- always a workgroup of the first dispatch round placed second on its CU, and always the low half of one packed
 // register pair x 16 lanes: a radial-filter value short of exactly one of its four interpolation terms.  Without the packed
 // instructions: 0 wrong molecules in 38 000 steps (both directions).  The mechanism behind it is not established
 // (profiles/r05_mol_fused2_soak.txt has the record); the forms stay opt-in.
-#include "nopk_begin.h"
 #include <stdlib.h>
 
 #include "common.h"
@@ -1018,5 +1017,3 @@ int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, con
   LAUNCH_CHECK();
   return 0;
 }
-
-#include "nopk_end.h"

@@ -17,7 +17,6 @@
 // activations pass from one GEMM to the next through a 16.5 KiB LDS tile, and the weights come straight from L2 as
 // the MFMA A operand (transposed formulation, as in mlp128.hip: D^T[feature][atom] = W X^T; every wave of the grid
 // with the same w reads the same 16 KiB of each matrix).
-#include "nopk_begin.h"
 #include <string.h>
 
 #include "common.h"
@@ -512,5 +511,3 @@ extern "C" int nnhip_direct_force(const float* atom_node, const float* force_nod
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
-
-#include "nopk_end.h"

@@ -10,7 +10,6 @@
 //   rows    : scaled per row by the largest magnitude of the row.  A row's 128 values live in 8 lanes of 4 waves: each lane
 //             publishes the maximum of its 16 values in LDS BEFORE the barrier that already separates two uses of the tile, so the
 //             exchange costs no extra barrier; the (hi, lo) pieces are written to the LDS tile in fragment order.
-#include "nopk_begin.h"
 #include <stdint.h>
 #include <string.h>
 
@@ -810,5 +809,3 @@ int launch_lin_wide_split(const float* X, int ldx, const char* img, float* Y, in
   LAUNCH_CHECK();
   return 0;
 }
-
-#include "nopk_end.h"

@@ -4,7 +4,6 @@
 // Mirrors NewtonNet.forward (newtonnet/models/newtonnet.py:74-104) for output_properties
 // ['energy', 'gradient_force'] and replaces torch.autograd.grad (newtonnet/models/output.py:66-73) by explicit
 // adjoint kernels.  Every launch goes to the caller's stream; nothing here synchronises.
-#include "nopk_begin.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -1295,5 +1294,3 @@ extern "C" int nnhip_head_out(const float* e2, const float* w4, const float* b4,
   return launch_head_out(e2, w4, b4, scale, shift, z, mol_ptr, n_atoms, n_mol, activation, atom_energy, g_e2, energy,
                          (hipStream_t)stream);
 }
-
-#include "nopk_end.h"

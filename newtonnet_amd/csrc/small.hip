@@ -25,7 +25,6 @@
 //
 // Scope: SiLU models without LayerNorm, at most SMALL_MAX_ATOMS atoms and SMALL_MAX_EDGES directed edges in the whole batch,
 // energy + forces (no virial); everything else takes the multi-kernel path.  Throughput is not the point of this kernel.
-#include "nopk_begin.h"
 #include <string.h>
 
 #include "common.h"
@@ -434,5 +433,3 @@ int launch_small_step(const SmallArgs& a, hipStream_t s) {
   LAUNCH_CHECK();
   return 0;
 }
-
-#include "nopk_end.h"

@@ -16,7 +16,6 @@
 //     wgrad_kernel, a split-K fp32-MFMA reduction with deterministic slab + tree-free final sum.
 // tests/tangent_ref.py writes the same four sweeps in fp64 torch; tests/test_hip_train.py checks every stage against it and
 // the result against the oracle's autograd double backward.
-#include "nopk_begin.h"
 #include <string.h>
 
 #include "edge_common.h"
@@ -1664,5 +1663,3 @@ extern "C" int nnhip_clip_adam_dev(float* params, const float* grads, float* exp
   return clip_adam_launch(params, grads, exp_avg, exp_avg_sq, n, scratch, state, 0.f, 0.f, 0.f, 0.f, 0.f, hyper_dev, mask_dev,
                           (hipStream_t)stream);
 }
-
-#include "nopk_end.h"

@@ -1,7 +1,6 @@
 // The two halves of a training step as single C calls: the per-stage entry points of include/newtonnet_hip.h strung together
 // exactly as tests/tangent_ref.py states the algorithm (sweeps 1-2 = values, 3-4 = tangents + weight gradients; csrc/train.hip has
 // the kernels and the derivation).  Host code only: every line is a call to an exported stage; the buffers belong to the caller.
-#include "nopk_begin.h"
 #include <string.h>
 
 #include "common.h"
@@ -508,5 +507,3 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
   TS_TRY(nnhip_species_sum(w->dGA, NF, NF, w->z, N, w->sp_scratch, w->g_embedding, 0, NF, NF, nullptr, 0, 0, 0, nullptr, 0, s));
   return nnhip_species_sum(w->scal, 4, 4, w->z, N, w->sp_scratch, w->g_scale, 0, 1, 1, w->g_shift, 1, 1, 1, w->g_head4_b, 2, s);
 }
-
-#include "nopk_end.h"
