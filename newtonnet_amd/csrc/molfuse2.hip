@@ -16,13 +16,11 @@
 // pair tile), as in molfuse.hip: the adjoint of either path can follow.
 // Reference semantics: newtonnet/models/newtonnet.py:207-227.
 //
-// BUILD NOTE: this file is compiled WITHOUT packed-fp32 instructions (build.sh: -target-feature -packed-fp32-ops, for every file of the library since; NNHIP_PACKED_FP32=1 bash build.sh restores them for
-// the A/B of profiles/r05_mol_fused2_soak.txt).  Compiled with
-// them (v_pk_fma_f32 / v_pk_mul_f32 chains for the float4 arithmetic), about one step in 200 of 1024 molecules returned ONE molecule
-// slightly wrong -- always a workgroup of the first dispatch round placed second on its CU, and always the low half of one packed
-// register pair x 16 lanes: a radial-filter value short of exactly one of its four interpolation terms.  Without the packed
-// instructions: 0 wrong molecules in 38 000 steps (both directions).  The mechanism behind it is not established
-// (profiles/r05_mol_fused2_soak.txt has the record); the forms stay opt-in.
+// BUILD NOTE: compiled WITHOUT packed-fp32 instructions, like every file of the library (build.sh).  This is the kernel in which the
+// problem behind that switch was found: with v_pk_fma_f32 / v_pk_mul_f32 chains for its float4 arithmetic, about one step in 200 of
+// 1024 molecules returned ONE molecule slightly wrong -- a radial-filter value short of exactly one of its four interpolation terms,
+// in the low half of one packed register pair x 16 lanes.  profiles/r05_mol_fused2_soak.txt has the hunt, tools/probes/
+// pk_chain_probe.hip the stand-alone reproducer (code-alignment dependent, two or more waves per SIMD, v_fma_f32 never fails).
 #include <stdlib.h>
 
 #include "common.h"
