@@ -209,7 +209,10 @@ int main(int argc, char** argv) {
   const char* names[8] = {"s_nop 0 (compiler)", "s_nop 1", "nothing", "s_nop 3", "s_nop 7", "2 x s_nop 7", "no op_sel, s_nop 0", "no op_sel, nothing"};
   for (int k = 0; k < 8; ++k) CHECK(hipFuncSetAttribute((const void*)kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one));
   // (separator, matrix phase on / off, workgroups per CU)
-  const int runs[][3] = {{0, 0, 2}, {0, 0, 1}, {0, 0, 3}, {0, 0, 4}};      // (.., .., workgroups per CU by LDS size)
+#ifndef CHAIN
+#define CHAIN 0      // 0: the op_sel chain with s_nop 0 between its instructions (what hipcc emits); 6: the same arithmetic without op_sel
+#endif
+  const int runs[][3] = {{CHAIN, 0, 2}, {CHAIN, 0, 1}};      // (chain form, .., workgroups per CU by LDS size)
   for (const auto& r : runs) {
     CHECK(hipMemset(bad, 0, sizeof(Bad)));
     const size_t lds = r[2] == 2 ? lds_two : r[2] == 1 ? lds_one : r[2] == 3 ? 52000 : 30000;
@@ -218,8 +221,8 @@ int main(int argc, char** argv) {
     Bad hb;
     CHECK(hipMemcpy(&hb, bad, sizeof(Bad), hipMemcpyDeviceToHost));
     const double chains = (double)launches * grid * 256 * (TILES * 4 - 0.5) * 2 * ROUNDS;
-    printf("pad %2d dwords, LDS for %d workgroup(s) per CU: %.3g chains; packed vs v_fma_f32 chain differ %llu (%llu low half, %llu lanes 16..31 / 48..63, %llu one term short); the packed chain evaluated twice differs %llu; the v_fma_f32 chain evaluated twice differs %llu\n",
-           PAD, r[2], chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short, hb.pk_twice_differ, hb.fma_twice_differ);
+    printf("pad %2d dwords, chain %d, LDS for %d workgroup(s) per CU: %.3g chains; packed vs v_fma_f32 chain differ %llu (%llu low half, %llu lanes 16..31 / 48..63, %llu one term short); the packed chain evaluated twice differs %llu; the v_fma_f32 chain evaluated twice differs %llu\n",
+           PAD, r[0], r[2], chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short, hb.pk_twice_differ, hb.fma_twice_differ);
     fflush(stdout);
   }
   return 0;
