@@ -644,8 +644,9 @@ static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, 
 // GEMM stages are 25 (profiles/r05_mol_fused_phase_clock.txt).  The form stays in the build, parity-tested,
 // behind NNHIP_MOL_FUSED=1; NNHIP_MOL_FUSED_MIN=<molecules> turns it on from a molecule count up without the switch.
 // The second form (molfuse2.hip, NNHIP_MOL_FUSED=4..7: two 4-wave workgroups per CU) does pay from ~400 conformers -- 512: 798 vs 877 us,
-// 1024: 1491 vs 1519, 4096: 5735 vs 5933 -- but not below (128: 547 vs 353) nor just above a multiple of 512 (640: 1180 vs 1029), and it
-// is correct only when compiled without packed fp32 for a reason not understood (profiles/r05_mol_fused2_soak.txt): opt-in as well.
+// 1024: 1491 vs 1519, 4096: 5735 vs 5933 -- but not below (128: 547 vs 353) nor just above a multiple of 512 (640: 1180 vs 1029), only
+// for uniform ~20-atom molecules (smaller shapes break even, a mix of sizes loses 33-53 %: profiles/r05_fused_by_molecule_size.txt):
+// opt-in as well.
 static bool mol_fused_pays(int n_atoms, int n_mol) {
   static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : 0x7fffffff;
   (void)n_atoms;
