@@ -209,6 +209,33 @@ def test_bench_self_launch_command(monkeypatch):
     assert not torch.cuda.is_initialized()
 
 
+def test_no_packed_fp32_instruction_in_any_kernel():
+    """build.sh compiles every kernel without packed-fp32 instructions: dependent v_pk_*_f32 chains with op_sel mis-execute on MI355X
+    for some code alignments (tools/probes/pk_chain_probe.hip; profiles/r05_mol_fused2_soak.txt), and which kernel is exposed changes
+    with every recompile.  Checked on the objects of the last build (skipped when there are none, e.g. before the first build)."""
+    import glob
+    import shutil
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    objs = sorted(glob.glob(os.path.join(ROOT, 'newtonnet_amd', 'csrc', 'build', 'obj', '*.o')))
+    if not objs or not (os.path.exists(objdump) or shutil.which('llvm-objdump')):
+        pytest.skip('no build objects / no llvm-objdump here')
+    objdump = objdump if os.path.exists(objdump) else shutil.which('llvm-objdump')
+    import tempfile
+    seen_mfma = False
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            # (`--offloading` unbundles the gfx950 code object next to the file it is given; the disassembly of that is the device code)
+            local = shutil.copy(o, tmp)
+            subprocess.run([objdump, '-d', '--offloading', local], capture_output=True, text=True, cwd=tmp)
+            dev = [f for f in glob.glob(local + '.*') if 'amdgcn' in f]
+            assert dev, f'no device code object unbundled from {o}'
+            dis = subprocess.run([objdump, '-d', dev[0]], capture_output=True, text=True).stdout
+            assert 'v_pk_fma_f32' not in dis and 'v_pk_mul_f32' not in dis and 'v_pk_add_f32' not in dis, o
+            seen_mfma |= 'v_mfma_' in dis
+    assert seen_mfma      # (the disassembly really is the device code)
+
+
 def test_tooling_builds_are_marked_and_refused(tmp_path):
     """A library compiled with any extra flag (the ablation switches of tools/ablate_*.sh produce WRONG results) carries
     nnhip_build_flags() bit 0 and the package refuses to load it; the shipped library is unmarked; defining an ablation switch
