@@ -56,6 +56,18 @@ __device__ __forceinline__ f2 chain(f2 t0, f2 t1, f2 t2, f2 t3, f2 wab, f2 wcd) 
   else if (SEP == 4) PK_CHAIN("s_nop 7\n\t");
   else if (SEP == 5) PK_CHAIN("s_nop 7\n\ts_nop 7\n\t");
   else if (SEP == 6) PK_CHAIN_PLAIN("s_nop 0\n\t");
+  else if (SEP == 20)     // only the FIRST instruction keeps its op_sel form (operands: %5 = (w.a, w.b) pair, %6.. broadcast weights)
+    asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel:[0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %6, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %3, %7, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %8, %0"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(waa), "v"(wdd), "v"(wcc));
+  else if (SEP == 21)     // only the SECOND (op_sel_hi:[1,0,1])
+    asm volatile("v_pk_mul_f32 %0, %1, %6\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %5, %0 op_sel_hi:[1,0,1]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %3, %7, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %8, %0"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wab), "v"(wbb), "v"(wdd), "v"(wcc));
+  else if (SEP == 22)     // only the THIRD (op_sel:[0,1,0])
+    asm volatile("v_pk_mul_f32 %0, %1, %6\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %7, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %3, %5, %0 op_sel:[0,1,0]\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %8, %0"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wcd), "v"(wbb), "v"(waa), "v"(wcc));
+  else if (SEP == 23)     // only the FOURTH (op_sel_hi:[1,0,1])
+    asm volatile("v_pk_mul_f32 %0, %1, %6\n\ts_nop 0\n\tv_pk_fma_f32 %0, %2, %7, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %3, %8, %0\n\ts_nop 0\n\tv_pk_fma_f32 %0, %4, %5, %0 op_sel_hi:[1,0,1]"
+                 : "=&v"(d) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(wcd), "v"(wbb), "v"(waa), "v"(wdd));
   else PK_CHAIN_PLAIN("");
   return d;
 }
@@ -162,6 +174,7 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
   }
   // the matrix phase of the edge MLPs: every wave of the workgroup on the MFMA pipe (the co-resident workgroup, dispatched a little
   // later, is still in its message pass when this starts)
+#ifndef NO_MFMA
   if (mfma_mode == 0 || true) {
     f16v c0, c1;
 #pragma unroll
@@ -177,6 +190,7 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
     acc += c0[0] + c1[3];
     __syncthreads();
   }
+#endif
   }
   if (acc == 123.456f) out[0] = acc;
   if (nbad | npk2 | nfma2) {
@@ -205,18 +219,17 @@ int main(int argc, char** argv) {
   }
   const size_t lds_two = 81000, lds_one = 100000;      // two workgroups per CU / one
   typedef void (*K)(const float*, int, const float*, float*, Bad*, uint32_t, int);
-  const K kernels[8] = {probe_kernel<0>, probe_kernel<1>, probe_kernel<2>, probe_kernel<3>, probe_kernel<4>, probe_kernel<5>, probe_kernel<6>, probe_kernel<7>};
-  const char* names[8] = {"s_nop 0 (compiler)", "s_nop 1", "nothing", "s_nop 3", "s_nop 7", "2 x s_nop 7", "no op_sel, s_nop 0", "no op_sel, nothing"};
-  for (int k = 0; k < 8; ++k) CHECK(hipFuncSetAttribute((const void*)kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one));
-  // (separator, matrix phase on / off, workgroups per CU)
 #ifndef CHAIN
-#define CHAIN 0      // 0: the op_sel chain with s_nop 0 between its instructions (what hipcc emits); 6: the same arithmetic without op_sel
-#endif
+#define CHAIN 0      // 0: the op_sel chain with s_nop 0 between its instructions (what hipcc emits); 6: the same arithmetic without op_sel;
+#endif               // 20..23: only the first / second / third / fourth instruction keeps its op_sel form
+  const K kernel = probe_kernel<CHAIN>;
+  CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one));
+  // (separator, matrix phase on / off, workgroups per CU)
   const int runs[][3] = {{CHAIN, 0, 2}, {CHAIN, 0, 1}};      // (chain form, .., workgroups per CU by LDS size)
   for (const auto& r : runs) {
     CHECK(hipMemset(bad, 0, sizeof(Bad)));
     const size_t lds = r[2] == 2 ? lds_two : r[2] == 1 ? lds_one : r[2] == 3 ? 52000 : 30000;
-    for (int k = 0; k < launches; ++k) kernels[r[0]]<<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k, r[1]);
+    for (int k = 0; k < launches; ++k) kernel<<<grid, 256, lds>>>(table, rows, nodes, out, bad, 77u + k, r[1]);
     CHECK(hipDeviceSynchronize());
     Bad hb;
     CHECK(hipMemcpy(&hb, bad, sizeof(Bad), hipMemcpyDeviceToHost));
