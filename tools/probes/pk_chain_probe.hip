@@ -9,6 +9,9 @@
 // The kernel imitates the message pass of mol2_edge_fwd_kernel, where this was first seen (profiles/r05_mol_fused2_soak.txt):
 // 512 four-wave workgroups, table rows prefetched one tile ahead (global_load_dwordx4), operands from LDS (ds_read_b128), global +
 // LDS stores, a DPP maximum, a half-empty last tile, then a short MFMA phase; two rounds of that per launch.
+// Variants (tools/probes/run_variants.sh, profiles/r05_pk_variants.txt): -DCHAIN=6 the chain without op_sel: clean at every padding;
+// -DCHAIN=20 / 22 only the first / third instruction keeps op_sel (its LOW half reads the HIGH register of the weight pair): fail;
+// -DCHAIN=21 / 23 only an op_sel_hi instruction: clean; -DNO_MFMA without the matrix phase: clean.
 // -DPAD=<k> puts k dwords of s_nop ahead of the kernel body: tools/probes/run_pad_sweep.sh compiles k = 0..15 and runs each --
 // on the boxes of this pool k = 0, 7, 8, 15 fail (period 32 bytes), the others are clean (profiles/r05_pk_pad_sweep.txt).
 // build: hipcc --offload-arch=gfx950 -O2 -DPAD=0 tools/probes/pk_chain_probe.hip -o /tmp/pk_probe ; run: /tmp/pk_probe [launches]
