@@ -35,7 +35,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct Bad { unsigned long long n, low_half, lanes16_31, one_term_short, pk_twice_differ, fma_twice_differ; };
+struct Bad { unsigned long long n, low_half, lanes16_31, one_term_short, pk_twice_differ, fma_twice_differ, mix_twice_differ, mix_vs_ref; };
 
 // SEP: 0 s_nop 0 (what the compiler emits) | 1 s_nop 1 | 2 nothing | 3 s_nop 3 | 4 s_nop 7 | 5 two s_nop 7 |
 //      6 no op_sel (weights broadcast to both halves), s_nop 0 | 7 no op_sel, nothing between
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
       for (int q = 0; q < 4; ++q) T[u][q] = *reinterpret_cast<const float4*>(table + (size_t)(row + q) * NF + c4);
     }
   };
-  unsigned long long nbad = 0, nlow = 0, n1631 = 0, nshort = 0, npk2 = 0, nfma2 = 0;
+  unsigned long long nbad = 0, nlow = 0, n1631 = 0, nshort = 0, npk2 = 0, nfma2 = 0, nmix2 = 0, nmixref = 0;
   float acc = 0.f;
 #pragma unroll 1
   for (int round = 0; round < ROUNDS; ++round) {
@@ -142,6 +142,23 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
         const f2 zw = chain<SEP>(f2{T[u][0].z, T[u][0].w}, f2{T[u][1].z, T[u][1].w}, f2{T[u][2].z, T[u][2].w}, f2{T[u][3].z, T[u][3].w}, wab, wcd);
         const float4 mj = *reinterpret_cast<const float4*>(sm_m + j * NF + c4);
         const float got[4] = {xy.x, xy.y, zw.x, zw.y};
+#ifdef MIX_PROBE   // the mixed-precision fma the split-f16 kernels use: x * s - (float)(high f16 of a packed pair), op_sel on the third operand
+        {
+          const float ma[4] = {T[u][0].x, T[u][0].y, T[u][0].z, T[u][0].w}, mc0[4] = {T[u][1].x, T[u][1].y, T[u][1].z, T[u][1].w},
+                      mc1[4] = {T[u][2].x, T[u][2].y, T[u][2].z, T[u][2].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            unsigned cpk;
+            float r1, r2, rr, tmp;
+            asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(cpk) : "v"(mc0[c]), "v"(mc1[c]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(ma[c]), "v"(w.y), "v"(cpk));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(ma[c]), "v"(w.y), "v"(cpk));
+            asm volatile("v_lshrrev_b32 %1, 16, %4\n\tv_cvt_f32_f16 %1, %1\n\ts_nop 1\n\tv_fma_f32 %0, %2, %3, -%1" : "=&v"(rr), "=&v"(tmp) : "v"(ma[c]), "v"(w.y), "v"(cpk));
+            if (__float_as_uint(r1) != __float_as_uint(r2)) ++nmix2;
+            if (__float_as_uint(r1) != __float_as_uint(rr)) ++nmixref;
+          }
+        }
+#endif
         const f2 xy2 = chain<SEP>(f2{T[u][0].x, T[u][0].y}, f2{T[u][1].x, T[u][1].y}, f2{T[u][2].x, T[u][2].y}, f2{T[u][3].x, T[u][3].y}, wab, wcd);
         const f2 zw2 = chain<SEP>(f2{T[u][0].z, T[u][0].w}, f2{T[u][1].z, T[u][1].w}, f2{T[u][2].z, T[u][2].w}, f2{T[u][3].z, T[u][3].w}, wab, wcd);
         const float got2[4] = {xy2.x, xy2.y, zw2.x, zw2.y};
@@ -196,7 +213,8 @@ __global__ void __launch_bounds__(256, 2) probe_kernel(const float* __restrict__
 #endif
   }
   if (acc == 123.456f) out[0] = acc;
-  if (nbad | npk2 | nfma2) {
+  if (nbad | npk2 | nfma2 | nmix2 | nmixref) {
+    atomicAdd(&bad->mix_twice_differ, nmix2), atomicAdd(&bad->mix_vs_ref, nmixref);
     atomicAdd(&bad->n, nbad), atomicAdd(&bad->low_half, nlow), atomicAdd(&bad->lanes16_31, n1631), atomicAdd(&bad->one_term_short, nshort);
     atomicAdd(&bad->pk_twice_differ, npk2), atomicAdd(&bad->fma_twice_differ, nfma2);
   }
@@ -237,8 +255,8 @@ int main(int argc, char** argv) {
     Bad hb;
     CHECK(hipMemcpy(&hb, bad, sizeof(Bad), hipMemcpyDeviceToHost));
     const double chains = (double)launches * grid * 256 * (TILES * 4 - 0.5) * 2 * ROUNDS;
-    printf("pad %2d dwords, chain %d, LDS for %d workgroup(s) per CU: %.3g chains; packed vs v_fma_f32 chain differ %llu (%llu low half, %llu lanes 16..31 / 48..63, %llu one term short); the packed chain evaluated twice differs %llu; the v_fma_f32 chain evaluated twice differs %llu\n",
-           PAD, r[0], r[2], chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short, hb.pk_twice_differ, hb.fma_twice_differ);
+    printf("pad %2d dwords, chain %d, LDS for %d workgroup(s) per CU: %.3g chains; packed vs v_fma_f32 chain differ %llu (%llu low half, %llu lanes 16..31 / 48..63, %llu one term short); the packed chain evaluated twice differs %llu; the v_fma_f32 chain evaluated twice differs %llu; v_fma_mix_f32 (op_sel) evaluated twice differs %llu, vs its v_fma_f32 form %llu\n",
+           PAD, r[0], r[2], chains, hb.n, hb.low_half, hb.lanes16_31, hb.one_term_short, hb.pk_twice_differ, hb.fma_twice_differ, hb.mix_twice_differ, hb.mix_vs_ref);
     fflush(stdout);
   }
   return 0;
