@@ -390,33 +390,3 @@ int launch_lin_wide_split(const float* X, int ldx, const char* img, float* Y, in
 bool split_products_enabled();   // mlp128.hip (NNHIP_MLP_SPLIT=0 turns every split-f16 kernel off)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-
-// ---- single-launch small-system step (small.hip) ----------------------------------------------------------------------
-// Everything nnhip_energy_forces does for a batch of at most SMALL_MAX_ATOMS atoms / SMALL_MAX_EDGES directed edges, in ONE
-// launch of ONE workgroup: the phases of pipeline.hip separated by workgroup barriers instead of kernel boundaries.
-#define SMALL_MAX_ATOMS 64
-#define SMALL_MAX_EDGES 4096
-struct SmallArgs {
-  const int64_t* z;
-  const int *mol_ptr, *row_ptr, *col, *rev, *pid;
-  const float* geo;
-  const int2* xg;
-  int N, E, B, L;
-  float inv_rc;
-  // parameters (prepared block + model)
-  const float *emb, *m_tab;
-  const float* ftab[NNHIP_MAX_LAYERS];
-  const char* img[NNHIP_MAX_LAYERS][IMG_PER_LAYER];
-  const char* img_head[IMG_HEAD_COUNT];
-  const float *node0_b[NNHIP_MAX_LAYERS], *node2_b[NNHIP_MAX_LAYERS];
-  const float *head0_b, *head2_b, *w4, *b4, *scale, *shift;
-  // workspace (the offsets of pipeline.hip:make_layout)
-  float* a0;
-  float *m[NNHIP_MAX_LAYERS], *hn[NNHIP_MAX_LAYERS], *msg[NNHIP_MAX_LAYERS], *h1[NNHIP_MAX_LAYERS], *h2[NNHIP_MAX_LAYERS];
-  float *phi1[NNHIP_MAX_LAYERS], *phi2[NNHIP_MAX_LAYERS], *a_mid[NNHIP_MAX_LAYERS], *a_out[NNHIP_MAX_LAYERS];
-  float *f_out[NNHIP_MAX_LAYERS], *q[NNHIP_MAX_LAYERS];
-  float *e1, *e2, *g_e, *g_a, *g_f[2], *gf, *g_phi1, *g_phi2, *g_msg, *g_m, *g_x, *g_u, *g_d;
-  // outputs
-  float *energy, *forces, *atom_energy, *atom_node_out, *force_node_out;
-};
-int launch_small_step(const SmallArgs& a, hipStream_t s);

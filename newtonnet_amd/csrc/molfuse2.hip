@@ -1,9 +1,15 @@
-// Molecule-resident fused edge phase, second form (round 5): TWO workgroups per CU.
+// Molecule-resident fused edge phase: messages, both edge MLPs, the force-message sums (and their adjoints) of a layer in ONE launch,
+// pair rows on chip.  TWO 4-wave workgroups per CU (256 threads x 256 registers, 80 KB of LDS each), so that two molecules share a CU
+// and one's latencies run under the other's matrix work.  (Round 5's first form -- one 8-wave workgroup per CU with a weight matrix in
+// LDS, 158 KB -- lost at every batch size and was removed in round 6; profiles/HISTORY_r05.md has its numbers.)
 //
-// molfuse.hip runs a molecule's edge phase as one 8-wave workgroup with a weight matrix in LDS -- 158 KB of LDS and the whole register
-// file of a CU, so nothing overlaps its ~17 barrier-separated phases.  This form spends half of each: a 4-wave
-// workgroup (256 threads x 256 registers), 80 KB of LDS, so that two molecules share a CU and one's latencies run under the other's
-// matrix work.  What makes it fit:
+// SCHEDULE (round 6): a PERSISTENT grid of at most 2 x 256 workgroups.  A workgroup takes molecules from a device-side queue -- one
+// returning atomicAdd on a head word per molecule, issued a whole molecule ahead -- over an ORDER that mol2_order_kernel builds once
+// per step from the finished neighbor list: molecules by their number of 32-pair tiles, largest first (a stable counting sort), so a
+// launch ends within one SMALL molecule of balanced instead of at the boundary of a round of workgroups that lasts as long as its
+// largest molecule (round 5: a mix of the nine MD17 shapes lost 33-53 % to the row path, 640 conformers cost two rounds).  Results do
+// not depend on the schedule: a molecule's arithmetic is its own.  Layer 0 (one edge MLP) loads its weight fragments once per launch.
+// What makes two workgroups per CU fit:
 //   * the edge MLPs stream the molecule's pair tiles ONE AT A TIME through a 17 KB operand tile (node128s.hip's row-local scheme:
 //     wave w = output block w of every GEMM, the weight fragments of its block resident in REGISTERS for all tiles of the molecule --
 //     2 x 64 registers per MLP, read once per workgroup from the fragment-order images; rows scaled by their maximum through a
@@ -13,7 +19,7 @@
 //   * the force-message sums live in 36 registers per lane (wave w owns atoms w, w + 4, ...; a full wave per incidence, two features
 //     per lane), added tile by tile in pair order: deterministic, no float atomics.
 // Global formats are the row path's (a_mid, f_out, msg, phi1 / phi2 [P][128], silu'(h) in mlp128s.hip's fragment order by GLOBAL
-// pair tile), as in molfuse.hip: the adjoint of either path can follow.
+// pair tile): the adjoint of either path can follow.
 // Reference semantics: newtonnet/models/newtonnet.py:207-227.
 //
 // BUILD NOTE: compiled WITHOUT packed-fp32 instructions, like every file of the library (build.sh).  This is the kernel in which the
@@ -32,6 +38,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define M2_WAVES 4
 #define M2_THREADS (64 * M2_WAVES)
+#define M2_GRID 512                                   // persistent workgroups: two per CU (80 KB of LDS each)
 #define M2_ATOMS NNHIP_MOL_STAGE_MAX
 #define M2_EDGES (M2_ATOMS * (M2_ATOMS - 1))
 #define M2_PAIRS (M2_EDGES / 2)
@@ -58,8 +65,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define M2_OFF_INC (M2_OFF_XG + M2_PAIRS * 8)
 #define M2_OFF_ROWB (M2_OFF_INC + M2_EDGES * 2)
 #define M2_OFF_PIJ (M2_OFF_ROWB + (M2_ATOMS + 1) * 4 + 4)
-#define M2_LDS (M2_OFF_PIJ + M2_PAIRS * 2 + 8)
+#define M2_OFF_Q (M2_OFF_PIJ + M2_PAIRS * 2 + 8)        // two queue slots (the next molecule's position, double-buffered)
+#define M2_LDS (M2_OFF_Q + 8)
 static_assert(M2_LDS <= 81920, "two workgroups per CU");
+static_assert(M2_OFF_Q % 4 == 0, "queue slots are ints");
 static_assert(32 * M2_PHI_PITCH * 4 <= M2_TILE && M2_ATOMS * NF * 4 <= M2_TILE, "aliases: m over the operand tile, the fp32 tile over the hidden tile");
 
 // tooling (-DMF_CLOCK_DEBUG): wall-clock stamps (100 MHz) of the first workgroup
@@ -201,6 +210,72 @@ __device__ __forceinline__ float m2_commit_known(const float (&v)[16], char* til
   return inv;
 }
 
+// -----------------------------------------------------------------------------------------------------------------------
+// The order the persistent workgroups take molecules in: by the number of 32-pair tiles (what a molecule costs: the tile loops are
+// 2/3 of a workgroup's time), LARGEST FIRST -- the longest-processing-time rule, so the launch ends within one small molecule of
+// balanced.  A stable counting sort in one workgroup (molecules of equal tile count keep the caller's order: the schedule, and so the
+// timing, is reproducible; the results never depend on it).  Also zeroes the head words of the step's launches.
+// -----------------------------------------------------------------------------------------------------------------------
+#define MO_THREADS 1024
+#define MO_BINS 16
+#define MO_QUEUES (2 * NNHIP_MAX_LAYERS)
+__global__ void __launch_bounds__(MO_THREADS) mol2_order_kernel(const int* __restrict__ mol_ptr, const int* __restrict__ pair_ptr, int n_mol,
+                                                                int* __restrict__ order, int* __restrict__ queue) {
+  __shared__ int hist[MO_BINS], base[MO_BINS], wcnt[MO_THREADS / 64][MO_BINS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < MO_QUEUES) queue[tid] = 0;
+  if (tid < MO_BINS) hist[tid] = 0;
+  __syncthreads();
+  auto key_of = [&](int b) {
+    const int a0 = mol_ptr[b], a1 = mol_ptr[b + 1];
+    const int np = a1 > a0 ? pair_ptr[a1] - pair_ptr[a0] : 0;
+    const int t = (max(np, 0) + 31) >> 5;
+    return MO_BINS - 1 - min(t, MO_BINS - 1);      // bin 0 = the most tiles
+  };
+  for (int b = tid; b < n_mol; b += MO_THREADS) atomicAdd(&hist[key_of(b)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < MO_BINS; ++k) {
+      base[k] = run;
+      run += hist[k];
+    }
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < n_mol; c0 += MO_THREADS) {
+    const int b = c0 + tid;
+    const int key = b < n_mol ? key_of(b) : -1;
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < MO_BINS; ++k) {
+      const unsigned long long mask = __ballot(key == k);
+      if (key == k) rank = __popcll(mask & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave][k] = __popcll(mask);
+    }
+    __syncthreads();
+    if (key >= 0) {
+      int off = base[key] + rank;
+      for (int w = 0; w < wave; ++w) off += wcnt[w][key];
+      order[off] = b;
+    }
+    __syncthreads();
+    if (tid < MO_BINS) {
+      int sum = 0;
+      for (int w = 0; w < MO_THREADS / 64; ++w) sum += wcnt[w][tid];
+      base[tid] += sum;
+    }
+    __syncthreads();
+  }
+}
+// order: n_mol ints; queue: MO_QUEUES ints (launch k of the step uses queue + k)
+int launch_mol2_order(const int* mol_ptr, const int* pair_ptr, int n_mol, int* order, int* queue, hipStream_t s) {
+  ScopedTimer t0(TC_GRAPH, s);
+  if (n_mol <= 0) return 0;
+  mol2_order_kernel<<<1, MO_THREADS, 0, s>>>(mol_ptr, pair_ptr, n_mol, order, queue);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 struct Mol2FwdArgs {
   const int *mol_ptr, *row_ptr, *pair_ptr, *col, *pid;
   const float* geo;
@@ -208,6 +283,8 @@ struct Mol2FwdArgs {
   const float *m, *a_in, *f_in, *table;
   const char *img10, *img12, *img20, *img22;
   float *a_mid, *f_out, *h1, *h2, *phi1, *phi2, *msg;
+  const int* order;   // molecules, largest first (mol2_order_kernel)
+  int* queue;         // head word of this launch: molecules handed out beyond the first gridDim.x
   int n_mol;
 };
 
@@ -225,24 +302,36 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
   int* sm_rowb = reinterpret_cast<int*>(lds + M2_OFF_ROWB);
   unsigned short* sm_pij = reinterpret_cast<unsigned short*>(lds + M2_OFF_PIJ);   // [pair] i | j << 8 (molecule-local)
 
-  const int b = blockIdx.x;
-  if (b >= A.n_mol) return;
-  const int a0 = A.mol_ptr[b], n = A.mol_ptr[b + 1] - a0;
-  if (n <= 0 || n > M2_ATOMS) return;                                // (uniform; see molfuse.hip:mf_molecule)
-  const int E0 = A.row_ptr[a0], nE = A.row_ptr[a0 + n] - E0;
-  const int P0 = A.pair_ptr[a0], nP = A.pair_ptr[a0 + n] - P0;
-  if (nE < 0 || nE > M2_EDGES || nP < 0 || nP > M2_PAIRS || nE != 2 * nP) return;
-  const int tid = threadIdx.x, lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
-  const bool hi = h != 0;
-  const int nT = (nP + 31) >> 5;
+  int* sm_q = reinterpret_cast<int*>(lds + M2_OFF_Q);
+  const int tid0 = threadIdx.x;
 
   M2Dbg dbg;
   dbg.init();
-  // ---- the first MLP's fragments are requested before anything else (they arrive under the list and message passes)
   M2Frag w1, w2;
-  m2_load_w(w1, A.img10, nb, r, h);
-  m2_load_w(w2, A.img12, nb, r, h);
+  if (!HAS_F) {             // layer 0 runs one edge MLP: its fragments stay in the registers for every molecule of the launch
+    const int lane0 = tid0 & 63;
+    m2_load_w(w1, A.img10, tid0 >> 6, lane0 & 31, lane0 >> 5);
+    m2_load_w(w2, A.img12, tid0 >> 6, lane0 & 31, lane0 >> 5);
+  }
+  // ---- one molecule (everything the kernel did per workgroup before round 6)
+  auto molecule = [&](const int b) {
+  // (the thread index passes through an empty asm once per molecule: hoisted out of the queue loop, the per-lane address arithmetic of
+  // the whole body would live across it -- 165 spilled registers instead of 20)
+  int tid = tid0;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
+  const int a0 = A.mol_ptr[b], n = A.mol_ptr[b + 1] - a0;
+  if (n <= 0 || n > M2_ATOMS) return;                                // (uniform: a workgroup serves whole molecules)
+  const int E0 = A.row_ptr[a0], nE = A.row_ptr[a0 + n] - E0;
+  const int P0 = A.pair_ptr[a0], nP = A.pair_ptr[a0 + n] - P0;
+  if (nE < 0 || nE > M2_EDGES || nP < 0 || nP > M2_PAIRS || nE != 2 * nP) return;
+  const int nT = (nP + 31) >> 5;
+  // ---- the first MLP's fragments are requested before anything else (they arrive under the list and message passes)
+  if (HAS_F) {
+    m2_load_w(w1, A.img10, nb, r, h);
+    m2_load_w(w2, A.img12, nb, r, h);
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- lists: wave w walks the rows of ITS atoms (w, w + 4, ...), a lane per edge.  The row's incidence descriptors stay in
@@ -378,9 +467,6 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
     }
   }
   __syncthreads();          // msg rows written (this workgroup reads them back below), m is dead: the tiles take its place
-#ifdef M2_DBG_P1_ONLY     // tooling: time the message pass alone (a pair-once, molecule-resident msg_fwd; results are then wrong)
-  return;
-#endif
   dbg.stamp();
 
   // ---- pass 2: the edge MLPs, tile by tile, and the force-message sums
@@ -535,13 +621,28 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_fwd_kernel(const Mol2
   run_mlp(std::integral_constant<int, 0>());
   if (HAS_F) run_mlp(std::integral_constant<int, 1>());
   dbg.stamp();
-  dbg.print(HAS_F ? "mol2_fwd<1>" : "mol2_fwd<0>");
+  };
+  // ---- the queue: position q of the order; the first gridDim.x positions are the workgroups' own, the head word hands out the
+  // rest.  The atomic for the NEXT molecule is issued before this one starts and its value is looked at when this one is done.
+  int it = 0;
+  for (int q = blockIdx.x; q < A.n_mol; ++it) {
+    int nxt = 0;
+    if (tid0 == 0) nxt = (int)gridDim.x + atomicAdd(A.queue, 1);
+    molecule(A.order[q]);
+    if (tid0 == 0) sm_q[it & 1] = nxt;
+    __syncthreads();          // (also: every wave is done with this molecule's LDS before the next one's lists land)
+    q = sm_q[it & 1];
+#ifdef MF_CLOCK_DEBUG
+    if (it == 0) dbg.print(HAS_F ? "mol2_fwd<1>" : "mol2_fwd<0>");
+#endif
+  }
 }
 
 int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
                          const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
                          const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
-                         float* h1, float* h2, float* phi1, float* phi2, float* msg, int n_mol, hipStream_t s) {
+                         float* h1, float* h2, float* phi1, float* phi2, float* msg, const int* order, int* queue, int n_mol,
+                         hipStream_t s) {
   ScopedTimer t0(TC_MOL_FWD, s);
   static const hipError_t rc0 = hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS);
   static const hipError_t rc1 = hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS);
@@ -549,7 +650,8 @@ int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, con
   HIP_TRY(rc1);
   if (n_mol <= 0) return 0;
   Mol2FwdArgs A = {mol_ptr, row_ptr, pair_ptr, col, pid, geo, reinterpret_cast<const int2*>(xg), m, a_in, f_in, table,
-                   img10, img12, img20, img22, a_mid, f_out, h1, h2, phi1, phi2, msg, n_mol};
+                   img10, img12, img20, img22, a_mid, f_out, h1, h2, phi1, phi2, msg, order, queue, n_mol};
+  const int grid = n_mol < M2_GRID ? n_mol : M2_GRID;
 #ifdef M2_DBG_ONE_PER_CU   // tooling: 100 KB of LDS per workgroup = one workgroup per CU
   const size_t lds_bytes = 102400;
   (void)hipFuncSetAttribute((const void*)mol2_edge_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -558,9 +660,9 @@ int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, con
   const size_t lds_bytes = M2_LDS;
 #endif
   if (has_f)
-    mol2_edge_fwd_kernel<true><<<n_mol, M2_THREADS, lds_bytes, s>>>(A);
+    mol2_edge_fwd_kernel<true><<<grid, M2_THREADS, lds_bytes, s>>>(A);
   else
-    mol2_edge_fwd_kernel<false><<<n_mol, M2_THREADS, lds_bytes, s>>>(A);
+    mol2_edge_fwd_kernel<false><<<grid, M2_THREADS, lds_bytes, s>>>(A);
   LAUNCH_CHECK();
   return 0;
 }
@@ -582,7 +684,8 @@ int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, con
 #define M2B_OFF_PIJ (M2B_OFF_XG + M2_PAIRS * 8)
 #define M2B_OFF_ROWB (M2B_OFF_PIJ + M2_PAIRS * 2)
 #define M2B_OFF_PAIRB (M2B_OFF_ROWB + (M2_ATOMS + 1) * 4)
-#define M2B_LDS (M2B_OFF_PAIRB + (M2_ATOMS + 1) * 4 + 8)
+#define M2B_OFF_Q (M2B_OFF_PAIRB + (M2_ATOMS + 1) * 4 + 8)   // two queue slots, as the forward
+#define M2B_LDS (M2B_OFF_Q + 8)
 #define M2B_OFF_M (2 * M2_TILE + 8 * 32 * 4)               // B2: operand tile | hidden / fp32 tile | row maxima | m | g_a
 #define M2B_OFF_GA (M2B_OFF_M + M2_ATOMS * NF * 4)
 static_assert(M2B_LDS <= 81920, "two workgroups per CU");
@@ -598,6 +701,8 @@ struct Mol2BwdArgs {
   float *g_fin, *g_m, *g_x, *g_u;
   float* g_phi;     // [P][256] scratch: g_phi1 | g_phi2 rows between B1 and B2 (the row path's g_h12 array)
   float* g_msg;     // [P][128] scratch: the first MLP's term of g_msg
+  const int* order;
+  int* queue;
   int n_mol;
 };
 
@@ -620,18 +725,27 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
   float* sm_m = reinterpret_cast<float*>(lds + M2B_OFF_M);
   float* sm_ga = reinterpret_cast<float*>(lds + M2B_OFF_GA);
 
-  const int b = blockIdx.x;
-  if (b >= A.n_mol) return;
+  int* sm_q = reinterpret_cast<int*>(lds + M2B_OFF_Q);
+  const int tid0 = threadIdx.x;
+  M2Dbg dbg;
+  dbg.init();
+  M2Frag w1, w2;
+  if (!LOWER) {             // layer 0 has one edge MLP: its adjoint's fragments are loaded once per launch
+    const int lane0 = tid0 & 63;
+    m2_load_w(w1, A.img12T, tid0 >> 6, lane0 & 31, lane0 >> 5);
+    m2_load_w(w2, A.img10T, tid0 >> 6, lane0 & 31, lane0 >> 5);
+  }
+  auto molecule = [&](const int b) {
+  int tid = tid0;             // (laundered once per molecule, as the forward)
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
   const int a0 = A.mol_ptr[b], n = A.mol_ptr[b + 1] - a0;
   if (n <= 0 || n > M2_ATOMS) return;
   const int E0 = A.row_ptr[a0], nE = A.row_ptr[a0 + n] - E0;
   const int P0 = A.pair_ptr[a0], nP = A.pair_ptr[a0 + n] - P0;
   if (nE < 0 || nE > M2_EDGES || nP < 0 || nP > M2_PAIRS || nE != 2 * nP) return;
-  const int tid = threadIdx.x, lane = tid & 63, nb = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, c4 = 4 * r, c2 = 2 * lane;
   const int nT = (nP + 31) >> 5;
-  M2Dbg dbg;
-  dbg.init();
 
   // ---- lists (as the forward) + gf
   if (tid <= n) {
@@ -695,7 +809,6 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
   __syncthreads();
   dbg.stamp();
 
-#ifndef M2_DBG_B3_ONLY    // (tooling: the message adjoint alone, fed by the row path's g_msg rows -- a pair-once, molecule-resident msg_bwd)
   // ---- B1a: per tile, the kept phi rows staged; g_u, g_phi1, g_fin
   {
     float2 acc[M2_OWN][3];
@@ -810,11 +923,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       st4(A.g_phi + ((size_t)P0 + pl) * 2 * NF + NF + c4, gp);
     }
   }
-#endif
   __syncthreads();          // the g_phi rows are written (read back below), gf / f_in are dead
-#ifdef M2_DBG_B1_ONLY     // tooling: time B1 alone (results are then wrong)
-  return;
-#endif
   dbg.stamp();
 
   // ---- B2 / B3
@@ -826,26 +935,21 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       reinterpret_cast<float4*>(sm_ga)[t] = sg_[t];
     }
   }
-  M2Frag w1, w2;
   float2 acc_m[M2_OWN];
 #pragma unroll
   for (int k = 0; k < M2_OWN; ++k) acc_m[k] = make_float2(0.f, 0.f);
   auto run_mlp = [&](auto MLP_, auto LAST_) {
     constexpr int mlp = decltype(MLP_)::value;
     constexpr bool last = decltype(LAST_)::value;      // the MLP whose second stage completes g_msg: the message adjoint follows per tile
-#ifndef M2_DBG_B3_ONLY
-    m2_load_w(w1, mlp ? A.img22T : A.img12T, nb, r, h);
-    m2_load_w(w2, mlp ? A.img20T : A.img10T, nb, r, h);
-#endif
+    if (LOWER) {
+      m2_load_w(w1, mlp ? A.img22T : A.img12T, nb, r, h);
+      m2_load_w(w2, mlp ? A.img20T : A.img10T, nb, r, h);
+    }
     const float* Hk = mlp ? A.h2 : A.h1;
     float x[16];
     auto load_x = [&](int t) {
       const int pl = 32 * t + r;
-#ifdef M2_DBG_B3_ONLY
-      const float4* xp = reinterpret_cast<const float4*>(A.g_msg + ((size_t)P0 + min(pl, max(nP - 1, 0))) * NF + nb * 32 + 4 * h);
-#else
       const float4* xp = reinterpret_cast<const float4*>(A.g_phi + ((size_t)P0 + min(pl, max(nP - 1, 0))) * 2 * NF + mlp * NF + nb * 32 + 4 * h);
-#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = (pl < nP) ? xp[2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -860,12 +964,6 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
       const size_t pg = (size_t)P0 + pl;
       const size_t tile_g = pg >> 5;
       const int lane_g = 32 * h + (int)(pg & 31);
-#ifdef M2_DBG_B3_ONLY
-      float y[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) y[q] = x[q];
-      (void)Hk, (void)tile_g, (void)lane_g;
-#else
       float inv_x;
       if (mlp == 0) {       // (row maxima of g_phi1 left in geo.w by B1a: no exchange)
         inv_x = m2_commit_known(x, xt, live ? sm_geo[32 * t + r].w : 0.f, nb, r, h);
@@ -911,7 +1009,6 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
           y[4 * q + 3] += add[q].w;
         }
       }
-#endif
       if (t + 1 < nT) load_x(t + 1);
       if (!last) {
         if (live) {
@@ -978,9 +1075,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
     }
   };
   if (LOWER) {
-#ifndef M2_DBG_B3_ONLY
     run_mlp(std::integral_constant<int, 0>(), std::false_type());
-#endif
     __syncthreads();        // (the first term's rows are in the L2 before any wave reads one back)
     run_mlp(std::integral_constant<int, 1>(), std::true_type());
 #pragma unroll
@@ -992,14 +1087,28 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mol2_edge_bwd_kernel(const Mol2
     run_mlp(std::integral_constant<int, 0>(), std::true_type());
   }
   dbg.stamp();
-  dbg.print(LOWER ? "mol2_bwd<1>" : "mol2_bwd<0>");
+  };
+  // ---- the queue (as the forward)
+  int it = 0;
+  for (int q = blockIdx.x; q < A.n_mol; ++it) {
+    int nxt = 0;
+    if (tid0 == 0) nxt = (int)gridDim.x + atomicAdd(A.queue, 1);
+    molecule(A.order[q]);
+    if (tid0 == 0) sm_q[it & 1] = nxt;
+    __syncthreads();
+    q = sm_q[it & 1];
+#ifdef MF_CLOCK_DEBUG
+    if (it == 0) dbg.print(LOWER ? "mol2_bwd<1>" : "mol2_bwd<0>");
+#endif
+  }
 }
 
 int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
                          const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
                          const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
                          const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
-                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, int n_mol, hipStream_t s) {
+                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, const int* order, int* queue, int n_mol,
+                         hipStream_t s) {
   ScopedTimer t0(TC_MOL_BWD, s);
   static const hipError_t rc0 = hipFuncSetAttribute((const void*)mol2_edge_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, M2B_LDS);
   static const hipError_t rc1 = hipFuncSetAttribute((const void*)mol2_edge_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, M2B_LDS);
@@ -1007,11 +1116,12 @@ int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, con
   HIP_TRY(rc1);
   if (n_mol <= 0) return 0;
   Mol2BwdArgs A = {mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, reinterpret_cast<const int2*>(xg), gf, g_a, m, f_in, table,
-                   img12T, img10T, img22T, img20T, h1, h2, phi1, phi2, g_fin, g_m, g_x, g_u, g_phi, g_msg, n_mol};
+                   img12T, img10T, img22T, img20T, h1, h2, phi1, phi2, g_fin, g_m, g_x, g_u, g_phi, g_msg, order, queue, n_mol};
+  const int grid = n_mol < M2_GRID ? n_mol : M2_GRID;
   if (lower)
-    mol2_edge_bwd_kernel<true><<<n_mol, M2_THREADS, M2B_LDS, s>>>(A);
+    mol2_edge_bwd_kernel<true><<<grid, M2_THREADS, M2B_LDS, s>>>(A);
   else
-    mol2_edge_bwd_kernel<false><<<n_mol, M2_THREADS, M2B_LDS, s>>>(A);
+    mol2_edge_bwd_kernel<false><<<grid, M2_THREADS, M2B_LDS, s>>>(A);
   LAUNCH_CHECK();
   return 0;
 }

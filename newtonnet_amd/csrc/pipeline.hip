@@ -42,25 +42,19 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s, bool small_molecules = false);
 int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
-// molfuse.hip: the edge phase of a layer / its adjoint in one launch, a workgroup per molecule
-int launch_mol_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
-                        const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
-                        const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
-                        float* h1, float* h2, float* phi1, float* phi2, int n_mol, hipStream_t s);
+// molfuse2.hip: the edge phase of a layer / its adjoint in one launch, persistent workgroups that take whole molecules from a queue
+int launch_mol2_order(const int* mol_ptr, const int* pair_ptr, int n_mol, int* order, int* queue, hipStream_t s);
 int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
                          const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
                          const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
-                         float* h1, float* h2, float* phi1, float* phi2, float* msg, int n_mol, hipStream_t s);   // molfuse2.hip
+                         float* h1, float* h2, float* phi1, float* phi2, float* msg, const int* order, int* queue, int n_mol,
+                         hipStream_t s);
 int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
                          const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
                          const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
                          const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
-                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, int n_mol, hipStream_t s);   // molfuse2.hip
-int launch_mol_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
-                        const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
-                        const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
-                        const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
-                        float* g_m, float* g_x, float* g_u, int n_mol, hipStream_t s);
+                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, const int* order, int* queue, int n_mol,
+                         hipStream_t s);
 
 // ---- errors ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -71,7 +65,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 106; }   // 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
+extern "C" int nnhip_version(void) { return 107; }   // 107: the fused edge phase on a persistent schedule (molfuse2.hip; nnhip_set_mol_fused), molfuse.hip / small.hip removed; 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
@@ -79,6 +73,56 @@ extern "C" int nnhip_build_flags(void) {
 #else
   return 0;
 #endif
+}
+
+// ---- the fused edge phase (molfuse2.hip): the switch and the policy -------------------------------------------------------------------
+// mode: -1 = the library decides (mol_fused_pays), 0 = never, 1 = both directions whenever eligible, 2 = forward only, 3 = adjoint only
+// (tests swap one direction at a time against the row path: every array between the two has the row path's layout).  The process
+// environment is read ONCE (NNHIP_MOL_FUSED, NNHIP_MOL_FUSED_MIN); afterwards only nnhip_set_mol_fused changes the mode -- no getenv
+// on the call path, which may run on several host threads.
+static std::atomic<int> g_mol_fused{-2};
+static int mol_fused_mode() {
+  int m = g_mol_fused.load(std::memory_order_relaxed);
+  if (m == -2) {
+    const char* ev = getenv("NNHIP_MOL_FUSED");
+    m = ev ? atoi(ev) : -1;
+    if (m < -1 || m > 3) m = -1;
+    g_mol_fused.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+extern "C" int nnhip_set_mol_fused(int mode) {
+  if (mode < -1 || mode > 3) {
+    nnhip_set_error("nnhip_set_mol_fused: mode %d (want -1 = automatic, 0 = off, 1 = on, 2 = forward only, 3 = adjoint only)", mode);
+    return NNHIP_E_INVALID;
+  }
+  mol_fused_mode();
+  g_mol_fused.store(mode, std::memory_order_relaxed);
+  return NNHIP_OK;
+}
+extern "C" int nnhip_get_mol_fused(void) { return mol_fused_mode(); }
+// Where the fused kernels pay (measured): from MOL_FUSED_MIN_DEFAULT molecules of at most NNHIP_MOL_STAGE_MAX
+// atoms up; below, a molecule's serial chain (lists, message pass, 5-9 pair tiles x two MLPs) has too few companions on its CU and the
+// row path -- which spreads a molecule over dozens of small workgroups -- wins.  NNHIP_MOL_FUSED_MIN=<molecules> moves the threshold.
+#define MOL_FUSED_MIN_DEFAULT 0x7fffffff
+static int mol_fused_min() {
+  static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : MOL_FUSED_MIN_DEFAULT;
+  return min_mol;
+}
+static bool mol_fused_pays(int n_atoms, int n_mol) {
+  (void)n_atoms;
+  return n_mol >= mol_fused_min();
+}
+static const char* mol_fused_describe() {
+  static thread_local char txt[96];
+  const int m = mol_fused_mode();
+  if (m == 0) return "off";
+  if (m == 1) return "on";
+  if (m == 2) return "forward only";
+  if (m == 3) return "adjoint only";
+  if (mol_fused_min() == 0x7fffffff) return "off (default)";
+  snprintf(txt, sizeof(txt), "from %d molecules (default)", mol_fused_min());
+  return txt;
 }
 
 // Every form choice the library makes, as one JSON object (bench.py prints it in its line; tests pin the non-default forms through
@@ -96,11 +140,10 @@ extern "C" int nnhip_config(char* buf, size_t n) {
   static const char* names[] = {"NNHIP_EDGE_LDS", "NNHIP_EDGE_SMALL_ATOMS", "NNHIP_EDGE_WPR", "NNHIP_FORCE_DIRECT_MOL", "NNHIP_FORCE_FWD_MOL", "NNHIP_GRAPH_MOL",
                                 "NNHIP_GRAPH_SMALL_ATOMS", "NNHIP_HEAD_OUT_MOL", "NNHIP_MLP_REGW", "NNHIP_MLP_REGW_SINGLE", "NNHIP_MLP_SPLIT",
                                 "NNHIP_MLP_WIDE_TILES", "NNHIP_MOL_FUSED", "NNHIP_MOL_FUSED_MIN", "NNHIP_MOL_KERNELS_MIN", "NNHIP_MSG_BWD_MOL",
-                                "NNHIP_SMALL_STEP", "NNHIP_WGRAD_FORM", "NNHIP_WGRAD_RPC"};
+                                "NNHIP_WGRAD_FORM", "NNHIP_WGRAD_RPC"};
   int small_atoms, mol_min, wpr[4], mol_forms;
   edge_config(&small_atoms, &mol_min, wpr, &mol_forms);
   const int forms = nnhip_mlp_forms();
-  const char* fused = getenv("NNHIP_MOL_FUSED");
   const char* graph_mol = getenv("NNHIP_GRAPH_MOL");
   size_t o = 0;
   auto put = [&](const char* fmt, auto... a) {
@@ -117,10 +160,7 @@ extern "C" int nnhip_config(char* buf, size_t n) {
   put("\"molecule_forms\": {\"max_atoms\": %d, \"edge_kernels_from_molecules\": %d, \"force_fwd\": %d, \"msg_bwd\": %d, \"force_direct\": %d, \"head_out\": %d, "
       "\"fused_edge_phase\": \"%s\"}, ",
       NNHIP_MOL_STAGE_MAX, mol_min, mol_forms & 1, (mol_forms >> 1) & 1, (mol_forms >> 2) & 1, (mol_forms >> 3) & 1,
-      fused ? (atoi(fused) == 0 ? "off" : atoi(fused) == 1 ? "on" : atoi(fused) == 2 ? "forward only" : atoi(fused) == 3 ? "adjoint only" :
-               atoi(fused) == 4 ? "second form, forward only" : atoi(fused) == 5 ? "second form forward, first form adjoint" :
-               atoi(fused) == 6 ? "second form" : "second form, adjoint only")
-            : (getenv("NNHIP_MOL_FUSED_MIN") ? "from NNHIP_MOL_FUSED_MIN molecules" : "off (default)"));
+      mol_fused_describe());
   put("\"edge_mlp\": {\"row_local_up_to_tiles\": %d, \"one_pass_adjoint\": %d, \"one_pass_forward\": %d, \"one_pass_single_adjoint\": %d, "
       "\"one_pass_single_forward\": %d}, ",
       mlp_wide_max_tiles_silu(), (forms >> 1) & 1, (forms >> 2) & 1, (forms >> 3) & 1, (forms >> 4) & 1);
@@ -226,6 +266,8 @@ struct WsInternal {
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
   size_t atom_energy;              // [N]
+  size_t mol_order;                // [B] ints: the molecules by pair-tile count, largest first (molfuse2.hip:mol2_order_kernel)
+  size_t mol_queue;                // [2 x NNHIP_MAX_LAYERS] ints: the head words of the persistent fused launches of a step
 };
 struct PrepLayout {
   size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
@@ -301,7 +343,6 @@ static size_t prep_bytes(int L) {
 }
 
 static void make_layout(int N, int E, int B, int L, WsInternal& w) {
-  (void)B;
   memset(&w, 0, sizeof(w));
   size_t off = 0;
   const size_t nf = (size_t)N * NF * 4;
@@ -338,6 +379,8 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   w.g_e = carve(off, nf);
   w.g_d = carve(off, (size_t)E * 16);
   w.atom_energy = carve(off, (size_t)N * 4);
+  w.mol_order = carve(off, (size_t)(B > 0 ? B : 0) * 4 + 4);
+  w.mol_queue = carve(off, 2 * NNHIP_MAX_LAYERS * 4);
   w.prep = carve(off, prep_bytes(L));   // used when the caller passes no prepared block
   w.pub.total = off;
 }
@@ -637,21 +680,6 @@ static int prepare_check_counter_impl(const nnhip_model* model, void* prepared, 
 // n_pairs_dev == NULL: E is the edge count.  Otherwise (nnhip_energy_forces_dev) E is the CAPACITY the per-edge arrays and the
 // workspace are sized for and *n_pairs_dev the true number of undirected pairs (= pair_ptr[N]): the row kernels walk row_ptr, the
 // per-edge kernels cover the capacity (rows beyond the count hold nothing anybody reads), the pair-row kernels read the count.
-// Where the fused molecule kernels (molfuse.hip) pay: NOWHERE on this hardware, as measured in round 5 -- the same box, aspirin
-// conformers, us per step row path / fused: 1 conformer 180 / 478, 48: 239 / 526, 128: 351 / 554, 512: 836 / 1243, 1024: 1467 / 2354
-// (profiles/r05_mol_fused_ab.txt).  One workgroup per CU (158 KB of LDS, 8 waves x 256 registers) runs its ~17 barrier-separated
-// phases as a latency chain with nothing to overlap them: 72 us per forward launch of ONE idle-chip molecule, of which the four
-// GEMM stages are 25 (profiles/r05_mol_fused_phase_clock.txt).  The form stays in the build, parity-tested,
-// behind NNHIP_MOL_FUSED=1; NNHIP_MOL_FUSED_MIN=<molecules> turns it on from a molecule count up without the switch.
-// The second form (molfuse2.hip, NNHIP_MOL_FUSED=4..7: two 4-wave workgroups per CU) does pay from ~400 conformers -- 512: 798 vs 877 us,
-// 1024: 1491 vs 1519, 4096: 5735 vs 5933 -- but not below (128: 547 vs 353) nor just above a multiple of 512 (640: 1180 vs 1029), only
-// for uniform ~20-atom molecules (smaller shapes break even, a mix of sizes loses 33-53 %: profiles/r05_fused_by_molecule_size.txt):
-// opt-in as well.
-static bool mol_fused_pays(int n_atoms, int n_mol) {
-  static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : 0x7fffffff;
-  (void)n_atoms;
-  return n_mol >= min_mol;
-}
 static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const float* pos, const float* cell,
                               const int32_t* mol_ptr, const int32_t* row_ptr, const int32_t* col,
                               const int32_t* rev, const int32_t* pid, const float* geo, const int32_t* xg,
@@ -717,103 +745,25 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
   auto Q = [&](size_t off) { return (float*)(pbase + off); };
   if (!prepared) TRY(run_prepare(model, pq, pbase, s));
   const bool split_nodes = split_products_enabled() && act == NNHIP_ACT_SILU;   // node128s.hip (images in the prepared block)
-  // The molecule-resident fused edge phase (molfuse.hip): batches of molecules of at most NNHIP_MOL_STAGE_MAX atoms (the caller's
+  // The molecule-resident fused edge phase (molfuse2.hip): batches of molecules of at most NNHIP_MOL_STAGE_MAX atoms (the caller's
   // `mol_kernels`: bit 8 of the list's status word is clear), SiLU with split-f16 products (its weights are the prepared images).
-  // NNHIP_MOL_FUSED (read per call): 0 = never, 1 = both directions whenever eligible, 2 = forward only, 3 = adjoint only (tests
-  // swap one direction at a time against the row path -- every array between the two has the row path's layout).
-  int fused_mode = 0;
+  bool fused_fwd2 = false, fused_bwd2 = false;
   {
-    const char* ev = getenv("NNHIP_MOL_FUSED");
-    const int want = ev ? atoi(ev) : -1;
+    const int want = mol_fused_mode();
     const bool eligible = mol_kernels && split_nodes && mol_ptr && pair_ptr && B > 0 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX;
+    int fused_mode = 0;
     if (eligible && want != 0) fused_mode = want > 0 ? want : (mol_fused_pays(N, B) ? 1 : 0);
-    // A mixed mode hands silu'(h) from a fused kernel to the row path or back in mlp128s.hip's fragment order, which the row path
-    // keeps only in its persistent edge-MLP kernels: below their threshold (the row-local kernels, H row-major) a mixed request
-    // runs both directions in the fused form it names.
-    if (cdiv(P_, 32) <= mlp_wide_max_tiles_silu()) {
-      if (fused_mode == 2 || fused_mode == 3) fused_mode = 1;
-      if (fused_mode == 4 || fused_mode == 7) fused_mode = 6;
-    }
+    // A one-direction mode hands silu'(h) from a fused kernel to the row path or back in mlp128s.hip's fragment order, which the row
+    // path keeps only in its persistent edge-MLP kernels: below their threshold (the row-local kernels, H row-major) such a request
+    // runs both directions fused.
+    if (cdiv(P_, 32) <= mlp_wide_max_tiles_silu() && fused_mode > 1) fused_mode = 1;
+    fused_fwd2 = fused_mode == 1 || fused_mode == 2;
+    fused_bwd2 = want_forces && (fused_mode == 1 || fused_mode == 3);
   }
-  // 4 .. 7: the second form (molfuse2.hip: 4-wave workgroups, two per CU) -- 4 / 5: its forward with the row path's / molfuse.hip's
-  // adjoint, 6: both directions, 7: its adjoint behind the row path's forward
-  const bool fused_fwd2 = fused_mode >= 4 && fused_mode <= 6, fused_bwd2 = fused_mode == 6 || fused_mode == 7;
-  const bool fused_fwd = fused_mode == 1 || fused_mode == 2, fused_bwd = fused_mode == 1 || fused_mode == 3 || fused_mode == 5;
-
-  // ------------------------------------------------------------------ small systems: the whole step in ONE launch (small.hip)
-  {
-    // OFF by default: measured on MI355X (profiles/r03_md_latency.txt) the single workgroup takes 905 us for the 21-atom step
-    // against 278 us for the 31 dependent launches below -- one CU serialises ~50 phases whose loads each pay the full L2 latency
-    // (two rounds of 14 dependent edge iterations per row phase, two to three rounds of GEMM units per dense phase).
-    // NNHIP_SMALL_STEP=1 selects it (read per call); tests keep it parity-checked.
-    const bool small_on = getenv("NNHIP_SMALL_STEP") && atoi(getenv("NNHIP_SMALL_STEP")) == 1;
-    bool plain = split_nodes && small_on && !virial && !n_pairs_dev && N <= SMALL_MAX_ATOMS && E <= SMALL_MAX_EDGES;
-    for (int l = 0; l < L; ++l) plain = plain && !model->layer[l].ln_w;
-    if (plain) {
-      SmallArgs a;
-      memset(&a, 0, sizeof(a));
-      a.z = z;
-      a.mol_ptr = mol_ptr;
-      a.row_ptr = row_ptr;
-      a.col = col;
-      a.rev = rev;
-      a.pid = pid;
-      a.geo = geo;
-      a.xg = reinterpret_cast<const int2*>(xg);
-      a.N = N;
-      a.E = E;
-      a.B = B;
-      a.L = L;
-      a.inv_rc = 1.0f / model->cutoff;
-      a.emb = model->node_embedding;
-      a.m_tab = Q(pq.m_tab);
-      for (int l = 0; l < L; ++l) {
-        a.ftab[l] = Q(pq.ftab[l]);
-        for (int k = 0; k < IMG_PER_LAYER; ++k) a.img[l][k] = pbase + pq.img[l][k];
-        a.node0_b[l] = model->layer[l].node0_b;
-        a.node2_b[l] = model->layer[l].node2_b;
-        a.m[l] = P(w.pub.m[l]);
-        a.hn[l] = P(w.pub.hn[l]);
-        a.msg[l] = P(w.pub.msg[l]);
-        a.h1[l] = P(w.pub.h12[l]);
-        a.h2[l] = P(w.pub.h12[l]) + h2_off;
-        a.phi1[l] = P(w.pub.phi1[l]);
-        a.phi2[l] = P(w.pub.phi2[l]);
-        a.a_mid[l] = P(w.pub.a_mid[l]);
-        a.a_out[l] = P(w.pub.a_out[l]);
-        a.f_out[l] = P(w.pub.f_out[l]);
-        a.q[l] = P(w.pub.q[l]);
-      }
-      for (int k = 0; k < IMG_HEAD_COUNT; ++k) a.img_head[k] = pbase + pq.img_head[k];
-      a.head0_b = model->head0_b;
-      a.head2_b = model->head2_b;
-      a.w4 = model->head4_w;
-      a.b4 = model->head4_b;
-      a.scale = model->scale;
-      a.shift = model->shift;
-      a.a0 = P(w.pub.a0);
-      a.e1 = P(w.pub.e1);
-      a.e2 = P(w.pub.e2);
-      a.g_e = P(w.g_e);
-      a.g_a = P(w.pub.g_a);
-      a.g_f[0] = P(w.pub.g_f);
-      a.g_f[1] = P(w.g_f2);
-      a.gf = P(w.gf_mid);
-      a.g_phi1 = P(w.g_h12);
-      a.g_phi2 = P(w.g_h12) + (size_t)((E + 1) / 2) * NF;
-      a.g_msg = P(w.g_msg);
-      a.g_m = P(w.g_m);
-      a.g_x = P(w.pub.g_x);
-      a.g_u = P(w.pub.g_u);
-      a.g_d = P(w.g_d);
-      a.energy = energy;
-      a.forces = forces;
-      a.atom_energy = atom_energy_out ? atom_energy_out : P(w.atom_energy);
-      a.atom_node_out = atom_node_out;
-      a.force_node_out = force_node_out;
-      return launch_small_step(a, s);
-    }
-  }
+  // the order the persistent workgroups take the molecules in (largest first) + the zeroed head words of the step's launches
+  int* mol_order = reinterpret_cast<int*>(ws + w.mol_order);
+  int* mol_queue = reinterpret_cast<int*>(ws + w.mol_queue);
+  if (fused_fwd2 || fused_bwd2) TRY(launch_mol2_order(mol_ptr, pair_ptr, B, mol_order, mol_queue, s));
 
   // ------------------------------------------------------------------ forward sweep
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
@@ -833,16 +783,11 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     // previous layer (by the per-element table for l = 0)
     // messages + invariant update
     if (fused_fwd2) {
+      // the whole edge phase of the layer in one launch (molfuse2.hip)
       TRY(launch_mol2_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
                                pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
                                pbase + pq.img[l][IMG_EQ2_2], P(w.pub.a_mid[l]), F_OUT(l), P(w.pub.h12[l]), P(w.pub.h12[l]) + h2_off,
-                               P(w.pub.phi1[l]), P(w.pub.phi2[l]), P(w.pub.msg[l]), B, s));
-    } else if (fused_fwd) {
-      // the whole edge phase of the layer in one launch, a workgroup per molecule (molfuse.hip)
-      TRY(launch_mol_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
-                              pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
-                              pbase + pq.img[l][IMG_EQ2_2], P(w.pub.a_mid[l]), F_OUT(l), P(w.pub.h12[l]), P(w.pub.h12[l]) + h2_off,
-                              P(w.pub.phi1[l]), P(w.pub.phi2[l]), B, s));
+                               P(w.pub.phi1[l]), P(w.pub.phi2[l]), P(w.pub.msg[l]), mol_order, mol_queue + l, B, s));
     } else {
       TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
       // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
@@ -981,14 +926,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
                                f_prev, Q(pq.ftab[l]), pbase + pq.img[l][IMG_EQ1_2_T], pbase + pq.img[l][IMG_EQ1_0_T],
                                pbase + pq.img[l][IMG_EQ2_2_T], pbase + pq.img[l][IMG_EQ2_0_T], h12, h12 + h2_off, P(w.pub.phi1[l]),
                                P(w.pub.phi2[l]), g_fin, P(w.g_m), P(w.pub.g_x) + (size_t)l * E, P(w.pub.g_u) + (size_t)l * E * 4,
-                               P(w.g_h12), P(w.g_msg), B, s));
-    } else if (fused_bwd) {
-      // the adjoint of the whole edge phase in one launch, a workgroup per molecule (molfuse.hip)
-      float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mol_edge_bwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, xg, P(w.gf_mid), P(w.pub.g_a), P(w.pub.m[l]),
-                              f_prev, Q(pq.ftab[l]), pbase + pq.img[l][IMG_EQ1_2_T], pbase + pq.img[l][IMG_EQ1_0_T],
-                              pbase + pq.img[l][IMG_EQ2_2_T], pbase + pq.img[l][IMG_EQ2_0_T], h12, h12 + h2_off, P(w.pub.phi1[l]),
-                              P(w.pub.phi2[l]), g_fin, P(w.g_m), P(w.pub.g_x) + (size_t)l * E, P(w.pub.g_u) + (size_t)l * E * 4, B, s));
+                               P(w.g_h12), P(w.g_msg), mol_order, mol_queue + NNHIP_MAX_LAYERS + l, B, s));
     } else {
       TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
                            P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));

@@ -703,44 +703,28 @@ class NewtonNet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _forward_train(self, z, pos, cell, batch, keys, energy_idx, displacement):
         """Train mode (create_graph=True): outputs stay attached to autograd so a force loss can be back-propagated
-        (trainer.py:301-313).  Built from twice-differentiable HIP primitives, see newtonnet_amd/train_ops.py."""
-        from newtonnet_amd import train_fused, train_ops
+        (trainer.py:301-313): newtonnet_amd/train_fused.py, no torch autograd graph inside the step."""
+        from newtonnet_amd import train_fused
         for key in keys:
             if key not in ('energy', 'gradient_force', 'direct_force'):
                 raise NotImplementedError(f"train-mode forward supports energy / gradient_force / direct_force (got '{key}')")
         self._hip_model(energy_idx)          # same support checks as the inference path (fp32, F=128, SiLU, ...)
         if 'gradient_force' in keys and not pos.requires_grad:
             raise RuntimeError('train-mode forward needs pos to be a leaf tensor that can require grad')
+        if not train_fused.supported(self, keys):
+            raise NotImplementedError('train-mode forward: LayerNorm on some interaction layers only (or a repeated output key) has no '
+                                      'hand-written training path')
         static = getattr(self, '_static_train_graph', None)
-        if train_fused.supported(self, keys) and os.environ.get('NNHIP_TRAIN_PATH', 'fused') == 'fused':
-            # every head set without LayerNorm: ONE autograd node on the hand-written kernels (tangent-over-reverse,
-            # csrc/train.hip; direct_force head csrc/heads.hip)
-            energy, forces, direct, g, ws = train_fused.forward_train(self, z, pos, cell, batch, graph=static)
-            outputs = CustomOutputSet(z=z, pos=pos, edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
-            outputs.lazy('atom_node', lambda: ws.a_out[-1].clone())
-            outputs.lazy('force_node', lambda: ws.f_out[-1].clone())
-            outputs.energy = energy
-            if 'gradient_force' in keys:
-                outputs.gradient_force = forces
-                outputs.lazy('pos_grad', lambda: -forces)
-            if 'direct_force' in keys:
-                outputs.direct_force = direct
-            return outputs
-        energy, atom_node, force_node, g = train_ops.forward_train(self, z, pos, cell, batch, energy_idx, graph=static)
-        outputs = CustomOutputSet(z=z, pos=pos, atom_node=atom_node, force_node=force_node, edge_index=g.edge_index,
-                                  cell=cell, displacement=displacement, batch=batch)
+        # ONE autograd node on the hand-written kernels (tangent-over-reverse, csrc/train.hip; direct_force head csrc/heads.hip;
+        # LayerNorm value / tangent kernels between unfused node stages)
+        energy, forces, direct, g, ws = train_fused.forward_train(self, z, pos, cell, batch, graph=static)
+        outputs = CustomOutputSet(z=z, pos=pos, edge_index=g.edge_index, cell=cell, displacement=displacement, batch=batch)
+        outputs.lazy('atom_node', lambda: ws.a_out[-1].clone())
+        outputs.lazy('force_node', lambda: ws.f_out[-1].clone())
         outputs.energy = energy
         if 'gradient_force' in keys:
-            (pos_grad,) = torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True,
-                                              retain_graph=True)
-            outputs.pos_grad = pos_grad
-            outputs.gradient_force = -pos_grad
-        if 'direct_force' in keys:      # output.py:130-132 + scalers.py:55-56, plain differentiable torch
-            k = keys.index('direct_force')
-            head = self.output_layers[k].layers
-            d = head(atom_node)      # Linear, act, Linear, act, Linear
-            df = (d.unsqueeze(1) * force_node).sum(dim=-1)
-            if self.scalers[k].scale is not None:
-                df = df * self.scalers[k].scale(z)
-            outputs.direct_force = df
+            outputs.gradient_force = forces
+            outputs.lazy('pos_grad', lambda: -forces)
+        if 'direct_force' in keys:
+            outputs.direct_force = direct
         return outputs

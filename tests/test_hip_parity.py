@@ -794,36 +794,6 @@ def test_properties_config2_size():
     assert torch.equal(o3.gradient_force.reshape(B, n, 3), o1.gradient_force.reshape(B, n, 3)[perm])
 
 
-@pytest.mark.parametrize('case', ['aspirin1_rand', 'aspirin1_ckpt', 'ethanol4_rand'])
-def test_single_launch_small_step_equals_the_multi_kernel_path(case):
-    """Batches of at most 64 atoms can run the whole step in ONE launch of one workgroup (csrc/small.hip; opt-in with
-    NNHIP_SMALL_STEP=1 -- measured slower than the multi-kernel path, kept parity-checked): against the oracle, and against the
-    multi-kernel path of the same library to fp32 rounding -- energies, forces, final node states."""
-    import os
-    model, sd = make_model('ckpt' if case.endswith('ckpt') else 'rand')
-    z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
-    args = (z.cuda(), pos.cuda(), cell.cuda(), batch.cuda())
-    assert z.shape[0] <= 64
-    outs = {}
-    for flag in ('1', '0'):
-        os.environ['NNHIP_SMALL_STEP'] = flag
-        try:
-            o = model(*args)
-            outs[flag] = (o.energy.cpu().double().numpy(), o.gradient_force.cpu().double().numpy(),
-                          o.atom_node.cpu().double().numpy(), o.force_node.cpu().double().numpy())
-        finally:
-            os.environ.pop('NNHIP_SMALL_STEP', None)
-    e1, f1, a1, n1 = outs['1']
-    e0, f0, a0, n0 = outs['0']
-    assert not np.array_equal(f1, f0) or case == ''            # (two different code paths really ran: not bitwise equal)
-    assert np.all(np.abs(e1 - e0) <= util.energy_tol(e0))
-    assert np.abs(f1 - f0).max() <= 2e-6 * max(1.0, np.abs(f0).max())
-    assert np.abs(a1 - a0).max() <= 2e-6 * max(1.0, np.abs(a0).max()) and np.abs(n1 - n0).max() <= 2e-6 * max(1.0, np.abs(n0).max())
-    want_e, want_f = c['f64_energy'], c['f64_forces']
-    assert np.all(np.abs(e1 - want_e) <= util.energy_tol(want_e))
-    check_forces(f1, want_f)
-
-
 def test_rotation_translation_invariance():
     z, pos, cell, batch, c = util.case_inputs('aspirin8_rand', torch.float32)
     model, _ = make_model('rand')

@@ -16,37 +16,25 @@ def make_model(which='rand'):
     return model.to('cuda'), sd
 
 
-def test_segment_sum_and_gather_double_backward():
-    """SegmentSum / Gather are each other's adjoints: first and second derivatives match torch index ops."""
-    from newtonnet_amd import hip, train_ops
+def test_segment_sum_and_gather_are_adjoint_linear_maps():
+    """nnhip_segment_sum / nnhip_gather_rows (per-stage entry points of the C ABI; scatter_sum over the receiver and the row gathers of
+    newtonnet.py:210-226): each against torch index ops, and <S x, y> == <x, G y> -- the two are each other's adjoints."""
+    from newtonnet_amd import hip
     z, pos, cell, batch, c = util.case_inputs('mixed_rand', torch.float32)
     freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
     g = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
-    eg = train_ops._EdgeGraph(g)
     i, j = g.edge_index[0], g.edge_index[1]
     gen = torch.Generator(device='cuda').manual_seed(0)
-    x = torch.randn(g.n_atoms, 3, 128, device='cuda', generator=gen, requires_grad=True)
+    x = torch.randn(g.n_atoms, 3, 128, device='cuda', generator=gen)
     w = torch.randn(g.n_edges, 3, 128, device='cuda', generator=gen)
-
-    def f_hip(x):
-        y = train_ops.Gather.apply(x, eg, 'col') * w + train_ops.Gather.apply(x, eg, 'row')
-        return train_ops.SegmentSum.apply(y * y, eg)
-
-    def f_ref(x):
-        y = x[j] * w + x[i]
-        return torch.zeros_like(x).index_add_(0, i, y * y)
-
-    for f in (f_hip, f_ref):
-        pass
-    out_h, out_r = f_hip(x), f_ref(x)
-    assert torch.allclose(out_h, out_r, rtol=1e-5, atol=1e-5)
-    v = torch.randn_like(out_h)
-    (g1h,) = torch.autograd.grad((out_h * v).sum(), x, create_graph=True)
-    (g1r,) = torch.autograd.grad((out_r * v).sum(), x, create_graph=True)
-    assert torch.allclose(g1h, g1r, rtol=1e-4, atol=1e-4)
-    (g2h,) = torch.autograd.grad(g1h.pow(2).sum(), x)
-    (g2r,) = torch.autograd.grad(g1r.pow(2).sum(), x)
-    assert torch.allclose(g2h, g2r, rtol=1e-3, atol=1e-2 * g2r.abs().max().item())
+    assert torch.equal(hip.gather_rows(x, g.col), x[j]) and torch.equal(hip.gather_rows(x, i.to(torch.int32)), x[i])
+    assert torch.equal(hip.gather_rows(w, g.rev), w[g.rev.long()])
+    seg = hip.segment_sum(w, g.row_ptr, g.n_atoms)
+    ref = torch.zeros_like(x).index_add_(0, i, w)
+    assert torch.allclose(seg, ref, rtol=1e-5, atol=1e-5)
+    lhs = (seg.double() * x.double()).sum().item()
+    rhs = (w.double() * hip.gather_rows(x, i.to(torch.int32)).double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * abs(rhs)
 
 
 @pytest.mark.parametrize('case', ['ethanol4_rand', 'mixed_rand', 'pbc216_rand'])

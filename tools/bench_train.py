@@ -57,7 +57,7 @@ def main():
         data = maker(B)
         args = [t.cuda() for t in data]
         res = {}
-        for path in (('fused',) if no_torch or (name == 'aspirin' and B > 128) else ('fused', 'torch')):
+        for path in ('fused',):      # (the torch-graph path of round 1 was removed in round 6)
             os.environ['NNHIP_TRAIN_PATH'] = path
             torch.manual_seed(0)
             model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
