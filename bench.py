@@ -627,7 +627,7 @@ def box_leg(device, steps=3):
     N = d[0].shape[0]
     for _ in range(2):
         out = model(*d)
-    E = int(out.edge_index.shape[1])
+    E = out.n_edges          # (the count from the finished list: no 5 M-key re-sort of edge_index into the caller's order)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

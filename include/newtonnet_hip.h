@@ -758,17 +758,6 @@ int nnhip_mlp_forms(void);
  * newtonnet/models/newtonnet.py:74-104). */
 int nnhip_config(char* buf, size_t n);
 
-/* The fused edge phase (csrc/molfuse2.hip: messages, both edge MLPs, force-message sums and their adjoints of a layer in one launch
- * per direction, pair rows on chip; persistent workgroups that take whole molecules of at most NNHIP_MOL_STAGE_MAX atoms from a
- * device-side queue, largest first).  Replaces the edge loop newtonnet/models/newtonnet.py:207-227 and its reverse sweep
- * (newtonnet/models/output.py:66-73) for eligible batches.  mode: -1 = the library decides from the batch shape (the default),
- * 0 = never, 1 = both directions whenever eligible, 2 = forward only, 3 = adjoint only (every array between the two directions has
- * the row path's layout).  The environment (NNHIP_MOL_FUSED, NNHIP_MOL_FUSED_MIN) is read once per process; this setter is how a
- * running process changes the mode (thread-safe; takes effect with the next call).  Results agree with the row path to fp32
- * rounding, never bit for bit (another summation order). */
-int nnhip_set_mol_fused(int32_t mode);
-int nnhip_get_mol_fused(void);
-
 /* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
@@ -776,8 +765,8 @@ int nnhip_get_mol_fused(void);
  *          3-6 = msg_fwd / force_fwd / force_bwd / msg_bwd, 7 = graph build, 8 = fused edge-MLP kernel (mlp128),
  *          9 = single linears (lin128), 10 = the batched weight-gradient kernel of training (wgrad_kernel, without its
  *          slab reduction), 11 = the one-pass register-weights form of the two edge MLPs (mlp_regw_kernel; its launches are
- *          counted in class 8 as well), 12 / 13 = the molecule-resident fused edge phase of a layer and its adjoint
- *          (mol2_edge_fwd_kernel / mol2_edge_bwd_kernel).  Disabled (0) by default.  on = 1: every class; any other non-zero value is a mask,
+ *          counted in class 8 as well), 12 / 13 = unused (the molecule-resident fused edge phase of rounds 5-6,
+ *          removed: slower than the row kernels, profiles/r06_fused_persistent_ab.txt).  Disabled (0) by default.  on = 1: every class; any other non-zero value is a mask,
  *          bit (k + 1) = class k: only those classes record events (bench.py times each class in a pass of its own, so that a
  *          kernel's duration is not stretched by the events of the kernels around it).
  * ------------------------------------------------------------------------ */

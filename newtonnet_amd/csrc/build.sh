@@ -23,13 +23,13 @@ if [ ${#extra[@]} -gt 0 ]; then
   extra+=("-DNNHIP_TOOLING=1")
 fi
 mkdir -p "$objdir"
-srcs=(graph edge lin128 mlp128 mlp128s mlp128r node128 node128s pipeline train train_step heads small molfuse molfuse2)
+srcs=(graph edge lin128 mlp128 mlp128s mlp128r node128 node128s pipeline train train_step heads)
 newest_header=$(ls -t "$here"/*.h "$here"/../../include/*.h | head -1)
 # No packed-fp32 instructions (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32) in any kernel.  On MI355X a chain of dependent v_pk_*_f32
 # instructions with op_sel modifiers returns a wrong LOW half for lanes 16..31 / 48..63 about once per 2e6 executions -- the value
 # short of exactly one term of the chain -- for some alignments of the code (period 32 bytes) and only with two or more waves per
 # SIMD; the same arithmetic as v_fma_f32 never fails (tools/probes/pk_chain_probe.hip + run_pad_sweep.sh: the stand-alone
-# reproducer; profiles/r05_mol_fused2_soak.txt: how it was found, in molfuse2.hip).  Which kernels are exposed changes with every
+# reproducer; profiles/r05_mol_fused2_soak.txt: how it was found, in round 5's molfuse2.hip -- removed in round 6).  Which kernels are exposed changes with every
 # recompile, so the instruction class is off for all of them.  Cost: none (profiles/r05_no_packed_fp32_ab.txt).  The flag reaches
 # the host pass too, which answers "not a recognized feature" once per file (filtered below).  A per-function
 # target("no-packed-fp32-ops") attribute does the same job 10 % slower (the edge kernels lose their inlining): not used.

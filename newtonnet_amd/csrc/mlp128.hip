@@ -373,7 +373,7 @@ static int launch_mlp_dispatch(int mode, bool accum_last, const MlpPair& P, hipS
 }
 
 int mlp_wide_max_tiles_silu() {   // (nnhip_config: below this many 32-row tiles the edge MLPs take the row-local form)
-  const int env_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : -1;
+  static const int env_max = getenv("NNHIP_MLP_WIDE_TILES") ? atoi(getenv("NNHIP_MLP_WIDE_TILES")) : -1;   // (read once: no getenv on a call path)
   return env_max >= 0 ? env_max : (split_products_enabled() ? MLPS_WIDE_MAX_TILES : MLP_WIDE_MAX_TILES);
 }
 static bool mlp_use_wide(const MlpArgs& a) {

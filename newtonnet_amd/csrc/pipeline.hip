@@ -42,20 +42,6 @@ int launch_head_out(const float* e2, const float* w4, const float* b4, const flo
                     const int64_t* z, const int* mol_ptr, int n_atoms, int n_mol, int act, float* atom_energy, float* g_e2,
                     float* energy, hipStream_t s, bool small_molecules = false);
 int launch_transposes(const float* const* src, float* const* dst, int count, hipStream_t s);
-// molfuse2.hip: the edge phase of a layer / its adjoint in one launch, persistent workgroups that take whole molecules from a queue
-int launch_mol2_order(const int* mol_ptr, const int* pair_ptr, int n_mol, int* order, int* queue, hipStream_t s);
-int launch_mol2_edge_fwd(bool has_f, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
-                         const float* geo, const int* xg, const float* m, const float* a_in, const float* f_in, const float* table,
-                         const char* img10, const char* img12, const char* img20, const char* img22, float* a_mid, float* f_out,
-                         float* h1, float* h2, float* phi1, float* phi2, float* msg, const int* order, int* queue, int n_mol,
-                         hipStream_t s);
-int launch_mol2_edge_bwd(bool lower, const int* mol_ptr, const int* row_ptr, const int* pair_ptr, const int* col, const int* pid,
-                         const int* rev, const float* geo, const int* xg, const float* gf, const float* g_a, const float* m,
-                         const float* f_in, const float* table, const char* img12T, const char* img10T, const char* img22T,
-                         const char* img20T, const float* h1, const float* h2, const float* phi1, const float* phi2, float* g_fin,
-                         float* g_m, float* g_x, float* g_u, float* g_phi, float* g_msg, const int* order, int* queue, int n_mol,
-                         hipStream_t s);
-
 // ---- errors ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 void nnhip_set_error(const char* fmt, ...) {
@@ -65,7 +51,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 107; }   // 107: the fused edge phase on a persistent schedule (molfuse2.hip; nnhip_set_mol_fused), molfuse.hip / small.hip removed; 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
+extern "C" int nnhip_version(void) { return 107; }   // 107: the molecule-resident fused edge phase (molfuse.hip, molfuse2.hip) and the single-launch small step (small.hip) removed -- measured slower than the row path, profiles/r06_fused_persistent_*.txt; 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
@@ -73,56 +59,6 @@ extern "C" int nnhip_build_flags(void) {
 #else
   return 0;
 #endif
-}
-
-// ---- the fused edge phase (molfuse2.hip): the switch and the policy -------------------------------------------------------------------
-// mode: -1 = the library decides (mol_fused_pays), 0 = never, 1 = both directions whenever eligible, 2 = forward only, 3 = adjoint only
-// (tests swap one direction at a time against the row path: every array between the two has the row path's layout).  The process
-// environment is read ONCE (NNHIP_MOL_FUSED, NNHIP_MOL_FUSED_MIN); afterwards only nnhip_set_mol_fused changes the mode -- no getenv
-// on the call path, which may run on several host threads.
-static std::atomic<int> g_mol_fused{-2};
-static int mol_fused_mode() {
-  int m = g_mol_fused.load(std::memory_order_relaxed);
-  if (m == -2) {
-    const char* ev = getenv("NNHIP_MOL_FUSED");
-    m = ev ? atoi(ev) : -1;
-    if (m < -1 || m > 3) m = -1;
-    g_mol_fused.store(m, std::memory_order_relaxed);
-  }
-  return m;
-}
-extern "C" int nnhip_set_mol_fused(int mode) {
-  if (mode < -1 || mode > 3) {
-    nnhip_set_error("nnhip_set_mol_fused: mode %d (want -1 = automatic, 0 = off, 1 = on, 2 = forward only, 3 = adjoint only)", mode);
-    return NNHIP_E_INVALID;
-  }
-  mol_fused_mode();
-  g_mol_fused.store(mode, std::memory_order_relaxed);
-  return NNHIP_OK;
-}
-extern "C" int nnhip_get_mol_fused(void) { return mol_fused_mode(); }
-// Where the fused kernels pay (measured): from MOL_FUSED_MIN_DEFAULT molecules of at most NNHIP_MOL_STAGE_MAX
-// atoms up; below, a molecule's serial chain (lists, message pass, 5-9 pair tiles x two MLPs) has too few companions on its CU and the
-// row path -- which spreads a molecule over dozens of small workgroups -- wins.  NNHIP_MOL_FUSED_MIN=<molecules> moves the threshold.
-#define MOL_FUSED_MIN_DEFAULT 0x7fffffff
-static int mol_fused_min() {
-  static const int min_mol = getenv("NNHIP_MOL_FUSED_MIN") ? atoi(getenv("NNHIP_MOL_FUSED_MIN")) : MOL_FUSED_MIN_DEFAULT;
-  return min_mol;
-}
-static bool mol_fused_pays(int n_atoms, int n_mol) {
-  (void)n_atoms;
-  return n_mol >= mol_fused_min();
-}
-static const char* mol_fused_describe() {
-  static thread_local char txt[96];
-  const int m = mol_fused_mode();
-  if (m == 0) return "off";
-  if (m == 1) return "on";
-  if (m == 2) return "forward only";
-  if (m == 3) return "adjoint only";
-  if (mol_fused_min() == 0x7fffffff) return "off (default)";
-  snprintf(txt, sizeof(txt), "from %d molecules (default)", mol_fused_min());
-  return txt;
 }
 
 // Every form choice the library makes, as one JSON object (bench.py prints it in its line; tests pin the non-default forms through
@@ -139,7 +75,7 @@ extern "C" int nnhip_config(char* buf, size_t n) {
   }
   static const char* names[] = {"NNHIP_EDGE_LDS", "NNHIP_EDGE_SMALL_ATOMS", "NNHIP_EDGE_WPR", "NNHIP_FORCE_DIRECT_MOL", "NNHIP_FORCE_FWD_MOL", "NNHIP_GRAPH_MOL",
                                 "NNHIP_GRAPH_SMALL_ATOMS", "NNHIP_HEAD_OUT_MOL", "NNHIP_MLP_REGW", "NNHIP_MLP_REGW_SINGLE", "NNHIP_MLP_SPLIT",
-                                "NNHIP_MLP_WIDE_TILES", "NNHIP_MOL_FUSED", "NNHIP_MOL_FUSED_MIN", "NNHIP_MOL_KERNELS_MIN", "NNHIP_MSG_BWD_MOL",
+                                "NNHIP_MLP_WIDE_TILES", "NNHIP_MOL_KERNELS_MIN", "NNHIP_MSG_BWD_MOL",
                                 "NNHIP_WGRAD_FORM", "NNHIP_WGRAD_RPC"};
   int small_atoms, mol_min, wpr[4], mol_forms;
   edge_config(&small_atoms, &mol_min, wpr, &mol_forms);
@@ -157,10 +93,8 @@ extern "C" int nnhip_config(char* buf, size_t n) {
       nnhip_graph_small_max_atoms(), (graph_mol && atoi(graph_mol) == 0) ? 0 : 1);
   put("\"edge_rows\": {\"waves_per_row\": {\"msg_fwd\": %d, \"force_fwd\": %d, \"force_bwd\": %d, \"msg_bwd\": %d}, \"four_waves_per_row_up_to_atoms\": %d}, ",
       wpr[0], wpr[1], wpr[2], wpr[3], small_atoms);
-  put("\"molecule_forms\": {\"max_atoms\": %d, \"edge_kernels_from_molecules\": %d, \"force_fwd\": %d, \"msg_bwd\": %d, \"force_direct\": %d, \"head_out\": %d, "
-      "\"fused_edge_phase\": \"%s\"}, ",
-      NNHIP_MOL_STAGE_MAX, mol_min, mol_forms & 1, (mol_forms >> 1) & 1, (mol_forms >> 2) & 1, (mol_forms >> 3) & 1,
-      mol_fused_describe());
+  put("\"molecule_forms\": {\"max_atoms\": %d, \"edge_kernels_from_molecules\": %d, \"force_fwd\": %d, \"msg_bwd\": %d, \"force_direct\": %d, \"head_out\": %d}, ",
+      NNHIP_MOL_STAGE_MAX, mol_min, mol_forms & 1, (mol_forms >> 1) & 1, (mol_forms >> 2) & 1, (mol_forms >> 3) & 1);
   put("\"edge_mlp\": {\"row_local_up_to_tiles\": %d, \"one_pass_adjoint\": %d, \"one_pass_forward\": %d, \"one_pass_single_adjoint\": %d, "
       "\"one_pass_single_forward\": %d}, ",
       mlp_wide_max_tiles_silu(), (forms >> 1) & 1, (forms >> 2) & 1, (forms >> 3) & 1, (forms >> 4) & 1);
@@ -169,7 +103,18 @@ extern "C" int nnhip_config(char* buf, size_t n) {
   for (const char* nm : names) {
     const char* v = getenv(nm);
     if (!v) continue;
-    put("%s\"%s\": \"%.24s\"", first ? "" : ", ", nm, v);
+    // (the value goes into a JSON string: keep [A-Za-z0-9_.,+-] and blank out everything else -- a quote or a backslash in a switch
+    // must not cost the caller its whole bench line)
+    char clean[25];
+    int k = 0;
+    for (; k < 24 && v[k]; ++k) {
+      const char ch = v[k];
+      const bool ok = (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch == '_' || ch == '.' ||
+                      ch == ',' || ch == '+' || ch == '-';
+      clean[k] = ok ? ch : '?';
+    }
+    clean[k] = 0;
+    put("%s\"%s\": \"%s\"", first ? "" : ", ", nm, clean);
     first = false;
   }
   put("%s", "}}");
@@ -266,8 +211,6 @@ struct WsInternal {
   size_t gf_mid;                   // [N][3][F] dE/d f_out of the layer after the update adjoint
   size_t g_d;                      // [E][4]
   size_t atom_energy;              // [N]
-  size_t mol_order;                // [B] ints: the molecules by pair-tile count, largest first (molfuse2.hip:mol2_order_kernel)
-  size_t mol_queue;                // [2 x NNHIP_MAX_LAYERS] ints: the head words of the persistent fused launches of a step
 };
 struct PrepLayout {
   size_t wT[NNHIP_MAX_LAYERS][7];  // transposed weights: node0, node2, eq1_0, eq1_2, eq2_0, eq2_2, update
@@ -343,6 +286,7 @@ static size_t prep_bytes(int L) {
 }
 
 static void make_layout(int N, int E, int B, int L, WsInternal& w) {
+  (void)B;
   memset(&w, 0, sizeof(w));
   size_t off = 0;
   const size_t nf = (size_t)N * NF * 4;
@@ -379,8 +323,6 @@ static void make_layout(int N, int E, int B, int L, WsInternal& w) {
   w.g_e = carve(off, nf);
   w.g_d = carve(off, (size_t)E * 16);
   w.atom_energy = carve(off, (size_t)N * 4);
-  w.mol_order = carve(off, (size_t)(B > 0 ? B : 0) * 4 + 4);
-  w.mol_queue = carve(off, 2 * NNHIP_MAX_LAYERS * 4);
   w.prep = carve(off, prep_bytes(L));   // used when the caller passes no prepared block
   w.pub.total = off;
 }
@@ -745,26 +687,6 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
   auto Q = [&](size_t off) { return (float*)(pbase + off); };
   if (!prepared) TRY(run_prepare(model, pq, pbase, s));
   const bool split_nodes = split_products_enabled() && act == NNHIP_ACT_SILU;   // node128s.hip (images in the prepared block)
-  // The molecule-resident fused edge phase (molfuse2.hip): batches of molecules of at most NNHIP_MOL_STAGE_MAX atoms (the caller's
-  // `mol_kernels`: bit 8 of the list's status word is clear), SiLU with split-f16 products (its weights are the prepared images).
-  bool fused_fwd2 = false, fused_bwd2 = false;
-  {
-    const int want = mol_fused_mode();
-    const bool eligible = mol_kernels && split_nodes && mol_ptr && pair_ptr && B > 0 && (long)N <= (long)B * NNHIP_MOL_STAGE_MAX;
-    int fused_mode = 0;
-    if (eligible && want != 0) fused_mode = want > 0 ? want : (mol_fused_pays(N, B) ? 1 : 0);
-    // A one-direction mode hands silu'(h) from a fused kernel to the row path or back in mlp128s.hip's fragment order, which the row
-    // path keeps only in its persistent edge-MLP kernels: below their threshold (the row-local kernels, H row-major) such a request
-    // runs both directions fused.
-    if (cdiv(P_, 32) <= mlp_wide_max_tiles_silu() && fused_mode > 1) fused_mode = 1;
-    fused_fwd2 = fused_mode == 1 || fused_mode == 2;
-    fused_bwd2 = want_forces && (fused_mode == 1 || fused_mode == 3);
-  }
-  // the order the persistent workgroups take the molecules in (largest first) + the zeroed head words of the step's launches
-  int* mol_order = reinterpret_cast<int*>(ws + w.mol_order);
-  int* mol_queue = reinterpret_cast<int*>(ws + w.mol_queue);
-  if (fused_fwd2 || fused_bwd2) TRY(launch_mol2_order(mol_ptr, pair_ptr, B, mol_order, mol_queue, s));
-
   // ------------------------------------------------------------------ forward sweep
   // The first message_nodepart acts on Embedding[z]: evaluate it once per element (the 119 embedding rows) and look the
   // atoms' rows up, instead of pushing N identical-by-element rows through the MLP.  (hn of layer 0 is not kept: its
@@ -782,13 +704,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     // message_nodepart (hn = a W0^T + b0 ; m = silu(hn) W2^T + b2) was produced by the fused node kernel that closed the
     // previous layer (by the per-element table for l = 0)
     // messages + invariant update
-    if (fused_fwd2) {
-      // the whole edge phase of the layer in one launch (molfuse2.hip)
-      TRY(launch_mol2_edge_fwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, geo, xg, P(w.pub.m[l]), a_in, f_in, Q(pq.ftab[l]),
-                               pbase + pq.img[l][IMG_EQ1_0], pbase + pq.img[l][IMG_EQ1_2], pbase + pq.img[l][IMG_EQ2_0],
-                               pbase + pq.img[l][IMG_EQ2_2], P(w.pub.a_mid[l]), F_OUT(l), P(w.pub.h12[l]), P(w.pub.h12[l]) + h2_off,
-                               P(w.pub.phi1[l]), P(w.pub.phi2[l]), P(w.pub.msg[l]), mol_order, mol_queue + l, B, s));
-    } else {
+    {
       TRY(launch_msg_fwd(P(w.pub.m[l]), xg, Q(pq.ftab[l]), row_ptr, col, pid, a_in, P(w.pub.msg[l]), P(w.pub.a_mid[l]), N, s));
       // equiv_message{1,2}: h12 = msg [V1_0 ; V2_0]^T ; phi_k = silu(h_k) V_k2^T   (layer 0: phi2 multiplies force_node == 0)
       if (E > 0) {  // fused Linear -> SiLU -> Linear per MLP; h1 | h2 are kept interleaved in h12[E][2F] for the adjoint
@@ -920,14 +836,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     const float* f_prev = has_f ? F_OUT(l - 1) : nullptr;
     // force-message adjoint
     float* g_fin = g_fbuf[pp];
-    if (fused_bwd2) {
-      float* h12 = P(w.pub.h12[l]);
-      TRY(launch_mol2_edge_bwd(has_f, mol_ptr, row_ptr, pair_ptr, col, pid, rev, geo, xg, P(w.gf_mid), P(w.pub.g_a), P(w.pub.m[l]),
-                               f_prev, Q(pq.ftab[l]), pbase + pq.img[l][IMG_EQ1_2_T], pbase + pq.img[l][IMG_EQ1_0_T],
-                               pbase + pq.img[l][IMG_EQ2_2_T], pbase + pq.img[l][IMG_EQ2_0_T], h12, h12 + h2_off, P(w.pub.phi1[l]),
-                               P(w.pub.phi2[l]), g_fin, P(w.g_m), P(w.pub.g_x) + (size_t)l * E, P(w.pub.g_u) + (size_t)l * E * 4,
-                               P(w.g_h12), P(w.g_msg), mol_order, mol_queue + NNHIP_MAX_LAYERS + l, B, s));
-    } else {
+    {
       TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
                            P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));
       if (E > 0) {

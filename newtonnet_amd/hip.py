@@ -269,7 +269,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
                     'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter', 'nnhip_graph_mol_dev',
-                    'nnhip_edge_index_from_csr', 'nnhip_config', 'nnhip_set_mol_fused', 'nnhip_get_mol_fused')
+                    'nnhip_edge_index_from_csr', 'nnhip_config')
 
 
 def _check(rc: int, what: str):
@@ -642,23 +642,6 @@ def config() -> dict:
     buf = C.create_string_buffer(4096)
     _check(L.nnhip_config(buf, 4096), 'nnhip_config')
     return json.loads(buf.value.decode())
-
-
-MOL_FUSED_MODES = {'auto': -1, 'off': 0, 'on': 1, 'forward': 2, 'adjoint': 3}
-
-
-def set_mol_fused(mode) -> int:
-    """Choose how the fused edge phase (csrc/molfuse2.hip) is used by the eval-mode step: 'auto' / -1 (the library decides from the
-    batch shape: the default), 'off' / 0, 'on' / 1 (whenever a batch is eligible), 'forward' / 2, 'adjoint' / 3 (one direction, the
-    other on the row kernels).  Returns the previous mode.  The environment (NNHIP_MOL_FUSED) only sets the process's initial mode."""
-    L = lib()
-    prev = int(L.nnhip_get_mol_fused())
-    _check(L.nnhip_set_mol_fused(int(MOL_FUSED_MODES.get(mode, mode))), 'nnhip_set_mol_fused')
-    return prev
-
-
-def get_mol_fused() -> int:
-    return int(lib().nnhip_get_mol_fused())
 
 
 def workspace_layout(N: int, E: int, B: int, n_layers: int) -> WsLayout:

@@ -118,19 +118,23 @@ class _CallGuard:
             with _LOCK_CREATION:
                 lock = d.setdefault('_call_lock', threading.RLock())
         lock.acquire()
-        cur = torch.cuda.current_stream(self.device)
-        prev = d.get('_last_stream')
-        if prev is not None and prev != cur:
-            if prev.device == cur.device:
-                cur.wait_stream(prev)
-            for name in ('_infer_ws',):
-                t = d.get(name)
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(cur)
-            blk = d.get('_prep_block')
-            if blk is not None and isinstance(blk[1], torch.Tensor):
-                blk[1].record_stream(cur)
-        d['_last_stream'] = cur
+        try:      # (anything below may raise -- a wrong device index, a freed storage: the lock must not stay held)
+            cur = torch.cuda.current_stream(self.device)
+            prev = d.get('_last_stream')
+            if prev is not None and prev != cur:
+                if prev.device == cur.device:
+                    cur.wait_stream(prev)
+                for name in ('_infer_ws',):
+                    t = d.get(name)
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
+                blk = d.get('_prep_block')
+                if blk is not None and isinstance(blk[1], torch.Tensor):
+                    blk[1].record_stream(cur)
+            d['_last_stream'] = cur
+        except BaseException:
+            lock.release()
+            raise
         return self
 
     def __exit__(self, *exc):
@@ -524,6 +528,8 @@ class NewtonNet(nn.Module):
         outputs.lazy('displacement', make_displacement)
         outputs.lazy('atom_node', lambda: own_order(rec.result('atom_node')))
         outputs.lazy('force_node', lambda: own_order(rec.result('force_node')))
+        # (the directed-edge count alone -- not an attribute of the reference's bag: callers that want E need not build [2][E] int64)
+        outputs.lazy('n_edges', lambda: int(rec.settle().graph.n_edges))
         if perm is None:
             outputs.lazy('edge_index', lambda: rec.settle().graph.edge_index)
         else:
@@ -686,19 +692,30 @@ class NewtonNet(nn.Module):
         """{'deferred_calls': eval calls queued without waiting for the device, 'repeats_needed': how many of them ran on an emptied
         graph, a stale prepared block, a wrong molecule-size guess or invalid inputs -- i.e. produced nothing usable until repeated}.
         The last queued call is settled first."""
-        rec = self.__dict__.get('_last_deferred')
-        if rec is not None:
-            rec.read_words()
-        st = dict(self.__dict__.setdefault('_deferred_stats', {'deferred_calls': 0, 'repeats_needed': 0}))
-        if reset:
-            self.__dict__['_deferred_stats'] = {'deferred_calls': 0, 'repeats_needed': 0}
+        with self._module_lock():      # (another thread may be settling the same record: count a repeat once, ADVICE r05)
+            rec = self.__dict__.get('_last_deferred')
+            if rec is not None:
+                rec.read_words()
+            st = dict(self.__dict__.setdefault('_deferred_stats', {'deferred_calls': 0, 'repeats_needed': 0}))
+            if reset:
+                self.__dict__['_deferred_stats'] = {'deferred_calls': 0, 'repeats_needed': 0}
         return st
 
     def synchronize_checks(self):
         """Settle the deferred host-side checks of the last eval-mode call now (raises what it would have raised)."""
-        rec = self.__dict__.get('_last_deferred')
-        if rec is not None:
-            rec.settle()
+        with self._module_lock():
+            rec = self.__dict__.get('_last_deferred')
+            if rec is not None:
+                rec.settle()
+
+    def _module_lock(self):
+        """The per-module re-entrant lock of _CallGuard (created on first use)."""
+        d = self.__dict__
+        lock = d.get('_call_lock')
+        if lock is None:
+            with _LOCK_CREATION:
+                lock = d.setdefault('_call_lock', threading.RLock())
+        return lock
 
     # ------------------------------------------------------------------------------------------
     def _forward_train(self, z, pos, cell, batch, keys, energy_idx, displacement):

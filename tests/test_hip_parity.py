@@ -61,8 +61,8 @@ def test_golden_case(case):
 @pytest.mark.parametrize('case', ['pbc216_rand', 'aspirin1_rand', 'aspirin1_ckpt'])
 @pytest.mark.parametrize('shuffle', [False, True])
 def test_golden_case_in_internal_spatial_order(case, shuffle):
-    """One big system runs on its atoms in Morton order of cutoff-sized cells (models/newtonnet.py:spatial_order; on from 8192 atoms of
-    a single molecule, forced on here for the single-molecule fixtures).  What the caller sees must not change: the neighbor list
+    """One big system runs on its atoms in Morton order of cutoff-sized cells (models/newtonnet.py:spatial_order; on from 16384 atoms of
+    a single molecule -- NNHIP_SPATIAL_ORDER_MIN -- forced on here for the single-molecule fixtures).  What the caller sees must not change: the neighbor list
     bit-exact in the reference's order, energy / forces / node states against the fp64 fixture -- also when the caller's own atom
     order is a random shuffle of the fixture's (every expected array shuffled alike)."""
     z, pos, cell, batch, c = util.case_inputs(case, torch.float32)
@@ -584,7 +584,6 @@ def test_one_module_on_two_streams_and_from_two_threads():
                             'NNHIP_GRAPH_MOL': '0'}),
     ('one wave per row', {'NNHIP_EDGE_WPR': '1'}),
     ('four waves per row', {'NNHIP_EDGE_WPR': '4'}),
-    ('fused edge phase', {'NNHIP_MOL_FUSED': '1'}),
 ])
 def test_non_default_forms_in_child_processes(tag, env):
     """VERDICT r04 item 7: the library picks one of several forms of most kernels by batch shape (hip.config() lists the choices);
@@ -928,6 +927,17 @@ def test_config5_full_size_properties():
     ei = o1.edge_index
     N, E = 100000, ei.shape[1]
     assert 5.0e6 < E < 5.8e6, E
+    assert o1.n_edges == E                     # (the count alone, without building the [2][E] int64 array: what bench.py reads)
+    # the module above took the DEFAULT route for a system of this size: the internal spatial order (on from 16384 atoms,
+    # models/newtonnet.py).  With it switched off the caller must see the same list bit for bit and the same numbers to rounding.
+    assert model.__dict__.get('_spatial_order_min') is None
+    plain, _ = make_model('rand')
+    plain.__dict__['_spatial_order_min'] = 0
+    o3 = plain(z, pos, cell, batch)
+    assert torch.equal(o3.edge_index, ei)
+    assert (o3.gradient_force - o1.gradient_force).abs().max().item() <= 2e-5
+    assert abs(o3.energy.item() - o1.energy.item()) <= 4 * float(np.spacing(np.float32(abs(o1.energy.item())))) + 1e-3 * N * 1e-6
+    del o3, plain
     deg = torch.bincount(ei[0], minlength=N)
     assert 25 <= int(deg.min()) and int(deg.max()) <= 90, (int(deg.min()), int(deg.max()))
     # CSR order (i ascending, j ascending within a row) and symmetry: the reversed list, re-sorted, is the list itself

@@ -2,18 +2,20 @@
 """List the places in the gfx950 ISA of a .hip file where a wave resumes on `s_waitcnt vmcnt(N)`, N > 0, while a STORE that is
 younger than a load the wait is meant to cover is still outstanding.
 
-Why: the compiler counts vector-memory loads and stores on one in-order counter (gfx9 family: no separate store counter), so
-`vmcnt(N)` is taken to mean "everything but the youngest N operations has completed".  On MI355X a store's acknowledgement can
-arrive before an OLDER load's data (measured: profiles/r05_mol_fused2_soak.txt -- one 16-lane piece of one register of a
-prefetched row was consumed before it landed, ~1 wave in 10^7, only under the memory pressure of a first dispatch round), and
-then the wait lets the wave through early.  A site is exposed when, in issue order, [... load L ... store S ...] are pending
-and the wave waits with N >= (operations issued after L) - so that S may stand in for L.
+Why it exists: the compiler counts vector-memory loads and stores on one in-order counter (gfx9 family: no separate store counter), so
+`vmcnt(N)` is taken to mean "everything but the youngest N operations has completed".  While hunting round 5's intermittent wrong
+molecule ONE HYPOTHESIS was that on MI355X a store's acknowledgement can overtake an OLDER load's data, letting such a wait through
+early.  That hypothesis was TESTED AND NOT CONFIRMED: tools/probes/vmcnt_order_probe.hip checked 1.5e10 lane-values under memory
+pressure with 0 wrong (profiles/r05_vmcnt_order_probe.txt), and the error was traced to packed-fp32 `op_sel` chains instead
+(profiles/r05_mol_fused2_soak.txt section 7; build.sh now compiles without them).  The compiler's vmcnt accounting is NOT known to be
+unsafe on this part.  The tool stays as an over-approximating audit helper: it lists where a kernel RELIES on load / store return
+order ([... load L ... store S ...] pending and a wait with N >= the operations issued after L), nothing more.
 
 The scan simulates the pending queue over the linear text of each kernel and replays every loop body once more from its
 back-edge (loop-carried prefetches).  It over-approximates (every path is taken as fall-through), so a clean report is the useful
 outcome; a listed site needs a look at the source.
 
-usage: python tools/scan_vmcnt.py newtonnet_amd/csrc/molfuse2.hip [-D...]     (or a .s file)"""
+usage: python tools/scan_vmcnt.py newtonnet_amd/csrc/edge.hip [-D...]     (or a .s file)"""
 import os, re, subprocess, sys, tempfile
 
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
