@@ -487,7 +487,11 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
     evs[0].record()
     for k in range(steps):
         step()
-        evs[k + 1].record()
+        st_ = getattr(step, 'last_stream', None)      # (a LaneStepper: the event goes onto the stream this step was queued on)
+        if st_ is not None:
+            evs[k + 1].record(st_)
+        else:
+            evs[k + 1].record()
     sync_all()
     gpu_steps = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
     order = sorted(range(regions), key=lambda k: region_dt[k])
@@ -504,7 +508,8 @@ def timed_regions(step, steps, warmup, sync_all, reduce_max, regions=N_REGIONS, 
             'step_ms_min': round(all_host[0], 4), 'step_ms_median': round(all_host[len(all_host) // 2], 4),
             'step_ms_max': round(all_host[-1], 4),
             'step_ms_gpu': [round(v, 4) for v in gpu_steps],
-            'step_ms_gpu_note': 'one extra region (not among the timed ones): HIP event after every step on the launch stream',
+            'step_ms_gpu_note': 'one extra region (not among the timed ones): HIP event after every step on the stream it was queued '
+                                'on; with several steps in flight the intervals between completions alternate (short / long)',
             'warmup_steps_run': n_warm, 'warmup_wall_s': round(warm_s, 3),
             'settle_ms_per_step': [round(1e3 * d / steps, 4) for d in settle],
             'warmup_rule': f'max(--warmup steps, {min_warm_s} s of wall time), then untimed regions of --steps steps until two in a '
@@ -571,6 +576,37 @@ def profiles_state():
     return {'csrc_sha_now': now, 'csrc_sha_of_profiles': then, 'stale': then != now}
 
 
+class LaneStepper:
+    """`streams` evaluation steps in flight: step k runs on lane k % streams of the module (model.inference_lanes: the same
+    parameters, a workspace of its own) and on that lane's HIP stream.  The steps of the benchmark are independent batches, so the
+    fill / drain phases of one step's ~45 dependent launches are covered by the other's kernels.  streams = 1: the module alone on
+    the current stream (what rounds 1-5 timed; still reported as `single_stream`)."""
+
+    def __init__(self, model, streams, device):
+        self.n = max(1, int(streams))
+        self.lanes = model.inference_lanes(self.n) if self.n > 1 else [model]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else [None]
+        self.k = 0
+        self.last_stream = None
+
+    def __call__(self, *d):
+        i = self.k % self.n
+        self.k += 1
+        if self.n == 1:
+            return self.lanes[0](*d)
+        self.last_stream = self.streams[i]
+        with torch.cuda.stream(self.streams[i]):
+            return self.lanes[i](*d)
+
+    def deferred_stats(self, reset=False):
+        tot = {'deferred_calls': 0, 'repeats_needed': 0}
+        for lane in self.lanes:
+            st = lane.deferred_stats(reset=reset)
+            for key in tot:
+                tot[key] += st.get(key, 0)
+        return tot
+
+
 def quick_time(fn, steps, sync_all, reduce_max, regions=3, warm=5):
     """median of `regions` regions of `steps` calls (barrier + synchronize around each, max over ranks), after `warm` calls"""
     for _ in range(warm):
@@ -586,7 +622,7 @@ def quick_time(fn, steps, sync_all, reduce_max, regions=3, warm=5):
     return sorted(dts)[len(dts) // 2] / steps, [round(1e3 * d / steps, 4) for d in dts]
 
 
-def strong_leg(model, device, world, rank, conformers, steps, sync_all, reduce_max, weak_ms):
+def strong_leg(model, device, world, rank, conformers, steps, sync_all, reduce_max, weak_ms, stepper=None):
     """The OTHER reading of "scaling at N GPUs" (north_star: >= 6x at 8): ONE batch of `conformers` conformers split into `world`
     contiguous shards by molecule, no collective (molecules never interact, representations.py:74-78); time = max over ranks.
     With one rank: the same shards timed one after the other on this GPU, as a projection (ranks are identical)."""
@@ -596,23 +632,25 @@ def strong_leg(model, device, world, rank, conformers, steps, sync_all, reduce_m
         per = conformers // n
         a, b = k * per * 21, (k + 1) * per * 21
         return z[a:b].contiguous(), pos[a:b].contiguous(), cell[k * per:(k + 1) * per].contiguous(), (batch[a:b] - k * per).contiguous()
+    run = stepper if stepper is not None else model
     if world > 1:
         d = shard(rank, world)
-        sec, regions = quick_time(lambda: model(*d), steps, sync_all, reduce_max)
+        sec, regions = quick_time(lambda: run(*d), steps, sync_all, reduce_max)
         return {'strong': {'conformers_total': conformers, 'conformers_per_gpu': conformers // world, 'n_gpus': world,
                            'ms_per_step': round(1e3 * sec, 4), 'region_ms_per_step': regions,
                            'value': round((conformers // world) * world * 21 / sec, 1), 'unit': 'atom-steps/s',
-                           'speedup_vs_n1_same_run': round(weak_ms / (1e3 * sec), 3)}}
-    full_sec, _ = quick_time(lambda: model(z, pos, cell, batch), steps, sync_all, reduce_max)
+                           'speedup_vs_n1_same_run': round(weak_ms / (1e3 * sec), 3), 'steps_in_flight': getattr(stepper, 'n', 1)}}
+    full_sec, _ = quick_time(lambda: run(z, pos, cell, batch), steps, sync_all, reduce_max)
     proj = {}
     for n in (2, 4, 8):
         if conformers % n:
             continue
         d = shard(n - 1, n)
-        sec, _ = quick_time(lambda: model(*d), steps, sync_all, reduce_max)
+        sec, _ = quick_time(lambda: run(*d), steps, sync_all, reduce_max)
         proj[str(n)] = {'conformers_per_gpu': conformers // n, 'ms_per_step': round(1e3 * sec, 4),
                         'speedup': round(full_sec / sec, 3), 'efficiency': round(full_sec / sec / n, 3)}
-    return {'strong_projection': {'conformers_total': conformers, 'ms_per_step_n1': round(1e3 * full_sec, 4), 'by_n_gpus': proj}}
+    return {'strong_projection': {'conformers_total': conformers, 'ms_per_step_n1': round(1e3 * full_sec, 4), 'by_n_gpus': proj,
+                                  'steps_in_flight': getattr(stepper, 'n', 1)}}
 
 
 def box_leg(device, steps=3):
@@ -671,6 +709,9 @@ def main():
     ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     ap.add_argument('--no-strong-leg', action='store_true', help='skip the strong-scaling leg (one batch split over the ranks)')
     ap.add_argument('--no-box-leg', action='store_true', help='skip the 100k-atom box summary (rank 0, N = 1)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='evaluation steps in flight: step k runs on lane k %% streams of the module, on that lane\'s HIP stream '
+                         '(model.inference_lanes); 1 = the module alone on one stream, which is also always reported (single_stream)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -731,10 +772,16 @@ def main():
     N = z.shape[0]
     n_calls = [0]
 
+    # aspirin workload: --streams steps in flight (LaneStepper); the 100k-atom box is one 24 ms step at a time
+    stepper = LaneStepper(model, args.streams if args.workload == 'aspirin' else 1, device)
+
     def step():
         d = data[n_calls[0] % n_batches]
         n_calls[0] += 1
-        return model(*d)
+        out_ = stepper(*d)
+        step.last_stream = stepper.last_stream
+        return out_
+    step.last_stream = None
 
     def sync_all():
         torch.cuda.synchronize()          # this rank's queued work is done ...
@@ -750,7 +797,7 @@ def main():
         return float(t.item())
 
     timing = timed_regions(step, args.steps, args.warmup, sync_all, reduce_max, regions=args.regions, min_warm_s=args.warm_seconds,
-                           after_warmup=lambda: model.deferred_stats(reset=True))
+                           after_warmup=lambda: stepper.deferred_stats(reset=True))
     dt = timing['dt']
     # every rank's own view of the run (a straggler shows here; `value` stays the max-over-ranks time of the median region)
     per_rank = {'ms_per_step': [round(timing['local_ms_per_step'], 4)], 'cores': [core_set]}
@@ -761,7 +808,18 @@ def main():
     per_rank['min'], per_rank['max'] = min(per_rank['ms_per_step']), max(per_rank['ms_per_step'])
     # a step that ran on an emptied graph (edge count beyond the capacity), on a stale prepared block or on a wrong guess
     # about the molecule sizes is not a step: how many of the timed regions' (and the diagnostic region's) steps needed a repeat
-    deferred = model.deferred_stats(reset=True)
+    deferred = stepper.deferred_stats(reset=True)
+    # the module alone on one stream (what rounds 1-5 reported as the headline): one step at a time on the GPU
+    single = None
+    if stepper.n > 1:
+        n_single = [0]
+
+        def step_single():
+            d = data[n_single[0] % n_batches]
+            n_single[0] += 1
+            return model(*d)
+        s_sec, s_regions = quick_time(step_single, args.steps, sync_all, reduce_max, regions=3, warm=max(5, args.warmup))
+        single = {'ms_per_step': round(1e3 * s_sec, 4), 'value': round(world * N / s_sec, 1), 'region_ms_per_step': s_regions}
     edge_counts = [int(model(*d).edge_index.shape[1]) for d in data]
     E = int(round(sum(edge_counts) / len(edge_counts)))          # (mean over the batches: what the byte / FLOP models below use)
     out = model(*data[0])                                         # batch 0: compared with the CPU baseline below
@@ -770,7 +828,7 @@ def main():
     strong = {}
     if not args.no_strong_leg and args.workload == 'aspirin' and args.conformers % max(world, 1) == 0:
         strong = strong_leg(model, device, world, rank, args.conformers, max(5, min(args.steps, 20)), sync_all, reduce_max,
-                            1e3 * dt / args.steps)
+                            1e3 * dt / args.steps, stepper=stepper)
 
     # ---- instrumented pass: per-kernel-class time with HIP events on the launch stream --------------------
     roofline = edge_roofline = onepass = edge_all_roofline = None
@@ -783,8 +841,8 @@ def main():
         for group in (('mlp128',), ('mlp_onepass',), ('edge_msg_fwd', 'edge_force_fwd', 'edge_force_bwd', 'edge_msg_bwd'),
                       ('lin128', 'graph', 'wgrad'), ('edge_all',), ('linear_mfma',), ('other',)):
             hip.timers_enable(True, classes=group)
-            for _ in range(n_inst):
-                step()
+            for k_ in range(n_inst):            # (the module alone on one stream: a kernel's duration with nothing beside it)
+                model(*data[k_ % n_batches])
             torch.cuda.synchronize()
             tm = hip.timers_read(reset=True)
             hip.timers_enable(False)
@@ -1032,7 +1090,7 @@ def main():
             'allreduce_us': train['allreduce_us'], 'roofline': train.get('roofline'), 'train': train}))
     elif rank == 0:
         kernel_sum = sum(classes[k]['ms_per_step'] for k in ('edge_all', 'linear_mfma', 'other', 'graph')) if classes else 0.0
-        host_gap = 1e3 * dt / args.steps - kernel_sum
+        host_gap = (single['ms_per_step'] if single else 1e3 * dt / args.steps) - kernel_sum
         box = train_large = None
         if world == 1 and args.workload == 'aspirin' and not args.no_box_leg:
             try:
@@ -1075,7 +1133,7 @@ def main():
                                  'or when the next step starts.  Per-module state that survives a step: the workspace allocation, '
                                  'the parameter-derived block (compared with the parameters bit for bit on every step, refilled on '
                                  'change) and that capacity -- no result of a step is reused')},
-            'timing_anomaly_rule': 'host_gap_ms = ms_per_step - kernel_sum_ms (event-timed classes edge_all + linear_mfma + other + '
+            'timing_anomaly_rule': 'host_gap_ms = (single_stream.ms_per_step, or ms_per_step with --streams 1) - kernel_sum_ms (event-timed classes edge_all + linear_mfma + other + '
                                    'graph of the same process); anomaly when it exceeds 15 % of kernel_sum_ms, or when a timed step '
                                    'needed a repeat (deferred.repeats_needed > 0).  The events around every launch of a class stretch '
                                    'it by a few per cent, so a healthy run shows a small NEGATIVE gap',
@@ -1095,11 +1153,12 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': (f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
-                                    f'fp32, energy+force, neighbor list included (BASELINE.json configs[1])')
+                                    f'fp32, energy+force, neighbor list included (BASELINE.json configs[1]); '
+                                    f'{stepper.n} independent step(s) in flight per GPU')
                        if args.workload == 'aspirin' else
                        'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights, 'distinct_batches': n_batches,
-                       'timed_regions': len(timing['region_ms_per_step']),
+                       'timed_regions': len(timing['region_ms_per_step']), 'steps_in_flight': stepper.n,
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'roofline': dict(slim(roofline, roof_keys) or {}, kernel=(roofline or {}).get('kernel', '')[:40],
@@ -1115,6 +1174,7 @@ def main():
             'kernel_sum_ms': round(kernel_sum, 4) if classes else None,
             'host_gap_ms': round(host_gap, 4) if classes else None,
             'deferred': deferred,
+            'single_stream': single,
             'timing_anomaly': bool((classes and host_gap > 0.15 * kernel_sum) or repeats > 0),
             'edge_kernel_frac': {k: v['frac_pair_bytes'] for k, v in (edge_all_roofline or {}).get('per_kernel', {}).items()},
             'counter_GB_per_step': {'edge_kernels': round((edge_all_roofline or {}).get('counter_bytes_per_step', 0) / 1e9, 3) or None,
@@ -1124,8 +1184,7 @@ def main():
                             'in_sync': train.get('replicas_in_sync'), 'error': train.get('error')} if train else None,
             'train_large': train_large, 'box100k': box,
             'forms': {'mlp': hip.mlp_forms(), 'wpr': config_lib['edge_rows']['waves_per_row'],
-                      'mol_min': config_lib['molecule_forms']['edge_kernels_from_molecules'],
-                      'fused': config_lib['molecule_forms']['fused_edge_phase'], 'env': config_lib['env']},
+                      'mol_min': config_lib['molecule_forms']['edge_kernels_from_molecules'], 'env': config_lib['env']},
         }
         line.update(strong)
         print(json.dumps(line))

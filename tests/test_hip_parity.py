@@ -579,6 +579,60 @@ def test_one_module_on_two_streams_and_from_two_threads():
     assert torch.equal(o.energy, want[2][0]) and torch.equal(o.gradient_force, want[2][1])
 
 
+def test_inference_lanes_keep_two_steps_in_flight():
+    """model.inference_lanes(n): n shallow views of one module (the same Parameter objects, their own workspaces / hints / deferred
+    checks), each driven from its own stream, so that independent batches overlap on the GPU.  Every lane returns bit for bit what
+    the module returns alone on the default stream -- with the steps of the lanes interleaved in flight, across batch shapes -- and
+    a parameter update on the owner reaches every lane."""
+    a = util.load_npz('aspirin_frames.npz')
+    gen = torch.Generator().manual_seed(23)
+    model, sd = make_model('rand')
+
+    def batch_of(B):
+        n = 21
+        pos = torch.from_numpy(a['train_pos'][0]).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=gen)
+        return (torch.from_numpy(a['z']).long().repeat(B).cuda(), pos.cuda(), torch.zeros(B, 3, 3, device='cuda'),
+                torch.repeat_interleave(torch.arange(B), n).cuda())
+
+    batches = [batch_of(256), batch_of(256), batch_of(64), batch_of(700), batch_of(256)]
+    want = []
+    for b in batches:
+        o = model(*b)
+        want.append((o.energy.clone(), o.gradient_force.clone(), o.edge_index.clone()))
+    torch.cuda.synchronize()
+    lanes = model.inference_lanes(3)
+    assert lanes[0] is model and len(lanes) == 3 and lanes[1] is not lanes[2]
+    assert all(l._parameters is model._parameters and l._modules is model._modules for l in lanes)
+    assert model.inference_lanes(2)[1] is lanes[1] and lanes[2].inference_lanes(3)[2] is lanes[2]       # (cached; a lane hands out its owner's)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rnd in range(4):          # (round 0: every lane's first, synchronous call of each shape; later rounds: deferred steps)
+        outs = []
+        for k in range(15):
+            b = (k + rnd) % len(batches)
+            with torch.cuda.stream(streams[k % 3]):
+                outs.append((b, k % 3, lanes[k % 3](*batches[b])))
+        for b, lane, o in outs:   # read after everything was queued: the steps of the three lanes overlapped
+            with torch.cuda.stream(streams[lane]):
+                e, f, ei = o.energy, o.gradient_force, o.edge_index
+            streams[lane].synchronize()
+            assert torch.equal(e, want[b][0]) and torch.equal(f, want[b][1]) and torch.equal(ei, want[b][2]), (rnd, b, lane)
+    stats = [l.deferred_stats() for l in lanes]
+    assert all(st['deferred_calls'] > 0 and st['repeats_needed'] == 0 for st in stats), stats
+    # the owner's parameters change (in place, as an optimizer step or load_state_dict does): every lane sees the new values
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        model.interaction_layers[1].equiv_message1[2].weight.mul_(1.25)
+    o_new = model(*batches[2])
+    e_new, f_new = o_new.energy.clone(), o_new.gradient_force.clone()
+    assert not torch.equal(f_new, want[2][1])
+    for k in (1, 2):
+        with torch.cuda.stream(streams[k]):
+            o = lanes[k](*batches[2])
+            e, f = o.energy, o.gradient_force
+        streams[k].synchronize()
+        assert torch.equal(e, e_new) and torch.equal(f, f_new), k
+
+
 @pytest.mark.parametrize('tag,env', [
     ('molecule forms off', {'NNHIP_FORCE_FWD_MOL': '0', 'NNHIP_MSG_BWD_MOL': '0', 'NNHIP_HEAD_OUT_MOL': '0', 'NNHIP_FORCE_DIRECT_MOL': '0',
                             'NNHIP_GRAPH_MOL': '0'}),
