@@ -810,16 +810,16 @@ def main():
     # about the molecule sizes is not a step: how many of the timed regions' (and the diagnostic region's) steps needed a repeat
     deferred = stepper.deferred_stats(reset=True)
     # the module alone on one stream (what rounds 1-5 reported as the headline): one step at a time on the GPU
-    single = None
+    single_stream = None
     if stepper.n > 1:
-        n_single = [0]
+        n_ss = [0]
 
         def step_single():
-            d = data[n_single[0] % n_batches]
-            n_single[0] += 1
+            d = data[n_ss[0] % n_batches]
+            n_ss[0] += 1
             return model(*d)
         s_sec, s_regions = quick_time(step_single, args.steps, sync_all, reduce_max, regions=3, warm=max(5, args.warmup))
-        single = {'ms_per_step': round(1e3 * s_sec, 4), 'value': round(world * N / s_sec, 1), 'region_ms_per_step': s_regions}
+        single_stream = {'ms_per_step': round(1e3 * s_sec, 4), 'value': round(world * N / s_sec, 1), 'region_ms_per_step': s_regions}
     edge_counts = [int(model(*d).edge_index.shape[1]) for d in data]
     E = int(round(sum(edge_counts) / len(edge_counts)))          # (mean over the batches: what the byte / FLOP models below use)
     out = model(*data[0])                                         # batch 0: compared with the CPU baseline below
@@ -1090,7 +1090,7 @@ def main():
             'allreduce_us': train['allreduce_us'], 'roofline': train.get('roofline'), 'train': train}))
     elif rank == 0:
         kernel_sum = sum(classes[k]['ms_per_step'] for k in ('edge_all', 'linear_mfma', 'other', 'graph')) if classes else 0.0
-        host_gap = (single['ms_per_step'] if single else 1e3 * dt / args.steps) - kernel_sum
+        host_gap = (single_stream['ms_per_step'] if single_stream else 1e3 * dt / args.steps) - kernel_sum
         box = train_large = None
         if world == 1 and args.workload == 'aspirin' and not args.no_box_leg:
             try:
@@ -1174,7 +1174,7 @@ def main():
             'kernel_sum_ms': round(kernel_sum, 4) if classes else None,
             'host_gap_ms': round(host_gap, 4) if classes else None,
             'deferred': deferred,
-            'single_stream': single,
+            'single_stream': single_stream,
             'timing_anomaly': bool((classes and host_gap > 0.15 * kernel_sum) or repeats > 0),
             'edge_kernel_frac': {k: v['frac_pair_bytes'] for k, v in (edge_all_roofline or {}).get('per_kernel', {}).items()},
             'counter_GB_per_step': {'edge_kernels': round((edge_all_roofline or {}).get('counter_bytes_per_step', 0) / 1e9, 3) or None,

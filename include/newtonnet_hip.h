@@ -677,7 +677,9 @@ int nnhip_colsum_batch(const nnhip_colsum_problem* problems_dev, int32_t n, floa
  *                       (ws->probs, ws->sums) and the g_* pointers say.
  * ------------------------------------------------------------------------ */
 typedef struct {
-  int32_t n_atoms, n_edges, n_mol, n_layers, n_basis, envelope, bf16_wgrad, pad_;
+  int32_t n_atoms, n_edges, n_mol, n_layers, n_basis, envelope, bf16_wgrad;
+  int32_t flags; /* bit 0: no molecule of the batch has more than NNHIP_MOL_STAGE_MAX atoms (bit 8 of the list's status word is
+                    clear): with pair_ptr below, the value sweeps take the molecule-resident force_fwd / msg_bwd forms */
   /* batch + graph (nnhip_graph_* / nnhip_edge_embed outputs; rbf / drbf are required) */
   const int64_t* z; const float* pos; const float* cell; const int64_t* batch;
   const int32_t* mol_ptr; const int32_t* row_ptr; const int32_t* col; const int32_t* rev; const int32_t* pid;
@@ -714,6 +716,9 @@ typedef struct {
   float* ln_xhat[NNHIP_MAX_LAYERS]; float* ln_rstd[NNHIP_MAX_LAYERS]; float* ln_dxhat[NNHIP_MAX_LAYERS];
   float* ln_drstd[NNHIP_MAX_LAYERS]; float* ln_gy[NNHIP_MAX_LAYERS]; float* ln_row_w[NNHIP_MAX_LAYERS];
   float* ln_row_b[NNHIP_MAX_LAYERS];
+  /* optional (NULL: the row kernels find a row's own pairs by a ballot): pair_ptr[N+1] of nnhip_graph_count_pairs -- the value sweeps
+   * then run the forms the inference step runs (round 6) */
+  const int32_t* pair_ptr;
 } nnhip_train_ws;
 size_t nnhip_train_ws_bytes(void); /* sizeof(nnhip_train_ws) of this build (bindings check their mirror against it) */
 int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws* ws, void* stream);

@@ -12,6 +12,17 @@ int launch_layer_norm_tan_fwd(float* da, const float* xhat, const float* rstd, c
 int launch_layer_norm_tan_bwd(const float* gy, float* dga, const float* xhat, const float* rstd, const float* dxhat,
                               const float* drstd, const float* gamma, int n_atoms, float* row_w, float* row_b, hipStream_t s);
 
+// edge.hip: the launchers the inference step uses (pair_ptr: per-row pair counts; mol_ptr: batches of small molecules)
+int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const float* geo, const int* row_ptr, const int* col,
+                     const int* pid, const float* f_in, float* f_out, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr,
+                     const int* mol_ptr, int n_mol);
+int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
+                     const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u, float* g_fin, int n_atoms,
+                     const int* xg, hipStream_t s, const int* pair_ptr);
+int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table, const int* row_ptr,
+                   const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm, hipStream_t s,
+                   const int* pair_ptr, const int* mol_ptr, int n_mol);
+
 #define TS_TRY(x)          \
   do {                     \
     int _r = (x);          \
@@ -154,6 +165,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   const bool img_on = train_images(model, w);
   const bool ln = has_ln(model);
   const bool node_img = img_on && !ln;
+  const bool mol_forms = (w->flags & 1) && w->pair_ptr && w->mol_ptr;   // every molecule fits the molecule-resident kernels
   // parameter-only data of this step: transposed weights, radial-filter tables
   {
     const float* src[40];
@@ -239,7 +251,9 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
                                LIMG(l, IMG_EQ2_2)), s));
     else
       TS_TRY(run1(d1, s));
-    TS_TRY(nnhip_force_message_fwd(w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_in, w->f_out[l], N, s));
+    // (round 6: as the inference step -- per-row pair counts, and for batches of small molecules the molecule-resident form)
+    TS_TRY(launch_force_fwd(f_in != nullptr, w->phi1[l], w->phi2[l], w->geo, w->row_ptr, w->col, w->pid, f_in, w->f_out[l], N, w->xg,
+                            (hipStream_t)s, w->pair_ptr, mol_forms ? w->mol_ptr : nullptr, B));
     if (ln) {   // update | LayerNorm (in place; x_hat, 1/sigma kept) | next message_nodepart or head, unfused
       const bool lastl = l + 1 == L;
       TS_TRY(nnhip_node_fwd(w->f_out[l], w->a_mid[l], lp.update_w, w->q[l], w->a_out[l], nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -286,8 +300,8 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   for (int l = L - 1; l >= 0; --l) {
     const float* f_prev = l > 0 ? w->f_out[l - 1] : nullptr;
     float* Gf = w->Gf[pp];
-    TS_TRY(nnhip_force_message_bwd(w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->xg, w->row_ptr, w->col, w->pid, f_prev,
-                                   w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, s));
+    TS_TRY(launch_force_bwd(f_prev != nullptr, w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->row_ptr, w->col, w->pid, f_prev,
+                            w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, w->xg, (hipStream_t)s, w->pair_ptr));
     nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act,
                                  LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T = w->t1[l];
@@ -300,8 +314,9 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     } else {
       TS_TRY(run1(d1, s));
     }
-    TS_TRY(nnhip_message_bwd(w->g_msg[l], w->GA[l], w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid,
-                             l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0 ? 1 : 0, s));
+    TS_TRY(launch_msg_bwd(w->g_msg[l], w->GA[l], w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid,
+                          l > 0 ? w->g_m[l] : nullptr, w->g_x + (size_t)l * E, N, l > 0, (hipStream_t)s, w->pair_ptr,
+                          mol_forms ? w->mol_ptr : nullptr, B));
     if (l > 0 && node_img) {
       TS_TRY(node_bwd_fused(w, w->g_m[l], w->hn[l], w->wimg[l][IMG_NODE2_T], w->wimg[l][IMG_NODE0_T], w->t_n[l], w->GA[l],
                             w->GA[l - 1], l - 1, Gf, N, act, s));

@@ -76,7 +76,7 @@ def _train_ws_fields():
     L, vp, i32 = NNHIP_MAX_LAYERS, C.c_void_p, C.c_int32
     one = lambda *names: [(n, vp) for n in names]            # noqa: E731
     per = lambda *names: [(n, vp * L) for n in names]        # noqa: E731
-    return ([(n, i32) for n in ('n_atoms', 'n_edges', 'n_mol', 'n_layers', 'n_basis', 'envelope', 'bf16_wgrad', 'pad_')]
+    return ([(n, i32) for n in ('n_atoms', 'n_edges', 'n_mol', 'n_layers', 'n_basis', 'envelope', 'bf16_wgrad', 'flags')]
             + one('z', 'pos', 'cell', 'batch', 'mol_ptr', 'row_ptr', 'col', 'rev', 'pid', 'edge_index', 'geo', 'disp', 'rbf',
                   'drbf', 'xg')
             + [('wT', (vp * 7) * L), ('headT', vp * 2)] + per('ftab') + [('wimg', (vp * 14) * L), ('himg', vp * 4)]
@@ -92,7 +92,8 @@ def _train_ws_fields():
             + one('probs', 'sums', 'slabs', 'cs_scratch', 'sp_scratch')
             + [(n, i32) for n in ('n_probs', 'chunks', 'n_sums', 'pad2_')]
             + one('g_embedding', 'g_scale', 'g_shift', 'g_head4_b')
-            + per('ln_xhat', 'ln_rstd', 'ln_dxhat', 'ln_drstd', 'ln_gy', 'ln_row_w', 'ln_row_b'))
+            + per('ln_xhat', 'ln_rstd', 'ln_dxhat', 'ln_drstd', 'ln_gy', 'ln_row_w', 'ln_row_b')
+            + one('pair_ptr'))
 
 
 class TrainWs(C.Structure):

@@ -327,6 +327,12 @@ class Runner:
                         ('row_ptr', g.row_ptr), ('col', g.col), ('rev', g.rev), ('pid', g.pid), ('edge_index', g.edge_index),
                         ('geo', g.geo), ('disp', g.disp), ('rbf', g.rbf), ('drbf', g.drbf), ('xg', g.xg)):
             setattr(c, name, t.data_ptr())
+        # the forms of the inference step for the value sweeps (round 6): per-row pair counts, and "every molecule fits the
+        # molecule-resident kernels" (bit 8 of the list's status word; a static candidate list carries neither: row forms)
+        pp = getattr(g, 'pair_ptr', None)
+        status = getattr(g, 'status', None)
+        c.pair_ptr = pp.data_ptr() if isinstance(pp, torch.Tensor) and pp.numel() == g.n_atoms + 1 else None
+        c.flags = 1 if (c.pair_ptr and isinstance(status, int) and not (status & hip.STATUS_BIG_MOLECULE)) else 0
         return C.byref(ws.model_c), C.byref(c)
 
     # -- sweeps 1 and 2: values (csrc/train_step.hip strings the stages together) ------------------------------------------
