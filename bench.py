@@ -237,6 +237,72 @@ def train_roofline(device, conformers=1024, reps=5):
     return r
 
 
+def synthetic_ethanol(B, seed=0, device='cpu'):
+    """ethanol-shaped molecules (9 atoms, C2H6O), an idealised geometry + N(0, 0.1^2) noise, seeded."""
+    eth0 = torch.tensor([[0.00, 0.00, 0.00], [1.52, 0.00, 0.00], [2.05, 1.32, 0.00], [-0.39, 1.02, 0.00],
+                         [-0.39, -0.51, 0.89], [-0.39, -0.51, -0.89], [1.90, -0.53, 0.88], [1.90, -0.53, -0.88],
+                         [3.01, 1.30, 0.00]])
+    g = torch.Generator().manual_seed(seed)
+    pos = eth0.repeat(B, 1) + 0.1 * torch.randn(9 * B, 3, generator=g)
+    z = torch.tensor([6, 6, 8, 1, 1, 1, 1, 1, 1]).repeat(B)
+    batch = torch.repeat_interleave(torch.arange(B), 9)
+    return z.to(device), pos.to(device), torch.zeros(B, 3, 3, device=device), batch.to(device)
+
+
+def train_bf16_leg(device, reps=8):
+    """BASELINE configs[2] names bf16.  The training step's values + loss + gradients (no optimizer, one rank) in its two compute
+    modes -- fp32-grade products, and the bf16 mode torch.autocast(bfloat16) selects: bf16 operands in the edge MLPs of all four
+    sweeps and in the weight-gradient products, fp32 accumulation, fp32 everywhere else -- on the ethanol-shaped batch of 32
+    molecules (config 3) and on 1024 aspirin conformers; the relative gradient-norm difference between the modes beside the times."""
+    from newtonnet_amd import hip, train_fused
+    from newtonnet_amd.models import NewtonNet
+    out = {}
+    for tag, data in (('ethanol32', synthetic_ethanol(32, 0, device)), ('aspirin1024', synthetic_aspirin(1024, seed=0, device=device))):
+        z, pos, cell, batch = data
+        N, B = pos.shape[0], cell.shape[0]
+        g = torch.Generator().manual_seed(1)
+        e_lab, f_lab = torch.randn(B, generator=g).to(device), torch.randn(N, 3, generator=g).to(device)
+        torch.manual_seed(0)
+        model = NewtonNet(output_properties=['energy', 'gradient_force']).to(device)
+        model.train()
+        emb = model.embedding_layers.edge_embedding
+        norm = torch.tensor([1.0 / B, 50.0 / (3 * N)], dtype=torch.float32, device=device)
+        loss, gE, gF = torch.zeros(1, device=device), torch.empty(B, device=device), torch.empty(N, 3, device=device)
+        res = {}
+        with torch.no_grad():
+            gr = hip.build_graph(pos, cell, batch, emb.cutoff, emb.embedding.frequencies, want_rbf=True, z=z, envelope=emb.envelope_id)
+            ws = train_fused.acquire_workspace(model, gr, device, static=True)
+            runner = train_fused.Runner(model, z, pos, cell, batch, gr, ws)
+
+            def one():
+                runner.values()
+                hip._check(hip.lib().nnhip_loss_grad(hip._ptr(ws.energy), hip._ptr(e_lab), B, hip._ptr(ws.forces), hip._ptr(f_lab), 3 * N,
+                                                     hip._ptr(norm), 0, 0, 1.0, 1.0, hip._ptr(loss), hip._ptr(gE), hip._ptr(gF),
+                                                     hip._stream(device)), 'nnhip_loss_grad')
+                runner.grads(gE, gF)
+            grads = {}
+            for mode in ('f32', 'bf16'):
+                runner.bf16 = mode == 'bf16'
+                n0 = hip.bf16_mlp_launches()
+                for _ in range(3):
+                    one()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    one()
+                torch.cuda.synchronize()
+                res[mode] = round(1e3 * (time.perf_counter() - t0) / reps, 4)
+                res[mode + '_bf16_mlp_launches_per_step'] = (hip.bf16_mlp_launches() - n0) / (reps + 3)
+                grads[mode] = ws.flat_grad.double().clone() if hasattr(ws, 'flat_grad') else None
+        if grads.get('f32') is not None and grads.get('bf16') is not None:
+            res['rel_grad_diff_bf16_vs_f32'] = float((grads['bf16'] - grads['f32']).norm() / grads['f32'].norm())
+        model.__dict__.pop('_train_ws', None)
+        out[tag] = {'ms_per_step': res['bf16'], 'ms_per_step_f32': res['f32'], 'dtype': 'bf16 operands (edge MLPs of all four sweeps + '
+                    'weight gradients), fp32 accumulate, fp32 elsewhere', 'bf16_mlp_launches_per_step': res['bf16_bf16_mlp_launches_per_step'],
+                    'rel_grad_diff_vs_f32': res.get('rel_grad_diff_bf16_vs_f32'), 'atoms': N, 'molecules': B}
+    return out
+
+
 def algorithmic_counts(N, E, L=3, F=128):
     """algorithmic bytes of the edge kernels and FLOPs of the dense linears, per step.
     The edge MLPs are evaluated once per undirected pair (P = E/2 rows): the FLOP counts below are the FLOPs actually
@@ -1076,6 +1142,11 @@ def main():
                 train['roofline'] = train_roofline(device)
             except Exception as exc:  # noqa: BLE001 -- reported, never fatal: a secondary measurement
                 train['roofline'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+        if rank == 0 and train is not None and 'error' not in train and not args.no_train_roofline:
+            try:
+                train['bf16'] = train_bf16_leg(device)
+            except Exception as exc:  # noqa: BLE001 -- reported, never fatal: a secondary measurement
+                train['bf16'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         if dist is not None:
             dist.barrier()
 
@@ -1182,7 +1253,9 @@ def main():
             'profiles': dict(pstate, quoted=quotes_profiles),
             'train_small': {'ms_per_step': train.get('ms_per_step'), 'allreduce_us': train.get('allreduce_us'),
                             'in_sync': train.get('replicas_in_sync'), 'error': train.get('error')} if train else None,
-            'train_large': train_large, 'box100k': box,
+            'train_large': train_large,
+            'train_large_bf16': ((train or {}).get('bf16') or {}).get('aspirin1024', (train or {}).get('bf16')),
+            'train_ethanol_bf16': ((train or {}).get('bf16') or {}).get('ethanol32'), 'box100k': box,
             'forms': {'mlp': hip.mlp_forms(), 'wpr': config_lib['edge_rows']['waves_per_row'],
                       'mol_min': config_lib['molecule_forms']['edge_kernels_from_molecules'], 'env': config_lib['env']},
         }

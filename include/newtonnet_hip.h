@@ -558,6 +558,11 @@ typedef struct {
   /* optional: split-f16 images of W1 / W2 (nnhip_weight_images; both or neither).  With them the row-local form of the kernel
    * (M <= 49 152 rows) takes the split-f16 product form instead of v_mfma_f32_32x32x2_f32; results agree to fp32 rounding. */
   const void* W1_image; const void* W2_image;
+  /* 0: fp32-grade products (the default).  1: the bf16 compute mode of training under torch.autocast(bfloat16) (BASELINE configs[2];
+   * the reference has no bf16, newtonnet/layers/precision.py:3-13): both operands of every product rounded to bf16, ONE
+   * v_mfma_f32_32x32x16_bf16 per 16 k-values instead of three f16 ones, fp32 accumulation, fp32 inputs / outputs; bias-free SiLU
+   * MLPs whose images were written by nnhip_weight_images_bf16. */
+  int32_t precision; int32_t pad_;
 } nnhip_mlp_desc;
 int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
 /* Split-f16 image of a [128][128] fp32 matrix (rows = output features): two f16 planes (hi, lo) of the matrix scaled by a power
@@ -566,6 +571,11 @@ int nnhip_mlp128_ex(const nnhip_mlp_desc* desc, void* stream);
  * one launch; each image takes nnhip_weight_image_bytes() bytes, 256-byte aligned. */
 size_t nnhip_weight_image_bytes(void);
 int nnhip_weight_images(const float* const* src, void* const* images, int32_t count, void* stream);
+/* the same images in the bf16 format (first plane = the matrix rounded to bf16, unscaled; a format word behind the inverse scale tells
+ * the kernels which form an image has): operands of nnhip_mlp_desc.precision = 1 */
+int nnhip_weight_images_bf16(const float* const* src, void* const* images, int32_t count, void* stream);
+/* how many nnhip_mlp128_ex / nnhip_mlp128_pair_ex calls have taken the bf16 compute mode since the library was loaded */
+int64_t nnhip_bf16_mlp_launches(void);
 /* two MLPs over the same M rows in one launch (same mode / activation; only the second may accumulate) */
 int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* desc0, const nnhip_mlp_desc* desc1, void* stream);
 

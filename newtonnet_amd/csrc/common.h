@@ -294,6 +294,9 @@ struct MlpArgs {
   // optional split-f16 images of W1 / W2 (node128s.hip:weight_image_kernel): the row-local kernel then takes the split-f16 form
   const char* W1_img;
   const char* W2_img;
+  // bf16 compute mode (training under torch.autocast(bfloat16), BASELINE configs[2]): operands rounded to bf16, ONE
+  // v_mfma_f32_32x32x16_bf16 per 16 k-values, fp32 accumulation; SiLU; the images (row-local form) must be WIMG_FMT_BF16
+  int bf16;
   // optional: the TRUE row count on the device (a step queued before the host knows its edge count: nnhip_energy_forces_dev).
   // M then is the capacity the arrays, the layout and the grid are sized for; the kernels process min(M, *M_dev) rows.
   const int* M_dev;
@@ -367,11 +370,14 @@ int launch_node_tan_bwd_split(const NodeTanBwdArgs& a, const struct NodeImages& 
 int launch_node_fwd(const NodeFwdArgs& a, hipStream_t s);
 int launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 // split-f16 forms (node128s.hip): the weights come as prepared (hi, lo) f16 images instead of the fp32 pointers of the arguments
-#define WIMG_BYTES (2 * NF * NF * 2 + 4)   // two f16 planes + the inverse scale
+#define WIMG_BYTES (2 * NF * NF * 2 + 8)   // two 16-bit planes + the inverse scale + the format word (WIMG_FMT_*)
+#define WIMG_FMT_SPLIT_F16 0               // hi / lo f16 planes of the matrix scaled by a power of two (fp32-grade products, 3 MFMAs)
+#define WIMG_FMT_BF16 1                    // first plane = the matrix rounded to bf16, unscaled; second plane unused (1 MFMA)
 #define WIMG_MAX_JOBS 40
 struct WeightImageJobs {
   const float* src[WIMG_MAX_JOBS];
   char* dst[WIMG_MAX_JOBS];
+  int fmt;                                  // WIMG_FMT_* of every image of the launch
 };
 // images kept per layer (prepared block / training workspace), and of the energy head
 enum { IMG_UPDATE = 0, IMG_NODE0, IMG_NODE2, IMG_UPDATE_T, IMG_NODE0_T, IMG_NODE2_T, IMG_EQ1_0, IMG_EQ1_2, IMG_EQ2_0, IMG_EQ2_2,
@@ -381,7 +387,7 @@ struct NodeImages {
   const char *Wu, *W0, *W2;      // node_fwd: equiv_update, next message_nodepart / head (first, second linear)
   const char *W2T, *W0T, *WuT;   // node_bwd: their transposes
 };
-int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s);
+int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s, int fmt = WIMG_FMT_SPLIT_F16);
 int launch_node_fwd_split(const NodeFwdArgs& a, const NodeImages& im, hipStream_t s);
 int launch_node_bwd_split(const NodeBwdArgs& a, const NodeImages& im, hipStream_t s);
 int launch_mlp_wide_split(int mode, bool accum, const MlpArgs& a, hipStream_t s);      // needs a.W1_img / a.W2_img, SiLU

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 
 #ifndef MLP_NT_H
@@ -502,12 +504,25 @@ static int desc_to_args(const nnhip_mlp_desc* d, MlpArgs& a, const char* who) {
   }
   a.W1_img = (const char*)d->W1_image;
   a.W2_img = (const char*)d->W2_image;
+  if (d->precision != 0 && d->precision != 1) {
+    nnhip_set_error("%s: precision %d (0 = fp32-grade products, 1 = bf16 operands)", who, d->precision);
+    return NNHIP_E_INVALID;
+  }
+  if (d->precision == 1 && (!split_products_enabled() || d->activation != NNHIP_ACT_SILU || !d->W1_image || d->b1 || d->b2)) {
+    nnhip_set_error("%s: the bf16 compute mode serves bias-free SiLU MLPs with bf16 weight images (nnhip_weight_images_bf16)", who);
+    return NNHIP_E_UNSUPPORTED;
+  }
+  a.bf16 = d->precision;
   return NNHIP_OK;
 }
+// launches that took the bf16 compute mode since the library was loaded (tests assert the form that ran)
+static std::atomic<long> g_bf16_mlp_launches{0};
+extern "C" int64_t nnhip_bf16_mlp_launches(void) { return (int64_t)g_bf16_mlp_launches.load(); }
 extern "C" int nnhip_mlp128_ex(const nnhip_mlp_desc* d, void* stream) {
   MlpArgs a;
   const int rc = desc_to_args(d, a, "nnhip_mlp128_ex");
   if (rc) return rc;
+  if (a.bf16 && a.M > 0) g_bf16_mlp_launches.fetch_add(1);
   return launch_mlp(d->mode, d->accumulate != 0, a, (hipStream_t)stream);
 }
 // Two MLPs over the same M rows in ONE launch (equiv_message1 | equiv_message2 and their adjoints / tangents): same mode and
@@ -522,5 +537,10 @@ extern "C" int nnhip_mlp128_pair_ex(const nnhip_mlp_desc* d0, const nnhip_mlp_de
     nnhip_set_error("nnhip_mlp128_pair_ex: the two MLPs must share mode, M and activation; only the second may accumulate");
     return NNHIP_E_INVALID;
   }
+  if (a0.bf16 != a1.bf16) {
+    nnhip_set_error("nnhip_mlp128_pair_ex: the two MLPs must share their precision");
+    return NNHIP_E_INVALID;
+  }
+  if (a0.bf16 && a0.M > 0) g_bf16_mlp_launches.fetch_add(1);
   return launch_mlp_pair(d0->mode, a0, false, a1, d1->accumulate != 0, (hipStream_t)stream);
 }

@@ -396,6 +396,7 @@ extern "C" int nnhip_mlp_forms(void) {
   return (split ? 1 : 0) | (level >= 1 ? 2 : 0) | (level >= 2 ? 4 : 0) | (single >= 1 ? 8 : 0) | (single >= 2 ? 16 : 0);
 }
 bool mlp_regw_serves(int mode, const MlpPair& P) {
+  if (P.a[0].bf16 || P.a[1].bf16) return false;   // (the bf16 compute mode of training: mlp128s.hip / the row-local form)
   const int level = mlp_regw_level();
   const int single = mlp_regw_single();
   if (P.n == 1)

@@ -29,6 +29,8 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 #define SW_PITCH 272                         // bytes per output row of one plane (128 f16 + 16 pad)
 #define SW_PLANE (NF * SW_PITCH)             // 34 816
@@ -99,13 +101,18 @@ __device__ __forceinline__ void mlps_load_x(float4 (&x)[16], const float* X, int
   {                                                                                                       \
     const int idx = threadIdx.x + 512 * q, o = idx >> 5, c = idx & 31;                                    \
     const int off = o * SW_PITCH + 2 * ((c >> 2) * 16 + (c & 1) * 8 + ((c >> 1) & 1) * 4);                \
-    h4 hi, lo;                                                                                            \
-    split4(w1v##q, sw1, hi, lo);                                                                          \
-    *reinterpret_cast<h4*>(img + off) = hi;                                                               \
-    *reinterpret_cast<h4*>(img + SW_PLANE + off) = lo;                                                    \
-    split4(w2v##q, sw2, hi, lo);                                                                          \
-    *reinterpret_cast<h4*>(img + SW_MAT + off) = hi;                                                      \
-    *reinterpret_cast<h4*>(img + SW_MAT + SW_PLANE + off) = lo;                                           \
+    if (bf) { /* bf16 compute mode: one unscaled bf16 plane per matrix */                                 \
+      *reinterpret_cast<b4*>(img + off) = to_b4(w1v##q);                                                  \
+      *reinterpret_cast<b4*>(img + SW_MAT + off) = to_b4(w2v##q);                                         \
+    } else {                                                                                              \
+      h4 hi, lo;                                                                                          \
+      split4(w1v##q, sw1, hi, lo);                                                                        \
+      *reinterpret_cast<h4*>(img + off) = hi;                                                             \
+      *reinterpret_cast<h4*>(img + SW_PLANE + off) = lo;                                                  \
+      split4(w2v##q, sw2, hi, lo);                                                                        \
+      *reinterpret_cast<h4*>(img + SW_MAT + off) = hi;                                                    \
+      *reinterpret_cast<h4*>(img + SW_MAT + SW_PLANE + off) = lo;                                         \
+    }                                                                                                     \
   }
 // (ends with the images visible to every wave; iw1 / iw2 = inverse scales of the two matrices)
 #define MLPS_W_COMMIT()                                                                                   \
@@ -128,10 +135,38 @@ __device__ __forceinline__ void mlps_load_x(float4 (&x)[16], const float* X, int
     float sw1, sw2;                                                                                       \
     pow2_scale(m1, sw1, iw1);                                                                             \
     pow2_scale(m2, sw2, iw2);                                                                             \
+    if (bf) iw1 = iw2 = 1.0f;                                                                             \
     MLPS_W_ST(0) MLPS_W_ST(1) MLPS_W_ST(2) MLPS_W_ST(3) MLPS_W_ST(4) MLPS_W_ST(5) MLPS_W_ST(6) MLPS_W_ST(7) \
     __syncthreads();                                                                                      \
   }
 
+__device__ __forceinline__ b4 to_b4(const float4& v) {
+  b4 w;
+  w[0] = (__bf16)v.x, w[1] = (__bf16)v.y, w[2] = (__bf16)v.z, w[3] = (__bf16)v.w;
+  return w;
+}
+// bf16 compute mode: the same block from ONE bf16 plane per operand (bh holds the bf16 bits), one MFMA per 16 k-values
+__device__ __forceinline__ f32x16 bf16_block(const char* wrow, const h8 (&bh)[8]) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  b8 a0 = *reinterpret_cast<const b8*>(wrow), a1 = *reinterpret_cast<const b8*>(wrow + 32);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    b8 a2;
+    if (T < 6) a2 = *reinterpret_cast<const b8*>(wrow + 32 * (T + 2));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(b8, bh[T]), acc, 0, 0, 0);
+    a0 = a1;
+    if (T < 6) a1 = a2;
+  }
+  return acc;
+}
+__device__ __forceinline__ h8 bf16_bits8(const float (&v)[8]) {
+  b8 w;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w[j] = (__bf16)v[j];
+  return __builtin_bit_cast(h8, w);
+}
 // one 32-feature block of D^T = W . B^T from the split operands: 8 MFMA triples, A fragments two triples ahead
 __device__ __forceinline__ f32x16 split_block(const char* wrow, const h8 (&bh)[8], const h8 (&bl)[8]) {
   f32x16 acc;
@@ -187,6 +222,7 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
   const int r = lane & 31, h = lane >> 5;
   const int M = mlp_rows(P.a[0]);
   if (M <= 0) return;   // (uniform; only possible with a device-side count)
+  const bool bf = P.a[0].bf16 != 0;   // (uniform) bf16 compute mode: one bf16 plane per operand, no scales, one MFMA per k-group
   const int n_tiles = (M + 31) >> 5;
   const char* w1row = img + r * SW_PITCH + 16 * h;             // + nb * 32 * SW_PITCH + 32 T
   const char* w2row = img + SW_MAT + r * SW_PITCH + 16 * h;
@@ -234,12 +270,15 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
         m = fmaxf(m, __shfl_xor(m, 32));
         float S, inv;
         pow2_scale(m, S, inv);
-        inv1 = inv * iw1;
+        inv1 = bf ? 1.0f : inv * iw1;
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
           const float v[8] = {x[2 * T].x, x[2 * T].y, x[2 * T].z, x[2 * T].w,
                               x[2 * T + 1].x, x[2 * T + 1].y, x[2 * T + 1].z, x[2 * T + 1].w};
-          split8(v, S, bh[T], bl[T]);
+          if (bf)
+            bh[T] = bf16_bits8(v);
+          else
+            split8(v, S, bh[T], bl[T]);
         }
       }
       if (MLPS_EARLY_X && MODE == MODE_FWD) MLPS_PREFETCH_X()
@@ -255,7 +294,7 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
 #pragma unroll
           for (int q = 0; q < 4; ++q) hin[q] = MLP_NT_HL ? ld4_nt(reinterpret_cast<const float*>(hp + hs4 * q)) : hp[hs4 * q];
         }
-        f32x16 acc = split_block(w1row + nb * 32 * SW_PITCH, bh, bl);
+        f32x16 acc = bf ? bf16_block(w1row + nb * 32 * SW_PITCH, bh) : split_block(w1row + nb * 32 * SW_PITCH, bh, bl);
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[k] *= inv1;
         if (MODE == MODE_FWD) {
@@ -331,13 +370,16 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
         m = fmaxf(m, __shfl_xor(m, 32));
         float S, inv;
         pow2_scale(m, S, inv);
-        inv2 = inv * iw2;
+        inv2 = bf ? 1.0f : inv * iw2;
 #pragma unroll
         for (int T = 0; T < 8; ++T) {
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = hs[T >> 1][8 * (T & 1) + j];
-          split8(v, S, bh[T], bl[T]);
+          if (bf)
+            bh[T] = bf16_bits8(v);
+          else
+            split8(v, S, bh[T], bl[T]);
         }
       }
 
@@ -348,7 +390,7 @@ __global__ void __launch_bounds__(MLPS_THREADS, MLPS_WAVES / 4) mlp128s_kernel(c
       // ---------------- stage 2: Y^T = W2 . act^T
 #pragma unroll
       for (int nb2 = 0; nb2 < 4; ++nb2) {
-        const f32x16 acc = split_block(w2row + nb2 * 32 * SW_PITCH, bh, bl);
+        const f32x16 acc = bf ? bf16_block(w2row + nb2 * 32 * SW_PITCH, bh) : split_block(w2row + nb2 * 32 * SW_PITCH, bh, bl);
         float4 yold[4];
         if (ACCUM_LAST) {   // (requested behind the MFMA chain: 16 more live registers across it would spill)
           const float4* yp = reinterpret_cast<const float4*>(p.Y + (size_t)ec * p.ldy + nb2 * 32 + 4 * h);

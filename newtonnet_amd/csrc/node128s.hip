@@ -17,6 +17,8 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 #ifndef NS_WG_PER_CU
 #define NS_WG_PER_CU 2   // launch-bounds hint: workgroups per CU (tooling: 3 = every tile of config 2 resident at once, 168 VGPRs)
@@ -63,11 +65,18 @@ __global__ void __launch_bounds__(1024) weight_image_kernel(WeightImageJobs jobs
   for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w]);
   float S, inv;
   ns_pow2_scale(m, S, inv);
+  const bool bf = jobs.fmt == WIMG_FMT_BF16;     // (uniform) bf16 has fp32's exponent range: no scale
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = threadIdx.x + 1024 * q, o = idx >> 5, c = idx & 31;
     // fragment (nb = o >> 5, T = c >> 2), lane 32 h + r (h = c & 1, r = o & 31), second half of the lane's 16 bytes when c & 2
     const int off = ((((o >> 5) * 8 + (c >> 2)) * 64 + (c & 1) * 32 + (o & 31)) << 4) + ((c >> 1) & 1) * 8;
+    if (bf) {
+      b4 w;
+      w[0] = (__bf16)v[q].x, w[1] = (__bf16)v[q].y, w[2] = (__bf16)v[q].z, w[3] = (__bf16)v[q].w;
+      *reinterpret_cast<b4*>(dst + off) = w;
+      continue;
+    }
     const float s[4] = {v[q].x * S, v[q].y * S, v[q].z * S, v[q].w * S};
     h4 hi, lo;
 #pragma unroll
@@ -79,11 +88,15 @@ __global__ void __launch_bounds__(1024) weight_image_kernel(WeightImageJobs jobs
     *reinterpret_cast<h4*>(dst + off) = hi;
     *reinterpret_cast<h4*>(dst + WIMG_PLANE + off) = lo;
   }
-  if (threadIdx.x == 0) *reinterpret_cast<float*>(dst + 2 * WIMG_PLANE) = inv;
+  if (threadIdx.x == 0) {
+    *reinterpret_cast<float*>(dst + 2 * WIMG_PLANE) = bf ? 1.0f : inv;
+    *reinterpret_cast<int*>(dst + 2 * WIMG_PLANE + 4) = jobs.fmt;
+  }
 }
-int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s) {
+int launch_weight_images(const float* const* src, char* const* dst, int n, hipStream_t s, int fmt) {
   for (int o = 0; o < n; o += WIMG_MAX_JOBS) {
     WeightImageJobs jobs;
+    jobs.fmt = fmt;
     const int c = n - o < WIMG_MAX_JOBS ? n - o : WIMG_MAX_JOBS;
     for (int k = 0; k < c; ++k) {
       jobs.src[k] = src[o + k];
@@ -189,6 +202,40 @@ __device__ __forceinline__ void tile_gemm_s(float (&out)[16], const STile& t, co
   const float sc = inv_row * w.inv;
 #pragma unroll
   for (int k = 0; k < 16; ++k) out[k] = acc[k] * sc;
+}
+
+// ---- bf16 operands (training under autocast(bfloat16)): the tile holds ONE plane of bf16 values in the same fragment order, no
+// row scale (bf16 has fp32's exponent range), and a GEMM step is one v_mfma_f32_32x32x16_bf16 instead of three f16 ones
+__device__ __forceinline__ void tile_commit_bf(const float (&v)[16], const STile& t) {
+  char* row = t.img + t.r * NS_PITCH + 2 * (t.nb * 32 + 8 * t.h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b4 w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = (__bf16)v[4 * q + c];
+    *reinterpret_cast<b4*>(row + 2 * ((q >> 1) * 16 + (q & 1) * 4)) = w;
+  }
+}
+__device__ __forceinline__ void tile_gemm_bf(float (&out)[16], const STile& t, const WFrag& w) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const char* xr = t.img + t.r * NS_PITCH + 16 * t.h;
+  b8 b0 = *reinterpret_cast<const b8*>(xr), b1 = *reinterpret_cast<const b8*>(xr + 32);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    b8 b2;
+    if (T < 6) b2 = *reinterpret_cast<const b8*>(xr + 32 * (T + 2));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, w.hi[T]), b0, acc, 0, 0, 0);
+    b0 = b1;
+    if (T < 6) b1 = b2;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) out[k] = acc[k];
+}
+// the format word of an image (uniform: a scalar load)
+__device__ __forceinline__ bool wimg_is_bf16(const char* __restrict__ img) {
+  return *reinterpret_cast<const int*>(img + 2 * WIMG_PLANE + 4) == WIMG_FMT_BF16;
 }
 
 // this lane's 16 values of column block nb (features nb*32 + (k&3) + 8 (k>>2) + 4h) of one row
@@ -640,16 +687,26 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
   const int rc = min(row, M - 1);
   const bool live = row < M;
 
+  // bf16 compute mode: what the IMAGES say (nnhip_weight_images_bf16 wrote them; the two images of an MLP share a format)
+  const bool bf = wimg_is_bf16(p.W1_img);
   WFrag wf;
   load_wimg(wf, t, p.W1_img);
   float x[16], hv[16], hin[16];
   sblk_load(x, p.X, (size_t)rc * p.ldx, t);
   if (MODE != MODE_FWD) sblk_load(hin, p.H, (size_t)rc * p.ldh, t);
-  tile_publish(x, t);
-  __syncthreads();
-  float inv = tile_commit(x, t);
-  __syncthreads();
-  tile_gemm_s(hv, t, wf, inv);
+  float inv = 1.0f;
+  if (bf) {
+    __syncthreads();
+    tile_commit_bf(x, t);
+    __syncthreads();
+    tile_gemm_bf(hv, t, wf);
+  } else {
+    tile_publish(x, t);
+    __syncthreads();
+    inv = tile_commit(x, t);
+    __syncthreads();
+    tile_gemm_s(hv, t, wf, inv);
+  }
   load_wimg(wf, t, p.W2_img);
   if (MODE == MODE_FWD) {
     if (p.b1) {
@@ -673,12 +730,19 @@ __device__ __forceinline__ void mlp_wide_split_body(const MlpArgs& p, const bool
 #pragma unroll
     for (int k = 0; k < 16; ++k) hv[k] *= dsilu_f(hin[k]);
   }
-  tile_publish(hv, t);
-  __syncthreads();
-  inv = tile_commit(hv, t);
-  __syncthreads();
   float y[16];
-  tile_gemm_s(y, t, wf, inv);
+  if (bf) {
+    __syncthreads();
+    tile_commit_bf(hv, t);
+    __syncthreads();
+    tile_gemm_bf(y, t, wf);
+  } else {
+    tile_publish(hv, t);
+    __syncthreads();
+    inv = tile_commit(hv, t);
+    __syncthreads();
+    tile_gemm_s(y, t, wf, inv);
+  }
   if (MODE == MODE_FWD && p.b2) {
     float b[16];
     sblk_load(b, p.b2, 0, t);
@@ -763,7 +827,14 @@ int launch_mlp_wide_pair_split(int mode, const MlpPair& P, hipStream_t s) {
 }
 
 extern "C" size_t nnhip_weight_image_bytes(void) { return ((size_t)WIMG_BYTES + 255) & ~(size_t)255; }
+static int weight_images_impl(const float* const* src, void* const* images, int32_t count, void* stream, int fmt);
 extern "C" int nnhip_weight_images(const float* const* src, void* const* images, int32_t count, void* stream) {
+  return weight_images_impl(src, images, count, stream, WIMG_FMT_SPLIT_F16);
+}
+extern "C" int nnhip_weight_images_bf16(const float* const* src, void* const* images, int32_t count, void* stream) {
+  return weight_images_impl(src, images, count, stream, WIMG_FMT_BF16);
+}
+static int weight_images_impl(const float* const* src, void* const* images, int32_t count, void* stream, int fmt) {
   if (!src || !images || count < 0) {
     nnhip_set_error("nnhip_weight_images: bad arguments");
     return NNHIP_E_INVALID;
@@ -773,7 +844,7 @@ extern "C" int nnhip_weight_images(const float* const* src, void* const* images,
       nnhip_set_error("nnhip_weight_images: matrix %d: null or misaligned pointer", k);
       return NNHIP_E_INVALID;
     }
-  return count ? launch_weight_images(src, reinterpret_cast<char* const*>(images), count, (hipStream_t)stream) : NNHIP_OK;
+  return count ? launch_weight_images(src, reinterpret_cast<char* const*>(images), count, (hipStream_t)stream, fmt) : NNHIP_OK;
 }
 
 // One dense linear Y (+)= X W^T, row-local, split-f16 products (node128.hip:lin128_wide_kernel with a weight image)

@@ -48,6 +48,18 @@ static nnhip_mlp_desc mlp_desc(int mode, const float* X, int ldx, const float* W
   d.W2_image = img2;
   return d;
 }
+// an edge MLP (equiv_message1/2, their adjoints and tangents) in the step's compute mode
+static nnhip_mlp_desc edge_desc(bool bf16, int mode, const float* X, int ldx, const float* W1, const float* W2, float* H, float* Y, int M,
+                                int act, const void* img1, const void* img2) {
+  nnhip_mlp_desc d = mlp_desc(mode, X, ldx, W1, W2, H, Y, M, act, img1, img2);
+  d.precision = bf16 ? 1 : 0;
+  return d;
+}
+// bf16 compute mode of the step (torch.autocast(bfloat16): nnhip_train_ws.bf16_wgrad == 1): the edge MLPs of all four sweeps take
+// bf16 operands next to the weight-gradient products; node-level kernels and everything elementwise stay fp32-grade
+static bool train_bf16(const nnhip_model* model, const nnhip_train_ws* w) {
+  return w->bf16_wgrad == 1 && split_products_enabled() && model->activation == NNHIP_ACT_SILU && w->himg[0] != nullptr;
+}
 static int run1(const nnhip_mlp_desc& d, void* s) { return d.M > 0 ? nnhip_mlp128_ex(&d, s) : NNHIP_OK; }
 static int run2(const nnhip_mlp_desc& a, const nnhip_mlp_desc& b, void* s) { return a.M > 0 ? nnhip_mlp128_pair_ex(&a, &b, s) : NNHIP_OK; }
 
@@ -166,6 +178,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   const bool ln = has_ln(model);
   const bool node_img = img_on && !ln;
   const bool mol_forms = (w->flags & 1) && w->pair_ptr && w->mol_ptr;   // every molecule fits the molecule-resident kernels
+  const bool bf = train_bf16(model, w);
   // parameter-only data of this step: transposed weights, radial-filter tables
   {
     const float* src[40];
@@ -224,6 +237,15 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
         idst[n++] = w->himg[k];
       }
       TS_TRY(nnhip_weight_images(isrc, idst, n, s));
+      if (train_bf16(model, w)) {     // the eight edge-MLP images of every layer once more, in the bf16 format
+        int nb_ = 0;
+        for (int l = 0; l < L; ++l)
+          for (int k = IMG_EQ1_0; k <= IMG_EQ2_2_T; ++k) {
+            isrc[nb_] = isrc[l * IMG_PER_LAYER + k];
+            idst[nb_++] = w->wimg[l][k];
+          }
+        TS_TRY(nnhip_weight_images_bf16(isrc, idst, nb_, s));
+      }
     }
     const float* ew[NNHIP_MAX_LAYERS];
     for (int l = 0; l < L; ++l) ew[l] = model->layer[l].edge_w;
@@ -244,10 +266,10 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
   for (int l = 0; l < L; ++l) {
     const nnhip_layer_params& lp = model->layer[l];
     TS_TRY(nnhip_message_fwd(w->m[l], w->xg, w->ftab[l], w->row_ptr, w->col, w->pid, a_in, w->msg[l], w->a_mid[l], N, s));
-    const nnhip_mlp_desc d1 = mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->phi1[l], P, act,
+    const nnhip_mlp_desc d1 = edge_desc(bf, MODE_FWD, w->msg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->phi1[l], P, act,
                                        LIMG(l, IMG_EQ1_0), LIMG(l, IMG_EQ1_2));
     if (l > 0)
-      TS_TRY(run2(d1, mlp_desc(MODE_FWD, w->msg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->phi2[l], P, act, LIMG(l, IMG_EQ2_0),
+      TS_TRY(run2(d1, edge_desc(bf, MODE_FWD, w->msg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->phi2[l], P, act, LIMG(l, IMG_EQ2_0),
                                LIMG(l, IMG_EQ2_2)), s));
     else
       TS_TRY(run1(d1, s));
@@ -302,11 +324,11 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     float* Gf = w->Gf[pp];
     TS_TRY(launch_force_bwd(f_prev != nullptr, w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->row_ptr, w->col, w->pid, f_prev,
                             w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, w->xg, (hipStream_t)s, w->pair_ptr));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act,
+    nnhip_mlp_desc d1 = edge_desc(bf, MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act,
                                  LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T = w->t1[l];
     if (l > 0) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->g_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->g_msg[l], P, act,
+      nnhip_mlp_desc d2 = edge_desc(bf, MODE_TAN, w->g_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->g_msg[l], P, act,
                                    LIMG(l, IMG_EQ2_2_T), LIMG(l, IMG_EQ2_0_T));
       d2.T = w->t2[l];
       d2.accumulate = 1;
@@ -357,6 +379,7 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
   const bool img_on = train_images(model, w);
   const bool ln = has_ln(model);
   const bool node_img = img_on && !ln;
+  const bool bf = train_bf16(model, w);
   // ---- sweep 3: tangent forward along v = -dL/dF
   TS_TRY(nnhip_edge_tangent_geom(g_forces, -1.0f, w->edge_index, w->geo, E, model->cutoff, w->tgeo, s));
   for (int l = 0; l < L; ++l) {
@@ -364,11 +387,11 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     const bool first = l == 0;
     TS_TRY(nnhip_message_tan_fwd(w->m[l], first ? nullptr : w->dm[l], w->xg, w->tgeo, w->ftab[l], w->row_ptr, w->col, w->pid,
                                  first ? nullptr : w->da_out[l - 1], w->dmsg[l], w->da_mid, N, s));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->dphi1[l], P, act, LIMG(l, IMG_EQ1_0),
+    nnhip_mlp_desc d1 = edge_desc(bf, MODE_TAN, w->dmsg[l], NF, lp.eq1_0_w, lp.eq1_2_w, w->h1[l], w->dphi1[l], P, act, LIMG(l, IMG_EQ1_0),
                                  LIMG(l, IMG_EQ1_2));
     d1.T = w->dh1[l];
     if (!first) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN, w->dmsg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->dphi2[l], P, act,
+      nnhip_mlp_desc d2 = edge_desc(bf, MODE_TAN, w->dmsg[l], NF, lp.eq2_0_w, lp.eq2_2_w, w->h2[l], w->dphi2[l], P, act,
                                    LIMG(l, IMG_EQ2_0), LIMG(l, IMG_EQ2_2));
       d2.T = w->dh2[l];
       TS_TRY(run2(d1, d2, s));
@@ -482,13 +505,13 @@ extern "C" int nnhip_train_grads_seeded(const nnhip_model* model, const nnhip_tr
     TS_TRY(nnhip_force_message_tan_bwd(w->gf[l], w->dgf, w->phi2[l], w->dphi2[l], w->geo, w->tgeo, w->xg, w->row_ptr, w->col,
                                        w->pid, first ? nullptr : w->f_out[l - 1], first ? nullptr : w->df_out[l - 1], w->dg_h12[l],
                                        first ? nullptr : nxt, N, s));
-    nnhip_mlp_desc d1 = mlp_desc(MODE_TAN2, w->dg_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->dg_msg, P, act,
+    nnhip_mlp_desc d1 = edge_desc(bf, MODE_TAN2, w->dg_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->dg_msg, P, act,
                                  LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T2 = w->t1[l];
     d1.Hd = w->dh1[l];
     d1.G = w->dg_h1[l];
     if (!first) {
-      nnhip_mlp_desc d2 = mlp_desc(MODE_TAN2, w->dg_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->dg_msg, P, act,
+      nnhip_mlp_desc d2 = edge_desc(bf, MODE_TAN2, w->dg_h12[l] + NF, 2 * NF, w->wT[l][5], w->wT[l][4], w->h2[l], w->dg_msg, P, act,
                                    LIMG(l, IMG_EQ2_2_T), LIMG(l, IMG_EQ2_0_T));
       d2.T2 = w->t2[l];
       d2.Hd = w->dh2[l];

@@ -57,7 +57,7 @@ class MlpDesc(C.Structure):
                 ('b2', C.c_void_p), ('H', C.c_void_p), ('ldh', C.c_int32), ('Y', C.c_void_p), ('ldy', C.c_int32),
                 ('M', C.c_int32), ('mode', C.c_int32), ('accumulate', C.c_int32), ('activation', C.c_int32),
                 ('T', C.c_void_p), ('T2', C.c_void_p), ('Hd', C.c_void_p), ('G', C.c_void_p),
-                ('W1_image', C.c_void_p), ('W2_image', C.c_void_p)]
+                ('W1_image', C.c_void_p), ('W2_image', C.c_void_p), ('precision', C.c_int32), ('pad_', C.c_int32)]
 
 
 class WgradProblem(C.Structure):
@@ -270,7 +270,7 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
                     'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter', 'nnhip_graph_mol_dev',
-                    'nnhip_edge_index_from_csr', 'nnhip_config')
+                    'nnhip_edge_index_from_csr', 'nnhip_config', 'nnhip_weight_images_bf16', 'nnhip_bf16_mlp_launches')
 
 
 def _check(rc: int, what: str):
@@ -625,6 +625,13 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     a.tail_host, a.event, a.seq, a.flags = tail_host_ptr, (event_handle or None), seq, (1 if small_molecules else 0)
     _check(L.nnhip_forward_dev(C.byref(model), C.byref(a), _stream(dev)), 'nnhip_forward_dev')
     return st
+
+
+def bf16_mlp_launches() -> int:
+    """Edge-MLP launches that took the bf16 compute mode (training under torch.autocast(bfloat16)) since the library was loaded."""
+    L = lib()
+    L.nnhip_bf16_mlp_launches.restype = C.c_int64
+    return int(L.nnhip_bf16_mlp_launches())
 
 
 def mlp_forms() -> dict:

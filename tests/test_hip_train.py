@@ -104,10 +104,14 @@ def test_train_step_reduces_loss():
 
 
 def test_bf16_autocast_training_gradients():
-    """BASELINE configs[2] ("bf16"): the dense linears of the train-mode path under torch.autocast(bfloat16) (bf16
-    operands, fp32 accumulation; gathers / segment sums / radial basis stay fp32).  The reference has no bf16
-    (precision.py:3-13), so parity is against the fp64 oracle: relative gradient-norm error <= 2e-2."""
+    """BASELINE configs[2] ("bf16"): under torch.autocast(bfloat16) the edge MLPs of all four sweeps (values, adjoint, tangent,
+    tangent of the adjoint) and the weight-gradient products take bf16 operands -- ONE v_mfma_f32_32x32x16_bf16 per product, fp32
+    accumulation; node-level kernels, gathers / segment sums / the radial basis stay fp32.  The reference has no bf16
+    (precision.py:3-13), so parity is against the fp64 oracle: relative gradient-norm error <= 2e-2.  The test asserts the
+    MLP form that ran (nnhip_bf16_mlp_launches)."""
     from oracle import newtonnet_ref as ref
+    from newtonnet_amd import hip
+    n_bf16_before = hip.bf16_mlp_launches()
     z, pos, cell, batch, c = util.case_inputs('ethanol4_rand', torch.float32)
     g = torch.Generator().manual_seed(3)
     e_lab, f_lab = torch.randn(4, generator=g), torch.randn(36, 3, generator=g)
@@ -128,9 +132,55 @@ def test_bf16_autocast_training_gradients():
             ref_n += want[name].norm().item() ** 2
     assert abs(loss.item() - want_loss.item()) <= 2e-2 * abs(want_loss.item())
     rel = np.sqrt(err / ref_n)
-    print(f'bf16-operand weight gradients: relative gradient-norm error {rel:.2e}')
+    print(f'bf16 compute mode (edge MLPs + weight gradients): relative gradient-norm error {rel:.2e}')
     assert rel <= 2e-2, (np.sqrt(err), np.sqrt(ref_n))
-    assert rel > 1e-5          # the bf16-operand weight-gradient kernel really ran (the fp32 one lands at ~5e-7)
+    assert rel > 1e-5          # the bf16-operand kernels really ran (the fp32 ones land at ~5e-7)
+    # 3 layers: 3 forward + 3 adjoint + 3 tangent + 3 tangent-of-adjoint edge-MLP launches (one or two MLPs each)
+    assert hip.bf16_mlp_launches() - n_bf16_before == 12, hip.bf16_mlp_launches() - n_bf16_before
+    # ... and the same step outside the autocast region takes none
+    model.zero_grad(set_to_none=True)
+    n0 = hip.bf16_mlp_launches()
+    out = model(z.cuda(), pos.cuda().requires_grad_(True), cell.cuda(), batch.cuda())
+    (torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(out.gradient_force, f_lab.cuda())).backward()
+    assert hip.bf16_mlp_launches() == n0
+
+
+def test_bf16_compute_mode_on_the_persistent_edge_mlp_kernels():
+    """The same mode at a batch size whose edge MLPs run the persistent kernels (mlp128s.hip; 320 aspirin conformers = 1 500 pair
+    tiles): gradients under autocast(bfloat16) against the fp32 step of the same batch -- relative gradient-norm difference between
+    1e-4 (the bf16 kernels ran) and 2e-2 (SURVEY 8d's bound; the fp32 step itself is 5e-7 from the fp64 oracle)."""
+    from newtonnet_amd import hip
+    from newtonnet_amd.models import NewtonNet
+    a = util.load_npz('aspirin_frames.npz')
+    B, n = 320, 21
+    g = torch.Generator().manual_seed(5)
+    pos = (torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=g)).cuda()
+    z = torch.from_numpy(a['z']).long().repeat(B).cuda()
+    batch = torch.repeat_interleave(torch.arange(B), n).cuda()
+    cell = torch.zeros(B, 3, 3, device='cuda')
+    e_lab, f_lab = torch.randn(B, generator=g).cuda(), torch.randn(B * n, 3, generator=g).cuda()
+    torch.manual_seed(0)
+    model = NewtonNet(output_properties=['energy', 'gradient_force']).cuda()
+    model.train()
+
+    def grads(autocast):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            out = model(z, pos.clone().requires_grad_(True), cell, batch)
+            loss = (torch.nn.functional.mse_loss(out.energy.float(), e_lab)
+                    + 50.0 * torch.nn.functional.mse_loss(out.gradient_force.float(), f_lab))
+        loss.backward()
+        return [p.grad.detach().double().clone() for p in model.parameters() if p.requires_grad], loss.item()
+    n0 = hip.bf16_mlp_launches()
+    g32, l32 = grads(False)
+    assert hip.bf16_mlp_launches() == n0
+    g16, l16 = grads(True)
+    assert hip.bf16_mlp_launches() - n0 == 12
+    err = sum((x - y).norm().item() ** 2 for x, y in zip(g16, g32)) ** 0.5
+    nrm = sum(y.norm().item() ** 2 for y in g32) ** 0.5
+    print(f'persistent edge-MLP kernels, bf16 vs fp32 step: relative gradient-norm difference {err / nrm:.2e}; loss {l16:.6f} vs {l32:.6f}')
+    assert 1e-4 < err / nrm <= 2e-2, err / nrm
+    assert abs(l16 - l32) <= 2e-2 * abs(l32)
 
 
 def test_graphed_train_step_matches_eager():
