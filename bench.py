@@ -661,6 +661,9 @@ class LaneStepper:
         if self.n == 1:
             return self.lanes[0](*d)
         self.last_stream = self.streams[i]
+        # (the inputs may have been produced on the caller's stream a moment ago -- the shards of the strong-scaling leg are: the
+        # lane's stream waits for it, as any consumer on another stream must; nothing runs on the caller's stream in steady state)
+        self.streams[i].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.streams[i]):
             return self.lanes[i](*d)
 
