@@ -648,15 +648,22 @@ class LaneStepper:
     fill / drain phases of one step's ~45 dependent launches are covered by the other's kernels.  streams = 1: the module alone on
     the current stream (what rounds 1-5 timed; still reported as `single_stream`)."""
 
+    AUTO_SMALL_ATOMS = 6000     # streams = 0 (automatic): three steps in flight up to this many atoms per step, two above
+                                # (profiles/r06_small_shard_forms_ab.txt: 128 conformers 355 / 269 / 236 us with 1 / 2 / 3 lanes, 512: 838 / 718 / 731)
+
     def __init__(self, model, streams, device):
-        self.n = max(1, int(streams))
+        self.auto = int(streams) <= 0
+        self.n = 3 if self.auto else max(1, int(streams))
         self.lanes = model.inference_lanes(self.n) if self.n > 1 else [model]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else [None]
         self.k = 0
         self.last_stream = None
 
+    def in_flight(self, n_atoms):
+        return self.n if not self.auto else (3 if n_atoms <= self.AUTO_SMALL_ATOMS else 2)
+
     def __call__(self, *d):
-        i = self.k % self.n
+        i = self.k % self.in_flight(d[0].shape[0])
         self.k += 1
         if self.n == 1:
             return self.lanes[0](*d)
@@ -708,7 +715,8 @@ def strong_leg(model, device, world, rank, conformers, steps, sync_all, reduce_m
         return {'strong': {'conformers_total': conformers, 'conformers_per_gpu': conformers // world, 'n_gpus': world,
                            'ms_per_step': round(1e3 * sec, 4), 'region_ms_per_step': regions,
                            'value': round((conformers // world) * world * 21 / sec, 1), 'unit': 'atom-steps/s',
-                           'speedup_vs_n1_same_run': round(weak_ms / (1e3 * sec), 3), 'steps_in_flight': getattr(stepper, 'n', 1)}}
+                           'speedup_vs_n1_same_run': round(weak_ms / (1e3 * sec), 3),
+                           'steps_in_flight': stepper.in_flight(21 * (conformers // world)) if stepper is not None else 1}}
     full_sec, _ = quick_time(lambda: run(z, pos, cell, batch), steps, sync_all, reduce_max)
     proj = {}
     for n in (2, 4, 8):
@@ -719,7 +727,8 @@ def strong_leg(model, device, world, rank, conformers, steps, sync_all, reduce_m
         proj[str(n)] = {'conformers_per_gpu': conformers // n, 'ms_per_step': round(1e3 * sec, 4),
                         'speedup': round(full_sec / sec, 3), 'efficiency': round(full_sec / sec / n, 3)}
     return {'strong_projection': {'conformers_total': conformers, 'ms_per_step_n1': round(1e3 * full_sec, 4), 'by_n_gpus': proj,
-                                  'steps_in_flight': getattr(stepper, 'n', 1)}}
+                                  'steps_in_flight': {str(n): (stepper.in_flight(21 * (conformers // n)) if stepper is not None else 1)
+                                                      for n in (1, 2, 4, 8) if conformers % n == 0}}}
 
 
 def box_leg(device, steps=3):
@@ -778,9 +787,10 @@ def main():
     ap.add_argument('--no-train-roofline', action='store_true', help='skip the large-batch training roofline pass (rank 0)')
     ap.add_argument('--no-strong-leg', action='store_true', help='skip the strong-scaling leg (one batch split over the ranks)')
     ap.add_argument('--no-box-leg', action='store_true', help='skip the 100k-atom box summary (rank 0, N = 1)')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=0,
                     help='evaluation steps in flight: step k runs on lane k %% streams of the module, on that lane\'s HIP stream '
-                         '(model.inference_lanes); 1 = the module alone on one stream, which is also always reported (single_stream)')
+                         '(model.inference_lanes); 0 (default) = automatic: 3 for steps of at most 6000 atoms, 2 above; 1 = the module '
+                         'alone on one stream, which is also always reported (single_stream)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -1228,11 +1238,11 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': (f'MD17 aspirin batched inference, {args.conformers} conformers x 21 atoms per GPU, '
                                     f'fp32, energy+force, neighbor list included (BASELINE.json configs[1]); '
-                                    f'{stepper.n} independent step(s) in flight per GPU')
+                                    f'{stepper.in_flight(N)} independent step(s) in flight per GPU')
                        if args.workload == 'aspirin' else
                        'synthetic 100k-atom periodic box, 5 A cutoff, fp32 energy+force (BASELINE.json configs[4])',
                        'atoms_per_gpu': N, 'edges_per_gpu': E, 'weights': args.weights, 'distinct_batches': n_batches,
-                       'timed_regions': len(timing['region_ms_per_step']), 'steps_in_flight': stepper.n,
+                       'timed_regions': len(timing['region_ms_per_step']), 'steps_in_flight': stepper.in_flight(N),
                        'parallelism': f'{world} independent shard(s), no data-path collective'},
             'backend': (backend if backend != 'nccl' else 'nccl (RCCL)') if world > 1 else None, 'ranks_joined': ranks_joined,
             'roofline': dict(slim(roofline, roof_keys) or {}, kernel=(roofline or {}).get('kernel', '')[:40],
