@@ -774,6 +774,23 @@ int nnhip_mlp_forms(void);
 int nnhip_config(char* buf, size_t n);
 
 /* --------------------------------------------------------------------------
+ * Internal spatial order of ONE big system (csrc/graph.hip, round 6).  The reference evaluates the atoms in the caller's order
+ * (newtonnet/layers/representations.py:74-98 over one molecule); the step of a molecule of >= 16 384 atoms runs on the atoms in Morton
+ * order of cells of max(cutoff, extent / 64) and hands everything back in the caller's order (newtonnet_amd/models/newtonnet.py).
+ *   nnhip_spatial_order: perm[k] = input index of the atom at position k, inv = its inverse (int32 [N] each), and -- optional -- z / pos
+ *     gathered through perm; deterministic (by cell key, then by input index); scratch of nnhip_spatial_order_scratch_bytes(N).
+ *   nnhip_permute_rows: out[k] = x[idx[k]] for rows of `width` floats (per-atom results back: idx = inv).
+ *   nnhip_edge_index_unpermute: the [2][E] int64 list of the permuted CSR (row_ptr_p, col_p) as the reference lists it for the caller's
+ *     order -- rows by ascending i, neighbors by ascending j; scratch of (N + 1 + N / 1024 + 2) ints.
+ * ------------------------------------------------------------------------ */
+size_t nnhip_spatial_order_scratch_bytes(int32_t n_atoms);
+int nnhip_spatial_order(const float* pos, const int64_t* z, int32_t n_atoms, float cutoff, int32_t* perm, int32_t* inv,
+                        int64_t* z_out, float* pos_out, void* scratch, void* stream);
+int nnhip_permute_rows(const float* x, const int32_t* idx, int32_t n_rows, int32_t width, float* out, void* stream);
+int nnhip_edge_index_unpermute(const int32_t* row_ptr_p, const int32_t* col_p, const int32_t* perm, const int32_t* inv,
+                               int32_t n_atoms, int32_t n_edges, int64_t* edge_index, int32_t* scratch, void* stream);
+
+/* --------------------------------------------------------------------------
  * Timing hook for bench.py: wraps the kernels of one nnhip_energy_forces call
  * in HIP events on `stream` and accumulates per-kernel-class milliseconds.
  * classes: 0 = edge kernels (message/force fwd+adjoint), 1 = all dense MFMA kernels, 2 = everything else,

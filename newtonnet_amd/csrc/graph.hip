@@ -1706,3 +1706,226 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
   LAUNCH_CHECK();
   return NNHIP_OK;
 }
+
+// =============================================================================================
+// Internal spatial order of ONE big system (round 6).  The step of a single molecule of >= 16 384 atoms runs on
+// its atoms in Morton order of cells (models/newtonnet.py) so that the partner rows of a pair lie tens to hundreds of rows apart
+// whatever order the caller stores the atoms in.  Round 5 built the permutation from torch ops (LUT gathers, a stable argsort, two
+// index_selects; a second argsort over all edges when edge_index is asked for); here it is the library's own kernels:
+//   1. bounding box of the positions (one workgroup); cells of max(cutoff, extent / 64) per axis, so at most 64^3 Morton keys
+//   2. count atoms per key (integer atomics), scan, place atoms into their key's slots (atomic cursor), then ONE thread per key
+//      sorts its few atoms by input index -- the order is "by key, then by input index", i.e. deterministic, as a stable sort's
+//   3. z and pos gathered through the permutation in the same launch that writes perm / inv
+// and, for callers that ask for the neighbor list, nnhip_edge_index_unpermute lists the permuted CSR in the reference's order for
+// the CALLER's atom order (rows by ascending i, neighbors by ascending j, representations.py:74-98) with a scan and a rank-by-counting
+// pass per row instead of a sort over all edges.
+// =============================================================================================
+#define SO_BITS 6
+#define SO_CELLS (1 << SO_BITS)                    // cells per axis at most
+#define SO_KEYS (1 << (3 * SO_BITS))               // 262 144 Morton keys
+__device__ __forceinline__ unsigned so_spread(unsigned v) {      // 6 bits -> every third bit
+  v &= 0x3fu;
+  v = (v | (v << 8)) & 0x300fu;
+  v = (v | (v << 4)) & 0x30c3u;
+  v = (v | (v << 2)) & 0x9249u;
+  return v;
+}
+__global__ void __launch_bounds__(1024) so_bbox_kernel(const float* __restrict__ pos, int n_atoms, float cutoff, float* __restrict__ box /*[6]*/) {
+  __shared__ float red[16][6];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = threadIdx.x; i < n_atoms; i += 1024)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float p = pos[3 * i + k];
+      lo[k] = fminf(lo[k], p);
+      hi[k] = fmaxf(hi[k], p);
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[k] = fminf(lo[k], __shfl_xor(lo[k], d));
+      hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], d));
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      red[threadIdx.x >> 6][k] = lo[k];
+      red[threadIdx.x >> 6][3 + k] = hi[k];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    float l = red[0][k], h = red[0][3 + k];
+    for (int w = 1; w < 16; ++w) {
+      l = fminf(l, red[w][k]);
+      h = fmaxf(h, red[w][3 + k]);
+    }
+    const float ext = fmaxf(h - l, 0.0f);
+    const float cell = fmaxf(cutoff, ext * (1.0f / ((float)SO_CELLS - 0.001f)));     // every coordinate lands in [0, SO_CELLS)
+    box[k] = l;
+    box[3 + k] = 1.0f / cell;
+  }
+}
+__device__ __forceinline__ int so_key(const float* __restrict__ pos, int i, const float* __restrict__ box) {
+  unsigned c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float s = (pos[3 * i + k] - box[k]) * box[3 + k];
+    const int ci = (int)s;                               // (s >= 0 up to rounding: truncation = floor)
+    c[k] = (unsigned)(ci < 0 ? 0 : (ci > SO_CELLS - 1 ? SO_CELLS - 1 : ci));
+  }
+  return (int)((so_spread(c[0]) << 2) | (so_spread(c[1]) << 1) | so_spread(c[2]));
+}
+__global__ void __launch_bounds__(256) so_count_kernel(const float* __restrict__ pos, int n_atoms, const float* __restrict__ box,
+                                                       int* __restrict__ key_of, int* __restrict__ cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int key = so_key(pos, i, box);
+  key_of[i] = key;
+  atomicAdd(&cnt[key], 1);
+}
+__global__ void __launch_bounds__(256) so_fill_kernel(const int* __restrict__ key_of, const int* __restrict__ key_ptr, int n_atoms,
+                                                      int* __restrict__ cursor, int* __restrict__ slots) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_atoms) return;
+  const int key = key_of[i];
+  slots[key_ptr[key] + atomicAdd(&cursor[key], 1)] = i;
+}
+// one thread per key: its atoms by ascending input index (a handful per key; whatever order the atomics placed them in, the
+// result is the same), then perm / inv and the permuted z / pos
+__global__ void __launch_bounds__(256) so_finish_kernel(const int* __restrict__ key_ptr, int* __restrict__ slots, const int64_t* __restrict__ z,
+                                                        const float* __restrict__ pos, int32_t* __restrict__ perm, int32_t* __restrict__ inv,
+                                                        int64_t* __restrict__ z_out, float* __restrict__ pos_out) {
+  const int key = blockIdx.x * 256 + threadIdx.x;
+  if (key >= SO_KEYS) return;
+  const int b = key_ptr[key], e = key_ptr[key + 1];
+  for (int a = b + 1; a < e; ++a) {          // insertion sort
+    const int v = slots[a];
+    int q = a - 1;
+    while (q >= b && slots[q] > v) {
+      slots[q + 1] = slots[q];
+      --q;
+    }
+    slots[q + 1] = v;
+  }
+  for (int k = b; k < e; ++k) {
+    const int i = slots[k];
+    perm[k] = i;
+    inv[i] = k;
+    if (z_out) z_out[k] = z[i];
+    if (pos_out) {
+      pos_out[3 * k] = pos[3 * i];
+      pos_out[3 * k + 1] = pos[3 * i + 1];
+      pos_out[3 * k + 2] = pos[3 * i + 2];
+    }
+  }
+}
+// ints of scratch: box (8) | key_of [N] | cnt -> key_ptr [KEYS + 1] | cursor [KEYS] | slots [N] | scan tiles
+extern "C" size_t nnhip_spatial_order_scratch_bytes(int32_t n_atoms) {
+  if (n_atoms < 0) return 0;
+  return sizeof(int32_t) * (8 + 2 * (size_t)n_atoms + 2 * (size_t)SO_KEYS + 1 + (size_t)SO_KEYS / SCAN_TILE + 2);
+}
+extern "C" int nnhip_spatial_order(const float* pos, const int64_t* z, int32_t n_atoms, float cutoff, int32_t* perm, int32_t* inv,
+                                   int64_t* z_out, float* pos_out, void* scratch, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!pos || n_atoms < 1 || !(cutoff > 0.0f) || !perm || !inv || !scratch || (z_out && !z)) {
+    nnhip_set_error("nnhip_spatial_order: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  ScopedTimer tm(TC_GRAPH, stream);
+  int* s = (int*)scratch;
+  float* box = (float*)s;
+  int* key_of = s + 8;
+  int* key_ptr = key_of + n_atoms;            // counts, then (in place) their exclusive scan
+  int* cursor = key_ptr + SO_KEYS + 1;
+  int* slots = cursor + SO_KEYS;
+  int* scan_tmp = slots + n_atoms;
+  HIP_TRY(hipMemsetAsync(key_ptr, 0, sizeof(int) * (2 * (size_t)SO_KEYS + 1), stream));
+  so_bbox_kernel<<<1, 1024, 0, stream>>>(pos, n_atoms, cutoff, box);
+  LAUNCH_CHECK();
+  so_count_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(pos, n_atoms, box, key_of, key_ptr);
+  LAUNCH_CHECK();
+  {
+    const int rc = launch_scan(key_ptr, SO_KEYS, key_ptr, scan_tmp, stream);
+    if (rc) return rc;
+  }
+  so_fill_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(key_of, key_ptr, n_atoms, cursor, slots);
+  LAUNCH_CHECK();
+  so_finish_kernel<<<SO_KEYS / 256, 256, 0, stream>>>(key_ptr, slots, z, pos, perm, inv, z_out, pos_out);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// out[k][0..width) = x[idx[k]][0..width)   (any width; the per-atom results of a permuted step back in the caller's order: idx = inv)
+__global__ void __launch_bounds__(256) permute_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, long n_elems,
+                                                           int width, float* __restrict__ out) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_elems) return;
+  const long k = t / width;
+  const int c = (int)(t - k * width);
+  out[t] = x[(long)idx[k] * width + c];
+}
+extern "C" int nnhip_permute_rows(const float* x, const int32_t* idx, int32_t n_rows, int32_t width, float* out, void* stream_) {
+  if (n_rows < 0 || width < 1 || (n_rows && (!x || !idx || !out))) {
+    nnhip_set_error("nnhip_permute_rows: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_rows == 0) return NNHIP_OK;
+  const long n = (long)n_rows * width;
+  permute_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(x, idx, n, width, out);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}
+
+// The neighbor list of a permuted step as the reference lists it for the caller's atom order.  Row a of the output is row inv[a] of
+// the permuted CSR with every neighbor mapped back (j = perm[j_p]) and the row sorted by j: rank by counting inside the row (a wave
+// per row; rows hold tens of entries).
+__global__ void __launch_bounds__(256) unperm_degree_kernel(const int* __restrict__ row_ptr_p, const int32_t* __restrict__ inv, int n_atoms,
+                                                            int* __restrict__ deg) {
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a < n_atoms) deg[a] = row_ptr_p[inv[a] + 1] - row_ptr_p[inv[a]];
+}
+__global__ void __launch_bounds__(256) unperm_rows_kernel(const int* __restrict__ row_ptr_p, const int* __restrict__ col_p,
+                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ inv,
+                                                          const int* __restrict__ start, int n_atoms, long n_edges,
+                                                          int64_t* __restrict__ edge_index) {
+  const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (a >= n_atoms) return;
+  const int lane = threadIdx.x & 63;
+  const int rb = row_ptr_p[inv[a]], re = row_ptr_p[inv[a] + 1], d = re - rb;
+  const long o = start[a];
+  for (int c0 = 0; c0 < d; c0 += 64) {                 // my element(s)
+    const int mine = c0 + lane < d ? perm[col_p[rb + c0 + lane]] : 0x7fffffff;
+    int rank = 0;
+    for (int q0 = 0; q0 < d; q0 += 64) {               // ... against every element of the row (distinct values: a neighbor occurs once)
+      const int other = q0 + lane < d ? perm[col_p[rb + q0 + lane]] : 0x7fffffff;
+      const int lim = min(64, d - q0);
+      for (int t = 0; t < lim; ++t) rank += __shfl(other, t) < mine ? 1 : 0;
+    }
+    if (c0 + lane < d) {
+      edge_index[o + rank] = a;
+      edge_index[n_edges + o + rank] = mine;
+    }
+  }
+}
+// scratch: (n_atoms + 1 + n_atoms / 1024 + 2) ints
+extern "C" int nnhip_edge_index_unpermute(const int32_t* row_ptr_p, const int32_t* col_p, const int32_t* perm, const int32_t* inv,
+                                          int32_t n_atoms, int32_t n_edges, int64_t* edge_index, int32_t* scratch, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_atoms < 1 || n_edges < 0 || !row_ptr_p || !perm || !inv || !scratch || (n_edges && (!col_p || !edge_index))) {
+    nnhip_set_error("nnhip_edge_index_unpermute: bad arguments");
+    return NNHIP_E_INVALID;
+  }
+  if (n_edges == 0) return NNHIP_OK;
+  int* start = scratch;
+  unperm_degree_kernel<<<cdiv(n_atoms, 256), 256, 0, stream>>>(row_ptr_p, inv, n_atoms, start);
+  LAUNCH_CHECK();
+  {
+    const int rc = launch_scan(start, n_atoms, start, scratch + n_atoms + 1, stream);
+    if (rc) return rc;
+  }
+  unperm_rows_kernel<<<cdiv(n_atoms, 4), 256, 0, stream>>>(row_ptr_p, col_p, perm, inv, start, n_atoms, (long)n_edges, edge_index);
+  LAUNCH_CHECK();
+  return NNHIP_OK;
+}

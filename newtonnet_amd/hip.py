@@ -270,7 +270,8 @@ EXPORTED_SYMBOLS = STAGE_SYMBOLS + ('nnhip_version', 'nnhip_last_error', 'nnhip_
                     'nnhip_graph_finish_cells', 'nnhip_graph_finish_dev', 'nnhip_energy_forces_dev', 'nnhip_mlp_forms',
                     'nnhip_step_layout_of', 'nnhip_forward_dev', 'nnhip_graph_small_dev', 'nnhip_graph_small_max_atoms',
                     'nnhip_energy_forces_pp', 'nnhip_graph_count_pairs_z', 'nnhip_prepare_check_counter', 'nnhip_graph_mol_dev',
-                    'nnhip_edge_index_from_csr', 'nnhip_config', 'nnhip_weight_images_bf16', 'nnhip_bf16_mlp_launches')
+                    'nnhip_edge_index_from_csr', 'nnhip_config', 'nnhip_weight_images_bf16', 'nnhip_bf16_mlp_launches',
+                    'nnhip_spatial_order_scratch_bytes', 'nnhip_spatial_order', 'nnhip_permute_rows', 'nnhip_edge_index_unpermute')
 
 
 def _check(rc: int, what: str):
@@ -581,6 +582,14 @@ class DevStep:
         return v
 
     @property
+    def row_ptr(self):
+        return self.i32[self.lay.row_ptr:self.lay.row_ptr + self.N + 1]
+
+    @property
+    def col(self):
+        return self.i32[self.lay.col:self.lay.col + self.n_edges]
+
+    @property
     def edge_index(self):
         # RadiusGraph's [2][E] array, made when a caller asks for it (most evaluation steps never do): receiver = the row of the
         # edge, sender = col (nnhip_edge_index_from_csr)
@@ -625,6 +634,49 @@ def forward_dev(model: Model, z, pos, cell, batch, cap: int, prepared: torch.Ten
     a.tail_host, a.event, a.seq, a.flags = tail_host_ptr, (event_handle or None), seq, (1 if small_molecules else 0)
     _check(L.nnhip_forward_dev(C.byref(model), C.byref(a), _stream(dev)), 'nnhip_forward_dev')
     return st
+
+
+def spatial_order(pos: torch.Tensor, z: torch.Tensor, cutoff: float):
+    """(perm, inv, z_perm, pos_perm): the atoms of ONE big system in Morton order of cells (nnhip_spatial_order; int32 perm / inv on
+    pos.device, no host round trip, deterministic: by cell, then by input index)."""
+    L = lib()
+    L.nnhip_spatial_order_scratch_bytes.restype = C.c_size_t
+    L.nnhip_spatial_order_scratch_bytes.argtypes = [C.c_int32]
+    L.nnhip_spatial_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float] + [C.c_void_p] * 6
+    pos = _f32c(pos, 'pos')
+    N, dev = pos.shape[0], pos.device
+    perm = torch.empty(N, dtype=torch.int32, device=dev)
+    inv = torch.empty(N, dtype=torch.int32, device=dev)
+    z_out, pos_out = torch.empty_like(z), torch.empty_like(pos)
+    scratch = torch.empty(L.nnhip_spatial_order_scratch_bytes(N), dtype=torch.uint8, device=dev)
+    _check(L.nnhip_spatial_order(_ptr(pos), _ptr(z), N, float(cutoff), _ptr(perm), _ptr(inv), _ptr(z_out), _ptr(pos_out),
+                                 _ptr(scratch), _stream(dev)), 'nnhip_spatial_order')
+    return perm, inv, z_out, pos_out
+
+
+def permute_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[k] = x[idx[k]] over dim 0 (idx int32): the per-atom results of a permuted step in the caller's order."""
+    L = lib()
+    L.nnhip_permute_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    x = _f32c(x, 'x')
+    width = 1
+    for d in x.shape[1:]:
+        width *= int(d)
+    out = torch.empty_like(x)
+    _check(L.nnhip_permute_rows(_ptr(x), _ptr(idx), x.shape[0], width, _ptr(out), _stream(x.device)), 'nnhip_permute_rows')
+    return out
+
+
+def edge_index_unpermute(row_ptr, col, perm, inv, n_atoms: int, n_edges: int) -> torch.Tensor:
+    """The [2][E] int64 neighbor list of a permuted step in the reference's order for the caller's atom order."""
+    L = lib()
+    L.nnhip_edge_index_unpermute.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    dev = perm.device
+    ei = torch.empty(2, n_edges, dtype=torch.int64, device=dev)
+    scratch = torch.empty(n_atoms + 1 + n_atoms // 1024 + 2, dtype=torch.int32, device=dev)
+    _check(L.nnhip_edge_index_unpermute(_ptr(row_ptr), _ptr(col), _ptr(perm), _ptr(inv), n_atoms, n_edges, _ptr(ei), _ptr(scratch),
+                                        _stream(dev)), 'nnhip_edge_index_unpermute')
+    return ei
 
 
 def bf16_mlp_launches() -> int:

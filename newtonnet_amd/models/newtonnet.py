@@ -33,52 +33,11 @@ _DEFERRED = os.environ.get('NNHIP_DEFERRED', '1') != '0'                 # 0: ev
 _GRAPH_EARLY = os.environ.get('NNHIP_GRAPH_EARLY', '1') != '0'           # (synchronous path) fill queued ahead of the wait
 _PREPARE_EVERY_CALL = os.environ.get('NNHIP_PREPARE_EVERY_CALL', '0') == '1'
 # One big system (a single molecule of at least this many atoms): the step runs on the atoms in Morton order of cutoff-sized cells
-# and hands every per-atom result back in the caller's order (0: off).  The re-ordering costs ~0.12 ms a call: at 16k atoms an
-# input that is already spatially ordered loses 3 % and a randomly ordered one gains 16 %, from 30k atoms up nothing is lost
-# (tools/box_order_ab.py, profiles/r05_box_order_ab.txt).
+# and hands every per-atom result back in the caller's order (0: off).  The permutation, its inverse and the permuted inputs come
+# from the library's own kernels (hip.spatial_order: csrc/graph.hip, five launches; round 5 used torch's argsort); the neighbor list
+# is mapped back on demand by nnhip_edge_index_unpermute.  At 16k atoms an input that is already spatially ordered loses 3 % and a
+# randomly ordered one gains 16 %, from 30k atoms up nothing is lost (tools/box_order_ab.py, profiles/r05_box_order_ab.txt).
 _SPATIAL_ORDER_MIN = int(os.environ.get('NNHIP_SPATIAL_ORDER_MIN', '16384'))
-
-
-def _spread3(v: torch.Tensor) -> torch.Tensor:
-    """The low 10 bits of an int64 tensor spread to every third bit (Morton interleave)."""
-    v = v & 0x3ff
-    v = (v | (v << 16)) & 0x30000ff
-    v = (v | (v << 8)) & 0x300f00f
-    v = (v | (v << 4)) & 0x30c30c3
-    return (v | (v << 2)) & 0x9249249
-
-
-_MORTON_LUT = {}
-
-
-def _morton_lut(device) -> torch.Tensor:
-    """[3 * 1024] int64: the spread bits of 0..1023 for the x, y and z digit of a Morton key (shifted by 2, 1, 0), per device."""
-    lut = _MORTON_LUT.get(device)
-    if lut is None:
-        s = _spread3(torch.arange(1024, dtype=torch.int64))
-        lut = _MORTON_LUT[device] = torch.cat((s << 2, s << 1, s)).to(device)
-    return lut
-
-
-def spatial_order(pos: torch.Tensor, cutoff: float) -> torch.Tensor:
-    """Permutation (int64 [N], on pos.device, no host round trip) that lists the atoms in Morton order of cells of one cutoff,
-    atoms of a cell in their input order.  Partner rows of a pair are then tens to hundreds of rows apart whatever order the caller
-    stores the atoms in: the 100k-atom box of BASELINE configs[4] takes 30.3 ms per step in a random input order, 24.3 in the
-    recipe's lattice raster and 23.2 in this one (tools/box_order_ab.py).  A dozen small launches (~0.1 ms): keys by table lookup."""
-    p = pos.detach()
-    c = ((p - p.amin(dim=0)) * (1.0 / float(cutoff))).clamp_(0.0, 1023.0).to(torch.int64)       # (truncation = floor: >= 0)
-    c += torch.arange(0, 3072, 1024, device=p.device)
-    key = _morton_lut(p.device)[c].sum(dim=1)             # (the three digits occupy disjoint bits)
-    return torch.argsort(key, stable=True)
-
-
-def _edges_in_input_order(edge_index: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
-    """The neighbor list of the permuted atoms as the reference lists it for the caller's order: endpoints mapped back, rows by
-    ascending i, a row's neighbors by ascending j (representations.py:74-98 over one molecule)."""
-    n = perm.shape[0]
-    i, j = perm[edge_index[0]], perm[edge_index[1]]
-    order = torch.argsort(i * n + j)
-    return torch.stack((i[order], j[order]))
 
 
 def _versions(tensors):
@@ -534,14 +493,14 @@ class NewtonNet(nn.Module):
             # nobody has looked at its outputs yet
             self._settle_last()
             model = self._hip_model(energy_idx)
-            # one big system: the kernels see the atoms in Morton order of cutoff-sized cells (spatial_order); every per-atom
-            # result below goes back through the inverse permutation, the neighbor list through _edges_in_input_order
+            # one big system: the kernels see the atoms in Morton order of cells (hip.spatial_order); every per-atom result below
+            # goes back through the inverse permutation (hip.permute_rows), the neighbor list through hip.edge_index_unpermute
             order_min = self.__dict__.get('_spatial_order_min', _SPATIAL_ORDER_MIN)
-            perm = None
+            perm = inv = None
+            z_in, pos_in = z, pos
             if order_min > 0 and cell.shape[0] == 1 and pos.shape[0] >= order_min and pos.dtype == torch.float32:
-                perm = spatial_order(pos, emb.edge_embedding.cutoff)
-            z_in = z if perm is None else z.index_select(0, perm)
-            pos_in = pos if perm is None else pos.detach().index_select(0, perm)
+                z64 = z.contiguous() if z.dtype == torch.int64 else z.long().contiguous()
+                perm, inv, z_in, pos_in = hip.spatial_order(pos.detach(), z64, emb.edge_embedding.cutoff)
             zc = z_in.contiguous() if z_in.dtype == torch.int64 else z_in.long().contiguous()
             rec = _Deferred(self, (z_in, pos_in, cell, batch), zc, energy_idx, want_forces, want_virial)
             rec.param_stamp = self.__dict__.get('_param_stamp')
@@ -550,11 +509,11 @@ class NewtonNet(nn.Module):
                 rec.state = _Deferred.DONE
 
         def own_order(t):       # a per-atom result of the call, in the caller's order
-            if perm is None:
-                return t
-            out = torch.empty_like(t)
-            out[perm] = t
-            return out
+            return t if perm is None else hip.permute_rows(t, inv)
+
+        def own_edges():        # the neighbor list as the reference lists it for the caller's order
+            g = rec.settle().graph
+            return hip.edge_index_unpermute(g.row_ptr, g.col, perm, inv, pos.shape[0], int(g.n_edges))
 
         # Every result of the call sits behind the record: touching one settles the deferred host-side checks first (a few
         # microseconds when the words have arrived, which they have unless the host is a whole step ahead of the GPU).
@@ -567,7 +526,7 @@ class NewtonNet(nn.Module):
         if perm is None:
             outputs.lazy('edge_index', lambda: rec.settle().graph.edge_index)
         else:
-            outputs.lazy('edge_index', lambda: _edges_in_input_order(rec.settle().graph.edge_index, perm))
+            outputs.lazy('edge_index', own_edges)
         if want_forces:
             outputs.lazy('pos_grad', lambda: -own_order(rec.result('forces')))
             if want_virial:

@@ -194,12 +194,14 @@ class MLAseCalculator(_Base):
         st = dict(z=z.copy(), cell=cell.copy(), cell_now=cell.copy(), ref=free.copy(), graph=None, want_forces=want_forces,
                   want_virial=want_virial, order=None)
         # one big system: the list, the device arrays and every step until the next rebuild use the atoms in Morton order of
-        # cutoff-sized cells (models/newtonnet.py:spatial_order -- partner rows close together whatever order the Atoms object
+        # cells (hip.spatial_order -- partner rows close together whatever order the Atoms object
         # has); positions are gathered and forces scattered on the host, energy and stress are sums
         from newtonnet_amd.models import newtonnet as nn_mod
         order_min = model.__dict__.get('_spatial_order_min', nn_mod._SPATIAL_ORDER_MIN)
         if order_min > 0 and n >= order_min:
-            st['order'] = nn_mod.spatial_order(torch.tensor(pos, dtype=torch.float32, device=dev), float(emb.cutoff)).cpu().numpy()
+            # (hip.spatial_order: the library's own kernels, csrc/graph.hip)
+            st['order'] = hip.spatial_order(torch.tensor(pos, dtype=torch.float32, device=dev),
+                                            torch.tensor(z, dtype=torch.long, device=dev), float(emb.cutoff))[0].cpu().numpy().astype(np.int64)
             z, pos = z[st['order']], pos[st['order']]
         st['z_dev'] = torch.tensor(z, dtype=torch.long, device=dev)
         st['pos'] = torch.tensor(pos, dtype=torch.float32, device=dev)

@@ -579,6 +579,50 @@ def test_one_module_on_two_streams_and_from_two_threads():
     assert torch.equal(o.energy, want[2][0]) and torch.equal(o.gradient_force, want[2][1])
 
 
+def test_spatial_order_kernels_against_numpy():
+    """csrc/graph.hip: nnhip_spatial_order (Morton order of cells of max(cutoff, extent / 64), atoms of a cell by input index),
+    nnhip_permute_rows and nnhip_edge_index_unpermute against a numpy restatement -- the permutation exactly (it is deterministic:
+    by key, then by input index), repeated calls identical, the neighbor list in the reference's order for the caller's order."""
+    from newtonnet_amd import hip
+    gen = torch.Generator().manual_seed(31)
+    for n, span in ((5000, 40.0), (40000, 75.0), (3000, 400.0)):       # (the last: extent / 64 > cutoff -- coarser cells)
+        pos = torch.rand(n, 3, generator=gen) * span - 0.3 * span
+        z = torch.randint(1, 9, (n,), generator=gen)
+        perm, inv, z_p, pos_p = hip.spatial_order(pos.cuda(), z.cuda(), 5.0)
+        perm2 = hip.spatial_order(pos.cuda(), z.cuda(), 5.0)[0]
+        assert torch.equal(perm, perm2)
+        p = pos.numpy()
+        lo, hi = p.min(0), p.max(0)
+        cellw = np.maximum(np.float32(5.0), (hi - lo).astype(np.float32) * np.float32(1.0 / (64 - 0.001)))
+        inv_w = (np.float32(1.0) / cellw).astype(np.float32)
+        c = np.clip(((p - lo).astype(np.float32) * inv_w).astype(np.int64), 0, 63)
+
+        def spread(v):
+            v = v & 0x3f
+            v = (v | (v << 8)) & 0x300f
+            v = (v | (v << 4)) & 0x30c3
+            return (v | (v << 2)) & 0x9249
+        key = (spread(c[:, 0]) << 2) | (spread(c[:, 1]) << 1) | spread(c[:, 2])
+        want = np.argsort(key, kind='stable')
+        got = perm.cpu().numpy()
+        assert np.array_equal(got, want), (n, span, int((got != want).sum()))
+        assert np.array_equal(inv.cpu().numpy()[got], np.arange(n))
+        assert torch.equal(z_p.cpu(), z[torch.from_numpy(want)]) and torch.equal(pos_p.cpu(), pos[torch.from_numpy(want)])
+        x = torch.randn(n, 3, 5, generator=gen)
+        assert torch.equal(hip.permute_rows(x.cuda(), inv).cpu(), x[inv.cpu().long()])
+    # the neighbor list of a permuted system, back in the caller's order
+    n = 2500
+    pos = torch.rand(n, 3, generator=gen) * 30.0
+    cell = torch.diag(torch.tensor([30.0, 30.0, 30.0])).unsqueeze(0)
+    batch = torch.zeros(n, dtype=torch.long)
+    freq = torch.arange(1, 21, dtype=torch.float32, device='cuda') * np.pi
+    g0 = hip.build_graph(pos.cuda(), cell.cuda(), batch.cuda(), 5.0, freq)
+    perm, inv, _, pos_p = hip.spatial_order(pos.cuda(), torch.ones(n, dtype=torch.long, device='cuda'), 5.0)
+    g1 = hip.build_graph(pos_p, cell.cuda(), batch.cuda(), 5.0, freq)
+    ei = hip.edge_index_unpermute(g1.row_ptr, g1.col, perm, inv, n, g1.n_edges)
+    assert g1.n_edges == g0.n_edges and torch.equal(ei, g0.edge_index)
+
+
 def test_inference_lanes_keep_two_steps_in_flight():
     """model.inference_lanes(n): n shallow views of one module (the same Parameter objects, their own workspaces / hints / deferred
     checks), each driven from its own stream, so that independent batches overlap on the GPU.  Every lane returns bit for bit what
