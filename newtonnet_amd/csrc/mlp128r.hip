@@ -191,7 +191,13 @@ __device__ __forceinline__ float rw_commit_block(const float (&v)[16], char* til
 }
 
 // MODE_FWD: a[0] / a[1] = the two MLPs over the same X (msg);  MODE_BWD: a[g].X = g_phi_g, a[g].H = h_g, both Y = g_msg.
-// H is always in fragment order (h_frag); W1_img / W2_img are the stage-1 / stage-2 images of each MLP.
+// H is in fragment order (h_frag) in those two modes; W1_img / W2_img are the stage-1 / stage-2 images of each MLP.
+// MODE_TAN / MODE_TAN2 (round 6): the adjoint-shaped launches of the TRAINING sweeps in the same one-pass form -- the value adjoint
+// that keeps its stage-1 product (T = g_phi V2, row-major, for the tangent sweeps and the weight gradients) and the tangent of that
+// adjoint (G = dT act'(h) + T2 act''(h) Hd, kept row-major).  There H holds the pre-activations themselves, row-major (the training
+// path needs act, act' and act'' of them), so the epilogue evaluates silu' / silu'' instead of reading a kept factor; both terms of
+// g_msg / dg_msg are summed on chip and written ONCE (the two-phase form of mlp128s.hip wrote, re-read and re-wrote them: 9 instead
+// of 11 row passes for MODE_TAN, 13 instead of 15 for MODE_TAN2).
 #ifdef RW_CLOCK_DEBUG   // tooling: wall-clock (100 MHz) time of every phase of the tile loop, summed over the tiles of one wave
 #define RW_DBG_DECL() long long dbg_t[12]; long long dbg_s[12]; int dbg_k = 0; int dbg_tiles = 0; for (int k_ = 0; k_ < 12; ++k_) dbg_s[k_] = 0;
 #define RW_DBG_TOP() dbg_k = 0; dbg_t[0] = wall_clock64(); ++dbg_tiles;
@@ -212,9 +218,12 @@ __device__ __forceinline__ float rw_commit_block(const float (&v)[16], char* til
 
 // SINGLE (adjoint only): ONE MLP (layer 0 has no equiv_message2 term) -- both groups hold the same two matrices and take
 // alternate tiles, each storing its own g_msg rows; the groups then never meet (no hand-over, own trip counts).
-template <int MODE, bool SINGLE = false>
+// SHARED_X: the two MLPs read the SAME input rows and write their own outputs (the forward; the tangent forward of training, MODE_TAN
+// with X = dmsg); otherwise every group has its own input and the two stage-2 results are summed into one output (the adjoints).
+template <int MODE, bool SINGLE = false, bool SHARED_X = (MODE == MODE_FWD && !SINGLE)>
 __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P) {
-  constexpr bool OWN_X = MODE != MODE_FWD || SINGLE;   // every group stages its own X tile (the two-MLP forward shares one)
+  constexpr bool OWN_X = !SHARED_X;                    // every group stages its own X tile (a shared-X launch stages one for both)
+  constexpr bool TRAIN = MODE == MODE_TAN || MODE == MODE_TAN2;   // H = pre-activations, row-major; T / G kept row-major
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   RwLds& L = *reinterpret_cast<RwLds*>(lds_raw);
   const int lane = threadIdx.x & 63;
@@ -235,12 +244,17 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
   // parity (a wave writes tile k + 1 only after its own tile k, and nobody passes the 8-wave arrival of tile k before every wave
   // has left tile k - 1, so the buffer of tile k - 1 is free by then).  Adjoint: 8 of the 32 rows of the group's own g_phi_g.
   constexpr int NX = OWN_X ? 4 : 2;
-  const float* Xg = (MODE == MODE_FWD || ga == 0) ? P.a[0].X : P.a[1].X;
-  const int ldx = (MODE == MODE_FWD || ga == 0) ? P.a[0].ldx : P.a[1].ldx;
+  const float* Xg = (SHARED_X || ga == 0) ? P.a[0].X : P.a[1].X;
+  const int ldx = (SHARED_X || ga == 0) ? P.a[0].ldx : P.a[1].ldx;
   const int xrow0 = OWN_X ? 8 * nb : 4 * wave;
   const float* Hg = ga ? P.a[1].H : P.a[0].H;
   float* Yg = ga ? P.a[1].Y : P.a[0].Y;
   const int ldy = ga ? P.a[1].ldy : P.a[0].ldy;
+  const int ldh = ga ? P.a[1].ldh : P.a[0].ldh;                 // (training modes: row pitch of H / T / T2 / Hd / G)
+  float* Tg = ga ? P.a[1].T : P.a[0].T;                         // MODE_TAN: out
+  const float* T2g = ga ? P.a[1].T2 : P.a[0].T2;                // MODE_TAN2: in
+  const float* Hdg = ga ? P.a[1].Hd : P.a[0].Hd;
+  float* Gg = ga ? P.a[1].G : P.a[0].G;
   const int tile0 = SINGLE ? 2 * (int)blockIdx.x + g : (int)blockIdx.x;
   const int tile_step = SINGLE ? 2 * (int)gridDim.x : (int)gridDim.x;
   unsigned* bar = &L.bar[g];
@@ -265,6 +279,11 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
 #pragma unroll
       for (int q = 0; q < 4; ++q) hq[q] = ld4_nt(reinterpret_cast<const float*>(hp + 64 * q));
     }
+    if (TRAIN) {   // this lane's 16 pre-activations of row r of the tile: features nb*32 + 8 q + 4 h + {0..3}
+      const float* hp = Hg + (size_t)min((tc << 5) + r, M - 1) * ldh + nb * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hq[q] = ld4(hp + 8 * q);
+    }
   };
   request(tile0);
   RW_DBG_DECL()
@@ -284,7 +303,7 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
 #pragma unroll
     for (int i = 0; i < NX; ++i) rw_commit_row(xq[i], xtile, invx, xrow0 + 2 * i + h, r, h);
     float4 hin[4];
-    if (MODE == MODE_BWD) {
+    if (MODE != MODE_FWD) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) hin[q] = hq[q];
     }
@@ -313,6 +332,28 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
           a[4 * q + 2] = silu_f(hv.z);
           a[4 * q + 3] = silu_f(hv.w);
         }
+      } else if (TRAIN) {
+        const size_t roff = (size_t)min(e, M - 1) * ldh + nb * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 t = make_float4(acc[4 * q] * sc, acc[4 * q + 1] * sc, acc[4 * q + 2] * sc, acc[4 * q + 3] * sc);
+          float4 v;
+          if (MODE == MODE_TAN) {      // keep the stage-1 product, then the act' factor
+            if (live) st4(Tg + (size_t)e * ldh + nb * 32 + 4 * h + 8 * q, t);
+            v = make_float4(t.x * dsilu_f(hin[q].x), t.y * dsilu_f(hin[q].y), t.z * dsilu_f(hin[q].z), t.w * dsilu_f(hin[q].w));
+          } else {                     // G = dT act'(h) + T2 act''(h) Hd, kept for the weight-gradient products
+            const float4 t2 = ld4(T2g + roff + 8 * q), hd = ld4(Hdg + roff + 8 * q);
+            v.x = fmaf(t.x, dsilu_f(hin[q].x), t2.x * d2silu_f(hin[q].x) * hd.x);
+            v.y = fmaf(t.y, dsilu_f(hin[q].y), t2.y * d2silu_f(hin[q].y) * hd.y);
+            v.z = fmaf(t.z, dsilu_f(hin[q].z), t2.z * d2silu_f(hin[q].z) * hd.z);
+            v.w = fmaf(t.w, dsilu_f(hin[q].w), t2.w * d2silu_f(hin[q].w) * hd.w);
+            if (live) st4(Gg + (size_t)e * ldh + nb * 32 + 4 * h + 8 * q, v);
+          }
+          a[4 * q] = v.x;
+          a[4 * q + 1] = v.y;
+          a[4 * q + 2] = v.z;
+          a[4 * q + 3] = v.w;
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -340,7 +381,7 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
       const f32x16 acc = rw_gemm(L.at[g], w2, r, h);
       RW_DBG()   // 7: GEMM 2
       const float sc = inv2 * w2.inv;
-      if (MODE == MODE_FWD || SINGLE) {
+      if (SHARED_X || SINGLE) {
         if (live) {
           float4* yp = reinterpret_cast<float4*>(Yg + (size_t)e * ldy + nb * 32 + 4 * h);
 #pragma unroll
@@ -399,6 +440,21 @@ bool mlp_regw_serves(int mode, const MlpPair& P) {
   if (P.a[0].bf16 || P.a[1].bf16) return false;   // (the bf16 compute mode of training: mlp128s.hip / the row-local form)
   const int level = mlp_regw_level();
   const int single = mlp_regw_single();
+  if (mode == MODE_TAN || mode == MODE_TAN2) {
+    // the adjoint-shaped launches of the training sweeps: one MLP (layer 0, no accumulate), or two MLPs whose outputs are summed
+    // into one Y (the second accumulating); H / T / T2 / Hd / G row-major with one pitch.  NNHIP_MLP_REGW_TRAIN=0: the two-phase form
+    static const bool train_on = !(getenv("NNHIP_MLP_REGW_TRAIN") && atoi(getenv("NNHIP_MLP_REGW_TRAIN")) == 0);
+    if (level <= 0 || !train_on || P.n < 1 || P.n > 2) return false;
+    for (int k = 0; k < P.n; ++k) {
+      const MlpArgs& a = P.a[k];
+      if (!a.W1_img || !a.W2_img || a.h_frag || a.act != NNHIP_ACT_SILU || a.b1 || a.b2 || a.M_dev || a.ldh != P.a[0].ldh) return false;
+      if (mode == MODE_TAN ? !a.T : (!a.T2 || !a.Hd || !a.G)) return false;
+    }
+    if (P.n == 1) return !P.accum[0];
+    if (mode == MODE_TAN && P.a[0].X == P.a[1].X && P.a[0].ldx == P.a[1].ldx && P.a[0].Y != P.a[1].Y && !P.accum[0] && !P.accum[1])
+      return true;      // the tangent forward: one input (dmsg), two outputs -- the shared-X shape of the forward
+    return P.a[0].Y == P.a[1].Y && P.a[0].ldy == P.a[1].ldy && !P.accum[0] && P.accum[1];
+  }
   if (P.n == 1)
     return level > 0 && ((mode == MODE_BWD && single >= 1) || (mode == MODE_FWD && single >= 2)) && P.a[0].W1_img &&
            P.a[0].W2_img && P.a[0].h_frag && P.a[0].act == NNHIP_ACT_SILU && !P.a[0].b1 && !P.a[0].b2 && !P.accum[0];
@@ -408,19 +464,22 @@ bool mlp_regw_serves(int mode, const MlpPair& P) {
   if (mode == MODE_FWD) return P.a[0].X == P.a[1].X && P.a[0].ldx == P.a[1].ldx && !P.accum[0] && !P.accum[1];
   return P.a[0].Y == P.a[1].Y && P.a[0].ldy == P.a[1].ldy && !P.accum[0] && P.accum[1];
 }
-template <int MODE, bool SINGLE>
+template <int MODE, bool SINGLE, bool SHARED_X = (MODE == MODE_FWD && !SINGLE)>
 static int launch_regw_t(const MlpPair& P, hipStream_t s) {
-  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp_regw_kernel<MODE, SINGLE>,
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void*)mlp_regw_kernel<MODE, SINGLE, SHARED_X>,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RwLds));
   HIP_TRY(attr_rc);
   const int n_tiles = (P.a[0].M + 31) / 32;
   const int units = SINGLE ? (n_tiles + 1) / 2 : n_tiles;   // (SINGLE: a workgroup takes two tiles per trip, one per group)
   const int blocks = units < 256 ? units : 256;              // one persistent workgroup per CU
-  mlp_regw_kernel<MODE, SINGLE><<<blocks, RW_THREADS, sizeof(RwLds), s>>>(P);
+  mlp_regw_kernel<MODE, SINGLE, SHARED_X><<<blocks, RW_THREADS, sizeof(RwLds), s>>>(P);
   LAUNCH_CHECK();
   return 0;
 }
 int launch_mlp_regw(int mode, const MlpPair& P, hipStream_t s) {
+  if (mode == MODE_TAN && P.n == 2 && P.a[0].X == P.a[1].X && !P.accum[1]) return launch_regw_t<MODE_TAN, false, true>(P, s);
+  if (mode == MODE_TAN) return P.n == 1 ? launch_regw_t<MODE_TAN, true>(P, s) : launch_regw_t<MODE_TAN, false>(P, s);
+  if (mode == MODE_TAN2) return P.n == 1 ? launch_regw_t<MODE_TAN2, true>(P, s) : launch_regw_t<MODE_TAN2, false>(P, s);
   if (P.n == 1) return mode == MODE_FWD ? launch_regw_t<MODE_FWD, true>(P, s) : launch_regw_t<MODE_BWD, true>(P, s);
   return mode == MODE_FWD ? launch_regw_t<MODE_FWD, false>(P, s) : launch_regw_t<MODE_BWD, false>(P, s);
 }

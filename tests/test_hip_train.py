@@ -183,6 +183,69 @@ def test_bf16_compute_mode_on_the_persistent_edge_mlp_kernels():
     assert abs(l16 - l32) <= 2e-2 * abs(l32)
 
 
+def test_one_pass_training_mlp_forms_against_the_oracle_and_the_two_phase_forms(tmp_path):
+    """Round 6: the adjoint-shaped edge-MLP launches of the training sweeps (value adjoint keeping T, tangent of the adjoint) run the
+    one-pass register-weights form (csrc/mlp128r.hip, MODE_TAN / MODE_TAN2) in the persistent regime; NNHIP_MLP_REGW_TRAIN=0 keeps
+    the two-phase form (mlp128s.hip).  Both forms -- forced at a size the fp64 oracle can follow with NNHIP_MLP_WIDE_TILES=0: 48 aspirin
+    conformers + one 13-atom molecule, a ragged last pair tile -- must reproduce the oracle's parameter gradients (double backward
+    of the force loss, trainer.py:299-313) to 1e-4 relative (5e-7 measured) and each other to fp32 rounding."""
+    import os
+    import subprocess
+    import sys
+    from oracle import newtonnet_ref as ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'run_case.py'
+    script.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np, torch\n"
+        "from tests import util\n"
+        "from tests.test_hip_train import make_model\n"
+        "from newtonnet_amd import hip\n"
+        "a = util.load_npz('aspirin_frames.npz')\n"
+        "B, n = 48, 21\n"
+        "g = torch.Generator().manual_seed(7)\n"
+        "pos = torch.from_numpy(a['test0_pos']).float().repeat(B, 1) + 0.05 * torch.randn(B * n, 3, generator=g)\n"
+        "z = torch.from_numpy(a['z']).long().repeat(B)\n"
+        "batch = torch.repeat_interleave(torch.arange(B), n)\n"
+        "pos = torch.cat([pos, pos[:13] + 0.01]); z = torch.cat([z, z[:13]]); batch = torch.cat([batch, torch.full((13,), B)])\n"
+        "e_lab, f_lab = torch.randn(B + 1, generator=g), torch.randn(pos.shape[0], 3, generator=g)\n"
+        "model, sd = make_model('rand')\n"
+        "model.train()\n"
+        "hip.timers_enable(True, classes=('mlp_onepass',))\n"
+        "out = model(z.cuda(), pos.cuda().requires_grad_(True), torch.zeros(B + 1, 3, 3, device='cuda'), batch.cuda())\n"
+        "loss = torch.nn.functional.mse_loss(out.energy, e_lab.cuda()) + 50.0 * torch.nn.functional.mse_loss(out.gradient_force, f_lab.cuda())\n"
+        "loss.backward()\n"
+        "torch.cuda.synchronize()\n"
+        "n_onepass = hip.timers_read(reset=True)['mlp_onepass'][1]\n"
+        "grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}\n"
+        "np.savez(sys.argv[1], n_onepass=n_onepass, loss=loss.item(), pos=pos.numpy(), z=z.numpy(), batch=batch.numpy(), e_lab=e_lab.numpy(),\n"
+        "         f_lab=f_lab.numpy(), **{'g_' + k: v for k, v in grads.items()})\n")
+    res = {}
+    for form in ('1', '0'):
+        out = tmp_path / f'out{form}.npz'
+        env = dict(os.environ, NNHIP_MLP_WIDE_TILES='0', NNHIP_MLP_REGW_TRAIN=form)
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[form] = dict(np.load(out))
+    # the forms that ran: one-pass launches = 3 (value adjoint) + 3 (tangent of the adjoint) + 3 (the tangent forward: two shared-input pairs and the single-MLP launch of
+    # layer 0) with the switch on, none with it off
+    assert int(res['1']['n_onepass']) == 9 and int(res['0']['n_onepass']) == 0, (res['1']['n_onepass'], res['0']['n_onepass'])
+    sd = util.load_state('rand', torch.float64)
+    d = res['1']
+    _, want = ref.training_loss_grads(sd, torch.from_numpy(d['z']), torch.from_numpy(d['pos']).double(),
+                                      torch.zeros(49, 3, 3, dtype=torch.float64), torch.from_numpy(d['batch']),
+                                      torch.from_numpy(d['e_lab']).double(), torch.from_numpy(d['f_lab']).double())
+    nrm = sum(want[k].norm().item() ** 2 for k in want if 'g_' + k in d) ** 0.5
+    for form in ('1', '0'):
+        err = sum(float(((torch.from_numpy(res[form]['g_' + k]).double() - want[k]) ** 2).sum()) for k in want if 'g_' + k in res[form]) ** 0.5
+        print(f'NNHIP_MLP_REGW_TRAIN={form}: relative gradient-norm error vs the fp64 oracle {err / nrm:.2e}')
+        assert err / nrm <= 1e-4, (form, err / nrm)
+    diff = sum(float(((res['1'][k].astype(np.float64) - res['0'][k]) ** 2).sum()) for k in res['1'] if k.startswith('g_')) ** 0.5
+    print(f'one-pass vs two-phase training forms: relative gradient-norm difference {diff / nrm:.2e}')
+    assert diff / nrm <= 5e-6
+
+
 def test_graphed_train_step_matches_eager():
     """GraphedTrainStep (static candidate list + HIP-graph replay) against the eager TrainStep from the same initial
     weights over the same three batches: same losses and parameters up to fp32 summation order; a batch of a different
