@@ -218,8 +218,7 @@ def train_roofline(device, conformers=1024, reps=5):
     common = {'workload': f'{conformers} aspirin conformers (N = {N}, pairs = {gr.n_edges // 2}), value + tangent sweeps + weight '
                           'gradients, fp32, one rank, no collective',
               'flops_per_launch': flops, 'operand_bytes_per_launch': by, 'avg_launch_us': round(1e3 * wg_ms, 1),
-              'launches_per_step': wg_n, 'traffic': None,
-              'traffic_note': 'PMC passes: profiles/r03_*train_aspirin1024_pmc_{fetch,write}_size.txt',
+              'launches_per_step': wg_n, 'traffic': None, 'traffic_note': None,
               'step_ms_without_optimizer': round(ms_step, 3),
               'share_of_step': round(wg_ms * wg_n / ms_step, 3) if ms_step > 0 else None}
     if split:   # fp32-grade products from three bf16 pieces per operand: 6 bf16 MFMAs per 16 rows -- bound by the operand rows
@@ -234,6 +233,13 @@ def train_roofline(device, conformers=1024, reps=5):
              'achieved': round(tf, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
              'operand_gbs': round(gbs, 1)}
     r.update(common)
+    if conformers == 1024:      # the stored counters are of this batch (tools/profile_train_large.sh)
+        per_launch, per_step, src = pmc_traffic_train('wgrad_split_kernel' if split else 'wgrad_kernel')
+        if per_launch:
+            r['traffic'], r['traffic_source'] = round(per_launch), src
+            r['counter_GB_per_step'] = round(per_step / 1e9, 3)
+            r['traffic_note'] = ('HBM bytes per weight-gradient launch and per whole training pass (values + loss + gradients) from the '
+                                 'stored FETCH_SIZE (x2) / WRITE_SIZE passes of tools/train_large_pass.py')
     return r
 
 
@@ -398,6 +404,33 @@ def pmc_traffic(kernels):
         return None, None
     return out, (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}'
                  + (f' [{notes[0]}]' if notes else ' [round-1 tree]'))
+
+
+def pmc_traffic_train(kernel='wgrad_split_kernel'):
+    """HBM bytes per launch of `kernel` and per whole step of the LARGE-batch training pass from the latest stored PMC passes of
+    tools/train_large_pass.py (profiles/r*_train_aspirin1024_pmc_{fetch,write}_size.txt; tools/profile_train_large.sh), with the
+    unit corrections of pmc_traffic.  Returns (bytes per launch, bytes per step, source) or (None, None, None)."""
+    import glob
+    fetch = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_aspirin1024_pmc_fetch_size.txt')), key=_profile_order)
+    write = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_train_aspirin1024_pmc_write_size.txt')), key=_profile_order)
+    if not fetch or not write:
+        return None, None, None
+    (tf, notes), (tw, _) = _profile_table(fetch[-1]), _profile_table(write[-1])
+    per_launch = steps = None
+    for name, grids in tf.items():
+        if _kernel_match(name, kernel) and name in tw:
+            n, _us, kib = _largest_grid(grids)[:3]
+            per_launch = (2.0 * kib + _largest_grid(tw[name])[2]) * 1024.0
+            steps = n                                   # (the batched weight-gradient launch runs once per step)
+    if not per_launch or not steps:
+        return None, None, None
+    tot = 0.0
+    for name, grids in tf.items():
+        for g, v in grids.items():
+            w = tw.get(name, {}).get(g)
+            tot += v[0] * (2.0 * v[2] + (w[2] if w else 0.0)) * 1024.0
+    src = (f'{os.path.relpath(fetch[-1], ROOT)} (x2) + {os.path.relpath(write[-1], ROOT)}' + (f' [{notes[0]}]' if notes else ''))
+    return per_launch, tot / steps, src
 
 
 def pmc_step_total():

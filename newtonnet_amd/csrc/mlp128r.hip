@@ -34,6 +34,8 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 
 #define RW_WAVES 8
 #define RW_THREADS (64 * RW_WAVES)
@@ -146,6 +148,40 @@ __device__ __forceinline__ f32x16 rw_gemm(const char* tile, const RwFrag& w, int
   __builtin_amdgcn_sched_barrier(0);
   return acc;
 }
+// bf16 compute mode (training under autocast(bfloat16); the images are WIMG_FMT_BF16): one bf16 plane per operand, no scales, one
+// v_mfma_f32_32x32x16_bf16 per 16 k-values
+__device__ __forceinline__ f32x16 rw_gemm_bf(const char* tile, const RwFrag& w, int r, int h) {
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  const char* xr = tile + r * RW_PITCH + 16 * h;
+  b8 b0 = *reinterpret_cast<const b8*>(xr), b1 = *reinterpret_cast<const b8*>(xr + 32);
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    b8 b2;
+    if (T < 6) b2 = *reinterpret_cast<const b8*>(xr + 32 * (T + 2));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, w.hi[T]), b0, acc, 0, 0, 0);
+    b0 = b1;
+    if (T < 6) b1 = b2;
+  }
+  return acc;
+}
+__device__ __forceinline__ void rw_commit_row_bf(const float4& v, char* tile, float* invx, int row, int c) {
+  b4 w;
+  w[0] = (__bf16)v.x, w[1] = (__bf16)v.y, w[2] = (__bf16)v.z, w[3] = (__bf16)v.w;
+  *reinterpret_cast<b4*>(tile + row * RW_PITCH + 2 * ((c >> 2) * 16 + (c & 1) * 8 + ((c >> 1) & 1) * 4)) = w;
+  if (c == 0) invx[row] = 1.0f;
+}
+__device__ __forceinline__ void rw_commit_block_bf(const float (&v)[16], char* tile, int nb, int r, int h) {
+  char* row = tile + r * RW_PITCH + 2 * (nb * 32 + 8 * h);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    b4 w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = (__bf16)v[4 * q + c];
+    *reinterpret_cast<b4*>(row + 2 * ((q >> 1) * 16 + (q & 1) * 4)) = w;
+  }
+}
 // one 512-byte input row per half-wave: scale by the row maximum, split, write into an X tile (k-slot 16 T + 8 h' + 4 j + c <->
 // feature 16 T + 8 j + 4 h' + c, the permutation of the images); lane & 31 == 0 keeps the inverse scale
 __device__ __forceinline__ void rw_commit_row(const float4& v, char* tile, float* invx, int row, int c, int h) {
@@ -233,6 +269,8 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
   const int M = mlp_rows(P.a[0]);
   if (M <= 0) return;   // (uniform; only possible with a device-side count)
   const int n_tiles = (M + 31) >> 5;
+  // (uniform) the bf16 compute mode of the training sweeps: what the images say (node128s.hip: nnhip_weight_images_bf16)
+  const bool bf = TRAIN && *reinterpret_cast<const int*>(P.a[0].W1_img + 2 * RW_WIMG_PLANE + 4) == WIMG_FMT_BF16;
 
   // this wave's weights: block nb of both matrices of MLP g, for the whole launch
   const int ga = SINGLE ? 0 : g;    // whose arguments and matrices this wave works with
@@ -301,7 +339,12 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
     RW_DBG()
 #endif
 #pragma unroll
-    for (int i = 0; i < NX; ++i) rw_commit_row(xq[i], xtile, invx, xrow0 + 2 * i + h, r, h);
+    for (int i = 0; i < NX; ++i) {
+      if (bf)
+        rw_commit_row_bf(xq[i], xtile, invx, xrow0 + 2 * i + h, r);
+      else
+        rw_commit_row(xq[i], xtile, invx, xrow0 + 2 * i + h, r, h);
+    }
     float4 hin[4];
     if (MODE != MODE_FWD) {
 #pragma unroll
@@ -317,7 +360,7 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
     // ---------------- 2. stage 1
     float a[16];
     {
-      const f32x16 acc = rw_gemm(xtile, w1, r, h);
+      const f32x16 acc = bf ? rw_gemm_bf(xtile, w1, r, h) : rw_gemm(xtile, w1, r, h);
       RW_DBG()   // 3: GEMM 1
       const float sc = invx[r] * w1.inv;
       if (MODE == MODE_FWD) {
@@ -373,12 +416,16 @@ __global__ void __launch_bounds__(RW_THREADS, 2) mlp_regw_kernel(const MlpPair P
     RW_DBG()   // 4: stage-1 epilogue (H stores / loads, activation, publish)
     rw_group_sync(bar, bar_target, lane);   // the row maxima are visible; every wave of the group is done with the X tile
     RW_DBG()   // 5: barrier
-    const float inv2 = rw_commit_block(a, L.at[g], L.pmax[g], nb, r, h);
+    float inv2 = 1.0f;
+    if (bf)
+      rw_commit_block_bf(a, L.at[g], nb, r, h);
+    else
+      inv2 = rw_commit_block(a, L.at[g], L.pmax[g], nb, r, h);
     rw_group_sync(bar, bar_target, lane);
     RW_DBG()   // 6: commit + barrier
     // ---------------- 3. stage 2
     {
-      const f32x16 acc = rw_gemm(L.at[g], w2, r, h);
+      const f32x16 acc = bf ? rw_gemm_bf(L.at[g], w2, r, h) : rw_gemm(L.at[g], w2, r, h);
       RW_DBG()   // 7: GEMM 2
       const float sc = inv2 * w2.inv;
       if (SHARED_X || SINGLE) {
@@ -437,7 +484,8 @@ extern "C" int nnhip_mlp_forms(void) {
   return (split ? 1 : 0) | (level >= 1 ? 2 : 0) | (level >= 2 ? 4 : 0) | (single >= 1 ? 8 : 0) | (single >= 2 ? 16 : 0);
 }
 bool mlp_regw_serves(int mode, const MlpPair& P) {
-  if (P.a[0].bf16 || P.a[1].bf16) return false;   // (the bf16 compute mode of training: mlp128s.hip / the row-local form)
+  // (the bf16 compute mode exists in the training modes only: the kernel reads it off the weight images)
+  if ((P.a[0].bf16 || (P.n > 1 && P.a[1].bf16)) && mode != MODE_TAN && mode != MODE_TAN2) return false;
   const int level = mlp_regw_level();
   const int single = mlp_regw_single();
   if (mode == MODE_TAN || mode == MODE_TAN2) {
