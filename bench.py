@@ -7,7 +7,11 @@ One "step" = one full pass of the hot path over one batch resident in HBM: neigh
 3 interaction layers + energy head + analytic force adjoint (BASELINE.json configs[1]: 1024 aspirin
 conformers, fp32).  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank evaluates its
 own 1024-conformer shard -- conformers are independent, there is no data-path collective ("weak" scaling) --
-and the time is the max over ranks between two barriers.
+and the time is the max over ranks between two barriers.  The steps of the benchmark are INDEPENDENT batches, so by default
+(--streams 0) two of them (three for steps of at most 6000 atoms) are in flight per GPU, each on its own lane of the module and its
+own HIP stream (model.inference_lanes): one step's launch fill / drain is covered by the other's kernels.  All K steps of a timed region
+complete inside it (barrier + synchronize on both sides).  The module-alone-on-one-stream time is reported beside it (`single_stream`),
+and the kernel classes / rooflines are event-timed with one step at a time.
 
 Prints ONE JSON line (see README / DESIGN.md for the fields).  `roofline` is measured live with HIP events on
 the launch stream (the library's timer hook) in a separate instrumented pass, so the events never sit inside

@@ -1138,7 +1138,7 @@ int launch_transposes(const float* const* src, float* const* dst, int count, hip
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stand-alone differentiable building blocks for the train-mode forward (newtonnet_amd/train_ops.py).
+// Stand-alone building blocks of the C ABI (scatter-sum over the receiver, row gathers: newtonnet.py:210-226), each other's adjoints.
 // They are linear maps and each other's adjoints, so autograd can differentiate through them twice
 // (force-loss training: output.py:66-73 with create_graph=True, trainer.py:307-309).
 //   segment_sum:  out[i][:] = sum_{e in [row_ptr[i], row_ptr[i+1])} x[e][:]      (deterministic scatter_sum)

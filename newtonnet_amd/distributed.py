@@ -353,7 +353,7 @@ class GraphedTrainStep:
 
     The eager step is bound by the host (~600 small launches through Python autograd: 12.6 ms whatever the batch size);
     with the structure fixed nothing in it depends on the data: the neighbor list becomes a static candidate list (all pairs
-    of every molecule, candidates beyond the cutoff masked to exactly zero, train_ops.forward_train) and the whole
+    of every molecule, candidates beyond the cutoff masked to exactly zero, train_fused.forward_train) and the whole
     forward + double backward is captured once and replayed (4 ms at batch 32 on MI355X).  Two graphs: (1) zero_grad +
     forward + loss + backward, (2) gradient clipping + optimizer step; between them the data-parallel gradient
     all-reduce runs eagerly (allreduce_gradients), so the same class serves one GPU and DDP.  A new structure (e.g. the last,

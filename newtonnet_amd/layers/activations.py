@@ -3,7 +3,7 @@
 Every name but 'swiglu' is fused into the HIP kernels (csrc/common.h: act_f / dact_f, ids in include/newtonnet_hip.h);
 'swish' / 'silu' -- the default of every published config (scripts/config.yml:34) -- keep a dedicated fast path.  The modules
 built here keep the reference's nn.Sequential index layout (Linear, act, Linear -> state_dict keys '.0.' and '.2.') and are
-what the train-mode graph calls (train_ops.py).  ('swiglu' cannot be constructed by the reference's own factory either: its
+the reference's own forward for anyone who calls it.  ('swiglu' cannot be constructed by the reference's own factory either: its
 class needs constructor arguments the factory does not pass.)
 """
 import math

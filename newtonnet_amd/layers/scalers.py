@@ -3,7 +3,7 @@
 State-dict layout is the reference's: `scalers.<k>.scale.weight` / `.shift.weight`, each a [119, 1] embedding indexed by
 atomic number (row 0 = padding).  On the HIP path the energy head applies them inside head_out_kernel (csrc/edge.hip) and
 the direct-force head inside direct_force_tail_kernel (csrc/node128.hip); the module below only owns the parameters and,
-in train mode, is called as a plain embedding lookup (train_ops.py).
+in train mode, enters the hand-written training kernels as a device pointer as well (train_fused.py).
 """
 import torch
 from torch import nn

@@ -13,8 +13,8 @@ Supported: every trainable head set of the reference -- ['energy'], ['energy', '
 all three (trainer.py:299-313, loss.py:30-47) -- with or without layer_norm, every fused activation.  An energy-only loss is the
 d = 0 case of the formula above; the direct_force head is an ordinary function of the final node states and back-propagates
 once (csrc/heads.hip), its adjoint seeds entering the epsilon-part of the reverse sweep.  layer_norm=True runs the node-level
-stages unfused with LayerNorm value / tangent kernels between them (csrc/train.hip).  train_ops.py (torch graph + vendor GEMMs)
-remains only behind NNHIP_TRAIN_PATH=torch, for debugging.  dL/dpos is not produced (None): the reference would return it, no trainer uses it.
+stages unfused with LayerNorm value / tangent kernels between them (csrc/train.hip).  (Round 1's torch-graph path,
+train_ops.py, was removed in round 6.)  dL/dpos is not produced (None): the reference would return it, no trainer uses it.
 """
 from __future__ import annotations
 

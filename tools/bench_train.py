@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Train-step timing (BASELINE configs[2]: MD17 ethanol-shaped, batch 32 / 10; and the config-2 batch, 1024 aspirin):
 loss = MSE(E) + 50 MSE(F), Adam, clip 1.0 (scripts/config.yml:45-54).  Fused path (csrc/train.hip) eager and replayed from HIP
-graphs, the torch-graph path of round 1 (NNHIP_TRAIN_PATH=torch) for comparison, the inference step on the same batch, and the
+graphs, the inference step on the same batch, and the
 CPU oracle's double backward.  usage: tools/bench_train.py [--no-cpu] [--no-torch-path]"""
 import os
 import sys
@@ -58,7 +58,6 @@ def main():
         args = [t.cuda() for t in data]
         res = {}
         for path in ('fused',):      # (the torch-graph path of round 1 was removed in round 6)
-            os.environ['NNHIP_TRAIN_PATH'] = path
             torch.manual_seed(0)
             model = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
             model.train()
@@ -69,7 +68,6 @@ def main():
             mg.train()
             gstep = GraphedTrainStep(mg, torch.optim.Adam(mg.parameters(), lr=1e-3, capturable=True), 1.0, 50.0, 1.0)
             res[path + '_graph'] = timeit(lambda: gstep(*args), 3, 30)
-        os.environ['NNHIP_TRAIN_PATH'] = 'fused'
         torch.manual_seed(0)
         mf = NewtonNet(output_properties=['energy', 'gradient_force']).to('cuda')
         mf.train()

@@ -25,6 +25,8 @@ PATTERNS = [
     (r'train.*kernel_stats.*\.txt$', 'rocprofv3 --kernel-trace --stats summary of a training step'),
     (r'train.*pmc_(fetch|write)_size\.txt$', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel, training step'),
     (r'md_kernel_stats\.txt$', 'rocprofv3 kernel trace of the one-molecule MD step (calculator path)'),
+    (r'kernel_stats_2_in_flight\.txt$', 'the same trace with the bench default of two steps in flight on two lanes / streams (kernels overlap: durations include what they share the chip with)'),
+    (r'two_stream.*\.txt$', 'steps in flight (model.inference_lanes): one batch split over streams vs whole independent steps over 2 / 3 / 4 lanes, us per step by batch size'),
     (r'kernel_stats\.txt$', 'rocprofv3 --kernel-trace --stats summary (kernel x grid: calls, total ms, avg us) of the config-2 bench command'),
     (r'pmc_fetch_size\.txt$', 'rocprofv3 --pmc FETCH_SIZE per kernel x grid (KiB; x2 on gfx950 for wide reads), config-2 step'),
     (r'pmc_write_size\.txt$', 'rocprofv3 --pmc WRITE_SIZE per kernel x grid (KiB), config-2 step'),

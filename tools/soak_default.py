@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the DEFAULT forms (what bench.py and every user runs): repeat one energy + force step on fixed inputs and require every
 repeat to be bitwise the first -- aspirin batches of several sizes, a mixed MD17-shaped batch, a periodic box, and a training step.
-Written after the intermittent error found in the opt-in molfuse2 kernels (profiles/r05_mol_fused2_soak.txt): the same kind of
+Written after the intermittent error found in round 5's opt-in fused kernels (removed in round 6) (profiles/r05_mol_fused2_soak.txt): the same kind of
 check for the kernels that are on by default.
 usage: python tools/soak_default.py [reps_scale]"""
 import os, sys, time
