@@ -292,7 +292,8 @@ class NewtonNet(nn.Module):
                 with torch.cuda.stream(streams[k % 2]):
                     outs.append(lanes[k % 2](z, pos, cell, batch))
 
-        (Inputs produced on another stream need the usual `streams[k].wait_stream(producer)` first.)
+        (The usual multi-stream rules apply: inputs produced on another stream need `streams[k].wait_stream(producer)` first, inputs
+        freed right after the call `record_stream`, and a lane's results are consumed on the stream that produced them.)
         One module serialises its calls on the GPU (they share one workspace); a step of this path is a chain of 30-45 dependent
         launches whose fill / drain phases leave the chip partly idle, and a second, independent step on another stream runs in
         those gaps: 1024 aspirin conformers 1.50 -> 1.38 ms per step, 128 conformers 353 -> 263 us (profiles/r06_two_stream.txt).
