@@ -1723,6 +1723,7 @@ extern "C" int nnhip_graph_pairs(const int32_t* row_ptr, const int32_t* col, con
 #define SO_BITS 6
 #define SO_CELLS (1 << SO_BITS)                    // cells per axis at most
 #define SO_KEYS (1 << (3 * SO_BITS))               // 262 144 Morton keys
+#define SO_SORT_MAX 2048                           // atoms of one key that are still sorted by input index
 __device__ __forceinline__ unsigned so_spread(unsigned v) {      // 6 bits -> every third bit
   v &= 0x3fu;
   v = (v | (v << 8)) & 0x300fu;
@@ -1800,7 +1801,9 @@ __global__ void __launch_bounds__(256) so_finish_kernel(const int* __restrict__ 
   const int key = blockIdx.x * 256 + threadIdx.x;
   if (key >= SO_KEYS) return;
   const int b = key_ptr[key], e = key_ptr[key + 1];
-  for (int a = b + 1; a < e; ++a) {          // insertion sort
+  // (a cell of a real system holds a handful of atoms.  Thousands in ONE cell -- a broken input, e.g. every position equal -- would
+  // make this quadratic loop run for minutes in one thread: such a cell keeps the order the atomics gave it, still a permutation)
+  for (int a = b + 1; a < e && e - b <= SO_SORT_MAX; ++a) {          // insertion sort
     const int v = slots[a];
     int q = a - 1;
     while (q >= b && slots[q] > v) {

@@ -316,6 +316,11 @@ class NewtonNet(nn.Module):
     # ------------------------------------------------------------------------------------------
     def train(self, mode=True):
         """As the reference (newtonnet.py:106-113): flips create_graph on derivative heads; returns None."""
+        if '_lane_of' in self.__dict__:     # an inference lane: its submodules are the OWNER's -- never touch their flags from here
+            if mode:
+                raise RuntimeError('an inference lane is eval-only (its submodules are the owner\'s): call train() on the owner module')
+            self.training = False
+            return
         super().train(mode)
         for output_layer in self.output_layers:
             if isinstance(output_layer, DerivativeProperty):
@@ -469,7 +474,9 @@ class NewtonNet(nn.Module):
         deriv_layers = [ol for ol in self.output_layers if isinstance(ol, DerivativeProperty)]
         # differentiable path: whenever the module is in train mode with autograd on -- with or without a derivative head
         # (the reference trains ['energy'] or ['energy', 'direct_force'] models just the same, trainer.py:299-313)
-        train_graph = torch.is_grad_enabled() and (self.training or any(ol.create_graph for ol in deriv_layers))
+        # (an inference lane shares its submodules -- and their create_graph flags -- with its owner, and is eval-only whatever the owner does)
+        train_graph = (torch.is_grad_enabled() and (self.training or any(ol.create_graph for ol in deriv_layers))
+                       and '_lane_of' not in self.__dict__)
         energy_idx = keys.index('energy')
         want_forces = len(deriv_layers) > 0
         want_virial = any(isinstance(ol, (VirialOutput, StressOutput)) for ol in deriv_layers)

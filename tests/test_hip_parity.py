@@ -662,6 +662,10 @@ def test_inference_lanes_keep_two_steps_in_flight():
             assert torch.equal(e, want[b][0]) and torch.equal(f, want[b][1]) and torch.equal(ei, want[b][2]), (rnd, b, lane)
     stats = [l.deferred_stats() for l in lanes]
     assert all(st['deferred_calls'] > 0 and st['repeats_needed'] == 0 for st in stats), stats
+    # a lane is eval-only, whatever its owner does
+    with pytest.raises(RuntimeError):
+        lanes[1].train()
+    assert lanes[1].eval() is None
     # the owner's parameters change (in place, as an optimizer step or load_state_dict does): every lane sees the new values
     torch.cuda.synchronize()
     with torch.no_grad():
