@@ -1300,6 +1300,11 @@ def main():
             'edge_kernel_frac': {k: v['frac_pair_bytes'] for k, v in (edge_all_roofline or {}).get('per_kernel', {}).items()},
             'counter_GB_per_step': {'edge_kernels': round((edge_all_roofline or {}).get('counter_bytes_per_step', 0) / 1e9, 3) or None,
                                     'whole_step': round((pmc_step_total() or 0) / 1e9, 3) or None} if quotes_profiles else None,
+            # the whole step against the HBM roof: the stored counter bytes of one step over this run's step time (two in flight)
+            'step_hbm': ({'counter_GB_per_step': round((pmc_step_total() or 0) / 1e9, 3),
+                          'achieved_GBs': round((pmc_step_total() or 0) / (dt / args.steps) / 1e9, 1),
+                          'frac_of_8TBs': round((pmc_step_total() or 0) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                         if quotes_profiles and pmc_step_total() else None),
             'profiles': dict(pstate, quoted=quotes_profiles),
             'train_small': {'ms_per_step': train.get('ms_per_step'), 'allreduce_us': train.get('allreduce_us'),
                             'in_sync': train.get('replicas_in_sync'), 'error': train.get('error')} if train else None,

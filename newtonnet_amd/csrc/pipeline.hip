@@ -51,7 +51,7 @@ void nnhip_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nnhip_last_error(void) { return g_err; }
-extern "C" int nnhip_version(void) { return 107; }   // 107: the molecule-resident fused edge phase (molfuse.hip, molfuse2.hip) and the single-launch small step (small.hip) removed -- measured slower than the row path, profiles/r06_fused_persistent_*.txt; 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
+extern "C" int nnhip_version(void) { return 108; }   // 108: nnhip_spatial_order / nnhip_permute_rows / nnhip_edge_index_unpermute, the bf16 compute mode (nnhip_mlp_desc.precision, nnhip_weight_images_bf16), one-pass training forms of the edge MLPs, nnhip_train_ws.pair_ptr / .flags; 107: the molecule-resident fused edge phase (molfuse.hip, molfuse2.hip) and the single-launch small step (small.hip) removed -- measured slower than the row path, profiles/r06_fused_persistent_*.txt; 106: the molecule-resident fused edge phase (molfuse.hip, NNHIP_MOL_FUSED), timer classes 12 / 13; 105: molecule-resident force_fwd (status bit 8, flags); 104: the deferred step (nnhip_forward_dev, nnhip_graph_small_dev), split rows; 103: nnhip_prepare_check
 // bit 0: tooling build (compiled with extra flags -- ablation / A-B switches); never loaded by the package by default
 extern "C" int nnhip_build_flags(void) {
 #ifdef NNHIP_TOOLING
