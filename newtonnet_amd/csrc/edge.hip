@@ -254,7 +254,11 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
                  const float* __restrict__ geo, const int* __restrict__ row_ptr, const int* __restrict__ col,
                  const int* __restrict__ pid, const float* __restrict__ f_in, float* __restrict__ g_h12 /*[P][2F]*/,
                  float* __restrict__ g_u /*[E][4]: gux,guy,guz,(unused)*/, float* __restrict__ g_fin, int n_atoms,
-                 const int2* __restrict__ xg, const int* __restrict__ pair_ptr) {
+                 const int2* __restrict__ xg, const int* __restrict__ pair_ptr, const int* __restrict__ rev) {
+  // rev != NULL (round 6; every caller that has the reverse-edge index): the pair's OWNER writes g_u of BOTH directed edges --
+  // g_u[rev e][k] = < gf[j][k], phi1[p] > from the gf[j] rows it gathers anyway -- so the other endpoint never reads phi1[p]:
+  // one pair-row read less per pair (80 of 560 MB per launch at config 2), and layer 0 (no phi2) visits only the pairs a row owns.
+  // Same operands, same lane layout, same reduction: the bits of g_u do not change.
   __shared__ float4 comb[EDGE_COMB_SIZE(WPR, 3)];
   int part;
   const int i_ = wave_row_split<WPR>(gridDim.x, part);
@@ -273,18 +277,18 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
   }
   const int beg = active ? row_ptr[i] : 0, end = active ? row_ptr[i + 1] : 0;
   const int mid = row_mid_of(pair_ptr, col, beg, end, i, lane, active);
-  // [beg, mid): pairs owned by the other endpoint -- g_u and the phi2 gather only
-  for (int e = beg + 2 * part; e < mid; e += 2 * WPR) {
+  const bool owner_gu = rev != nullptr;   // (uniform)
+  // [beg, mid): pairs owned by the other endpoint -- the phi2 gather (and, without rev, this direction's g_u)
+  for (int e = beg + 2 * part; e < mid && (HAS_F || !owner_gu); e += 2 * WPR) {
     const int e1 = min(e + 1, mid - 1);
     const int p0 = pid[e], p1 = pid[e1];
     const int eh = hi ? e1 : e;
     const size_t p = (size_t)(hi ? p1 : p0);
     const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;   // (see force_fwd_kernel: candidates outside the cutoff contribute nothing)
-    if ((!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
+    if (!owner_gu && (!hi || e + 1 < mid) && !inside && (lane & 31) == 31)
       reinterpret_cast<float4*>(g_u)[eh] = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((!hi || e + 1 < mid) && inside) {
-      const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
       float4 gfj[3];
       if (HAS_F) {
         const int j0 = col[e], j1 = col[e1];
@@ -296,10 +300,13 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
           acc[k] = fma4(v2, gfj[k], acc[k]);
         }
       }
-      const float s0 = half_sum_top(dot4(gfi[0], v1));
-      const float s1 = half_sum_top(dot4(gfi[1], v1));
-      const float s2 = half_sum_top(dot4(gfi[2], v1));
-      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
+      if (!owner_gu) {
+        const float4 v1 = ld4p<EDGE_NT_PHI_BWD != 0>(phi1 + (size_t)ABL_P(p, i) * NF + c4);
+        const float s0 = half_sum_top(dot4(gfi[0], v1));
+        const float s1 = half_sum_top(dot4(gfi[1], v1));
+        const float s2 = half_sum_top(dot4(gfi[2], v1));
+        if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
+      }
     }
   }
   // [mid, end): pairs this row owns -- additionally the adjoints of the shared phi rows
@@ -315,11 +322,16 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
     const float4 g = hi ? g1 : g0;
     const int gz0 = xg ? xg[e].x : 0, gz1 = xg ? xg[e1].x : 0;   // (xg == NULL: nothing to mask)
     const bool inside = (hi ? gz1 : gz0) != FT_ZERO_ROW;
+    const int er0 = owner_gu ? rev[e] : 0, er1 = owner_gu ? rev[e1] : 0;   // (the reverse edges: wave-uniform loads)
+    const int er = hi ? er1 : er0;
     if ((!hi || e + 1 < end) && !inside) {   // outside the cutoff: zero adjoints for the pair rows this row owns
       const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
       st4(g_h12 + p * 2 * NF + c4, zero);
       if (HAS_F) st4(g_h12 + p * 2 * NF + NF + c4, zero);
-      if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = zero;
+      if ((lane & 31) == 31) {
+        reinterpret_cast<float4*>(g_u)[eh] = zero;
+        if (owner_gu) reinterpret_cast<float4*>(g_u)[er] = zero;
+      }
     }
     if ((!hi || e + 1 < end) && inside) {
       const float4 v1 = ld4(phi1 + (size_t)ABL_P(p, i) * NF + c4);
@@ -345,6 +357,12 @@ force_bwd_kernel(const float* __restrict__ gf, const float* __restrict__ phi1, c
       const float s1 = half_sum_top(dot4(gfi[1], v1));
       const float s2 = half_sum_top(dot4(gfi[2], v1));
       if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[eh] = make_float4(s0, s1, s2, 0.f);
+      if (owner_gu) {      // the other direction's g_u: what row j computed from gf[j] and this same phi1 row
+        const float t0 = half_sum_top(dot4(gfj[0], v1));
+        const float t1 = half_sum_top(dot4(gfj[1], v1));
+        const float t2 = half_sum_top(dot4(gfj[2], v1));
+        if ((lane & 31) == 31) reinterpret_cast<float4*>(g_u)[er] = make_float4(t0, t1, t2, 0.f);
+      }
     }
   }
   if (HAS_F) {
@@ -964,13 +982,15 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
 
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr) {
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr, const int* rev) {
   ScopedTimer t0(TC_EDGE, s);
   ScopedTimer t1(TC_EDGE_BWD_FORCE, s);
+  static const bool owner_off = getenv("NNHIP_FORCE_BWD_OWNER_GU") && atoi(getenv("NNHIP_FORCE_BWD_OWNER_GU")) == 0;   // (A/B)
+  if (owner_off) rev = nullptr;
   if (has_f)
-    EDGE_LAUNCH_B(force_bwd_kernel, true, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
+    EDGE_LAUNCH_B(force_bwd_kernel, true, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr, rev);
   else
-    EDGE_LAUNCH_B(force_bwd_kernel, false, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr);
+    EDGE_LAUNCH_B(force_bwd_kernel, false, EDGE_WPR_FORCE_BWD, gf, phi1, phi2, geo, row_ptr, col, pid, f_in, g_h12, g_u, g_fin, n_atoms, reinterpret_cast<const int2*>(xg), pair_ptr, rev);
   LAUNCH_CHECK();
   return 0;
 }

@@ -24,7 +24,7 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
                      const int* pair_ptr = nullptr, const int* mol_ptr = nullptr, int n_mol = 0);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo,
                      const int* row_ptr, const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u,
-                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr = nullptr);
+                     float* g_fin, int n_atoms, const int* xg, hipStream_t s, const int* pair_ptr = nullptr, const int* rev = nullptr);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table,
                    const int* row_ptr, const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm,
                    hipStream_t s, const int* pair_ptr = nullptr, const int* mol_ptr = nullptr, int n_mol = 0);
@@ -838,7 +838,7 @@ static int energy_forces_impl(const nnhip_model* model, const int64_t* z, const 
     float* g_fin = g_fbuf[pp];
     {
       TRY(launch_force_bwd(has_f, P(w.gf_mid), P(w.pub.phi1[l]), P(w.pub.phi2[l]), geo, row_ptr, col, pid, f_prev,
-                           P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr));
+                           P(w.g_h12), P(w.pub.g_u) + (size_t)l * E * 4, g_fin, N, mask_xg, s, pair_ptr, rev));
       if (E > 0) {
         // g_msg = ((g_phi1 V12) * silu'(h1)) V10 + ((g_phi2 V22) * silu'(h2)) V20, each term one fused launch
         float* gp = P(w.g_h12);   // [P][2F]: g_phi1 | g_phi2 written by force_bwd (pair space)

@@ -18,7 +18,7 @@ int launch_force_fwd(bool has_f, const float* phi1, const float* phi2, const flo
                      const int* mol_ptr, int n_mol);
 int launch_force_bwd(bool has_f, const float* gf, const float* phi1, const float* phi2, const float* geo, const int* row_ptr,
                      const int* col, const int* pid, const float* f_in, float* g_h12, float* g_u, float* g_fin, int n_atoms,
-                     const int* xg, hipStream_t s, const int* pair_ptr);
+                     const int* xg, hipStream_t s, const int* pair_ptr, const int* rev);
 int launch_msg_bwd(const float* g_msg, const float* g_a, const float* m, const int* xg, const float* table, const int* row_ptr,
                    const int* col, const int* pid, float* g_m, float* g_x, int n_atoms, bool need_gm, hipStream_t s,
                    const int* pair_ptr, const int* mol_ptr, int n_mol);
@@ -323,7 +323,7 @@ extern "C" int nnhip_train_values(const nnhip_model* model, const nnhip_train_ws
     const float* f_prev = l > 0 ? w->f_out[l - 1] : nullptr;
     float* Gf = w->Gf[pp];
     TS_TRY(launch_force_bwd(f_prev != nullptr, w->gf[l], w->phi1[l], w->phi2[l], w->geo, w->row_ptr, w->col, w->pid, f_prev,
-                            w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, w->xg, (hipStream_t)s, w->pair_ptr));
+                            w->g_h12[l], w->g_u + (size_t)4 * l * E, Gf, N, w->xg, (hipStream_t)s, w->pair_ptr, w->rev));
     nnhip_mlp_desc d1 = edge_desc(bf, MODE_TAN, w->g_h12[l], 2 * NF, w->wT[l][3], w->wT[l][2], w->h1[l], w->g_msg[l], P, act,
                                  LIMG(l, IMG_EQ1_2_T), LIMG(l, IMG_EQ1_0_T));
     d1.T = w->t1[l];
