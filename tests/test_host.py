@@ -277,3 +277,33 @@ def test_fused_step_refuses_a_model_with_both_force_heads():
     assert _force_key(NewtonNet(output_properties=['energy'])) is None
     with pytest.raises(NotImplementedError):
         _force_key(NewtonNet(output_properties=['energy', 'gradient_force', 'direct_force']))
+
+
+def test_inference_lanes_share_parameters_and_nothing_else(tmp_path):
+    """model.inference_lanes(n) (host logic, no GPU): lane 0 is the module; the other lanes are shallow views with the SAME Parameter
+    and submodule objects and NONE of the run-time state; they are cached, handed out by any lane, eval-only without touching the
+    owner's flags, and never travel in a pickle (trainer.py:219 saves whole modules)."""
+    import pickle
+    from newtonnet_amd.models import NewtonNet
+    m = NewtonNet(output_properties=['energy', 'gradient_force'])
+    m.train()
+    m.__dict__['_edge_hint'] = (21, 400)            # (run-time state a call would have left)
+    lanes = m.inference_lanes(3)
+    assert lanes[0] is m and len({id(l) for l in lanes}) == 3
+    for l in lanes[1:]:
+        assert l._parameters is m._parameters and l._modules is m._modules and l.interaction_layers is m.interaction_layers
+        assert '_edge_hint' not in l.__dict__ and '_lanes' not in l.__dict__ and l.__dict__['_lane_of'] is m
+        assert l.training is False
+        with pytest.raises(RuntimeError):
+            l.train()
+        assert l.eval() is None
+    assert m.training and m.interaction_layers.training and all(ol.create_graph for ol in m.output_layers if hasattr(ol, 'create_graph'))
+    assert m.inference_lanes(2)[1] is lanes[1] and lanes[2].inference_lanes(3)[1] is lanes[1]
+    # a parameter update on the owner is the lanes' update (same objects)
+    with torch.no_grad():
+        m.interaction_layers[0].equiv_update.weight.add_(1.0)
+    assert torch.equal(lanes[1].interaction_layers[0].equiv_update.weight, m.interaction_layers[0].equiv_update.weight)
+    back = pickle.loads(pickle.dumps(m))
+    assert '_lanes' not in back.__dict__ and '_edge_hint' not in back.__dict__
+    lane_back = pickle.loads(pickle.dumps(lanes[1]))
+    assert '_lane_of' not in lane_back.__dict__             # (a pickled lane comes back as an ordinary module)
