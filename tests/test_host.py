@@ -307,3 +307,20 @@ def test_inference_lanes_share_parameters_and_nothing_else(tmp_path):
     assert '_lanes' not in back.__dict__ and '_edge_hint' not in back.__dict__
     lane_back = pickle.loads(pickle.dumps(lanes[1]))
     assert '_lane_of' not in lane_back.__dict__             # (a pickled lane comes back as an ordinary module)
+
+
+def test_library_config_survives_hostile_environment_values():
+    """nnhip_config writes the NNHIP_* switches that are set into a JSON string; a value with a quote or a backslash must not
+    cost the caller its bench line (bench.py calls hip.config() on rank 0).  No GPU needed: the call only formats text."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from newtonnet_amd import hip\n"
+            "print(json.dumps(hip.config()))\n" % ROOT)
+    env = dict(os.environ, NNHIP_EDGE_LDS='12"3\\4', NNHIP_MOL_KERNELS_MIN='700')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cfg = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cfg['env']['NNHIP_EDGE_LDS'] == '12?3?4' and cfg['env']['NNHIP_MOL_KERNELS_MIN'] == '700'
+    assert cfg['molecule_forms']['edge_kernels_from_molecules'] == 700 and cfg['version'] >= 108
